@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself.
+
+Run in the build container only (``/root/reference`` is mounted there and nowhere else):
+
+    python tests/golden/make_golden.py
+
+The reference is pure Python; it is imported from /root/reference with empty stub modules for its
+module-level third-party imports that are absent here (librosa, soundfile, onnxruntime, pesq, pystoi
+-- none is touched on the model path).  Nothing of the reference's source is copied: the
+fixtures hold inputs, weights (synthetic, or the MIT-licensed baseline_s checkpoint re-serialised)
+and the reference's outputs.  Per-step membranes are captured with forward hooks on the reference's
+own ``GSUCell`` modules, the enhanced spectrum by wrapping the module's ``istft`` attribute.
+
+Fixture metadata records the torch version that served as the oracle's oracle.
+"""
+from __future__ import annotations
+
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))  # tests/
+REF = "/root/reference"
+FROZEN_DIR = f"{REF}/recipes/intel_ndns/spiking_fullsubnet_freeze_phase"
+
+
+def import_reference():
+    for name in ("librosa", "soundfile", "onnxruntime", "pesq", "pystoi"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+            sys.modules[name] = m
+    sys.modules["pesq"].pesq = None
+    sys.modules["pystoi"].stoi = None
+    sys.path.insert(0, REF)
+    sys.path.insert(0, FROZEN_DIR)
+    import torch  # noqa
+    from audiozen.models.spiking_fullsubnet import efficient_spiking_neuron as neuron
+    from audiozen.models.spiking_fullsubnet import modeling_spiking_fullsubnet as live
+    import model_low_freq as frozen
+    from audiozen import metric
+    return neuron, live, frozen, metric
+
+
+def pack(spk: np.ndarray) -> np.ndarray:
+    return np.packbits(spk.astype(np.uint8).reshape(-1))
+
+
+def to_torch_sd(sd):
+    import torch
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+class CellTap:
+    """Forward hooks on every GSUCell: records the post-BN membrane cy of every step, per cell."""
+
+    def __init__(self, model, neuron):
+        self.mem = {}
+        self.handles = []
+        for name, mod in model.named_modules():
+            if isinstance(mod, neuron.GSUCell) or type(mod).__name__ == "GSUCell":
+                self.mem[name] = []
+                self.handles.append(mod.register_forward_hook(self._mk(name)))
+
+    def _mk(self, name):
+        def hook(_m, _inp, out):
+            self.mem[name].append(out[1][1].detach().numpy().copy())
+        return hook
+
+    def stacked(self):
+        return {k: np.stack(v) for k, v in self.mem.items()}
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+
+
+def gsn_cases(neuron, out):
+    import torch
+    cases = [  # name, I, H, L, R, T, shared, bn, nonzero_state
+        ("tiny_shared_bn", 12, 32, 2, 5, 40, True, True, False),
+        ("tiny_unshared_nobn", 9, 16, 2, 4, 30, False, False, False),
+        ("tiny_unshared_bn_state", 20, 48, 1, 3, 25, False, True, True),
+        ("sb_m_shape", 38, 224, 2, 3, 24, True, True, False),
+        ("fb_m_shape_state", 64, 320, 1, 2, 16, True, True, True),
+    ]
+    meta = []
+    for ci, (name, I, H, L, R, T, shared, bn, st) in enumerate(cases):
+        rng = np.random.default_rng(100 + ci)
+        import refweights
+        sd = {}
+        for l in range(L):
+            refweights._cell(rng, f"layers.{l}.cell.", I if l == 0 else H, H, shared, bn, sd)
+        net = neuron.efficient_spiking_neuron(I, H, L, shared_weights=shared, bn=bn).eval()
+        net.load_state_dict(to_torch_sd(sd), strict=True)
+        x = rng.standard_normal((T, R, I)).astype(np.float32)
+        if st:
+            h0 = [(rng.random((R, H)) > 0.5).astype(np.float32) for _ in range(L)]
+            c0 = [rng.standard_normal((R, H)).astype(np.float32) for _ in range(L)]
+        else:
+            h0 = [np.zeros((R, H), np.float32) for _ in range(L)]
+            c0 = [np.zeros((R, H), np.float32) for _ in range(L)]
+        tap = CellTap(net, neuron)
+        with torch.no_grad():
+            states = [neuron.MemoryState(torch.from_numpy(h0[l].copy()), torch.from_numpy(c0[l].copy())) for l in range(L)]
+            y, out_states, all_out = net(torch.from_numpy(x), states)
+        mems = tap.stacked()
+        tap.close()
+        out[f"{name}/x"] = x
+        for k, v in sd.items():
+            out[f"{name}/sd/{k}"] = v
+        for l in range(L):
+            out[f"{name}/h0/{l}"] = h0[l]
+            out[f"{name}/c0/{l}"] = c0[l]
+            out[f"{name}/spikes/{l}"] = all_out[l + 1].numpy()
+            out[f"{name}/membrane/{l}"] = mems[f"layers.{l}.cell"]
+            out[f"{name}/hT/{l}"] = out_states[l][0].numpy()
+            out[f"{name}/cT/{l}"] = out_states[l][1].numpy()
+        meta.append((name, I, H, L, R, T, int(shared), int(bn)))
+    out["cases"] = np.array([m[0] for m in meta])
+    out["dims"] = np.array([m[1:] for m in meta], dtype=np.int64)
+
+
+def run_model(model, neuron, wave, frozen_front):
+    """Run a reference model on a waveform; return dict of path inputs/outputs."""
+    import torch
+    captured = {}
+    tap = CellTap(model, neuron)
+    if frozen_front:
+        real_istft = torch.istft
+
+        def tap_istft(x, *a, **k):
+            captured["enh_stft"] = x.detach().numpy().copy()
+            return real_istft(x, *a, **k)
+        torch.istft, saved = tap_istft, real_istft
+    else:
+        inner = model.istft
+
+        def tap_istft(x, *a, **k):
+            captured["enh_stft"] = x.detach().numpy().copy()
+            return inner(x, *a, **k)
+        model.istft = tap_istft
+    try:
+        with torch.no_grad():
+            outs = model(torch.from_numpy(wave))
+            stft = torch.stft(torch.from_numpy(wave), 512, 128, 512, window=torch.hann_window(512), return_complex=True,
+                              pad_mode="constant")
+    finally:
+        if frozen_front:
+            torch.istft = saved
+    mems = tap.stacked()
+    tap.close()
+    res = dict(wave=wave, stft=stft.numpy(), enh_stft=captured["enh_stft"], enh_y=outs[0].numpy())
+    if len(outs) == 4:
+        res["enh_mag"] = outs[1].numpy()
+        fb_all, sb_all = outs[2], outs[3]
+    else:
+        fb_all, sb_all = outs[1], outs[2]
+    res["fb_all"] = [a.numpy() for a in fb_all]
+    res["sb_all"] = [[a.numpy() for a in lst] for lst in sb_all]
+    res["mem"] = mems
+    return res
+
+
+def store_model_case(out, res, store_membranes: bool, near_tau=(1e-4, 1e-3)):
+    for k in ("wave", "stft", "enh_stft", "enh_y"):
+        out[k] = res[k]
+    if "enh_mag" in res:
+        out["enh_mag"] = res["enh_mag"]
+
+    def put(prefix, lst, mem_prefix):
+        out[f"{prefix}/x"] = lst[0]
+        out[f"{prefix}/proj"] = lst[-1]
+        for l, spk in enumerate(lst[1:-1]):
+            out[f"{prefix}/spikes_packed/{l}"] = pack(spk)
+            out[f"{prefix}/spikes_shape/{l}"] = np.array(spk.shape, dtype=np.int64)
+            mem = res["mem"][f"{mem_prefix}sequence_model.layers.{l}.cell"]
+            if store_membranes:
+                out[f"{prefix}/membrane/{l}"] = mem
+            for tau in near_tau:
+                out[f"{prefix}/near{tau:g}/{l}"] = pack(np.abs(mem) < tau)
+
+    put("fb", res["fb_all"], "fb_model.")
+    for g, lst in enumerate(res["sb_all"]):
+        put(f"sb{g}", lst, f"sb_model.sb_models.{g}.")
+    out["n_groups"] = np.asarray(len(res["sb_all"]))
+
+
+def main():
+    import torch
+    import refweights as rw
+    neuron, live, frozen, metric = import_reference()
+    torch.set_num_threads(4)
+    meta = dict(torch_version=torch.__version__, numpy_version=np.__version__)
+
+    out = {}
+    gsn_cases(neuron, out)
+    np.savez_compressed(os.path.join(HERE, "gsn_cells.npz"), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
+    print("gsn_cells.npz", len(out))
+
+    def live_case(fname, kw, seed, B, T, store_mem, wave_seed=0):
+        sd = rw.live_state_dict(kw, seed)
+        model = live.SpikingFullSubNet(**kw).eval()
+        model.load_state_dict(to_torch_sd(sd), strict=True)
+        res = run_model(model, neuron, rw.synth_wave(B, T, wave_seed), frozen_front=False)
+        out = {}
+        store_model_case(out, res, store_mem)
+        out["weight_seed"] = np.asarray(seed)
+        if kw.get("num_spks", 1) == 1:
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                out["synops"] = np.asarray(metric.compute_synops([torch.from_numpy(a) for a in res["fb_all"]],
+                                           [[torch.from_numpy(a) for a in l] for l in res["sb_all"]], kw["shared_weights"]))
+                out["neuronops"] = np.asarray(metric.compute_neuronops([torch.from_numpy(a) for a in res["fb_all"]],
+                                              [[torch.from_numpy(a) for a in l] for l in res["sb_all"]]))
+        np.savez_compressed(os.path.join(HERE, fname), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
+        print(fname, {k: v.shape for k, v in out.items() if k in ("stft", "enh_stft")})
+
+    live_case("live_tiny.npz", rw.LIVE_TINY, 11, 2, 24, True)
+    live_case("live_tiny_2spk.npz", rw.LIVE_TINY_2SPK, 12, 2, 20, True)
+    live_case("live_tiny_unshared.npz", rw.LIVE_TINY_UNSHARED, 13, 1, 20, True)
+    live_case("live_m.npz", rw.LIVE_M, 21, 1, 40, False)
+
+    def frozen_case(fname, kw, sd, B, T, store_mem, store_weights):
+        model = frozen.Separator(**kw).eval()
+        model.load_state_dict(to_torch_sd(sd), strict=True)
+        res = run_model(model, neuron, rw.synth_wave(B, T, 1), frozen_front=True)
+        out = {}
+        store_model_case(out, res, store_mem)
+        if store_weights:
+            for k, v in sd.items():
+                out[f"sd/{k}"] = np.asarray(v)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            out["synops"] = np.asarray(metric.compute_synops([torch.from_numpy(a) for a in res["fb_all"]],
+                                       [[torch.from_numpy(a) for a in l] for l in res["sb_all"]], kw["shared_weights"]))
+            out["neuronops"] = np.asarray(metric.compute_neuronops([torch.from_numpy(a) for a in res["fb_all"]],
+                                          [[torch.from_numpy(a) for a in l] for l in res["sb_all"]]))
+        np.savez_compressed(os.path.join(HERE, fname), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
+        print(fname)
+
+    frozen_case("frozen_tiny.npz", rw.FROZEN_TINY, rw.frozen_state_dict(rw.FROZEN_TINY, 31), 2, 24, True, False)
+    zoo = torch.load(f"{REF}/model_zoo/intel_ndns/spike_fsb/baseline_s/checkpoints/best/pytorch_model.bin", map_location="cpu")
+    zoo = {k: v.numpy() for k, v in zoo.items()}
+    frozen_case("frozen_s_zoo.npz", rw.FROZEN_S, zoo, 1, 126, False, True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+"""Parity rules for a discontinuous (spiking) recurrence -- shared by the oracle-vs-golden tests (CPU)
+and the HIP-vs-oracle tests (GPU).
+
+The spike threshold ``membrane >= 0`` (efficient_spiking_neuron.py:89) makes the map discontinuous: two
+correct fp32 evaluations that differ by one rounding in a dot product flip a spike whose membrane is
+within rounding noise of zero, and the flip then perturbs every later frame of that row and of every
+chain fed by it.  (The reference disagrees with *itself* in fp64 vs fp32 on 0-0.07 % of spikes,
+SURVEY 0.)  A blanket element-wise tolerance is therefore either meaningless or unattainable; the rule
+used everywhere instead is CAUSAL:
+
+  * every chain (one row of one layer) must agree with the reference EXACTLY on spikes, and within
+    ``MEM_ATOL`` on membranes / ``REL``-``ATOL`` on continuous outputs, at every frame before the first
+    divergence of the chain or of anything upstream of it;
+  * a chain's own first divergence is accepted only if every differing neuron at that frame had a
+    reference membrane with ``|c| < TAU`` (a don't-care band around the threshold);
+  * what comes after a divergence is reported (agreement rates) but not asserted.
+
+Tolerances (north star: <= 1e-4 rel fp32 on the enhanced spectrum):
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TAU = 1e-4        # don't-care half-width around the spike threshold (post-BN membrane units, O(1) scale)
+MEM_ATOL = 2e-5   # membrane agreement before any divergence: |err| <= MEM_ATOL + MEM_RTOL*|c_ref|
+MEM_RTOL = 2e-5   # relative to the neuron's running max |c_ref|: chains with gain > 1 (forget gate ~1 x BN scale > 1, also present in the trained zoo weights) amplify rounding noise step over step
+REL = 1e-4        # relative tolerance on continuous outputs (proj, enh_stft, enh_mag)
+ATOL = 2e-5       # absolute floor for continuous outputs (values are O(0.1-10))
+
+
+def unpack(packed: np.ndarray, shape) -> np.ndarray:
+    n = int(np.prod(shape))
+    return np.unpackbits(packed)[:n].reshape(shape).astype(bool)
+
+
+def first_true(mask_tr: np.ndarray) -> np.ndarray:
+    """mask [T, R] -> first t with mask true per row, T if none."""
+    T = mask_tr.shape[0]
+    any_ = mask_tr.any(0)
+    return np.where(any_, mask_tr.argmax(0), T)
+
+
+def check_chain(spk, spk_ref, near_ref, t_up, name="", mem=None, mem_ref=None):
+    """One layer: spk, spk_ref [T,R,H] (0/1), near_ref [T,R,H] bool (|ref membrane| < TAU), t_up [R] upstream
+    validity horizon.  Asserts the causal rule; returns (t_valid [R], stats dict)."""
+    spk = np.asarray(spk) > 0.5
+    spk_ref = np.asarray(spk_ref) > 0.5
+    T, R, H = spk_ref.shape
+    assert spk.shape == spk_ref.shape, (name, spk.shape, spk_ref.shape)
+    diff = spk != spk_ref
+    first = first_true(diff.any(-1))
+    t_valid = np.minimum(first, t_up)
+    explained = unexplained = 0
+    for r in np.nonzero(first < t_up)[0]:
+        d = diff[first[r], r]
+        ok = near_ref[first[r], r][d].all()
+        explained += int(ok)
+        unexplained += int(not ok)
+        assert ok, (f"{name}: row {r} diverges at t={first[r]} on {int(d.sum())} neuron(s) whose reference membrane is "
+                    f"outside the +-{TAU:g} don't-care band")
+    if mem is not None and mem_ref is not None:
+        tt = np.arange(T)[:, None] < t_valid[None, :]
+        ref64 = np.asarray(mem_ref, np.float64)
+        # a chain with gain > 1 (saturated forget gate x BatchNorm scale > 1: seen with random BN statistics)
+        # carries its rounding noise forward, so the relative term uses the running max of |c_ref| of that neuron
+        scale = np.maximum.accumulate(np.abs(ref64), axis=0)
+        err = (np.abs(np.asarray(mem, np.float64) - ref64) - MEM_RTOL * scale)[tt]
+        if err.size:
+            assert err.max() <= MEM_ATOL, f"{name}: membrane error exceeds {MEM_ATOL:g}+{MEM_RTOL:g}*|c| by {err.max() - MEM_ATOL:.3g} before any divergence"
+    stats = dict(name=name, rows=R, diverged=int((first < T).sum()), own_explained=explained,
+                 spike_agreement=float(1.0 - diff.mean()), valid_frac=float(t_valid.sum() / max(1, T * R)))
+    return t_valid, stats
+
+
+def check_continuous(y, y_ref, t_valid_rows, name="", rel=REL, atol=ATOL):
+    """y, y_ref [T, R, P]: compare where t < t_valid[r]."""
+    y = np.asarray(y, np.float64)
+    y_ref = np.asarray(y_ref, np.float64)
+    assert y.shape == y_ref.shape, (name, y.shape, y_ref.shape)
+    T = y.shape[0]
+    ok = np.arange(T)[:, None] < t_valid_rows[None, :]
+    err = np.abs(y - y_ref)[ok]
+    tol = (atol + rel * np.abs(y_ref))[ok]
+    if err.size:
+        worst = (err - tol).max()
+        assert worst <= 0, f"{name}: max excess error {worst:.3g} (max abs err {err.max():.3g})"
+    return float(err.max()) if err.size else 0.0
+
+
+def check_model(out, gold, spec, tag=""):
+    """Whole-model causal comparison.
+
+    out:  dict(fb_all=[x, S1.., proj], sb_all=[[...]...], enh_stft [B,S,F,T] complex, enh_mag)
+    gold: npz-like mapping written by tests/golden/make_golden.py::store_model_case (or a dict with the same
+          keys built from an oracle run by ``gold_from_oracle``).
+    spec: oracle.model spec (front, cutoffs, ctr, num_spks ...).
+    Returns a list of per-layer stats.
+    """
+    stats = []
+    fb_all = out["fb_all"]
+    T, B, _ = fb_all[0].shape
+    L = len(fb_all) - 2
+
+    def layer_gold(prefix, l):
+        shape = tuple(int(v) for v in gold[f"{prefix}/spikes_shape/{l}"])
+        return unpack(gold[f"{prefix}/spikes_packed/{l}"], shape), unpack(gold[f"{prefix}/near{TAU:g}/{l}"], shape)
+
+    def seq(prefix, outs, t_up):
+        check_continuous(outs[0], gold[f"{prefix}/x"], t_up, f"{tag}{prefix}/x")
+        t_valid = t_up
+        for l in range(len(outs) - 2):
+            ref, near = layer_gold(prefix, l)
+            mem_ref = gold[f"{prefix}/membrane/{l}"] if f"{prefix}/membrane/{l}" in gold else None
+            mem = out.get("mem", {}).get((prefix, l)) if mem_ref is not None else None
+            t_valid, st = check_chain(outs[l + 1], ref, near, t_valid, f"{tag}{prefix}/L{l}", mem, mem_ref)
+            stats.append(st)
+        check_continuous(outs[-1], gold[f"{prefix}/proj"], t_valid, f"{tag}{prefix}/proj")
+        return t_valid
+
+    t_fb = seq("fb", fb_all, np.full(B, T))
+    # upstream horizon for the sub-band rows of clip b: live front-end is causal in fb_out (same frame);
+    # the frozen front-end's utterance-level Laplace mean is not -- any full-band divergence voids the clip.
+    up_b = t_fb if spec["front"] == "live" else np.where(t_fb < T, 0, T)
+    cut, S = spec["cutoffs"], spec["num_spks"]
+    enh = np.asarray(out["enh_stft"])
+    enh_ref = np.asarray(gold["enh_stft"]).reshape(enh.shape)
+    lo = 0
+    for g, outs in enumerate(out["sb_all"]):
+        N = (cut[g + 1] - cut[g]) // spec["ctr"][g]
+        t_up = np.repeat(up_b, N)
+        t_valid = seq(f"sb{g}", outs, t_up)
+        fc = spec["ctr"][g]
+        tv = t_valid.reshape(B, N)
+        for b in range(B):
+            for k in range(N):
+                sl = (b, slice(None), slice(lo + k * fc, lo + (k + 1) * fc), slice(0, tv[b, k]))
+                e, r = enh[sl], enh_ref[sl]
+                if e.size:
+                    err = np.abs(e - r)
+                    assert (err <= ATOL + REL * np.abs(r)).all(), f"{tag}enh_stft group {g} clip {b} unit {k}: {err.max():.3g}"
+        lo += N * fc
+    # untouched bins (>= lo, at least Nyquist) are bit-exact pass-through
+    assert np.array_equal(enh[:, :, lo:, :], enh_ref[:, :, lo:, :]), f"{tag}pass-through bins differ"
+    return stats
+
+
+def gold_from_oracle(res: dict, tau_list=(TAU,)) -> dict:
+    """Shape an ``oracle.model.forward_from_stft(..., want_membrane=True)`` result like a golden fixture."""
+    g = {"enh_stft": res["enh_stft"]}
+
+    def put(prefix, outs, mems):
+        g[f"{prefix}/x"] = outs[0]
+        g[f"{prefix}/proj"] = outs[-1]
+        for l, spk in enumerate(outs[1:-1]):
+            g[f"{prefix}/spikes_packed/{l}"] = np.packbits((spk > 0.5).astype(np.uint8).reshape(-1))
+            g[f"{prefix}/spikes_shape/{l}"] = np.array(spk.shape, dtype=np.int64)
+            g[f"{prefix}/membrane/{l}"] = mems[l]
+            for tau in tau_list:
+                g[f"{prefix}/near{tau:g}/{l}"] = np.packbits((np.abs(mems[l]) < tau).reshape(-1))
+
+    put("fb", res["fb_all"], res["fb_mem"])
+    for i, outs in enumerate(res["sb_all"]):
+        put(f"sb{i}", outs, res["sb_mem"][i])
+    return g
