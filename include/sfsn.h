@@ -1,0 +1,181 @@
+/*
+ * sfsn.h -- C ABI of libsfsn_hip.so: the MI355X (gfx950) implementation of Spiking-FullSubNet's
+ * recurrent inference hot path (full-band + stacked sub-band Gated-Spiking-Neuron scans with the
+ * feature prologue and deep-filter epilogue around them).
+ *
+ * The reference (haoxiangsnr/spiking-fullsubnet) is pure Python and has no FFI of its own; the seam this
+ * ABI fills is the one SURVEY.md 8b defines: everything an `nn.Module.forward` of the reference does
+ * between `stft()` and `istft()`.  Each entry point names the reference lines it replaces (paths relative
+ * to the reference root):
+ *     NEURON = audiozen/models/spiking_fullsubnet/efficient_spiking_neuron.py
+ *     MODEL  = audiozen/models/spiking_fullsubnet/modeling_spiking_fullsubnet.py
+ *     FROZEN = recipes/intel_ndns/spiking_fullsubnet_freeze_phase/model_low_freq.py
+ *
+ * Conventions
+ *   - plain pointers, ints and floats only; no torch / HIP types in signatures (`stream` is a hipStream_t
+ *     passed as void*, NULL = the null stream);
+ *   - every pointer named in a launch is DEVICE memory owned by the caller; the library never allocates,
+ *     frees or retains caller memory and keeps no global state: all entry points are re-entrant;
+ *   - launches are asynchronous on `stream`; the return value reports argument / launch errors only;
+ *   - layouts are the reference's: time-major [T][R][feat] inside a sequence model, [B][F][T] for
+ *     spectra, interleaved (re, im) floats for complex64;
+ *   - return codes: SFSN_OK or a negative SFSN_E* value; sfsn_strerror() names them.
+ *
+ * There is no CPU implementation behind this ABI and no fallback: without a gfx950 device every launch
+ * returns SFSN_EHIP.
+ */
+#ifndef SFSN_H
+#define SFSN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFSN_ABI_VERSION 1
+
+#define SFSN_OK 0
+#define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
+#define SFSN_EUNSUPPORTED (-2) /* valid request the kernels do not cover (e.g. hidden size > 320)               */
+#define SFSN_EHIP (-3)         /* HIP runtime error at launch (no device, invalid pointer, ...)                 */
+#define SFSN_EDIVISIBLE (-4)   /* band width not divisible by the centre size: the reference's ValueError       */
+
+#define SFSN_MAX_SEGMENTS 8    /* independent row segments (sub-band groups) per grouped launch                 */
+#define SFSN_MAX_HIDDEN 320    /* largest hidden size held register-resident (baseline_m/l/xl full-band)        */
+#define SFSN_MAX_GROUPS 8      /* sub-band groups per model                                                     */
+
+int sfsn_abi_version(void);
+const char* sfsn_strerror(int code);
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int sfsn_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Weight packing (HOST function, pure integer/bit work, no device needed).
+ *
+ * The recurrent product h.W_hh^T (NEURON:143), the layer>=2 input product S.W_ih^T (NEURON:141 with a
+ * spike input) and the projection S.W_p^T (MODEL:118, FROZEN:125) all have a BINARY left operand
+ * (spikes are exactly 0.0/1.0, NEURON:89).  They run on the int8 matrix cores: each fp32 weight row n is
+ * split into three signed base-256 digits of a 24-bit fixed-point value with a per-row power-of-two scale,
+ *     W[n][k] ~= (d2*65536 + d1*256 + d0) * dq[n],   dq[n] = 2^e[n] * 2^-23,  |W - W~| <= dq[n]/2,
+ * (i.e. at most one fp32 ulp of the row's largest binade), the three int32 accumulators are exact, and
+ * their recombination rounds once -- more accurate than, and independent of the summation order of, any
+ * fp32 GEMM.  The digits are stored in MFMA A-fragment order for v_mfma_i32_16x16x64_i8:
+ *     packed[d][nt][ks][lane][16]  with n = nt*16 + (lane & 15),  k = ks*64 + (lane >> 4)*16 + byte,
+ * zero padded to NT = ceil(n_out/16) row tiles and KS = ceil(k_in/64) k-steps.
+ * ---------------------------------------------------------------------------------------------------- */
+size_t sfsn_w3_packed_bytes(int n_out, int k_in);               /* 3 * NT * KS * 1024 */
+int sfsn_w3_padded_rows(int n_out);                            /* NT * 16 (length of dq) */
+int sfsn_w3_pack(const float* w /* [n_out][k_in] host */, int n_out, int k_in, int8_t* packed /* host */,
+                 float* dq /* [NT*16] host */);
+/* Inverse (tests): reconstruct W~ [n_out][k_in] from the packed digits. */
+int sfsn_w3_unpack(const int8_t* packed, const float* dq, int n_out, int k_in, float* w);
+
+/* ------------------------------------------------------------------------------------------------------
+ * GSN layer scan -- replaces GSULayer.forward (NEURON:75-81: the python loop over T), GSUCell.forward
+ * (NEURON:132-153) and Triangle.forward (NEURON:84-92), for several independent row segments at once
+ * (the sub-band groups share H, MODEL:239-261).
+ *
+ * Per segment and per frame t:
+ *     pre_f = (zin[t][r][j]      + bias[j])     + (h . W_hh^T)[j]          NEURON:140-145
+ *     pre_g = (zin[t][r][gofs+j] + bias[H + j]) + (h . W_hh^T)[gofs + j]   (gofs = 0 shared, H otherwise)
+ *     f = sigmoid(pre_f);  c' = f*c + (1-f)*pre_g;  c'' = fma(c', bn_alpha[j], bn_beta[j])
+ *     h' = (c'' >= 0);  carry (h', c'')                                    NEURON:146-153
+ * zin = x . W_ih^T is precomputed by sfsn_input_proj_f32 / sfsn_spike_proj (time-parallel);  bn_alpha /
+ * bn_beta are eval-mode BatchNorm1d folded the way ATen's CPU kernel evaluates it (alpha = gamma /
+ * sqrt(var + eps), beta = fma(-mean, alpha, bias); identity = (1, 0) when bn=False).
+ * The hidden state h lives in LDS as int8, the membrane c in registers, W_hh in registers as packed int8
+ * digits for the whole scan; one workgroup owns 16 rows.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct sfsn_scan_segment {
+    const float* zin;      /* [T][R][G*H], G = 1 shared / 2 unshared                                         */
+    const int8_t* w_hh;    /* sfsn_w3_pack(W_hh [G*H][H])                                                     */
+    const float* w_dq;     /* [pad16(G*H)] from sfsn_w3_pack                                                  */
+    const float* bias;     /* [2H]  bias_ih                                                                   */
+    const float* bn_alpha; /* [H]                                                                             */
+    const float* bn_beta;  /* [H]                                                                             */
+    float* h_state;        /* [R][H] in: h at t=-1 (0/1), out: h at t=T-1   (NEURON:50-62 state in/out)       */
+    float* c_state;        /* [R][H] in/out membrane                                                          */
+    float* spikes_f32;     /* [T][R][H] out, nullable  (the reference's all_layer_outputs entry)              */
+    int8_t* spikes_i8;     /* [T][R][pad64(H)] out, nullable (B operand of the next sfsn_spike_proj)          */
+    float* membrane;       /* [T][R][H] out, nullable  (post-BN membrane; parity tests only)                  */
+    int R;                 /* rows in this segment (> 0)                                                      */
+} sfsn_scan_segment;
+
+int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs /* host array */, int n_segs, int T, int H, int shared,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Time-parallel products.
+ * sfsn_input_proj_f32: z[m][n] = sum_k x[m][k] * w[n][k]           (NEURON:141 for layer 0: real-valued x)
+ *     exact-fp32 MFMA (v_mfma_f32_16x16x4_f32); x [M][K], w [N][K] row-major fp32, z [M][ldz] (columns 0..N-1 written;
+ *     ldz > N lets the two gate halves of an unshared cell land side by side).
+ * sfsn_spike_proj:     y[m][n] = dq[n] * sum_k s[m][k] * Wq[n][k] (+ bias[n])
+ *     s int8 0/1 [M][pad64(K)] as written by the scan; Wq/dq from sfsn_w3_pack(W [N][K]); y [M][N] fp32.
+ *     Used for layer>=1 input products (bias NULL: NEURON:141) and the projection (nn.Linear MODEL:49-52,118;
+ *     FROZEN:71-76,125: bias added after the product).
+ * ---------------------------------------------------------------------------------------------------- */
+int sfsn_input_proj_f32(const float* x, const float* w, float* z, int M, int K, int N, int ldz /* >= N: row stride of z */,
+                        void* stream);
+int sfsn_spike_proj(const int8_t* s, const int8_t* w_packed, const float* w_dq, const float* bias /* nullable */,
+                    float* y, int M, int K, int N, int ldy /* >= N: row stride of y */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Feature prologue -- replaces MODEL:434-440 (|X|^fdrc, drop Nyquist, band select), SubbandModel.forward's
+ * two _freq_unfold calls + cat (MODEL:239-258, 265-312; FROZEN:350-431,451-474), the "b f t -> t b f"
+ * transposes (MODEL:108,155) and the input normalisation: nn.LayerNorm (MODEL:27-28,111-112) or the frozen
+ * model's offline_laplace_norm (FROZEN:147-169, 475, 578).
+ *
+ * A feature group g produces x_g [T][B*N][I], row r = b*N + k, I = (ctr + 2 nbr) + (ctr_fb + 2 nbr_fb):
+ *     j <  ctr+2nbr : mag[b][reflect(lo + k*ctr - nbr + j)][t]            (reflect: f<0 -> -f, f>nf-1 -> 2(nf-1)-f)
+ *     j >= ctr+2nbr : fb[t][b][reflect(lo + k*ctr_fb - nbr_fb + j') % FB]  (the tiled full-band output, MODEL:442-443)
+ * with mag = |stft|^fdrc on bins 0..nf-1 (nf = F-1).  The full-band model's own input is the group
+ * {lo=0, n_units=1, ctr=FB, nbr=0, ctr_fb=0}.
+ * ---------------------------------------------------------------------------------------------------- */
+#define SFSN_NORM_NONE 0
+#define SFSN_NORM_LAYERNORM 1 /* (x - mean) * rstd * ln_w + ln_b over the I features, eps inside the sqrt       */
+#define SFSN_NORM_LAPLACE 2   /* x / (mu[b] + 2.220446049250313e-16), mu from sfsn_laplace_means                 */
+
+typedef struct sfsn_feature_group {
+    float* x;           /* out [T][B*n_units][I]                                                             */
+    const float* ln_w;  /* [I] (LAYERNORM)                                                                    */
+    const float* ln_b;  /* [I] (LAYERNORM)                                                                    */
+    const float* mu;    /* [B] (LAPLACE)                                                                      */
+    int lo, n_units, ctr, nbr, ctr_fb, nbr_fb;
+    int norm;           /* SFSN_NORM_*                                                                        */
+    float ln_eps;
+} sfsn_feature_group;
+
+int sfsn_features(const float* stft_ri /* [B][F][T][2] */, const float* fb_tbf /* [T][B][FB], NULL if unused */,
+                  int B, int F, int T, int FB, float fdrc, const sfsn_feature_group* groups /* host */, int n_groups,
+                  void* stream);
+
+/* Per-clip means for offline_laplace_norm (FROZEN:162-164: mean over all non-batch dims of the gathered,
+ * un-normalised group tensor).  mu_out [n_groups][B].  Two launches: row sums of mag / fb, then the
+ * weighted combination; `scratch` needs B*(F-1+FB) floats. */
+int sfsn_laplace_means(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc,
+                       const sfsn_feature_group* groups /* host; only geometry fields are read */, int n_groups,
+                       float* mu_out, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Deep-filter epilogue -- replaces the output re-index of SubBandSequenceModel.forward (MODEL:160-167,
+ * FROZEN:259-265), deepfiltering (MODEL:315-346, FROZEN:15-39) and the reconstruction MODEL:450-472 /
+ * FROZEN:588-607 (cat groups, Nyquist bin passes through, |.|).
+ *     Y[b][s][f][t] = sum_{d<df} X[b][f][t-(df-1)+d] * C[d]   (zero for t-(df-1)+d < 0)
+ *     C[d] = proj[t][b*N+k][((0*fc+fci)*df+d)*S+s] + i proj[t][b*N+k][((1*fc+fci)*df+d)*S+s],  f = lo + k*fc + fci
+ * Groups are laid end to end from bin 0; bins not covered (>= sum N*fc, at least Nyquist) are copied.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct sfsn_df_group {
+    const float* proj; /* [T][B*n_units][2*fc*df*S] */
+    int n_units, fc, df;
+} sfsn_df_group;
+
+int sfsn_deepfilter(const float* stft_ri /* [B][F][T][2] */, int B, int F, int T, int S,
+                    const sfsn_df_group* groups /* host */, int n_groups, float* enh_ri /* [B][S][F][T][2] */,
+                    float* enh_mag /* [B][S][F][T], nullable */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFSN_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of ``libsfsn_hip.so`` (the C ABI declared in ``include/sfsn.h``).
+
+There is no fallback: if the library has not been built the import of any compute entry point raises,
+and every launch on a box without a gfx950 device raises ``RuntimeError`` (``SFSN_EHIP``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
+
+SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
+NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE = 0, 1, 2
+MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+
+class ScanSegment(ctypes.Structure):
+    _fields_ = [("zin", _P), ("w_hh", _P), ("w_dq", _P), ("bias", _P), ("bn_alpha", _P), ("bn_beta", _P),
+                ("h_state", _P), ("c_state", _P), ("spikes_f32", _P), ("spikes_i8", _P), ("membrane", _P), ("R", _I)]
+
+
+class FeatureGroup(ctypes.Structure):
+    _fields_ = [("x", _P), ("ln_w", _P), ("ln_b", _P), ("mu", _P), ("lo", _I), ("n_units", _I), ("ctr", _I), ("nbr", _I),
+                ("ctr_fb", _I), ("nbr_fb", _I), ("norm", _I), ("ln_eps", _F)]
+
+
+class DfGroup(ctypes.Structure):
+    _fields_ = [("proj", _P), ("n_units", _I), ("fc", _I), ("df", _I)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (``make -C csrc``); hipcc cross-compiles without a GPU."""
+    srcs = [os.path.join(CSRC, f) for f in ("sfsn_kernels.hip", "sfsn_pack.cpp")] + [
+        os.path.join(_HERE, "..", "include", "sfsn.h")]
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", CSRC, "-s"] + (["-B"] if force else []), check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library; raises ImportError with the build recipe when it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is not built. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C spiking_fullsubnet_amd/csrc`). There is no CPU or eager fallback for this path.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.sfsn_abi_version.restype = _I
+    L.sfsn_strerror.restype = ctypes.c_char_p
+    L.sfsn_strerror.argtypes = [_I]
+    L.sfsn_device_count.restype = _I
+    L.sfsn_w3_packed_bytes.restype = ctypes.c_size_t
+    L.sfsn_w3_packed_bytes.argtypes = [_I, _I]
+    L.sfsn_w3_padded_rows.restype = _I
+    L.sfsn_w3_padded_rows.argtypes = [_I]
+    L.sfsn_w3_pack.restype = _I
+    L.sfsn_w3_pack.argtypes = [_P, _I, _I, _P, _P]
+    L.sfsn_w3_unpack.restype = _I
+    L.sfsn_w3_unpack.argtypes = [_P, _P, _I, _I, _P]
+    L.sfsn_gsn_layer_scan.restype = _I
+    L.sfsn_gsn_layer_scan.argtypes = [ctypes.POINTER(ScanSegment), _I, _I, _I, _I, _P]
+    L.sfsn_input_proj_f32.restype = _I
+    L.sfsn_input_proj_f32.argtypes = [_P, _P, _P, _I, _I, _I, _I, _P]
+    L.sfsn_spike_proj.restype = _I
+    L.sfsn_spike_proj.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]
+    L.sfsn_features.restype = _I
+    L.sfsn_features.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _P]
+    L.sfsn_laplace_means.restype = _I
+    L.sfsn_laplace_means.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _P, _P, _P]
+    L.sfsn_deepfilter.restype = _I
+    L.sfsn_deepfilter.argtypes = [_P, _I, _I, _I, _I, ctypes.POINTER(DfGroup), _I, _P, _P, _P]
+    if L.sfsn_abi_version() != 1:
+        raise ImportError(f"{LIB_PATH}: ABI version {L.sfsn_abi_version()} != 1; rebuild")
+    _lib = L
+    return L
+
+
+EXPORTS = ("sfsn_abi_version", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
+           "sfsn_w3_pack", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
+           "sfsn_laplace_means", "sfsn_deepfilter")
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map a C-ABI status to the exception the reference's own code would raise for the same condition."""
+    if rc == SFSN_OK:
+        return
+    msg = f"{what}: {lib().sfsn_strerror(rc).decode()}" if what else lib().sfsn_strerror(rc).decode()
+    if rc == SFSN_EDIVISIBLE:
+        raise ValueError(msg)  # modeling_spiking_fullsubnet.py:283-287
+    if rc == SFSN_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == SFSN_EINVAL:
+        raise ValueError(msg)
+    raise RuntimeError(msg)

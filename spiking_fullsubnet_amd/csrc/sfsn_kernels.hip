@@ -1,0 +1,806 @@
+// sfsn_kernels.hip -- gfx950 (MI355X / CDNA4) kernels behind include/sfsn.h.
+//
+// Written for gfx950 only: 64-lane wavefronts, v_mfma_i32_16x16x64_i8 / v_mfma_f32_16x16x4_f32,
+// 160 KiB LDS, 512-entry unified VGPR/AGPR file.  No other target is supported or guarded for.
+//
+// Design notes (DESIGN.md has the full discussion):
+//  * Spikes are exactly {0,1} (efficient_spiking_neuron.py:89), so every product whose left operand is a
+//    spike tensor runs on the int8 matrix cores with the fp32 weights split into three base-256 digits
+//    (sfsn_w3_pack): integer accumulation is exact and order independent, the recombination rounds once.
+//  * MFMA orientation: A = weights (16 output neurons x 64 k), B = spikes^T (64 k x 16 rows).  The
+//    accumulator then holds, per lane, 4 CONSECUTIVE output neurons of ONE row (row = lane & 15,
+//    neuron = 16*tile + 4*(lane >> 4) + r), so every global access of the epilogue is a 16-byte vector
+//    and the new spikes go to LDS as one packed dword.
+//  * The scan keeps W_hh register resident for all T steps (one workgroup = 16 rows, W tiles dealt
+//    round-robin to the waves so the four SIMDs carry equal MFMA load), the hidden state in LDS as int8
+//    (double buffered: one barrier per step), the membrane in registers in accumulator layout.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sfsn.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define SFSN_WAVE 64
+
+// =====================================================================================================
+// GSN layer scan
+// =====================================================================================================
+struct ScanSegDev {
+    const float* zin;
+    const int8_t* w_hh;
+    const float* w_dq;
+    const float* bias;
+    const float* bn_alpha;
+    const float* bn_beta;
+    float* h_state;
+    float* c_state;
+    float* spikes_f32;
+    int8_t* spikes_i8;
+    float* membrane;
+    int R;
+    int tile0;  // first workgroup (row tile) of this segment
+};
+
+struct ScanParams {
+    ScanSegDev seg[SFSN_MAX_SEGMENTS];
+    int nseg, T, H, NT;  // NT = H / 16 output tiles per gate
+};
+
+__device__ __forceinline__ float recombine3(int a0, int a1, int a2) {
+    // exact value (a2*65536 + a1*256 + a0) rounded ONCE to fp32: |a1*256 + a0| < 2^24 is exact as a float,
+    // |a2| < 2^16 is exact, the fma rounds the sum once.
+    return __builtin_fmaf((float)a2, 65536.0f, (float)(a1 * 256 + a0));
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    // 1 / (1 + e^-x) with the hardware exp2 / rcp (each ~1 ulp): |error| <~ 2e-7 absolute.
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+
+// G = 1: shared gate weights (W [H][*] used for both gates); G = 2: separate forget / cell weights.
+// TPW = output tiles per wave, KS = 64-wide k steps, NW = waves per workgroup (8 -> 256 VGPRs per wave,
+// 4 -> 512: the H = 320 full-band model needs 300 registers of weights per wave).
+template <int G, int TPW, int KS, int NW>
+__global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
+    constexpr int LDH = KS * 64 + 16;  // +16 B row pad: the 16 rows of a B fragment land on distinct LDS banks
+    constexpr int HP = KS * 64;        // padded hidden size
+    constexpr int NC = 4 + G;          // per-neuron constant vectors: bias_f, bias_g, alpha, beta, dq[G]
+    __shared__ __attribute__((aligned(16))) int8_t hbuf[2][16 * LDH];
+    __shared__ __attribute__((aligned(16))) float cst[NC][HP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15;  // row within the tile (B / D column)
+    const int q = lane >> 4;  // k group for A/B fragments; 4-neuron group for D
+
+    int s = 0;
+    for (int i = 1; i < p.nseg; ++i)
+        if ((int)blockIdx.x >= p.seg[i].tile0) s = i;
+    const ScanSegDev sg = p.seg[s];
+    const int H = p.H, NT = p.NT, T = p.T, R = sg.R;
+    const int row0 = ((int)blockIdx.x - sg.tile0) * 16;
+    const int row = row0 + n;
+    const bool valid = row < R;
+    const int rowc = valid ? row : R - 1;
+    const int ldz = G * H;
+
+    // ---- per-neuron constants -> LDS; zero the hidden-state buffers (pads must read as 0 spikes) --------
+    for (int j = tid; j < HP; j += NW * 64) {
+        const bool in = j < H;
+        cst[0][j] = in ? sg.bias[j] : 0.0f;
+        cst[1][j] = in ? sg.bias[H + j] : 0.0f;
+        cst[2][j] = in ? sg.bn_alpha[j] : 0.0f;
+        cst[3][j] = in ? sg.bn_beta[j] : 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) cst[4 + g][j] = in ? sg.w_dq[g * H + j] : 0.0f;
+    }
+    for (int i = tid; i < 2 * 16 * LDH / 4; i += NW * 64) reinterpret_cast<int*>(&hbuf[0][0])[i] = 0;
+
+    // ---- register-resident recurrent weights, membrane state -----------------------------------------
+    v4i W[TPW][G][KS][3];
+    v4f c[TPW];
+    bool have_t[TPW];  // wave-uniform: does tile i of this wave exist
+    int col[TPW];      // first neuron of my 4-neuron group in tile i
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int ct = wave + NW * i;
+        const bool have = ct < NT;
+        have_t[i] = have;
+        col[i] = have ? ct * 16 + q * 4 : 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const size_t tile = (size_t)d * (G * NT) + (size_t)g * NT + (have ? ct : 0);
+                    W[i][g][ks][d] = *reinterpret_cast<const v4i*>(sg.w_hh + ((tile * KS + ks) * 64 + lane) * 16);
+                }
+        c[i] = *reinterpret_cast<const v4f*>(sg.c_state + (size_t)rowc * H + col[i]);
+    }
+    __syncthreads();
+    // initial hidden state h_{-1} -> hbuf[0] as int8
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+        if (have_t[i]) {
+            const v4f h = *reinterpret_cast<const v4f*>(sg.h_state + (size_t)rowc * H + col[i]);
+            const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
+                                (h.w > 0.5f ? 0x1000000u : 0u);
+            *reinterpret_cast<unsigned*>(&hbuf[0][n * LDH + col[i]]) = pk;
+        }
+    __syncthreads();
+
+    // ---- input term for t = 0 ---------------------------------------------------------------------------
+    v4f zf[TPW], zg[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        zf[i] = v4f{0, 0, 0, 0};
+        zg[i] = v4f{0, 0, 0, 0};
+        if (have_t[i] && T > 0) {
+            const float* zp = sg.zin + (size_t)rowc * ldz + col[i];
+            zf[i] = *reinterpret_cast<const v4f*>(zp);
+            if (G == 2) zg[i] = *reinterpret_cast<const v4f*>(zp + H);
+        }
+    }
+
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const int8_t* hc = hbuf[t & 1];
+        int8_t* hn = hbuf[(t & 1) ^ 1];
+        // next step's input term: in flight during this step's MFMA phase
+        v4f zfn[TPW], zgn[TPW];
+        const int tn = (t + 1 < T) ? t + 1 : t;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            zfn[i] = zf[i];
+            zgn[i] = zg[i];
+            if (have_t[i]) {
+                const float* zp = sg.zin + ((size_t)tn * R + rowc) * ldz + col[i];
+                zfn[i] = *reinterpret_cast<const v4f*>(zp);
+                if (G == 2) zgn[i] = *reinterpret_cast<const v4f*>(zp + H);
+            }
+        }
+        // B fragments: h_{t-1} of my row, 16 consecutive k per lane per k-step
+        v4i b[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(hc + n * LDH + ks * 64 + q * 16);
+
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            if (!have_t[i]) continue;  // wave-uniform (scalar branch)
+            const int cc = col[i];
+            float rec[G][4];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][0], b[ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][1], b[ks], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][2], b[ks], a2, 0, 0, 0);
+                }
+                const v4f dq = *reinterpret_cast<const v4f*>(&cst[4 + g][cc]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rec[g][r] = recombine3(a0[r], a1[r], a2[r]) * dq[r];
+            }
+            const v4f bias_f = *reinterpret_cast<const v4f*>(&cst[0][cc]);
+            const v4f bias_g = *reinterpret_cast<const v4f*>(&cst[1][cc]);
+            const v4f alpha = *reinterpret_cast<const v4f*>(&cst[2][cc]);
+            const v4f beta = *reinterpret_cast<const v4f*>(&cst[3][cc]);
+            v4f cy, sp;
+            unsigned pk = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float zin_f = zf[i][r];
+                const float zin_g = (G == 2) ? zg[i][r] : zin_f;
+                const float pre_f = (zin_f + bias_f[r]) + rec[0][r];      // NEURON:140-145 association
+                const float pre_g = (zin_g + bias_g[r]) + rec[G - 1][r];
+                const float f = fast_sigmoid(pre_f);
+                const float m = f * c[i][r] + (1.0f - f) * pre_g;         // four roundings (contraction off)
+                const float y = __builtin_fmaf(m, alpha[r], beta[r]);     // eval BatchNorm, ATen form
+                cy[r] = y;
+                const bool fire = y >= 0.0f;                               // Triangle.forward, NEURON:89
+                sp[r] = fire ? 1.0f : 0.0f;
+                pk |= fire ? (1u << (8 * r)) : 0u;
+            }
+            c[i] = cy;
+            *reinterpret_cast<unsigned*>(hn + n * LDH + cc) = pk;
+            if (valid) {
+                const size_t o = ((size_t)t * R + row);
+                if (sg.spikes_f32) *reinterpret_cast<v4f*>(sg.spikes_f32 + o * H + cc) = sp;
+                if (sg.spikes_i8) *reinterpret_cast<unsigned*>(sg.spikes_i8 + o * HP + cc) = pk;
+                if (sg.membrane) *reinterpret_cast<v4f*>(sg.membrane + o * H + cc) = cy;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            zf[i] = zfn[i];
+            zg[i] = zgn[i];
+        }
+        __syncthreads();  // h_t complete in hn before anyone reads it; hc free for step t+1's writes
+    }
+
+    if (valid) {
+        const int8_t* hl = hbuf[T & 1];  // h_{T-1} (or the untouched initial state when T == 0)
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (have_t[i]) {
+                *reinterpret_cast<v4f*>(sg.c_state + (size_t)row * H + col[i]) = c[i];
+                const unsigned pk = *reinterpret_cast<const unsigned*>(hl + n * LDH + col[i]);
+                const v4f h = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)((pk >> 24) & 1u)};
+                *reinterpret_cast<v4f*>(sg.h_state + (size_t)row * H + col[i]) = h;
+            }
+    }
+}
+
+// =====================================================================================================
+// spike projection: y[m][n] = dq[n] * sum_k s[m][k] * Wq[n][k] (+ bias[n]);  s int8 0/1
+// Waves are dealt (column-tile group cg, row-tile lane mw); each wave keeps its W tiles in registers and
+// streams 16-row B fragments straight from global memory (16 B per lane, L1/L2 served for the sibling waves).
+// =====================================================================================================
+template <int TPW, int KS>
+__global__ __launch_bounds__(512) void spike_proj_kernel(const int8_t* __restrict__ s, const int8_t* __restrict__ w,
+                                                          const float* __restrict__ dq, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int M, int N, int ldy, int NT, int NWN) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int MW = 8 / NWN;
+    const int cg = wave % NWN, mw = wave / NWN;
+    if (mw >= MW) return;
+    constexpr int KP = KS * 64;
+
+    v4i W[TPW][KS][3];
+    v4f dqv[TPW], bv[TPW];
+    int col[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int ct = cg + NWN * i;
+        const bool have = ct < NT;
+        col[i] = have ? ct * 16 + q * 4 : -1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const size_t tile = (size_t)d * NT + (have ? ct : 0);
+                W[i][ks][d] = *reinterpret_cast<const v4i*>(w + ((tile * KS + ks) * 64 + lane) * 16);
+            }
+        dqv[i] = *reinterpret_cast<const v4f*>(dq + (have ? col[i] : 0));  // dq is padded to NT*16
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[i][r] = (bias && have && col[i] + r < N) ? bias[col[i] + r] : 0.0f;
+    }
+
+    const int MT = (M + 15) >> 4;
+    const bool vec = (ldy & 3) == 0;
+    for (int mt = (int)blockIdx.x * MW + mw; mt < MT; mt += (int)gridDim.x * MW) {
+        const int row = mt * 16 + n;
+        const int rowc = row < M ? row : M - 1;
+        v4i b[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(s + (size_t)rowc * KP + ks * 64 + q * 16);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            if (col[i] < 0) continue;
+            v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][ks][0], b[ks], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][ks][1], b[ks], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][ks][2], b[ks], a2, 0, 0, 0);
+            }
+            v4f o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = recombine3(a0[r], a1[r], a2[r]) * dqv[i][r] + bv[i][r];
+            if (row < M) {
+                float* yp = y + (size_t)row * ldy + col[i];
+                if (vec && col[i] + 3 < N) {
+                    *reinterpret_cast<v4f*>(yp) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col[i] + r < N) yp[r] = o[r];
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// input projection (real-valued x): z[m][n] = sum_k x[m][k] w[n][k], exact fp32 on v_mfma_f32_16x16x4_f32.
+// k is consumed in chunks of 16: lane (n|m, q) holds k = 16c + 4q + e for MFMA e of chunk c -- the same
+// map for A and B, so the pairing is correct and the B operand is four consecutive floats per lane.
+// =====================================================================================================
+template <int TPW, int KC>
+__global__ __launch_bounds__(512) void input_proj_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ z, int M, int K, int N, int ldz, int NT, int NWN) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int MW = 8 / NWN;
+    const int cg = wave % NWN, mw = wave / NWN;
+    if (mw >= MW) return;
+
+    float W[TPW][KC][4];
+    int col[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int ct = cg + NWN * i;
+        const bool have = ct < NT;
+        col[i] = have ? ct * 16 + q * 4 : -1;
+        const int wr = ct * 16 + n;  // weight row this lane supplies as A
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = c * 16 + q * 4 + e;
+                W[i][c][e] = (have && wr < N && k < K) ? w[(size_t)wr * K + k] : 0.0f;
+            }
+    }
+
+    const int MT = (M + 15) >> 4;
+    for (int mt = (int)blockIdx.x * MW + mw; mt < MT; mt += (int)gridDim.x * MW) {
+        const int row = mt * 16 + n;
+        const int rowc = row < M ? row : M - 1;
+        const float* xp = x + (size_t)rowc * K;
+        float b[KC][4];
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = c * 16 + q * 4 + e;
+                b[c][e] = k < K ? xp[k] : 0.0f;
+            }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            if (col[i] < 0) continue;
+            v4f acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[i][c][e], b[c][e], acc, 0, 0, 0);
+            if (row < M) {
+                float* zp = z + (size_t)row * ldz + col[i];
+                if ((ldz & 3) == 0 && col[i] + 3 < N) {
+                    *reinterpret_cast<v4f*>(zp) = acc;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col[i] + r < N) zp[r] = acc[r];
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// feature prologue
+// =====================================================================================================
+struct FeatGroupDev {
+    float* x;
+    const float* ln_w;
+    const float* ln_b;
+    const float* mu;
+    int lo, N, ctr, nbr, ctr_fb, nbr_fb, I1, I, norm;
+    float eps;
+};
+struct FeatParams {
+    FeatGroupDev g[SFSN_MAX_GROUPS];
+    int ng, B, F, T, FB;
+    float fdrc;
+};
+
+#define FEAT_TT 32  // frames per workgroup
+
+__device__ __forceinline__ int reflect_bin(int f, int nf) { return f < 0 ? -f : (f > nf - 1 ? 2 * (nf - 1) - f : f); }
+
+__device__ __forceinline__ float compress_mag(float re, float im, float fdrc) {
+    const float m = hypotf(re, im);                  // torch.abs(complex)
+    return fdrc == 0.5f ? sqrtf(m) : powf(m, fdrc);  // ATen evaluates pow(x, 0.5) as sqrt
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// grid (ceil(T/32), B), 256 threads.  LDS: mag tile [nf][33] + full-band tile [32][FB].
+__global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ stft, const float* __restrict__ fb,
+                                                        const FeatParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nf = p.F - 1, T = p.T, B = p.B, FB = p.FB;
+    float* magT = smem;                        // [nf][33]
+    float* fbT = smem + (size_t)nf * 33;       // [32][FB]
+    const int b = blockIdx.y, t0 = blockIdx.x * FEAT_TT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int idx = tid; idx < nf * FEAT_TT; idx += 256) {
+        const int f = idx >> 5, tt = idx & 31, t = t0 + tt;
+        float v = 0.0f;
+        if (t < T) {
+            const float2 c = *reinterpret_cast<const float2*>(stft + (((size_t)b * p.F + f) * T + t) * 2);
+            v = compress_mag(c.x, c.y, p.fdrc);
+        }
+        magT[f * 33 + tt] = v;
+    }
+    if (fb) {
+        for (int idx = tid; idx < FEAT_TT * FB; idx += 256) {
+            const int tt = idx / FB, f = idx - tt * FB, t = t0 + tt;
+            fbT[idx] = t < T ? fb[((size_t)t * B + b) * FB + f] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    for (int gi = 0; gi < p.ng; ++gi) {
+        const FeatGroupDev g = p.g[gi];
+        const int rows = FEAT_TT * g.N;
+        for (int idx = wave; idx < rows; idx += 4) {
+            const int tt = idx / g.N, k = idx - tt * g.N, t = t0 + tt;
+            if (t >= T) continue;  // wave-uniform
+            float v[4];
+            float sum = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = lane + 64 * u;
+                v[u] = 0.0f;
+                if (j < g.I1) {
+                    v[u] = magT[reflect_bin(g.lo + k * g.ctr - g.nbr + j, nf) * 33 + tt];
+                } else if (j < g.I) {
+                    const int f = reflect_bin(g.lo + k * g.ctr_fb - g.nbr_fb + (j - g.I1), nf);
+                    v[u] = fbT[tt * FB + (f % FB)];
+                }
+                sum += v[u];
+            }
+            float* out = g.x + ((size_t)t * B * g.N + (size_t)b * g.N + k) * g.I;
+            if (g.norm == SFSN_NORM_LAYERNORM) {
+                const float mean = wave_sum(sum) / (float)g.I;
+                float ss = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d = v[u] - mean;
+                    if (lane + 64 * u < g.I) ss += d * d;
+                }
+                const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)g.I + g.eps);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = lane + 64 * u;
+                    if (j < g.I) out[j] = ((v[u] - mean) * rstd) * g.ln_w[j] + g.ln_b[j];
+                }
+            } else if (g.norm == SFSN_NORM_LAPLACE) {
+                const float den = g.mu[b] + 2.220446049250313e-16f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = lane + 64 * u;
+                    if (j < g.I) out[j] = v[u] / den;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = lane + 64 * u;
+                    if (j < g.I) out[j] = v[u];
+                }
+            }
+        }
+    }
+}
+
+// ---- Laplace means -----------------------------------------------------------------------------------
+// rs[b][f] = sum_t mag[b][f][t] (f < nf), then rs[b][nf + f'] = sum_t fb[t][b][f'].  One wave per row.
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ stft, const float* __restrict__ fb,
+                                                      float* __restrict__ rs, int B, int F, int T, int FB, float fdrc) {
+    const int nf = F - 1, per_b = nf + FB;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wid >= B * per_b) return;
+    const int b = wid / per_b, f = wid - b * per_b;
+    double acc = 0.0;
+    if (f < nf) {
+        const float* src = stft + ((size_t)b * F + f) * T * 2;
+        for (int t = lane; t < T; t += 64) {
+            const float2 c = *reinterpret_cast<const float2*>(src + 2 * (size_t)t);
+            acc += (double)compress_mag(c.x, c.y, fdrc);
+        }
+    } else if (fb) {
+        for (int t = lane; t < T; t += 64) acc += (double)fb[((size_t)t * B + b) * FB + (f - nf)];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) rs[wid] = (float)acc;
+}
+
+// mu[g][b] = (sum over the gathered index multiset of row sums) / (T * N * I).  One wave per (g, b).
+__global__ __launch_bounds__(64) void laplace_mu_kernel(const float* __restrict__ rs, const FeatParams p,
+                                                         float* __restrict__ mu) {
+    const int gi = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const FeatGroupDev g = p.g[gi];
+    const int nf = p.F - 1, per_b = nf + p.FB;
+    const float* r = rs + (size_t)b * per_b;
+    double acc = 0.0;
+    for (int k = 0; k < g.N; ++k)
+        for (int j = lane; j < g.I; j += 64) {
+            if (j < g.I1)
+                acc += (double)r[reflect_bin(g.lo + k * g.ctr - g.nbr + j, nf)];
+            else
+                acc += (double)r[nf + (reflect_bin(g.lo + k * g.ctr_fb - g.nbr_fb + (j - g.I1), nf) % p.FB)];
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) mu[(size_t)gi * p.B + b] = (float)(acc / ((double)p.T * g.N * g.I));
+}
+
+// =====================================================================================================
+// deep-filter epilogue
+// =====================================================================================================
+struct DfGroupDev {
+    const float* proj;
+    int N, fc, df, lo;
+};
+struct DfParams {
+    DfGroupDev g[SFSN_MAX_GROUPS];
+    int ng, B, F, T, S, fcov;  // fcov = first bin not covered by any group
+};
+
+// grid (ceil(T/32), B), 256 threads; LDS: one unit's projection tile [32][P+1].
+__global__ __launch_bounds__(256) void deepfilter_kernel(const float* __restrict__ stft, const DfParams p,
+                                                          float* __restrict__ enh, float* __restrict__ mag) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int B = p.B, F = p.F, T = p.T, S = p.S;
+    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, tt = tid & 31, fs = tid >> 5, t = t0 + tt;
+
+    for (int gi = 0; gi < p.ng; ++gi) {
+        const DfGroupDev g = p.g[gi];
+        const int P = 2 * g.fc * g.df * S, LDP = P + 1;
+        for (int k = 0; k < g.N; ++k) {
+            __syncthreads();
+            for (int idx = tid; idx < 32 * P; idx += 256) {
+                const int r = idx / P, c = idx - r * P, tr = t0 + r;
+                smem[r * LDP + c] = tr < T ? g.proj[((size_t)tr * B * g.N + (size_t)b * g.N + k) * P + c] : 0.0f;
+            }
+            __syncthreads();
+            if (t < T) {
+                const float* pr = smem + tt * LDP;
+                for (int fci = fs; fci < g.fc; fci += 8) {
+                    const int f = g.lo + k * g.fc + fci;
+                    const float* xrow = stft + ((size_t)b * F + f) * T * 2;
+                    for (int s = 0; s < S; ++s) {
+                        float yr = 0.0f, yi = 0.0f;
+                        for (int d = 0; d < g.df; ++d) {
+                            const int ts = t - (g.df - 1) + d;
+                            float xr = 0.0f, xi = 0.0f;
+                            if (ts >= 0) {
+                                const float2 xv = *reinterpret_cast<const float2*>(xrow + 2 * (size_t)ts);
+                                xr = xv.x;
+                                xi = xv.y;
+                            }
+                            const float cr = pr[((0 * g.fc + fci) * g.df + d) * S + s];
+                            const float ci = pr[((1 * g.fc + fci) * g.df + d) * S + s];
+                            yr += xr * cr - xi * ci;
+                            yi += xr * ci + xi * cr;
+                        }
+                        const size_t o = (((size_t)b * S + s) * F + f) * T + t;
+                        *reinterpret_cast<float2*>(enh + 2 * o) = make_float2(yr, yi);
+                        if (mag) mag[o] = hypotf(yr, yi);
+                    }
+                }
+            }
+        }
+    }
+    // bins no group covers (at least the Nyquist bin) pass through untouched (MODEL:461-470)
+    if (t < T)
+        for (int f = p.fcov + fs; f < F; f += 8) {
+            const float2 xv = *reinterpret_cast<const float2*>(stft + (((size_t)b * F + f) * T + t) * 2);
+            for (int s = 0; s < S; ++s) {
+                const size_t o = (((size_t)b * S + s) * F + f) * T + t;
+                *reinterpret_cast<float2*>(enh + 2 * o) = xv;
+                if (mag) mag[o] = hypotf(xv.x, xv.y);
+            }
+        }
+}
+
+// =====================================================================================================
+// host side: argument checks, dispatch on compile-time shapes, launches
+// =====================================================================================================
+static inline int hip_ok(hipError_t e) { return e == hipSuccess ? SFSN_OK : SFSN_EHIP; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" int sfsn_abi_version(void) { return SFSN_ABI_VERSION; }
+
+extern "C" const char* sfsn_strerror(int code) {
+    switch (code) {
+        case SFSN_OK: return "ok";
+        case SFSN_EINVAL: return "invalid argument";
+        case SFSN_EUNSUPPORTED: return "unsupported shape for the gfx950 kernels";
+        case SFSN_EHIP: return "HIP runtime error (no gfx950 device, bad pointer or failed launch)";
+        case SFSN_EDIVISIBLE: return "Number of frequency bins must be divisible by the center frequency";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int sfsn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+template <int G, int TPW, int KS, int NW>
+static int launch_scan(const ScanParams& p, int tiles, hipStream_t st) {
+    hipLaunchKernelGGL((gsn_scan_kernel<G, TPW, KS, NW>), dim3(tiles), dim3(NW * 64), 0, st, p);
+    return hip_ok(hipGetLastError());
+}
+
+extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, int T, int H, int shared, void* stream) {
+    if (!segs || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0) return SFSN_EINVAL;
+    if (H % 16 != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
+    ScanParams p;
+    int tiles = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const sfsn_scan_segment& s = segs[i];
+        if (s.R <= 0 || !s.zin || !s.w_hh || !s.w_dq || !s.bias || !s.bn_alpha || !s.bn_beta || !s.h_state || !s.c_state)
+            return SFSN_EINVAL;
+        if (!aligned16(s.zin) || !aligned16(s.w_hh) || !aligned16(s.h_state) || !aligned16(s.c_state) ||
+            !aligned16(s.spikes_f32) || !aligned16(s.spikes_i8) || !aligned16(s.membrane))
+            return SFSN_EINVAL;
+        ScanSegDev& d = p.seg[i];
+        d.zin = s.zin; d.w_hh = s.w_hh; d.w_dq = s.w_dq; d.bias = s.bias; d.bn_alpha = s.bn_alpha; d.bn_beta = s.bn_beta;
+        d.h_state = s.h_state; d.c_state = s.c_state; d.spikes_f32 = s.spikes_f32; d.spikes_i8 = s.spikes_i8;
+        d.membrane = s.membrane; d.R = s.R; d.tile0 = tiles;
+        tiles += (s.R + 15) / 16;
+    }
+    p.nseg = n_segs; p.T = T; p.H = H; p.NT = H / 16;
+    const int NT = p.NT, KS = (H + 63) / 64;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // 8 waves (2 per SIMD, <= 256 VGPRs) while the wave's share of W fits, else 4 waves with 512 VGPRs each.
+    const int NW = shared ? (H <= 256 ? 8 : 4) : (H <= 128 ? 8 : 4);
+    const int TPW = (NT + NW - 1) / NW;
+#define SCAN_CASE(G_, TPW_, KS_, NW_) \
+    if (NW == NW_ && TPW == TPW_ && KS == KS_) return launch_scan<G_, TPW_, KS_, NW_>(p, tiles, st);
+    if (shared) {
+        SCAN_CASE(1, 1, 1, 8) SCAN_CASE(1, 1, 2, 8) SCAN_CASE(1, 2, 3, 8) SCAN_CASE(1, 2, 4, 8) SCAN_CASE(1, 5, 5, 4)
+    } else {
+        SCAN_CASE(2, 1, 1, 8) SCAN_CASE(2, 1, 2, 8) SCAN_CASE(2, 3, 3, 4) SCAN_CASE(2, 4, 4, 4)
+    }
+#undef SCAN_CASE
+    return SFSN_EUNSUPPORTED;
+}
+
+static inline void pick_tiling(int NT, int& TPW, int& NWN) {
+    TPW = (NT + 7) / 8;
+    NWN = (NT + TPW - 1) / TPW;
+}
+
+extern "C" int sfsn_spike_proj(const int8_t* s, const int8_t* w_packed, const float* w_dq, const float* bias, float* y, int M,
+                               int K, int N, int ldy, void* stream) {
+    if (!s || !w_packed || !w_dq || !y || M <= 0 || K <= 0 || N <= 0 || ldy < N) return SFSN_EINVAL;
+    if (!aligned16(s) || !aligned16(w_packed) || !aligned16(w_dq) || !aligned16(y)) return SFSN_EINVAL;
+    const int NT = (N + 15) / 16, KS = (K + 63) / 64;
+    int TPW, NWN;
+    pick_tiling(NT, TPW, NWN);
+    if (TPW > 3 || KS > 5) return SFSN_EUNSUPPORTED;
+    const int MW = 8 / NWN, MT = (M + 15) / 16;
+    int grid = (MT + MW - 1) / MW;
+    if (grid > 2048) grid = 2048;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define SP_CASE(TPW_, KS_)                                                                                          \
+    if (TPW == TPW_ && KS == KS_) {                                                                                 \
+        hipLaunchKernelGGL((spike_proj_kernel<TPW_, KS_>), dim3(grid), dim3(512), 0, st, s, w_packed, w_dq, bias, y, M, N, \
+                           ldy, NT, NWN);                                                                                \
+        return hip_ok(hipGetLastError());                                                                           \
+    }
+    SP_CASE(1, 1) SP_CASE(1, 2) SP_CASE(1, 3) SP_CASE(1, 4) SP_CASE(1, 5)
+    SP_CASE(2, 1) SP_CASE(2, 2) SP_CASE(2, 3) SP_CASE(2, 4) SP_CASE(2, 5)
+    SP_CASE(3, 4) SP_CASE(3, 5)
+#undef SP_CASE
+    return SFSN_EUNSUPPORTED;
+}
+
+extern "C" int sfsn_input_proj_f32(const float* x, const float* w, float* z, int M, int K, int N, int ldz, void* stream) {
+    if (!x || !w || !z || M <= 0 || K <= 0 || N <= 0 || ldz < N) return SFSN_EINVAL;
+    if (!aligned16(z)) return SFSN_EINVAL;
+    const int NT = (N + 15) / 16, KC = (K + 15) / 16;
+    int TPW, NWN;
+    pick_tiling(NT, TPW, NWN);
+    if (TPW > 3 || KC > 12) return SFSN_EUNSUPPORTED;
+    const int MW = 8 / NWN, MT = (M + 15) / 16;
+    int grid = (MT + MW - 1) / MW;
+    if (grid > 2048) grid = 2048;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int KCB = KC <= 3 ? 3 : (KC <= 6 ? 6 : 12);
+#define IP_CASE(TPW_, KC_)                                                                                           \
+    if (TPW == TPW_ && KCB == KC_) {                                                                                 \
+        hipLaunchKernelGGL((input_proj_kernel<TPW_, KC_>), dim3(grid), dim3(512), 0, st, x, w, z, M, K, N, ldz, NT, \
+                           NWN);                                                                                     \
+        return hip_ok(hipGetLastError());                                                                            \
+    }
+    IP_CASE(1, 3) IP_CASE(1, 6) IP_CASE(1, 12) IP_CASE(2, 3) IP_CASE(2, 6) IP_CASE(2, 12) IP_CASE(3, 3) IP_CASE(3, 6)
+    IP_CASE(3, 12)
+#undef IP_CASE
+    return SFSN_EUNSUPPORTED;
+}
+
+static int fill_feat(FeatParams& p, const sfsn_feature_group* groups, int n_groups, int B, int F, int T, int FB, float fdrc,
+                     bool need_x) {
+    if (!groups || n_groups <= 0 || n_groups > SFSN_MAX_GROUPS || B <= 0 || F < 2 || T <= 0 || FB < 0) return SFSN_EINVAL;
+    const int nf = F - 1;
+    p.ng = n_groups; p.B = B; p.F = F; p.T = T; p.FB = FB; p.fdrc = fdrc;
+    for (int i = 0; i < n_groups; ++i) {
+        const sfsn_feature_group& g = groups[i];
+        if (g.n_units <= 0 || g.ctr <= 0 || g.nbr < 0 || g.ctr_fb < 0 || g.nbr_fb < 0 || g.lo < 0) return SFSN_EINVAL;
+        const int I1 = g.ctr + 2 * g.nbr, I2 = g.ctr_fb > 0 ? g.ctr_fb + 2 * g.nbr_fb : 0;
+        if (I1 + I2 > 256) return SFSN_EUNSUPPORTED;
+        if (g.lo + g.n_units * g.ctr > nf || g.nbr >= nf || (I2 && (FB <= 0 || g.nbr_fb >= nf))) return SFSN_EINVAL;
+        if (need_x && (!g.x || (g.norm == SFSN_NORM_LAYERNORM && (!g.ln_w || !g.ln_b)) || (g.norm == SFSN_NORM_LAPLACE && !g.mu)))
+            return SFSN_EINVAL;
+        FeatGroupDev& d = p.g[i];
+        d.x = g.x; d.ln_w = g.ln_w; d.ln_b = g.ln_b; d.mu = g.mu; d.lo = g.lo; d.N = g.n_units; d.ctr = g.ctr; d.nbr = g.nbr;
+        d.ctr_fb = g.ctr_fb; d.nbr_fb = g.nbr_fb; d.I1 = I1; d.I = I1 + I2; d.norm = g.norm; d.eps = g.ln_eps;
+    }
+    return SFSN_OK;
+}
+
+extern "C" int sfsn_features(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc,
+                             const sfsn_feature_group* groups, int n_groups, void* stream) {
+    if (!stft_ri) return SFSN_EINVAL;
+    FeatParams p;
+    int rc = fill_feat(p, groups, n_groups, B, F, T, FB, fdrc, true);
+    if (rc != SFSN_OK) return rc;
+    for (int i = 0; i < n_groups; ++i)
+        if (groups[i].ctr_fb > 0 && !fb_tbf) return SFSN_EINVAL;
+    const size_t lds = ((size_t)(F - 1) * 33 + (size_t)FEAT_TT * (FB > 0 ? FB : 1)) * sizeof(float);
+    if (lds > 150 * 1024) return SFSN_EUNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return SFSN_EHIP;
+    }
+    hipLaunchKernelGGL(features_kernel, dim3((T + FEAT_TT - 1) / FEAT_TT, B), dim3(256), lds, st, stft_ri, fb_tbf, p);
+    return hip_ok(hipGetLastError());
+}
+
+extern "C" int sfsn_laplace_means(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc,
+                                  const sfsn_feature_group* groups, int n_groups, float* mu_out, float* scratch, void* stream) {
+    if (!stft_ri || !mu_out || !scratch) return SFSN_EINVAL;
+    FeatParams p;
+    int rc = fill_feat(p, groups, n_groups, B, F, T, FB, fdrc, false);
+    if (rc != SFSN_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rows = B * (F - 1 + FB);
+    hipLaunchKernelGGL(rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, stft_ri, fb_tbf, scratch, B, F, T, FB, fdrc);
+    hipLaunchKernelGGL(laplace_mu_kernel, dim3(n_groups, B), dim3(64), 0, st, scratch, p, mu_out);
+    return hip_ok(hipGetLastError());
+}
+
+extern "C" int sfsn_deepfilter(const float* stft_ri, int B, int F, int T, int S, const sfsn_df_group* groups, int n_groups,
+                               float* enh_ri, float* enh_mag, void* stream) {
+    if (!stft_ri || !enh_ri || !groups || n_groups <= 0 || n_groups > SFSN_MAX_GROUPS || B <= 0 || F < 2 || T <= 0 || S <= 0)
+        return SFSN_EINVAL;
+    DfParams p;
+    p.ng = n_groups; p.B = B; p.F = F; p.T = T; p.S = S;
+    int lo = 0, maxP = 1;
+    for (int i = 0; i < n_groups; ++i) {
+        const sfsn_df_group& g = groups[i];
+        if (!g.proj || g.n_units <= 0 || g.fc <= 0 || g.df <= 0) return SFSN_EINVAL;
+        p.g[i].proj = g.proj; p.g[i].N = g.n_units; p.g[i].fc = g.fc; p.g[i].df = g.df; p.g[i].lo = lo;
+        lo += g.n_units * g.fc;
+        const int P = 2 * g.fc * g.df * S;
+        if (P > maxP) maxP = P;
+    }
+    if (lo > F) return SFSN_EINVAL;
+    p.fcov = lo;
+    const size_t lds = (size_t)32 * (maxP + 1) * sizeof(float);
+    if (lds > 150 * 1024) return SFSN_EUNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deepfilter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return SFSN_EHIP;
+    }
+    hipLaunchKernelGGL(deepfilter_kernel, dim3((T + 31) / 32, B), dim3(256), lds, st, stft_ri, p, enh_ri, enh_mag);
+    return hip_ok(hipGetLastError());
+}

@@ -1,0 +1,335 @@
+"""Host-side driver of the hot path: packs a model's weights for the gfx950 kernels and enqueues the
+launch sequence of one forward (complex STFT in HBM -> enhanced STFT / magnitude + the per-layer
+tensors the reference's modules return) on torch's current HIP stream, through the C ABI only.
+
+PyTorch is used here for device memory and streams; every arithmetic step of the path runs in
+``libsfsn_hip.so``.  There is no CPU / eager fallback: CPU tensors raise.
+
+Reference call stack replaced: ``SpikingFullSubNet.forward`` modeling_spiking_fullsubnet.py:434-472
+(frozen twin ``Separator.forward`` model_low_freq.py:574-607) and everything below it.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DfGroup, FeatureGroup, ScanSegment, check
+
+
+@dataclass
+class PathSpec:
+    """Geometry of one model, normalised over the live and frozen front-ends."""
+    front: str                    # "live" (LayerNorm inputs, `proj`) | "frozen" (offline Laplace norm, `fc_output_layer`)
+    n_fft: int
+    fdrc: float
+    fb_in: int
+    fb_hidden: int
+    fb_layers: int
+    fb_proj: int
+    sb_hidden: int
+    sb_layers: int
+    cutoffs: List[int]
+    ctr: List[int]
+    nbr: List[int]
+    ctr_fb: List[int]
+    nbr_fb: List[int]
+    df: List[int]
+    num_spks: int = 1
+    shared: bool = False
+    bn: bool = False
+    ln_fb: bool = True
+    ln_sb: bool = True
+    laplace: bool = False
+    proj_name: str = "proj"
+
+    @property
+    def n_groups(self) -> int:
+        return len(self.ctr)
+
+    @property
+    def num_freqs(self) -> int:  # bins the network processes (Nyquist excluded)
+        return self.n_fft // 2
+
+    def units(self, g: int) -> int:
+        return (self.cutoffs[g + 1] - self.cutoffs[g]) // self.ctr[g]
+
+    def sb_input_size(self, g: int) -> int:
+        return (self.ctr[g] + 2 * self.nbr[g]) + (self.ctr_fb[g] + 2 * self.nbr_fb[g])
+
+    def sb_proj_size(self, g: int) -> int:
+        return 2 * self.ctr[g] * self.df[g] * self.num_spks
+
+
+def _dev(a: np.ndarray, device) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def pack_w3(w: np.ndarray):
+    """fp32 [N, K] -> (int8 digits in MFMA fragment order, dq [pad16(N)]) as numpy arrays (host packing)."""
+    L = _lib.lib()
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    n, k = w.shape
+    packed = np.empty(L.sfsn_w3_packed_bytes(n, k), np.int8)
+    dq = np.empty(L.sfsn_w3_padded_rows(n), np.float32)
+    check(L.sfsn_w3_pack(w.ctypes.data, n, k, packed.ctypes.data, dq.ctypes.data), "sfsn_w3_pack")
+    return packed, dq
+
+
+def unpack_w3(packed: np.ndarray, dq: np.ndarray, n: int, k: int) -> np.ndarray:
+    L = _lib.lib()
+    w = np.empty((n, k), np.float32)
+    check(L.sfsn_w3_unpack(packed.ctypes.data, dq.ctypes.data, n, k, w.ctypes.data), "sfsn_w3_unpack")
+    return w
+
+
+def fold_batchnorm(weight, bias, mean, var, eps=1e-5):
+    """Eval-mode BatchNorm1d as ATen's CPU kernel evaluates it (probed bit-exact, see oracle/sfsn_oracle.c):
+    alpha = gamma / sqrt(var + eps), beta = fma(-mean, alpha, bias), y = fma(x, alpha, beta)."""
+    f32 = np.float32
+    invstd = (f32(1) / np.sqrt(var.astype(f32) + f32(eps))).astype(f32)
+    alpha = (invstd * weight.astype(f32)).astype(f32)
+    beta = (bias.astype(np.float64) - mean.astype(np.float64) * alpha.astype(np.float64)).astype(f32)
+    return alpha, beta
+
+
+@dataclass
+class _Cell:
+    H: int
+    G: int
+    w_ih_f32: Optional[torch.Tensor] = None                 # layer 0: [G*H, I] fp32
+    w_ih_q: List[tuple] = field(default_factory=list)        # layer >= 1: per gate (packed, dq) of [H, H]
+    w_hh_q: Optional[torch.Tensor] = None                    # packed [G*H, H]
+    w_hh_dq: Optional[torch.Tensor] = None
+    bias: Optional[torch.Tensor] = None
+    alpha: Optional[torch.Tensor] = None
+    beta: Optional[torch.Tensor] = None
+
+
+@dataclass
+class _Seq:
+    I: int
+    H: int
+    P: int
+    cells: List[_Cell]
+    proj_q: torch.Tensor
+    proj_dq: torch.Tensor
+    proj_b: torch.Tensor
+    ln_w: Optional[torch.Tensor] = None
+    ln_b: Optional[torch.Tensor] = None
+
+
+def _pack_seq(sd: Dict[str, np.ndarray], prefix: str, spec: PathSpec, I: int, H: int, L: int, P: int, use_ln: bool, device) -> _Seq:
+    G = 1 if spec.shared else 2
+    cells = []
+    for l in range(L):
+        p = f"{prefix}sequence_model.layers.{l}.cell."
+        w_ih, w_hh, b = sd[p + "weight_ih"], sd[p + "weight_hh"], sd[p + "bias_ih"]
+        Il = I if l == 0 else H
+        assert w_ih.shape == (G * H, Il) and w_hh.shape == (G * H, H) and b.shape == (2 * H,), (p, w_ih.shape, w_hh.shape)
+        cell = _Cell(H=H, G=G)
+        if l == 0:
+            cell.w_ih_f32 = _dev(w_ih.astype(np.float32), device)
+        else:
+            for g in range(G):
+                pk, dq = pack_w3(w_ih[g * H:(g + 1) * H])
+                cell.w_ih_q.append((_dev(pk, device), _dev(dq, device)))
+        pk, dq = pack_w3(w_hh)
+        cell.w_hh_q, cell.w_hh_dq = _dev(pk, device), _dev(dq, device)
+        cell.bias = _dev(b.astype(np.float32), device)
+        if spec.bn:
+            a, be = fold_batchnorm(sd[p + "batchnorm.weight"], sd[p + "batchnorm.bias"], sd[p + "batchnorm.running_mean"],
+                                   sd[p + "batchnorm.running_var"])
+        else:
+            a, be = np.ones(H, np.float32), np.zeros(H, np.float32)
+        cell.alpha, cell.beta = _dev(a, device), _dev(be, device)
+        cells.append(cell)
+    pn = prefix + spec.proj_name
+    pw, pb = sd[pn + ".weight"], sd[pn + ".bias"]
+    assert pw.shape == (P, H), (pn, pw.shape, (P, H))
+    pk, dq = pack_w3(pw)
+    seq = _Seq(I=I, H=H, P=P, cells=cells, proj_q=_dev(pk, device), proj_dq=_dev(dq, device), proj_b=_dev(pb.astype(np.float32), device))
+    if use_ln:
+        seq.ln_w = _dev(sd[prefix + "pre_layer_norm.weight"].astype(np.float32), device)
+        seq.ln_b = _dev(sd[prefix + "pre_layer_norm.bias"].astype(np.float32), device)
+    return seq
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """Packed weights + launch sequence for one model on one device."""
+
+    def __init__(self, spec: PathSpec, state_dict: Dict[str, np.ndarray], device):
+        self.spec = spec
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("spiking_fullsubnet_amd runs on a HIP device only (no CPU path); move the module to 'cuda'")
+        self.lib = _lib.lib()
+        for H in (spec.fb_hidden, spec.sb_hidden):
+            if H % 16 != 0 or H > _lib.MAX_HIDDEN:
+                raise NotImplementedError(f"hidden size {H}: the gfx950 scan holds W_hh register-resident for H % 16 == 0, H <= {_lib.MAX_HIDDEN}")
+        if spec.n_groups > _lib.MAX_SEGMENTS:
+            raise NotImplementedError(f"more than {_lib.MAX_SEGMENTS} sub-band groups")
+        if len(spec.cutoffs) == 2:
+            raise NotImplementedError("single-group models hit a latent reflect-pad quirk of the reference (SubbandModel._freq_unfold)")
+        sd = {k: np.asarray(v) for k, v in state_dict.items()}
+        self.fb = _pack_seq(sd, "fb_model.", spec, spec.fb_in, spec.fb_hidden, spec.fb_layers, spec.fb_proj, spec.ln_fb, self.device)
+        self.sb = [_pack_seq(sd, f"sb_model.sb_models.{g}.", spec, spec.sb_input_size(g), spec.sb_hidden, spec.sb_layers,
+                             spec.sb_proj_size(g), spec.ln_sb, self.device) for g in range(spec.n_groups)]
+        self._ws: Dict[tuple, dict] = {}
+
+    # ---------------------------------------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, key, make):
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) > 4:
+                self._ws.clear()
+            ws = self._ws[key] = make()
+        return ws
+
+    def _run_stack(self, seqs: List[_Seq], xs: List[torch.Tensor], T: int, want_layers: bool, want_membrane: bool, tag: str):
+        """One or several independent sequence models sharing (H, L): SequenceModel.forward modeling:81-125.
+
+        xs[i] is the normalised time-major input [T, R_i, I_i].  Returns (proj list, all_layer_outputs lists, membranes).
+        """
+        L, st, spec = self.lib, self._stream(), self.spec
+        H, G, nl = seqs[0].H, seqs[0].cells[0].G, len(seqs[0].cells)
+        HP = (H + 63) // 64 * 64
+        dev = self.device
+        Rs = [x.shape[1] for x in xs]
+        ws = self._workspace((tag, T, tuple(Rs)), lambda: dict(
+            zin=[torch.empty((T, R, G * H), dtype=torch.float32, device=dev) for R in Rs],
+            s8=[[torch.zeros((T, R, HP), dtype=torch.int8, device=dev) for R in Rs] for _ in range(2)]))
+        outs = [[x] for x in xs]
+        mems = [[] for _ in xs]
+        for l in range(nl):
+            # ---- input term zin = (layer input) . W_ih^T, time-parallel
+            for i, (seq, x, R) in enumerate(zip(seqs, xs, Rs)):
+                cell, z, M = seq.cells[l], ws["zin"][i], T * R
+                if l == 0:
+                    for g in range(G):
+                        check(L.sfsn_input_proj_f32(_ptr(x), ctypes.c_void_p(cell.w_ih_f32.data_ptr() + g * H * seq.I * 4),
+                                                    ctypes.c_void_p(z.data_ptr() + g * H * 4), M, seq.I, H, G * H, st), "sfsn_input_proj_f32")
+                else:
+                    s_prev = ws["s8"][(l - 1) & 1][i]
+                    for g in range(G):
+                        pk, dq = cell.w_ih_q[g]
+                        check(L.sfsn_spike_proj(_ptr(s_prev), _ptr(pk), _ptr(dq), None, ctypes.c_void_p(z.data_ptr() + g * H * 4),
+                                                M, H, H, G * H, st), "sfsn_spike_proj")
+            # ---- the recurrent scan, all segments in one launch
+            segs = (ScanSegment * len(seqs))()
+            keep = []
+            for i, (seq, R) in enumerate(zip(seqs, Rs)):
+                cell = seq.cells[l]
+                h0 = torch.zeros((R, H), dtype=torch.float32, device=dev)  # states start at zero, modeling:100-106
+                c0 = torch.zeros((R, H), dtype=torch.float32, device=dev)
+                spk = torch.empty((T, R, H), dtype=torch.float32, device=dev) if want_layers else None
+                mem = torch.empty((T, R, H), dtype=torch.float32, device=dev) if want_membrane else None
+                s8 = ws["s8"][l & 1][i]
+                keep += [h0, c0]
+                sg = segs[i]
+                sg.zin, sg.w_hh, sg.w_dq, sg.bias = _ptr(ws["zin"][i]), _ptr(cell.w_hh_q), _ptr(cell.w_hh_dq), _ptr(cell.bias)
+                sg.bn_alpha, sg.bn_beta, sg.h_state, sg.c_state = _ptr(cell.alpha), _ptr(cell.beta), _ptr(h0), _ptr(c0)
+                sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.R = _ptr(spk), _ptr(s8), _ptr(mem), R
+                outs[i].append(spk)
+                mems[i].append(mem)
+            check(L.sfsn_gsn_layer_scan(segs, len(seqs), T, H, int(spec.shared), st), "sfsn_gsn_layer_scan")
+        # ---- projection (nn.Linear on the last layer's spikes)
+        projs = []
+        for i, (seq, R) in enumerate(zip(seqs, Rs)):
+            y = torch.empty((T, R, seq.P), dtype=torch.float32, device=dev)
+            check(L.sfsn_spike_proj(_ptr(ws["s8"][(nl - 1) & 1][i]), _ptr(seq.proj_q), _ptr(seq.proj_dq), _ptr(seq.proj_b), _ptr(y),
+                                    T * R, H, seq.P, seq.P, st), "sfsn_spike_proj(proj)")
+            projs.append(y)
+            outs[i].append(y)
+        return projs, outs, mems
+
+    def _feature_groups(self, which: str, xs, mu):
+        spec = self.spec
+        if which == "fb":
+            g = FeatureGroup()
+            g.x, g.lo, g.n_units, g.ctr, g.nbr, g.ctr_fb, g.nbr_fb = _ptr(xs[0]), 0, 1, spec.fb_in, 0, 0, 0
+            g.ln_eps = 1e-5
+            if spec.laplace:
+                g.norm, g.mu = _lib.NORM_LAPLACE, _ptr(mu)
+            elif spec.ln_fb:
+                g.norm, g.ln_w, g.ln_b = _lib.NORM_LAYERNORM, _ptr(self.fb.ln_w), _ptr(self.fb.ln_b)
+            else:
+                g.norm = _lib.NORM_NONE
+            arr = (FeatureGroup * 1)()
+            arr[0] = g
+            return arr
+        arr = (FeatureGroup * spec.n_groups)()
+        for i in range(spec.n_groups):
+            g = arr[i]
+            g.x = _ptr(xs[i]) if xs is not None else None
+            g.lo, g.n_units, g.ctr, g.nbr = spec.cutoffs[i], spec.units(i), spec.ctr[i], spec.nbr[i]
+            g.ctr_fb, g.nbr_fb, g.ln_eps = spec.ctr_fb[i], spec.nbr_fb[i], 1e-5
+            if spec.laplace:
+                g.norm = _lib.NORM_LAPLACE
+                g.mu = ctypes.c_void_p(mu.data_ptr() + i * mu.shape[1] * 4) if mu is not None else None
+            elif spec.ln_sb:
+                g.norm, g.ln_w, g.ln_b = _lib.NORM_LAYERNORM, _ptr(self.sb[i].ln_w), _ptr(self.sb[i].ln_b)
+            else:
+                g.norm = _lib.NORM_NONE
+        return arr
+
+    def forward_stft(self, stft: torch.Tensor, want_layers: bool = True, want_membrane: bool = False) -> dict:
+        """complex64 [B, n_fft/2+1, T] on the device -> dict(enh_stft [B,S,F,T] complex64, enh_mag [B,S,F,T],
+        fb_all, sb_all (the reference's all_layer_outputs lists; spike entries are None when want_layers=False))."""
+        spec, L = self.spec, self.lib
+        if stft.device != self.device or stft.dtype != torch.complex64 or stft.dim() != 3:
+            raise RuntimeError(f"expected a complex64 [B, F, T] tensor on {self.device}, got {stft.dtype} {tuple(stft.shape)} on {stft.device}")
+        B, F, T = stft.shape
+        if F != spec.n_fft // 2 + 1:
+            raise ValueError(f"expected {spec.n_fft // 2 + 1} frequency bins, got {F}")
+        for g in range(spec.n_groups):  # the reference's ValueError, modeling_spiking_fullsubnet.py:283-287
+            lo, hi, c = spec.cutoffs[g], spec.cutoffs[g + 1], spec.ctr[g]
+            if (hi - lo) % c != 0:
+                raise ValueError(f"Number of frequency bins must be divisible by the center frequency.GOT: ctr_freq={c}, "
+                                 f"upper_cutoff_freq={hi}, lower_cutoff_freq={lo}")
+        st, dev = self._stream(), self.device
+        ri = torch.view_as_real(stft.contiguous())  # [B, F, T, 2] float32 view, no copy
+        f32 = dict(dtype=torch.float32, device=dev)
+        # ---------------- full-band model
+        x_fb = torch.empty((T, B, spec.fb_in), **f32)
+        mu_fb = None
+        scratch = None
+        if spec.laplace:
+            mu_fb = torch.empty((1, B), **f32)
+            scratch = torch.empty((B * (F - 1 + spec.fb_proj),), **f32)
+            check(L.sfsn_laplace_means(_ptr(ri), None, B, F, T, 0, spec.fdrc, self._feature_groups("fb", [x_fb], mu_fb), 1,
+                                       _ptr(mu_fb), _ptr(scratch), st), "sfsn_laplace_means(fb)")
+        check(L.sfsn_features(_ptr(ri), None, B, F, T, 0, spec.fdrc, self._feature_groups("fb", [x_fb], mu_fb), 1, st), "sfsn_features(fb)")
+        fb_projs, fb_outs, fb_mems = self._run_stack([self.fb], [x_fb], T, want_layers, want_membrane, "fb")
+        fb_proj = fb_projs[0]  # [T, B, FB]
+        # ---------------- sub-band models
+        xs = [torch.empty((T, B * spec.units(g), spec.sb_input_size(g)), **f32) for g in range(spec.n_groups)]
+        mu_sb = None
+        if spec.laplace:
+            mu_sb = torch.empty((spec.n_groups, B), **f32)
+            check(L.sfsn_laplace_means(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, self._feature_groups("sb", None, None),
+                                       spec.n_groups, _ptr(mu_sb), _ptr(scratch), st), "sfsn_laplace_means(sb)")
+        check(L.sfsn_features(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, self._feature_groups("sb", xs, mu_sb),
+                              spec.n_groups, st), "sfsn_features(sb)")
+        sb_projs, sb_outs, sb_mems = self._run_stack(self.sb, xs, T, want_layers, want_membrane, "sb")
+        # ---------------- deep filter + reconstruction
+        S = spec.num_spks
+        enh = torch.empty((B, S, F, T), dtype=torch.complex64, device=dev)
+        enh_mag = torch.empty((B, S, F, T), **f32)
+        dfg = (DfGroup * spec.n_groups)()
+        for g in range(spec.n_groups):
+            dfg[g].proj, dfg[g].n_units, dfg[g].fc, dfg[g].df = _ptr(sb_projs[g]), spec.units(g), spec.ctr[g], spec.df[g]
+        check(L.sfsn_deepfilter(_ptr(ri), B, F, T, S, dfg, spec.n_groups, _ptr(torch.view_as_real(enh)), _ptr(enh_mag), st), "sfsn_deepfilter")
+        return dict(enh_stft=enh, enh_mag=enh_mag, fb_all=fb_outs[0], sb_all=sb_outs, fb_mem=fb_mems[0], sb_mem=sb_mems,
+                    mu_fb=mu_fb, mu_sb=mu_sb)

@@ -1,0 +1,118 @@
+"""Drop-in for the frozen competition model ``model_low_freq.Separator``
+(recipes/intel_ndns/spiking_fullsubnet_freeze_phase/model_low_freq.py:485-618) -- the architecture of
+``baseline_s`` and of every ``model_zoo`` checkpoint.
+
+Same constructor keywords (:486-509), same state-dict names (``fc_output_layer`` instead of ``proj``, no
+``pre_layer_norm``; the zoo checkpoints load with ``strict=True``), same ``forward`` return tuple (:618).
+A frozen-recipe TOML switches over with ``[model_g] path = "spiking_fullsubnet_amd.model_low_freq.Separator"``.
+
+Input normalisation is the utterance-level ``offline_laplace_norm`` (:147-169) -- the setting of all zoo
+checkpoints.  ``cumulative_laplace_norm`` crashes on the 5-D sub-band tensor in the reference itself
+ and is rejected here.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .engine import PathSpec
+from .modeling_spiking_fullsubnet import StackedGSU, _EngineMixin
+
+
+class SequenceModel(nn.Module):
+    """Container for model_low_freq.py:42-98 (sequence_model, fc_output_layer)."""
+
+    def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional, sequence_model="GSU",
+                 output_activate_function="Tanh", num_groups=4, mogrify_steps=5, dropout=0.0, shared_weights=False, bn=False):
+        super().__init__()
+        if sequence_model != "GSU":
+            raise NotImplementedError(f"Not implemented {sequence_model}")
+        if bidirectional:
+            raise NotImplementedError("bidirectional GSU is not used by the reference (model_low_freq.py:524,332 pass False)")
+        self.sequence_model = StackedGSU(input_size, hidden_size, num_layers, shared_weights, bn)
+        if not int(output_size):
+            raise NotImplementedError("output_size = 0 is not used by any reference config")
+        self.fc_output_layer = nn.Linear(hidden_size, output_size)
+        if output_activate_function:
+            raise NotImplementedError("output activations are not fused yet; every zoo config uses `false`")
+        self.output_activate_function, self.output_size = output_activate_function, output_size
+        self.sequence_model_name, self.hidden_size, self.num_layers = sequence_model, hidden_size, num_layers
+
+
+class SubBandSequenceWrapper(SequenceModel):
+    def __init__(self, df_order, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.df_order = df_order
+
+
+class SubbandModel(nn.Module):
+    """Container for model_low_freq.py:293-348."""
+
+    def __init__(self, freq_cutoffs, sb_num_center_freqs, sb_num_neighbor_freqs, fb_num_center_freqs, fb_num_neighbor_freqs,
+                 sb_df_orders, sequence_model, hidden_size, activate_function=False, norm_type="offline_laplace_norm",
+                 shared_weights=False, bn=False):
+        super().__init__()
+        self.sb_models = nn.ModuleList([
+            SubBandSequenceWrapper(df_order=d, input_size=(c + n * 2) + (cf + nf * 2), output_size=c * 2 * d, hidden_size=hidden_size,
+                                   num_layers=2, sequence_model=sequence_model, bidirectional=False,
+                                   output_activate_function=activate_function, shared_weights=shared_weights, bn=bn)
+            for c, n, cf, nf, d in zip(sb_num_center_freqs, sb_num_neighbor_freqs, fb_num_center_freqs, fb_num_neighbor_freqs, sb_df_orders)])
+        self.freq_cutoffs = freq_cutoffs
+        self.sb_num_center_freqs, self.sb_num_neighbor_freqs = sb_num_center_freqs, sb_num_neighbor_freqs
+        self.fb_num_center_freqs, self.fb_num_neighbor_freqs = fb_num_center_freqs, fb_num_neighbor_freqs
+
+
+class Separator(_EngineMixin, nn.Module):
+    def __init__(self, sr, n_fft, hop_length, win_length, fdrc, num_freqs, fb_freqs, freq_cutoffs, sb_num_center_freqs,
+                 sb_num_neighbor_freqs, fb_num_center_freqs, fb_num_neighbor_freqs, fb_hidden_size, sb_hidden_size, sb_df_orders,
+                 sequence_model, fb_output_activate_function, sb_output_activate_function, norm_type, shared_weights=False, bn=False):
+        super().__init__()
+        if norm_type != "offline_laplace_norm":
+            raise NotImplementedError(
+                f"norm_type={norm_type!r}: only offline_laplace_norm (all zoo checkpoints) is built; cumulative_laplace_norm "
+                "raises `too many values to unpack` on the sub-band tensor in the reference itself")
+        self.n_fft, self.hop_length, self.win_length, self.fdrc = n_fft, hop_length, win_length, fdrc
+        self.freq_cutoffs, self.sb_df_orders = freq_cutoffs, sb_df_orders
+        self.num_repeats, self.fb_freqs = num_freqs // fb_freqs, fb_freqs
+        self.fb_model = SequenceModel(input_size=fb_freqs, output_size=fb_freqs, hidden_size=fb_hidden_size, num_layers=2,
+                                      bidirectional=False, sequence_model=sequence_model,
+                                      output_activate_function=fb_output_activate_function, shared_weights=shared_weights, bn=bn)
+        self.sb_model = SubbandModel(freq_cutoffs=freq_cutoffs, sb_num_center_freqs=sb_num_center_freqs,
+                                     sb_num_neighbor_freqs=sb_num_neighbor_freqs, fb_num_center_freqs=fb_num_center_freqs,
+                                     fb_num_neighbor_freqs=fb_num_neighbor_freqs, sb_df_orders=sb_df_orders,
+                                     hidden_size=sb_hidden_size, sequence_model=sequence_model,
+                                     activate_function=sb_output_activate_function, shared_weights=shared_weights, bn=bn,
+                                     norm_type=norm_type)
+        if num_freqs != n_fft // 2 or num_freqs % fb_freqs != 0:
+            raise NotImplementedError("num_freqs must be n_fft/2 and a multiple of fb_freqs (as in every zoo config)")
+        self._path_spec = PathSpec(
+            front="frozen", n_fft=n_fft, fdrc=fdrc, fb_in=fb_freqs, fb_hidden=fb_hidden_size, fb_layers=2, fb_proj=fb_freqs,
+            sb_hidden=sb_hidden_size, sb_layers=2, cutoffs=[0] + list(freq_cutoffs) + [num_freqs], ctr=list(sb_num_center_freqs),
+            nbr=list(sb_num_neighbor_freqs), ctr_fb=list(fb_num_center_freqs), nbr_fb=list(fb_num_neighbor_freqs),
+            df=list(sb_df_orders), num_spks=1, shared=shared_weights, bn=bn, ln_fb=False, ln_sb=False, laplace=True,
+            proj_name="fc_output_layer")
+
+    def _spec(self) -> PathSpec:
+        return self._path_spec
+
+    @torch.no_grad()
+    def forward_stft(self, complex_stft, want_layers=True, want_membrane=False):
+        self._check_mode()
+        return self.engine().forward_stft(complex_stft, want_layers=want_layers, want_membrane=want_membrane)
+
+    @torch.no_grad()
+    def forward(self, noisy_y):
+        ndim = noisy_y.dim()
+        assert ndim in (2, 3), "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
+        if ndim == 3:
+            assert noisy_y.size(1) == 1, "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
+            noisy_y = noisy_y.squeeze(1)
+        self._check_mode()
+        window = torch.hann_window(self.n_fft, device=noisy_y.device)
+        stft = torch.stft(noisy_y, self.n_fft, self.hop_length, self.win_length, window=window, return_complex=True,
+                          pad_mode="constant")
+        res = self.engine().forward_stft(stft)
+        enhanced_stft = res["enh_stft"][:, 0]
+        enhanced_y = torch.istft(enhanced_stft, n_fft=self.n_fft, hop_length=self.hop_length, win_length=self.win_length,
+                                 window=torch.hann_window(self.win_length, device=noisy_y.device), length=noisy_y.size(-1))
+        return enhanced_y, res["enh_mag"][:, 0], res["fb_all"], res["sb_all"]

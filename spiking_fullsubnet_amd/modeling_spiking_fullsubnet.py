@@ -1,0 +1,184 @@
+"""Drop-in for ``audiozen.models.spiking_fullsubnet.modeling_spiking_fullsubnet.SpikingFullSubNet``.
+
+Same constructor keywords (modeling_spiking_fullsubnet.py:350-373), same parameter / buffer names (so
+``accelerator.load_state`` / ``load_state_dict(strict=True)`` of a reference checkpoint works),
+same ``forward(input[B, samples])`` return tuple (:415-474).  A recipe switches over by changing only
+
+    [model]
+    path = "spiking_fullsubnet_amd.modeling_spiking_fullsubnet.SpikingFullSubNet"
+
+The sub-modules below are parameter containers that mirror the reference's module tree; all arithmetic
+between ``stft`` and ``istft`` runs in the gfx950 kernels of ``libsfsn_hip.so`` via ``Engine``.  Inference
+only: there is no autograd graph and no training-mode (batch-statistics) BatchNorm -- see DESIGN.md.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn import Parameter
+
+from .engine import Engine, PathSpec
+
+
+# ---- parameter containers mirroring efficient_spiking_neuron.py:43-130 ---------------------------------
+class GSUCell(nn.Module):
+    """Parameters of one gated spiking cell (efficient_spiking_neuron.py:104-130), reference initialisation."""
+
+    def __init__(self, input_size, hidden_size, shared_weights=False, bn=False):
+        super().__init__()
+        self.input_size, self.hidden_size, self.shared_weights, self.use_bn = input_size, hidden_size, shared_weights, bn
+        rows = hidden_size if shared_weights else 2 * hidden_size
+        self.weight_ih = Parameter(torch.empty(rows, input_size))
+        self.weight_hh = Parameter(torch.empty(rows, hidden_size))
+        self.bias_ih = Parameter(torch.zeros(2 * hidden_size))
+        stdv = 1.0 / math.sqrt(hidden_size) if hidden_size > 0 else 0
+        for weight in self.parameters():
+            torch.nn.init.uniform_(weight, -stdv, stdv)
+        if bn:
+            self.batchnorm = nn.BatchNorm1d(hidden_size)
+
+
+class GSULayer(nn.Module):
+    def __init__(self, *cell_args):
+        super().__init__()
+        self.cell = GSUCell(*cell_args)
+
+
+class StackedGSU(nn.Module):
+    def __init__(self, input_size, hidden_size, num_layers, shared_weights, bn):
+        super().__init__()
+        self.layers = nn.ModuleList([GSULayer(input_size if l == 0 else hidden_size, hidden_size, shared_weights, bn)
+                                     for l in range(num_layers)])
+
+
+class SequenceModel(nn.Module):
+    """Container for modeling_spiking_fullsubnet.py:12-79 (pre_layer_norm, sequence_model, proj)."""
+
+    def __init__(self, input_size, hidden_size, num_layers, sequence_model="GSN", proj_size=0, shared_weights=False,
+                 output_activate_function=None, bn=False, use_pre_layer_norm=True):
+        super().__init__()
+        if use_pre_layer_norm:
+            self.pre_layer_norm = nn.LayerNorm(input_size)
+        if sequence_model == "GSN":
+            self.sequence_model = StackedGSU(input_size, hidden_size, num_layers, shared_weights, bn)
+        elif sequence_model == "LSTM":
+            raise NotImplementedError("sequence_model='LSTM' is the reference's nn.LSTM ablation, not the GSN hot path this "
+                                      "package accelerates; use the reference module for it")
+        else:
+            raise NotImplementedError(f"Sequence model {sequence_model} not implemented.")
+        if proj_size <= 0:
+            raise NotImplementedError("proj_size = 0 (Identity projection) is not used by any reference config")
+        self.proj = nn.Linear(hidden_size, proj_size)
+        if output_activate_function in ("tanh", "sigmoid", "relu"):
+            raise NotImplementedError("output activations are not fused yet; every reference config uses `false` (Identity)")
+        self.output_activate_function = nn.Identity()
+        self.hidden_size, self.num_layers = hidden_size, num_layers
+        self.use_pre_layer_norm, self.sequence_model_name = use_pre_layer_norm, sequence_model
+
+
+class SubBandSequenceModel(SequenceModel):
+    def __init__(self, df_order, num_spks, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.df_order, self.num_spks = df_order, num_spks
+
+
+class SubbandModel(nn.Module):
+    """Container for modeling_spiking_fullsubnet.py:172-214."""
+
+    def __init__(self, freq_cutoffs, center_freq_sizes, neighbor_freq_sizes, df_orders, num_spks, **kwargs):
+        super().__init__()
+        assert len(freq_cutoffs) - 1 == len(center_freq_sizes), "Number of subbands must be equal to len(cutoffs)."
+        self.sb_models = nn.ModuleList([
+            SubBandSequenceModel(input_size=(c + n * 2) + c, proj_size=2 * c * d * num_spks, df_order=d, num_spks=num_spks, **kwargs)
+            for c, n, d in zip(center_freq_sizes, neighbor_freq_sizes, df_orders)])
+        self.freq_cutoffs, self.center_freq_sizes = freq_cutoffs, center_freq_sizes
+        self.neighbor_freq_sizes, self.df_orders = neighbor_freq_sizes, df_orders
+
+
+class _EngineMixin:
+    """Lazy (re)packing of the module's weights for the kernels, keyed on parameter versions and device."""
+
+    _engine = None
+    _engine_key = None
+
+    def _spec(self) -> PathSpec:  # pragma: no cover - provided by subclasses
+        raise NotImplementedError
+
+    def engine(self) -> Engine:
+        tensors = list(self.state_dict(keep_vars=True).items())
+        dev = tensors[0][1].device
+        key = (str(dev),) + tuple((k, t.data_ptr(), t._version) for k, t in tensors)
+        if self._engine is None or self._engine_key != key:
+            if dev.type != "cuda":
+                raise RuntimeError("spiking_fullsubnet_amd has no CPU path: move the module to a HIP device (`.to('cuda')`) first")
+            sd = {k: t.detach().cpu().numpy() for k, t in tensors}
+            self._engine = Engine(self._spec(), sd, dev)
+            self._engine_key = key
+        return self._engine
+
+    def _check_mode(self):
+        if self.training:
+            raise RuntimeError(
+                "training-mode forward (per-time-step batch-statistics BatchNorm and BPTT through the spike surrogate, "
+                "efficient_spiking_neuron.py:94-101,149-150) is not built in this package (SURVEY 8f rank 4); call .eval()")
+
+
+class SpikingFullSubNet(_EngineMixin, nn.Module):
+    def __init__(self, n_fft, hop_length, win_length, fdrc, fb_input_size, fb_hidden_size, fb_num_layers, fb_proj_size,
+                 fb_output_activate_function, sb_hidden_size, sb_num_layers, freq_cutoffs, df_orders, center_freq_sizes,
+                 neighbor_freq_sizes, use_pre_layer_norm_fb=True, use_pre_layer_norm_sb=True, bn=False, shared_weights=False,
+                 sequence_model="GSN", num_spks=1):
+        super().__init__()
+        self.fb_model = SequenceModel(input_size=fb_input_size, hidden_size=fb_hidden_size, num_layers=fb_num_layers,
+                                      shared_weights=shared_weights, sequence_model=sequence_model, proj_size=fb_proj_size,
+                                      output_activate_function=fb_output_activate_function, bn=bn,
+                                      use_pre_layer_norm=use_pre_layer_norm_fb)
+        self.sb_model = SubbandModel(freq_cutoffs=freq_cutoffs, center_freq_sizes=center_freq_sizes,
+                                     neighbor_freq_sizes=neighbor_freq_sizes, df_orders=df_orders, num_spks=num_spks,
+                                     hidden_size=sb_hidden_size, num_layers=sb_num_layers, shared_weights=shared_weights,
+                                     sequence_model=sequence_model, bn=bn, use_pre_layer_norm=use_pre_layer_norm_sb)
+        self.subband_model = None
+        self.fb_input_size, self.n_fft, self.hop_length, self.win_length = fb_input_size, n_fft, hop_length, win_length
+        self.fdrc, self.df_orders, self.num_spks = fdrc, df_orders, num_spks
+        self._path_spec = PathSpec(
+            front="live", n_fft=n_fft, fdrc=fdrc, fb_in=fb_input_size, fb_hidden=fb_hidden_size, fb_layers=fb_num_layers,
+            fb_proj=fb_proj_size, sb_hidden=sb_hidden_size, sb_layers=sb_num_layers, cutoffs=list(freq_cutoffs),
+            ctr=list(center_freq_sizes), nbr=list(neighbor_freq_sizes), ctr_fb=list(center_freq_sizes),
+            nbr_fb=[0] * len(center_freq_sizes), df=list(df_orders), num_spks=num_spks, shared=shared_weights, bn=bn,
+            ln_fb=use_pre_layer_norm_fb, ln_sb=use_pre_layer_norm_sb, laplace=False, proj_name="proj")
+        if fb_proj_size != fb_input_size or (n_fft // 2) % fb_input_size != 0:
+            # the reference tiles the full-band output (n_fft//2+1)//fb_input_size times to cover the spectrum (:442-443)
+            raise NotImplementedError("fb_proj_size must equal fb_input_size and divide n_fft/2 (as in every reference config)")
+
+    def _spec(self) -> PathSpec:
+        return self._path_spec
+
+    # ---- the two edges of the path: plain torch.stft / torch.istft (audio_feature.py:236-347) -------------
+    def stft(self, y):
+        window = torch.hann_window(self.n_fft, device=y.device)
+        return torch.stft(y, self.n_fft, self.hop_length, self.win_length, window=window, return_complex=True, pad_mode="constant")
+
+    def istft(self, spec, length=None):
+        window = torch.hann_window(self.n_fft, device=spec.device)
+        return torch.istft(spec, self.n_fft, self.hop_length, self.win_length, window=window, length=length)
+
+    @torch.no_grad()
+    def forward_stft(self, noisy_cmp, want_layers=True, want_membrane=False):
+        """The hot path alone: complex64 [B, 257, T] -> Engine.forward_stft result dict."""
+        self._check_mode()
+        return self.engine().forward_stft(noisy_cmp, want_layers=want_layers, want_membrane=want_membrane)
+
+    @torch.no_grad()
+    def forward(self, input):
+        assert input.ndim == 2, f"Input tensor must be 2D, but got {input.ndim}D."
+        self._check_mode()
+        batch_size, sequence_length = input.shape
+        res = self.engine().forward_stft(self.stft(input))
+        enh_stft = res["enh_stft"]  # [B, S, F, T]
+        if self.num_spks > 1:
+            enh_y = self.istft(enh_stft.reshape(batch_size * self.num_spks, *enh_stft.shape[2:]), length=sequence_length)
+            return enh_y.reshape(batch_size, self.num_spks, -1), res["fb_all"], res["sb_all"]
+        enh_y = self.istft(enh_stft[:, 0], length=sequence_length)
+        return enh_y, res["enh_mag"][:, 0], res["fb_all"], res["sb_all"]
