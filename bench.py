@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X -- the metric BASELINE.json names.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+complex noisy STFT [B=64, 257, T=1000] -> enhanced STFT + enhanced magnitude, INCLUDING every per-layer
+tensor the reference module returns (API-faithful: layer inputs, fp32 spike tensors, projections).
+Workload = BASELINE.json configs[2] (single MI355X, full model: full-band + sub-band groups, B=64, T=1000)
+with the live `baseline_m` sizes, in the fp32 parity mode (the mode the parity tests gate).
+For N > 1 every rank owns 64 clips (weak scaling: the path shards over independent clips, no data-path
+collective) and each step ends with the RCCL all-gather of the enhanced magnitudes -- the analogue of the
+reference's `accelerator.gather_for_metrics` (audiozen/trainer.py:511,555).
+
+Prints ONE JSON line on rank 0 (see the task contract), carrying
+  roofline      -- the dominant kernel (the fused sub-band GSN scan): algorithmic bytes per launch / HIP-event
+                   measured launch duration, against the 8 TB/s HBM3E peak;
+  cpu_baseline  -- the CPU oracle (oracle/, a C restatement of the reference, OpenMP over rows) timed on this
+                   host on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# API-faithful algorithmic bytes per clip-frame of the sub-band scan, baseline_m sizes:
+#   read 256 (noisy_mag) + 64 (fb_out) floats, write 1,152 coefficients and both layers' fp32 spikes
+#   (13 rows x 2 x 224) = 29,184 B.  The scan kernel is launched once per layer, so one launch is charged half.
+SB_SCAN_BYTES_PER_FRAME_PER_LAUNCH = 29184 / 2
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-layer-outputs", action="store_true", help="skip the fp32 spike tensors of the module API (reported in config)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    import refweights as rw
+    import spiking_fullsubnet_amd as pkg
+
+    kw = rw.LIVE_M
+    B, T = args.batch, args.frames
+    sd = rw.live_state_dict(kw, 21)
+    model = pkg.SpikingFullSubNet(**kw)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model = model.eval().to(dev)
+    wave = torch.from_numpy(rw.synth_wave(B, T, seed=rank)).to(dev)
+    stft = model.stft(wave).contiguous()  # untimed: the STFT is the edge of the path
+    assert stft.shape == (B, 257, T)
+    eng = model.engine()
+    want_layers = not args.no_layer_outputs
+    gathered = torch.empty((world * B, 1, 257, T), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        res = eng.forward_stft(stft, want_layers=want_layers)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, res["enh_mag"])
+        return res
+
+    for _ in range(args.warmup):
+        step()
+    eng.timers = {}  # HIP events around the scan launches, on the launch stream (engine.py)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    scan_ms = eng.timer_summary()
+    eng.timers = None
+
+    if rank == 0:
+        frames = world * B * T * args.steps
+        ms_per_step = 1e3 * dt / args.steps
+        sb_ms = scan_ms.get("scan:sb")
+        roofline = None
+        if sb_ms:
+            bytes_per_launch = SB_SCAN_BYTES_PER_FRAME_PER_LAUNCH * B * T
+            achieved = bytes_per_launch / (sb_ms["mean_ms"] * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("B") == B and tj.get("T") == T:
+                    traffic = tj.get("sb_scan_hbm_bytes_per_launch")
+            roofline = dict(bound="hbm", kernel="gsn_scan_kernel<G=1,TPW=2,KS=4,NW=8> (sub-band groups, one launch per layer)",
+                            achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
+                            traffic=traffic, launch_ms=round(sb_ms["mean_ms"], 4), launches=sb_ms["n"],
+                            algorithmic_bytes_per_launch=int(bytes_per_launch),
+                            per_step_us=round(1e3 * sb_ms["mean_ms"] / T, 3),
+                            other_kernels_ms={k: round(v["mean_ms"], 4) for k, v in scan_ms.items() if k != "scan:sb"})
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(kw, sd, stft)
+        line = dict(metric="STFT frames/sec at B=64 T=1000 F=257 (hot path: noisy STFT -> enhanced STFT + magnitude)",
+                    value=round(frames / dt, 1), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                    ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                    data="synthetic (0.05*randn waveform -> Hann-512/128 STFT, resident in HBM; seeded random weights, randomised BN stats)",
+                    config=dict(workload="configs[2]: single MI355X, full model (full-band + 3 sub-band groups / 13 units), "
+                                         "live baseline_m sizes, fp32 parity mode", clips_per_gpu=B, frames=T, bins=257,
+                                layer_outputs="api-faithful (fp32 spikes returned)" if want_layers else "skipped",
+                                parallelism=f"clip-sharded x{world}" + (" + RCCL all_gather(enh_mag)" if world > 1 else "")),
+                    roofline=roofline, cpu_baseline=cpu)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(kw, sd, stft):
+    """The CPU oracle (C restatement of the reference, OpenMP over rows) on a bounded sample of the same workload."""
+    from oracle import model as omodel
+    spec = omodel.spec_from_live_kwargs(kw)
+    Ts = 128
+    sample = stft[:, :, :Ts].cpu().numpy()  # all 64 clips x 128 frames (the model is causal: a prefix is a valid workload)
+    omodel.forward_from_stft(spec, sd, sample[:4], "f32")  # warm the OpenMP pool / page in
+    n, t0 = 0, time.perf_counter()
+    while True:
+        omodel.forward_from_stft(spec, sd, sample, "f32")
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or n >= 20:
+            break
+    frames = n * sample.shape[0] * Ts
+    return dict(value=round(frames / el, 1), unit="frames/s", cores=os.cpu_count(), kind="port",
+                sample=f"{n} x (B={sample.shape[0]}, T={Ts} prefix of the same synthetic batch), {el:.1f} s of wall time, fp32 oracle "
+                       f"(oracle/sfsn_oracle.c via oracle.model), OpenMP threads = all {os.cpu_count()} host cores",
+                reference_pytorch_cpu="3,265 frames/s for the reference's own PyTorch forward at B=64,T=1000 on 8 vCPU (BASELINE.md section 2, survey container)")
+
+
+if __name__ == "__main__":
+    main()

@@ -78,18 +78,23 @@ int sfsn_w3_unpack(const int8_t* packed, const float* dq, int n_out, int k_in, f
  * (the sub-band groups share H, MODEL:239-261).
  *
  * Per segment and per frame t:
- *     pre_f = (zin[t][r][j]      + bias[j])     + (h . W_hh^T)[j]          NEURON:140-145
- *     pre_g = (zin[t][r][gofs+j] + bias[H + j]) + (h . W_hh^T)[gofs + j]   (gofs = 0 shared, H otherwise)
+ *     pre_f = zin[t][r][j] + (h . W_hh^T)[j]                               NEURON:140-145
+ *     pre_g = zin[t][r][H + j] + (h . W_hh^T)[H + j]                       (unshared weights)
+ *           = pre_f + (bias[H + j] - bias[j])                              (shared weights: one product serves both gates)
  *     f = sigmoid(pre_f);  c' = f*c + (1-f)*pre_g;  c'' = fma(c', bn_alpha[j], bn_beta[j])
  *     h' = (c'' >= 0);  carry (h', c'')                                    NEURON:146-153
- * zin = x . W_ih^T is precomputed by sfsn_input_proj_f32 / sfsn_spike_proj (time-parallel);  bn_alpha /
+ * zin is the time-parallel INPUT TERM INCLUDING bias_ih, as the reference associates it ((x.W_ih^T + bias) + h.W_hh^T):
+ *     shared:   zin[.][j] = (x . W_ih^T)[j] + bias[j]            (forget-gate bias; the scan adds the bias difference)
+ *     unshared: zin[.][g*H + j] = (x . W_ih^T)[g*H + j] + bias[g*H + j]
+ * precomputed by sfsn_input_proj_f32 / sfsn_spike_proj with their bias argument;  bn_alpha /
  * bn_beta are eval-mode BatchNorm1d folded the way ATen's CPU kernel evaluates it (alpha = gamma /
  * sqrt(var + eps), beta = fma(-mean, alpha, bias); identity = (1, 0) when bn=False).
  * The hidden state h lives in LDS as int8, the membrane c in registers, W_hh in registers as packed int8
- * digits for the whole scan; one workgroup owns 16 rows.
+ * digits for the whole scan; one workgroup owns 16 rows.  All segments of one launch must request the same set
+ * of optional outputs (it selects the compiled kernel variant).
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct sfsn_scan_segment {
-    const float* zin;      /* [T][R][G*H], G = 1 shared / 2 unshared                                         */
+    const float* zin;      /* [T][R][G*H] input term incl. bias (see above), G = 1 shared / 2 unshared      */
     const int8_t* w_hh;    /* sfsn_w3_pack(W_hh [G*H][H])                                                     */
     const float* w_dq;     /* [pad16(G*H)] from sfsn_w3_pack                                                  */
     const float* bias;     /* [2H]  bias_ih                                                                   */
@@ -98,8 +103,8 @@ typedef struct sfsn_scan_segment {
     float* h_state;        /* [R][H] in: h at t=-1 (0/1), out: h at t=T-1   (NEURON:50-62 state in/out)       */
     float* c_state;        /* [R][H] in/out membrane                                                          */
     float* spikes_f32;     /* [T][R][H] out, nullable  (the reference's all_layer_outputs entry)              */
-    int8_t* spikes_i8;     /* [T][R][pad64(H)] out, nullable (B operand of the next sfsn_spike_proj)          */
-    float* membrane;       /* [T][R][H] out, nullable  (post-BN membrane; parity tests only)                  */
+    int8_t* spikes_i8;     /* [T][R][pad64(H)] out, REQUIRED (B operand of the next sfsn_spike_proj)         */
+    float* membrane;       /* [T][R][H] out, nullable  (post-BN membrane; parity tests only; needs spikes_f32)*/
     int R;                 /* rows in this segment (> 0)                                                      */
 } sfsn_scan_segment;
 
@@ -108,7 +113,7 @@ int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs /* host array */, int n_se
 
 /* ------------------------------------------------------------------------------------------------------
  * Time-parallel products.
- * sfsn_input_proj_f32: z[m][n] = sum_k x[m][k] * w[n][k]           (NEURON:141 for layer 0: real-valued x)
+ * sfsn_input_proj_f32: z[m][n] = sum_k x[m][k] * w[n][k] (+ bias[n])  (NEURON:141-142 for layer 0: real-valued x)
  *     exact-fp32 MFMA (v_mfma_f32_16x16x4_f32); x [M][K], w [N][K] row-major fp32, z [M][ldz] (columns 0..N-1 written;
  *     ldz > N lets the two gate halves of an unshared cell land side by side).
  * sfsn_spike_proj:     y[m][n] = dq[n] * sum_k s[m][k] * Wq[n][k] (+ bias[n])
@@ -116,8 +121,8 @@ int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs /* host array */, int n_se
  *     Used for layer>=1 input products (bias NULL: NEURON:141) and the projection (nn.Linear MODEL:49-52,118;
  *     FROZEN:71-76,125: bias added after the product).
  * ---------------------------------------------------------------------------------------------------- */
-int sfsn_input_proj_f32(const float* x, const float* w, float* z, int M, int K, int N, int ldz /* >= N: row stride of z */,
-                        void* stream);
+int sfsn_input_proj_f32(const float* x, const float* w, const float* bias /* [N], nullable */, float* z, int M, int K, int N,
+                        int ldz /* >= N: row stride of z */, void* stream);
 int sfsn_spike_proj(const int8_t* s, const int8_t* w_packed, const float* w_dq, const float* bias /* nullable */,
                     float* y, int M, int K, int N, int ldy /* >= N: row stride of y */, void* stream);
 

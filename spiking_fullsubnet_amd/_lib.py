@@ -74,7 +74,7 @@ def lib() -> ctypes.CDLL:
     L.sfsn_gsn_layer_scan.restype = _I
     L.sfsn_gsn_layer_scan.argtypes = [ctypes.POINTER(ScanSegment), _I, _I, _I, _I, _P]
     L.sfsn_input_proj_f32.restype = _I
-    L.sfsn_input_proj_f32.argtypes = [_P, _P, _P, _I, _I, _I, _I, _P]
+    L.sfsn_input_proj_f32.argtypes = [_P, _P, _P, _P, _I, _I, _I, _I, _P]
     L.sfsn_spike_proj.restype = _I
     L.sfsn_spike_proj.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]
     L.sfsn_features.restype = _I

@@ -16,6 +16,9 @@
 //    (double buffered: one barrier per step), the membrane in registers in accumulator layout.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "sfsn.h"
 
@@ -54,19 +57,241 @@ __device__ __forceinline__ float recombine3(int a0, int a1, int a2) {
     return __builtin_fmaf((float)a2, 65536.0f, (float)(a1 * 256 + a0));
 }
 
-__device__ __forceinline__ float fast_sigmoid(float x) {
-    // 1 / (1 + e^-x) with the hardware exp2 / rcp (each ~1 ulp): |error| <~ 2e-7 absolute.
-    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+// ---- input-term prefetch hidden from the compiler's s_waitcnt bookkeeping ------------------------------------
+// hipcc merges control-flow paths conservatively and ends up draining vmcnt (to 0, or to a count that includes the
+// spike stores issued a few hundred cycles earlier) before every use of a prefetched register: measured 1.36 us
+// per step instead of 0.83.  The loads are therefore issued from inline asm (invisible to the scoreboard) and
+// waited for by an explicit COUNTED s_waitcnt whose statement names every destination register as "+v", which
+// pins all consumers behind it (cdna_hip_programming.md 5.7, form ii).
+__device__ __forceinline__ void prefetch16(v4f& dst, const float* src) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
+template <int COUNT, int NREG>
+__device__ __forceinline__ void wait_prefetch(const v4f* zc) {
+    v4f* z = const_cast<v4f*>(zc);
+    static_assert(COUNT <= 63, "vmcnt is a 6-bit field");
+    if constexpr (NREG == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(z[0]) : "n"(COUNT));
+    if constexpr (NREG == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(z[0]), "+v"(z[1]) : "n"(COUNT));
+    if constexpr (NREG == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]) : "n"(COUNT));
+    if constexpr (NREG == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]) : "n"(COUNT));
+    if constexpr (NREG == 5)
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]) : "n"(COUNT));
+    static_assert(NREG >= 1 && NREG <= 5, "extend wait_prefetch");
+}
+
+// ---- the scan body for a wave that owns NTL (compile-time) output tiles -------------------------------------
+// Straight-line code per step: no per-tile or per-row branch.  Rows past R are CLAMPED duplicates of row R-1: they
+// run the same instruction sequence on the same data, produce bit-identical values and store them to the same
+// addresses as the original (a benign duplicate write), so a step is one basic block the scheduler can interleave
+// and every s_waitcnt sits on the straight path.
+//
+// Global traffic of a step:
+//   * the input term of step t+1 is prefetched at the top of step t (prefetch16 / wait_prefetch above);
+//   * the spikes of step t-1 are FLUSHED from the LDS hidden-state buffer (which holds them all as int8) at the top
+//     of step t by all threads of the workgroup, each thread owning FL 4-neuron chunks: whole rows go out as full,
+//     contiguous cache lines (fp32: 16 B per lane, int8: 4 B per lane).  Storing the accumulator fragments directly
+//     (64 B per row per tile) made every store a partial-line write; those took longer than a step to retire and
+//     the in-order vmcnt queue stalled the prefetch behind them (measured 1.4 us per step vs 0.8 without stores).
+template <int KS, int NW, int OUT>
+struct ScanFlush {
+    static constexpr int LDH = KS * 64 + 16;
+    static constexpr int HP = KS * 64;
+    static constexpr int CHUNKS = 16 * (HP / 4);                       // 4-neuron chunks of the padded 16 x HP tile
+    static constexpr int FL = (CHUNKS + NW * 64 - 1) / (NW * 64);      // chunks per thread
+    static constexpr int NSTF = ((OUT & 1) ? 1 : 0) + ((OUT & 2) ? 1 : 0);  // stores per chunk
+    int off_f32[FL], off_i8[FL], off_lds[FL];
+
+    __device__ __forceinline__ void init(int tid, int row0, int R, int H) {
+#pragma unroll
+        for (int k = 0; k < FL; ++k) {
+            const int c = (tid + k * NW * 64) % CHUNKS;  // surplus threads duplicate a chunk (same data, same address)
+            const int rr = c / (HP / 4);
+            int j4 = (c - rr * (HP / 4)) * 4;
+            if (j4 > H - 4) j4 = H - 4;    // pad columns duplicate the row's last real chunk
+            const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;  // rows past R duplicate row R-1 (LDS holds the same values)
+            off_lds[k] = rr * LDH + j4;
+            off_f32[k] = rsrc * H + j4;
+            off_i8[k] = rsrc * HP + j4;
+        }
+    }
+    // spikes of step ts (held in hsrc) -> global
+    __device__ __forceinline__ void run(const int8_t* hsrc, float* __restrict__ spikes_f32, int8_t* __restrict__ spikes_i8, int ts,
+                                        int R, int H) const {
+        if constexpr (NSTF > 0) {
+            float* pf = spikes_f32 + (size_t)ts * R * H;
+            int8_t* p8 = spikes_i8 + (size_t)ts * R * HP;
+#pragma unroll
+            for (int k = 0; k < FL; ++k) {
+                const unsigned pk = *reinterpret_cast<const unsigned*>(hsrc + off_lds[k]);
+                if (OUT & 2) *reinterpret_cast<unsigned*>(p8 + off_i8[k]) = pk;
+                if (OUT & 1) {
+                    const v4f sp = {(float)(pk & 0xffu), (float)((pk >> 8) & 0xffu), (float)((pk >> 16) & 0xffu), (float)(pk >> 24)};
+                    *reinterpret_cast<v4f*>(pf + off_f32[k]) = sp;
+                }
+            }
+        }
+    }
+};
+
+template <int G, int KS, int NW, int OUT, int NTL>
+__device__ __forceinline__ void scan_body(const float* __restrict__ zin, const int8_t* __restrict__ w_hh,
+                                          float* __restrict__ spikes_f32, int8_t* __restrict__ spikes_i8,
+                                          float* __restrict__ membrane, float* __restrict__ h_state, float* __restrict__ c_state,
+                                          const float (*cst)[KS * 64], int8_t (*hbuf)[16 * (KS * 64 + 16)], int T, int H, int NT,
+                                          int R, int row0, int rowc, int n, int q, int tid, int wave) {
+    constexpr int LDH = KS * 64 + 16;
+    using Flush = ScanFlush<KS, NW, OUT>;
+    Flush fl;
+    fl.init(tid, row0, R, H);
+    const int lane = tid & 63;
+    if constexpr (NTL == 0) {
+        // a wave without tiles still flushes its share of the spikes and keeps the workgroup's barrier count
+        for (int t = 0; t < T; ++t) {
+            if (t > 0) fl.run(hbuf[t & 1], spikes_f32, spikes_i8, t - 1, R, H);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (T > 0) fl.run(hbuf[T & 1], spikes_f32, spikes_i8, T - 1, R, H);
+        return;
+    } else {
+        const int ldz = G * H;
+        constexpr int NMEM = (OUT & 4) ? NTL : 0;  // membrane stores per step (test output, accumulator layout)
+        // register-resident recurrent weights (int8 digits in MFMA A-fragment order) and membrane state
+        v4i W[NTL][G][KS][3];
+        v4f c[NTL];
+        int col[NTL];  // first neuron of my 4-neuron group in tile i
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+            const int ct = wave + NW * i;
+            col[i] = ct * 16 + q * 4;
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const size_t tile = (size_t)d * (G * NT) + (size_t)g * NT + ct;
+                        W[i][g][ks][d] = *reinterpret_cast<const v4i*>(w_hh + ((tile * KS + ks) * 64 + lane) * 16);
+                    }
+            c[i] = *reinterpret_cast<const v4f*>(c_state + (size_t)rowc * H + col[i]);
+        }
+        // input term for t = 0 (zA: even t, zB: odd t -- ping-pong so that a prefetch is consumed a step later
+        // without a register copy)
+        v4f zA[NTL][G], zB[NTL][G];
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                zA[i][g] = zB[i][g] = v4f{0, 0, 0, 0};
+                if (T > 0) zA[i][g] = *reinterpret_cast<const v4f*>(zin + (size_t)rowc * ldz + g * H + col[i]);
+            }
+        // Drain every prologue load HERE, once: otherwise the compiler's conservative scoreboard re-waits for the
+        // weight registers with vmcnt(0) inside the loop, which also drains the in-flight stores of the previous step.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+
+        // FIRST = the peeled step 0: nothing to flush (hc is the initial state) and its input term was loaded and
+        // drained in the prologue, so no wait either.
+        auto step = [&](const v4f (&z)[NTL][G], v4f (&zn)[NTL][G], const int8_t* hc, int8_t* hn, int t, int tn, auto first)
+                        __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first)::value;
+            const float* zt = zin + (size_t)tn * R * ldz;
+#pragma unroll
+            for (int i = 0; i < NTL; ++i)
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (!(OUT & 8)) prefetch16(zn[i][g], zt + rowc * ldz + g * H + col[i]);
+            v4i b[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(hc + n * LDH + ks * 64 + q * 16);
+            if constexpr (!FIRST) {
+                // spikes of step t-1 (= hc) -> global
+                fl.run(hc, spikes_f32, spikes_i8, t - 1, R, H);
+                // This step's input term was requested one step ago.  vmcnt retires in order and counts stores too, so
+                // the wait is COUNTED: what was issued after those loads -- last step's membrane stores, the loads and
+                // the flush stores just issued -- may stay in flight; only stores a full step old are waited for.
+                if (!(OUT & 8)) wait_prefetch<NMEM + NTL * G + Flush::FL * Flush::NSTF, NTL * G>(&z[0][0]);
+            }
+#pragma unroll
+            for (int i = 0; i < NTL; ++i) {
+                const int cc = col[i];
+                v4f pre[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][0], b[ks], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][1], b[ks], a1, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][2], b[ks], a2, 0, 0, 0);
+                    }
+                    const v4f dq = *reinterpret_cast<const v4f*>(&cst[3 + g][cc]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)  // dq is a power of two: fma(rec, dq, z) == z + rec*dq with ONE rounding
+                        pre[g][r] = __builtin_fmaf(recombine3(a0[r], a1[r], a2[r]), dq[r], z[i][g][r]);
+                }
+                const v4f alpha = *reinterpret_cast<const v4f*>(&cst[1][cc]);
+                const v4f beta = *reinterpret_cast<const v4f*>(&cst[2][cc]);
+                v4f pre_g;
+                if constexpr (G == 2) {
+                    pre_g = pre[1];
+                } else {
+                    const v4f db = *reinterpret_cast<const v4f*>(&cst[0][cc]);  // bias_g - bias_f
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pre_g[r] = pre[0][r] + db[r];
+                }
+                v4f cy;
+                unsigned pk = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // f = sigmoid(pre_f) with the hardware exp2 / rcp (~1 ulp each)
+                    const float f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre[0][r] * -1.44269504088896341f));
+                    const float m = __builtin_fmaf(f, c[i][r] - pre_g[r], pre_g[r]);  // f*c + (1-f)*g
+                    const float y = __builtin_fmaf(m, alpha[r], beta[r]);              // eval BatchNorm, ATen form
+                    cy[r] = y;
+                    pk |= (y >= 0.0f) ? (1u << (8 * r)) : 0u;                           // Triangle.forward, NEURON:89
+                }
+                c[i] = cy;
+                *reinterpret_cast<unsigned*>(hn + n * LDH + cc) = pk;
+                if (OUT & 4) *reinterpret_cast<v4f*>(membrane + ((size_t)t * R + rowc) * H + cc) = cy;
+            }
+            // h_t complete in hn before anyone reads it; hc is free for the next step's writes.  Only LDS traffic has
+            // to drain here -- global stores stay in flight across the barrier.
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0), vmcnt/expcnt untouched
+            __builtin_amdgcn_s_barrier();
+        };
+
+        if (T > 0) step(zA, zB, hbuf[0], hbuf[1], 0, (1 < T) ? 1 : 0, std::true_type{});
+#pragma unroll 1
+        for (int t = 1; t < T; t += 2) {
+            step(zB, zA, hbuf[1], hbuf[0], t, (t + 1 < T) ? t + 1 : t, std::false_type{});
+            if (t + 1 < T) step(zA, zB, hbuf[0], hbuf[1], t + 1, (t + 2 < T) ? t + 2 : t + 1, std::false_type{});
+        }
+
+        // the last step's (unused) prefetch is invisible to the compiler: drain it before its registers are reused
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (T > 0) fl.run(hbuf[T & 1], spikes_f32, spikes_i8, T - 1, R, H);
+        // final state (duplicate rows write the same values to the same place)
+        const int8_t* hl = hbuf[T & 1];  // h_{T-1} (or the untouched initial state when T == 0)
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+            *reinterpret_cast<v4f*>(c_state + (size_t)rowc * H + col[i]) = c[i];
+            const unsigned pk = *reinterpret_cast<const unsigned*>(hl + n * LDH + col[i]);
+            const v4f h = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)((pk >> 24) & 1u)};
+            *reinterpret_cast<v4f*>(h_state + (size_t)rowc * H + col[i]) = h;
+        }
+    }
 }
 
 // G = 1: shared gate weights (W [H][*] used for both gates); G = 2: separate forget / cell weights.
-// TPW = output tiles per wave, KS = 64-wide k steps, NW = waves per workgroup (8 -> 256 VGPRs per wave,
-// 4 -> 512: the H = 320 full-band model needs 300 registers of weights per wave).
-template <int G, int TPW, int KS, int NW>
+// KS = 64-wide k steps; NW = waves per workgroup; TPW = tiles owned by the first (NT - NW*(TPW-1)) waves, the
+// rest own TPW-1 (tiles are dealt round-robin, so the four SIMDs carry equal MFMA load and no wave computes a
+// tile that does not exist).  OUT bit 0: fp32 spikes, bit 1: int8 spikes, bit 2: membranes -- compile-time so that
+// the stores are straight-line code.
+template <int G, int KS, int NW, int TPW, int OUT>
 __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
     constexpr int LDH = KS * 64 + 16;  // +16 B row pad: the 16 rows of a B fragment land on distinct LDS banks
     constexpr int HP = KS * 64;        // padded hidden size
-    constexpr int NC = 4 + G;          // per-neuron constant vectors: bias_f, bias_g, alpha, beta, dq[G]
+    constexpr int NC = 3 + G;          // per-neuron constant vectors: (bias_g - bias_f), alpha, beta, dq[G]
     __shared__ __attribute__((aligned(16))) int8_t hbuf[2][16 * LDH];
     __shared__ __attribute__((aligned(16))) float cst[NC][HP];
 
@@ -82,158 +307,37 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
     const ScanSegDev sg = p.seg[s];
     const int H = p.H, NT = p.NT, T = p.T, R = sg.R;
     const int row0 = ((int)blockIdx.x - sg.tile0) * 16;
-    const int row = row0 + n;
-    const bool valid = row < R;
-    const int rowc = valid ? row : R - 1;
-    const int ldz = G * H;
+    const int rowc = (row0 + n < R) ? row0 + n : R - 1;
 
-    // ---- per-neuron constants -> LDS; zero the hidden-state buffers (pads must read as 0 spikes) --------
+    // per-neuron constants -> LDS; zero the hidden-state buffers (pads must read as 0 spikes)
     for (int j = tid; j < HP; j += NW * 64) {
         const bool in = j < H;
-        cst[0][j] = in ? sg.bias[j] : 0.0f;
-        cst[1][j] = in ? sg.bias[H + j] : 0.0f;
-        cst[2][j] = in ? sg.bn_alpha[j] : 0.0f;
-        cst[3][j] = in ? sg.bn_beta[j] : 0.0f;
+        cst[0][j] = in ? sg.bias[H + j] - sg.bias[j] : 0.0f;
+        cst[1][j] = in ? sg.bn_alpha[j] : 0.0f;
+        cst[2][j] = in ? sg.bn_beta[j] : 0.0f;
 #pragma unroll
-        for (int g = 0; g < G; ++g) cst[4 + g][j] = in ? sg.w_dq[g * H + j] : 0.0f;
+        for (int g = 0; g < G; ++g) cst[3 + g][j] = in ? sg.w_dq[g * H + j] : 0.0f;
     }
     for (int i = tid; i < 2 * 16 * LDH / 4; i += NW * 64) reinterpret_cast<int*>(&hbuf[0][0])[i] = 0;
-
-    // ---- register-resident recurrent weights, membrane state -----------------------------------------
-    v4i W[TPW][G][KS][3];
-    v4f c[TPW];
-    bool have_t[TPW];  // wave-uniform: does tile i of this wave exist
-    int col[TPW];      // first neuron of my 4-neuron group in tile i
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int ct = wave + NW * i;
-        const bool have = ct < NT;
-        have_t[i] = have;
-        col[i] = have ? ct * 16 + q * 4 : 0;
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const size_t tile = (size_t)d * (G * NT) + (size_t)g * NT + (have ? ct : 0);
-                    W[i][g][ks][d] = *reinterpret_cast<const v4i*>(sg.w_hh + ((tile * KS + ks) * 64 + lane) * 16);
-                }
-        c[i] = *reinterpret_cast<const v4f*>(sg.c_state + (size_t)rowc * H + col[i]);
+    __syncthreads();
+    // initial hidden state h_{-1} -> hbuf[0] as int8 (all threads cooperate; 4 neurons per thread-iteration)
+    for (int idx = tid; idx < 16 * (H / 4); idx += NW * 64) {
+        const int rr = idx / (H / 4), j4 = (idx - rr * (H / 4)) * 4;
+        const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;
+        const v4f h = *reinterpret_cast<const v4f*>(sg.h_state + (size_t)rsrc * H + j4);
+        const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
+                            (h.w > 0.5f ? 0x1000000u : 0u);
+        *reinterpret_cast<unsigned*>(&hbuf[0][rr * LDH + j4]) = pk;
     }
     __syncthreads();
-    // initial hidden state h_{-1} -> hbuf[0] as int8
-#pragma unroll
-    for (int i = 0; i < TPW; ++i)
-        if (have_t[i]) {
-            const v4f h = *reinterpret_cast<const v4f*>(sg.h_state + (size_t)rowc * H + col[i]);
-            const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
-                                (h.w > 0.5f ? 0x1000000u : 0u);
-            *reinterpret_cast<unsigned*>(&hbuf[0][n * LDH + col[i]]) = pk;
-        }
-    __syncthreads();
 
-    // ---- input term for t = 0 ---------------------------------------------------------------------------
-    v4f zf[TPW], zg[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        zf[i] = v4f{0, 0, 0, 0};
-        zg[i] = v4f{0, 0, 0, 0};
-        if (have_t[i] && T > 0) {
-            const float* zp = sg.zin + (size_t)rowc * ldz + col[i];
-            zf[i] = *reinterpret_cast<const v4f*>(zp);
-            if (G == 2) zg[i] = *reinterpret_cast<const v4f*>(zp + H);
-        }
-    }
-
-#pragma unroll 1
-    for (int t = 0; t < T; ++t) {
-        const int8_t* hc = hbuf[t & 1];
-        int8_t* hn = hbuf[(t & 1) ^ 1];
-        // next step's input term: in flight during this step's MFMA phase
-        v4f zfn[TPW], zgn[TPW];
-        const int tn = (t + 1 < T) ? t + 1 : t;
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            zfn[i] = zf[i];
-            zgn[i] = zg[i];
-            if (have_t[i]) {
-                const float* zp = sg.zin + ((size_t)tn * R + rowc) * ldz + col[i];
-                zfn[i] = *reinterpret_cast<const v4f*>(zp);
-                if (G == 2) zgn[i] = *reinterpret_cast<const v4f*>(zp + H);
-            }
-        }
-        // B fragments: h_{t-1} of my row, 16 consecutive k per lane per k-step
-        v4i b[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(hc + n * LDH + ks * 64 + q * 16);
-
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            if (!have_t[i]) continue;  // wave-uniform (scalar branch)
-            const int cc = col[i];
-            float rec[G][4];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][0], b[ks], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][1], b[ks], a1, 0, 0, 0);
-                    a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][2], b[ks], a2, 0, 0, 0);
-                }
-                const v4f dq = *reinterpret_cast<const v4f*>(&cst[4 + g][cc]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rec[g][r] = recombine3(a0[r], a1[r], a2[r]) * dq[r];
-            }
-            const v4f bias_f = *reinterpret_cast<const v4f*>(&cst[0][cc]);
-            const v4f bias_g = *reinterpret_cast<const v4f*>(&cst[1][cc]);
-            const v4f alpha = *reinterpret_cast<const v4f*>(&cst[2][cc]);
-            const v4f beta = *reinterpret_cast<const v4f*>(&cst[3][cc]);
-            v4f cy, sp;
-            unsigned pk = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float zin_f = zf[i][r];
-                const float zin_g = (G == 2) ? zg[i][r] : zin_f;
-                const float pre_f = (zin_f + bias_f[r]) + rec[0][r];      // NEURON:140-145 association
-                const float pre_g = (zin_g + bias_g[r]) + rec[G - 1][r];
-                const float f = fast_sigmoid(pre_f);
-                const float m = f * c[i][r] + (1.0f - f) * pre_g;         // four roundings (contraction off)
-                const float y = __builtin_fmaf(m, alpha[r], beta[r]);     // eval BatchNorm, ATen form
-                cy[r] = y;
-                const bool fire = y >= 0.0f;                               // Triangle.forward, NEURON:89
-                sp[r] = fire ? 1.0f : 0.0f;
-                pk |= fire ? (1u << (8 * r)) : 0u;
-            }
-            c[i] = cy;
-            *reinterpret_cast<unsigned*>(hn + n * LDH + cc) = pk;
-            if (valid) {
-                const size_t o = ((size_t)t * R + row);
-                if (sg.spikes_f32) *reinterpret_cast<v4f*>(sg.spikes_f32 + o * H + cc) = sp;
-                if (sg.spikes_i8) *reinterpret_cast<unsigned*>(sg.spikes_i8 + o * HP + cc) = pk;
-                if (sg.membrane) *reinterpret_cast<v4f*>(sg.membrane + o * H + cc) = cy;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            zf[i] = zfn[i];
-            zg[i] = zgn[i];
-        }
-        __syncthreads();  // h_t complete in hn before anyone reads it; hc free for step t+1's writes
-    }
-
-    if (valid) {
-        const int8_t* hl = hbuf[T & 1];  // h_{T-1} (or the untouched initial state when T == 0)
-#pragma unroll
-        for (int i = 0; i < TPW; ++i)
-            if (have_t[i]) {
-                *reinterpret_cast<v4f*>(sg.c_state + (size_t)row * H + col[i]) = c[i];
-                const unsigned pk = *reinterpret_cast<const unsigned*>(hl + n * LDH + col[i]);
-                const v4f h = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)((pk >> 24) & 1u)};
-                *reinterpret_cast<v4f*>(sg.h_state + (size_t)row * H + col[i]) = h;
-            }
-    }
+    const int n_hi = NT - NW * (TPW - 1);  // waves [0, n_hi) own TPW tiles, the others TPW-1
+    if (wave < n_hi)
+        scan_body<G, KS, NW, OUT, TPW>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state, cst, hbuf,
+                                       T, H, NT, R, row0, rowc, n, q, tid, wave);
+    else
+        scan_body<G, KS, NW, OUT, TPW - 1>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state, cst,
+                                           hbuf, T, H, NT, R, row0, rowc, n, q, tid, wave);
 }
 
 // =====================================================================================================
@@ -315,7 +419,8 @@ __global__ __launch_bounds__(512) void spike_proj_kernel(const int8_t* __restric
 // =====================================================================================================
 template <int TPW, int KC>
 __global__ __launch_bounds__(512) void input_proj_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          float* __restrict__ z, int M, int K, int N, int ldz, int NT, int NWN) {
+                                                          const float* __restrict__ bias, float* __restrict__ z, int M, int K, int N, int ldz, int NT,
+                                                          int NWN) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
@@ -324,12 +429,15 @@ __global__ __launch_bounds__(512) void input_proj_kernel(const float* __restrict
     if (mw >= MW) return;
 
     float W[TPW][KC][4];
+    v4f bv[TPW];
     int col[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int ct = cg + NWN * i;
         const bool have = ct < NT;
         col[i] = have ? ct * 16 + q * 4 : -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[i][r] = (bias && have && col[i] + r < N) ? bias[col[i] + r] : 0.0f;
         const int wr = ct * 16 + n;  // weight row this lane supplies as A
 #pragma unroll
         for (int c = 0; c < KC; ++c)
@@ -361,6 +469,8 @@ __global__ __launch_bounds__(512) void input_proj_kernel(const float* __restrict
             for (int c = 0; c < KC; ++c)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[i][c][e], b[c][e], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += bv[i][r];
             if (row < M) {
                 float* zp = z + (size_t)row * ldz + col[i];
                 if ((ldz & 3) == 0 && col[i] + 3 < N) {
@@ -628,9 +738,20 @@ extern "C" int sfsn_device_count(void) {
     return n;
 }
 
-template <int G, int TPW, int KS, int NW>
-static int launch_scan(const ScanParams& p, int tiles, hipStream_t st) {
-    hipLaunchKernelGGL((gsn_scan_kernel<G, TPW, KS, NW>), dim3(tiles), dim3(NW * 64), 0, st, p);
+template <int G, int KS, int NW, int TPW>
+static int launch_scan(const ScanParams& p, int tiles, int out, hipStream_t st) {
+    // output sets compiled: int8 only (downstream products need it), fp32 + int8 (module API), + membranes (tests)
+    switch (out) {
+        case 2: hipLaunchKernelGGL((gsn_scan_kernel<G, KS, NW, TPW, 2>), dim3(tiles), dim3(NW * 64), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gsn_scan_kernel<G, KS, NW, TPW, 3>), dim3(tiles), dim3(NW * 64), 0, st, p); break;
+        case 7: hipLaunchKernelGGL((gsn_scan_kernel<G, KS, NW, TPW, 7>), dim3(tiles), dim3(NW * 64), 0, st, p); break;
+#ifdef SFSN_TIMING_EXPERIMENTS  // wrong-result variants for bottleneck attribution only (scripts/exp_scan.sh)
+        case 0: hipLaunchKernelGGL((gsn_scan_kernel<G, KS, NW, TPW, 0>), dim3(tiles), dim3(NW * 64), 0, st, p); break;
+        case 8: hipLaunchKernelGGL((gsn_scan_kernel<G, KS, NW, TPW, 8>), dim3(tiles), dim3(NW * 64), 0, st, p); break;
+        case 11: hipLaunchKernelGGL((gsn_scan_kernel<G, KS, NW, TPW, 11>), dim3(tiles), dim3(NW * 64), 0, st, p); break;
+#endif
+        default: return SFSN_EUNSUPPORTED;
+    }
     return hip_ok(hipGetLastError());
 }
 
@@ -639,8 +760,14 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
     if (H % 16 != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     ScanParams p;
     int tiles = 0;
+    // the set of outputs must be the same for every segment of a launch (it selects the kernel variant);
+    // the int8 spikes are always produced (every consumer of a scan in this library reads them)
+    int out = 2 | (segs[0].spikes_f32 ? 1 : 0) | (segs[0].membrane ? 4 : 0);
+    if (out == 6) return SFSN_EUNSUPPORTED;  // membranes are a test output: request them together with fp32 spikes
     for (int i = 0; i < n_segs; ++i) {
         const sfsn_scan_segment& s = segs[i];
+        if (!s.spikes_i8 || (s.spikes_f32 != nullptr) != ((out & 1) != 0) || (s.membrane != nullptr) != ((out & 4) != 0))
+            return SFSN_EINVAL;
         if (s.R <= 0 || !s.zin || !s.w_hh || !s.w_dq || !s.bias || !s.bn_alpha || !s.bn_beta || !s.h_state || !s.c_state)
             return SFSN_EINVAL;
         if (!aligned16(s.zin) || !aligned16(s.w_hh) || !aligned16(s.h_state) || !aligned16(s.c_state) ||
@@ -653,17 +780,27 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
         tiles += (s.R + 15) / 16;
     }
     p.nseg = n_segs; p.T = T; p.H = H; p.NT = H / 16;
+#ifdef SFSN_TIMING_EXPERIMENTS
+    if (const char* e = getenv("SFSN_SCAN_DEBUG_OUT")) out = atoi(e);
+#endif
     const int NT = p.NT, KS = (H + 63) / 64;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // 8 waves (2 per SIMD, <= 256 VGPRs) while the wave's share of W fits, else 4 waves with 512 VGPRs each.
-    const int NW = shared ? (H <= 256 ? 8 : 4) : (H <= 128 ? 8 : 4);
-    const int TPW = (NT + NW - 1) / NW;
-#define SCAN_CASE(G_, TPW_, KS_, NW_) \
-    if (NW == NW_ && TPW == TPW_ && KS == KS_) return launch_scan<G_, TPW_, KS_, NW_>(p, tiles, st);
+    // Waves per workgroup: as many as the per-wave share of W allows registers for (16 waves -> 128 VGPRs, 8 -> 256):
+    // more waves per SIMD overlap one wave's epilogue VALU with another's MFMAs and hide LDS / VMEM latency.
+    int NW, TPW;
     if (shared) {
-        SCAN_CASE(1, 1, 1, 8) SCAN_CASE(1, 1, 2, 8) SCAN_CASE(1, 2, 3, 8) SCAN_CASE(1, 2, 4, 8) SCAN_CASE(1, 5, 5, 4)
+        NW = H <= 256 ? 16 : 4;  // H = 320: 300 weight registers per wave need the whole 512-entry file (1 wave / SIMD)
     } else {
-        SCAN_CASE(2, 1, 1, 8) SCAN_CASE(2, 1, 2, 8) SCAN_CASE(2, 3, 3, 4) SCAN_CASE(2, 4, 4, 4)
+        NW = H <= 128 ? 16 : 8;
+        if (H > 256) return SFSN_EUNSUPPORTED;  // 2 gates x 320^2 x 3 digits does not fit one CU's register file
+    }
+    TPW = (NT + NW - 1) / NW;
+#define SCAN_CASE(G_, KS_, NW_, TPW_) \
+    if (KS == KS_ && NW == NW_ && TPW == TPW_) return launch_scan<G_, KS_, NW_, TPW_>(p, tiles, out, st);
+    if (shared) {
+        SCAN_CASE(1, 1, 16, 1) SCAN_CASE(1, 2, 16, 1) SCAN_CASE(1, 3, 16, 1) SCAN_CASE(1, 4, 16, 1) SCAN_CASE(1, 5, 4, 5)
+    } else {
+        SCAN_CASE(2, 1, 16, 1) SCAN_CASE(2, 2, 16, 1) SCAN_CASE(2, 3, 8, 2) SCAN_CASE(2, 4, 8, 2)
     }
 #undef SCAN_CASE
     return SFSN_EUNSUPPORTED;
@@ -694,12 +831,13 @@ extern "C" int sfsn_spike_proj(const int8_t* s, const int8_t* w_packed, const fl
     }
     SP_CASE(1, 1) SP_CASE(1, 2) SP_CASE(1, 3) SP_CASE(1, 4) SP_CASE(1, 5)
     SP_CASE(2, 1) SP_CASE(2, 2) SP_CASE(2, 3) SP_CASE(2, 4) SP_CASE(2, 5)
-    SP_CASE(3, 4) SP_CASE(3, 5)
+    SP_CASE(3, 1) SP_CASE(3, 2) SP_CASE(3, 3) SP_CASE(3, 4) SP_CASE(3, 5)
 #undef SP_CASE
     return SFSN_EUNSUPPORTED;
 }
 
-extern "C" int sfsn_input_proj_f32(const float* x, const float* w, float* z, int M, int K, int N, int ldz, void* stream) {
+extern "C" int sfsn_input_proj_f32(const float* x, const float* w, const float* bias, float* z, int M, int K, int N, int ldz,
+                                   void* stream) {
     if (!x || !w || !z || M <= 0 || K <= 0 || N <= 0 || ldz < N) return SFSN_EINVAL;
     if (!aligned16(z)) return SFSN_EINVAL;
     const int NT = (N + 15) / 16, KC = (K + 15) / 16;
@@ -713,7 +851,7 @@ extern "C" int sfsn_input_proj_f32(const float* x, const float* w, float* z, int
     const int KCB = KC <= 3 ? 3 : (KC <= 6 ? 6 : 12);
 #define IP_CASE(TPW_, KC_)                                                                                           \
     if (TPW == TPW_ && KCB == KC_) {                                                                                 \
-        hipLaunchKernelGGL((input_proj_kernel<TPW_, KC_>), dim3(grid), dim3(512), 0, st, x, w, z, M, K, N, ldz, NT, \
+        hipLaunchKernelGGL((input_proj_kernel<TPW_, KC_>), dim3(grid), dim3(512), 0, st, x, w, bias, z, M, K, N, ldz, NT, \
                            NWN);                                                                                     \
         return hip_ok(hipGetLastError());                                                                            \
     }

@@ -184,10 +184,44 @@ class Engine:
         self.sb = [_pack_seq(sd, f"sb_model.sb_models.{g}.", spec, spec.sb_input_size(g), spec.sb_hidden, spec.sb_layers,
                              spec.sb_proj_size(g), spec.ln_sb, self.device) for g in range(spec.n_groups)]
         self._ws: Dict[tuple, dict] = {}
+        self.timers: Optional[dict] = None  # set to {} to record HIP events around each launch group (bench.py)
 
     # ---------------------------------------------------------------------------------------------
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    class _Timed:
+        """HIP events on the launch stream around a group of launches; no-op unless ``engine.timers`` is a dict."""
+
+        def __init__(self, eng, tag):
+            self.eng, self.tag = eng, tag
+
+        def __enter__(self):
+            if self.eng.timers is not None:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e1 = torch.cuda.Event(enable_timing=True)
+                self.e0.record(torch.cuda.current_stream(self.eng.device))
+            return self
+
+        def __exit__(self, *exc):
+            if self.eng.timers is not None:
+                self.e1.record(torch.cuda.current_stream(self.eng.device))
+                self.eng.timers.setdefault(self.tag, []).append((self.e0, self.e1))
+            return False
+
+    def timed(self, tag):
+        return Engine._Timed(self, tag)
+
+    def timer_summary(self) -> dict:
+        """{tag: {mean_ms, n}} per launch group (one group = the launches of one call site in one forward)."""
+        if not self.timers:
+            return {}
+        torch.cuda.synchronize(self.device)
+        out = {}
+        for tag, evs in self.timers.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[tag] = dict(mean_ms=float(np.mean(ms)), min_ms=float(np.min(ms)), n=len(ms))
+        return out
 
     def _workspace(self, key, make):
         ws = self._ws.get(key)
@@ -214,18 +248,22 @@ class Engine:
         mems = [[] for _ in xs]
         for l in range(nl):
             # ---- input term zin = (layer input) . W_ih^T, time-parallel
+            tm = self.timed(("inproj:" if l == 0 else "spikeproj_in:") + tag)
+            tm.__enter__()
             for i, (seq, x, R) in enumerate(zip(seqs, xs, Rs)):
                 cell, z, M = seq.cells[l], ws["zin"][i], T * R
                 if l == 0:
                     for g in range(G):
                         check(L.sfsn_input_proj_f32(_ptr(x), ctypes.c_void_p(cell.w_ih_f32.data_ptr() + g * H * seq.I * 4),
+                                                    ctypes.c_void_p(cell.bias.data_ptr() + g * H * 4),
                                                     ctypes.c_void_p(z.data_ptr() + g * H * 4), M, seq.I, H, G * H, st), "sfsn_input_proj_f32")
                 else:
                     s_prev = ws["s8"][(l - 1) & 1][i]
                     for g in range(G):
                         pk, dq = cell.w_ih_q[g]
-                        check(L.sfsn_spike_proj(_ptr(s_prev), _ptr(pk), _ptr(dq), None, ctypes.c_void_p(z.data_ptr() + g * H * 4),
-                                                M, H, H, G * H, st), "sfsn_spike_proj")
+                        check(L.sfsn_spike_proj(_ptr(s_prev), _ptr(pk), _ptr(dq), ctypes.c_void_p(cell.bias.data_ptr() + g * H * 4),
+                                                ctypes.c_void_p(z.data_ptr() + g * H * 4), M, H, H, G * H, st), "sfsn_spike_proj")
+            tm.__exit__()
             # ---- the recurrent scan, all segments in one launch
             segs = (ScanSegment * len(seqs))()
             keep = []
@@ -243,15 +281,17 @@ class Engine:
                 sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.R = _ptr(spk), _ptr(s8), _ptr(mem), R
                 outs[i].append(spk)
                 mems[i].append(mem)
-            check(L.sfsn_gsn_layer_scan(segs, len(seqs), T, H, int(spec.shared), st), "sfsn_gsn_layer_scan")
+            with self.timed("scan:" + tag):
+                check(L.sfsn_gsn_layer_scan(segs, len(seqs), T, H, int(spec.shared), st), "sfsn_gsn_layer_scan")
         # ---- projection (nn.Linear on the last layer's spikes)
         projs = []
-        for i, (seq, R) in enumerate(zip(seqs, Rs)):
-            y = torch.empty((T, R, seq.P), dtype=torch.float32, device=dev)
-            check(L.sfsn_spike_proj(_ptr(ws["s8"][(nl - 1) & 1][i]), _ptr(seq.proj_q), _ptr(seq.proj_dq), _ptr(seq.proj_b), _ptr(y),
-                                    T * R, H, seq.P, seq.P, st), "sfsn_spike_proj(proj)")
-            projs.append(y)
-            outs[i].append(y)
+        with self.timed("proj:" + tag):
+            for i, (seq, R) in enumerate(zip(seqs, Rs)):
+                y = torch.empty((T, R, seq.P), dtype=torch.float32, device=dev)
+                check(L.sfsn_spike_proj(_ptr(ws["s8"][(nl - 1) & 1][i]), _ptr(seq.proj_q), _ptr(seq.proj_dq), _ptr(seq.proj_b), _ptr(y),
+                                        T * R, H, seq.P, seq.P, st), "sfsn_spike_proj(proj)")
+                projs.append(y)
+                outs[i].append(y)
         return projs, outs, mems
 
     def _feature_groups(self, which: str, xs, mu):
@@ -288,6 +328,7 @@ class Engine:
         """complex64 [B, n_fft/2+1, T] on the device -> dict(enh_stft [B,S,F,T] complex64, enh_mag [B,S,F,T],
         fb_all, sb_all (the reference's all_layer_outputs lists; spike entries are None when want_layers=False))."""
         spec, L = self.spec, self.lib
+        want_layers = want_layers or want_membrane  # membranes are a test output of the fp32-spike kernel variant
         if stft.device != self.device or stft.dtype != torch.complex64 or stft.dim() != 3:
             raise RuntimeError(f"expected a complex64 [B, F, T] tensor on {self.device}, got {stft.dtype} {tuple(stft.shape)} on {stft.device}")
         B, F, T = stft.shape
@@ -310,7 +351,8 @@ class Engine:
             scratch = torch.empty((B * (F - 1 + spec.fb_proj),), **f32)
             check(L.sfsn_laplace_means(_ptr(ri), None, B, F, T, 0, spec.fdrc, self._feature_groups("fb", [x_fb], mu_fb), 1,
                                        _ptr(mu_fb), _ptr(scratch), st), "sfsn_laplace_means(fb)")
-        check(L.sfsn_features(_ptr(ri), None, B, F, T, 0, spec.fdrc, self._feature_groups("fb", [x_fb], mu_fb), 1, st), "sfsn_features(fb)")
+        with self.timed("features:fb"):
+            check(L.sfsn_features(_ptr(ri), None, B, F, T, 0, spec.fdrc, self._feature_groups("fb", [x_fb], mu_fb), 1, st), "sfsn_features(fb)")
         fb_projs, fb_outs, fb_mems = self._run_stack([self.fb], [x_fb], T, want_layers, want_membrane, "fb")
         fb_proj = fb_projs[0]  # [T, B, FB]
         # ---------------- sub-band models
@@ -320,8 +362,9 @@ class Engine:
             mu_sb = torch.empty((spec.n_groups, B), **f32)
             check(L.sfsn_laplace_means(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, self._feature_groups("sb", None, None),
                                        spec.n_groups, _ptr(mu_sb), _ptr(scratch), st), "sfsn_laplace_means(sb)")
-        check(L.sfsn_features(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, self._feature_groups("sb", xs, mu_sb),
-                              spec.n_groups, st), "sfsn_features(sb)")
+        with self.timed("features:sb"):
+            check(L.sfsn_features(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, self._feature_groups("sb", xs, mu_sb),
+                                  spec.n_groups, st), "sfsn_features(sb)")
         sb_projs, sb_outs, sb_mems = self._run_stack(self.sb, xs, T, want_layers, want_membrane, "sb")
         # ---------------- deep filter + reconstruction
         S = spec.num_spks
@@ -330,6 +373,7 @@ class Engine:
         dfg = (DfGroup * spec.n_groups)()
         for g in range(spec.n_groups):
             dfg[g].proj, dfg[g].n_units, dfg[g].fc, dfg[g].df = _ptr(sb_projs[g]), spec.units(g), spec.ctr[g], spec.df[g]
-        check(L.sfsn_deepfilter(_ptr(ri), B, F, T, S, dfg, spec.n_groups, _ptr(torch.view_as_real(enh)), _ptr(enh_mag), st), "sfsn_deepfilter")
+        with self.timed("deepfilter"):
+            check(L.sfsn_deepfilter(_ptr(ri), B, F, T, S, dfg, spec.n_groups, _ptr(torch.view_as_real(enh)), _ptr(enh_mag), st), "sfsn_deepfilter")
         return dict(enh_stft=enh, enh_mag=enh_mag, fb_all=fb_outs[0], sb_all=sb_outs, fb_mem=fb_mems[0], sb_mem=sb_mems,
                     mu_fb=mu_fb, mu_sb=mu_sb)

@@ -23,7 +23,9 @@ import numpy as np
 
 TAU = 1e-4        # don't-care half-width around the spike threshold (post-BN membrane units, O(1) scale)
 MEM_ATOL = 2e-5   # membrane agreement before any divergence: |err| <= MEM_ATOL + MEM_RTOL*|c_ref|
-MEM_RTOL = 2e-5   # relative to the neuron's running max |c_ref|: chains with gain > 1 (forget gate ~1 x BN scale > 1, also present in the trained zoo weights) amplify rounding noise step over step
+MEM_RTOL = 1e-4   # free-running chains only, relative to the neuron's running max |c_ref|: a chain with gain > 1 (forget gate ~1 x BN scale > 1,
+                  # present in the trained zoo weights too) amplifies per-step rounding noise ~1.3x per frame; the per-step accuracy gate is
+                  # the teacher-forced test (1e-5 + 2e-6*|c| per step), spikes must agree exactly outside the TAU band regardless
 REL = 1e-4        # relative tolerance on continuous outputs (proj, enh_stft, enh_mag)
 ATOL = 2e-5       # absolute floor for continuous outputs (values are O(0.1-10))
 

@@ -1,0 +1,331 @@
+"""GPU parity tests: the HIP path (through the C ABI / the drop-in modules) against the CPU oracle on the
+same seeded inputs, against the committed golden fixtures made by the reference, and -- at BASELINE.json's
+full sizes -- through size-independent properties (state carry across chunks, batch independence,
+run-to-run bit stability).  Tolerances and the causal comparison rule live in tests/parity.py."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+import refweights as rw
+from oracle import Oracle
+from oracle import model as omodel
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda:0"
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name), allow_pickle=False))
+
+
+def _t(a, dtype=None):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV) if dtype is None else torch.from_numpy(np.ascontiguousarray(a)).to(DEV, dtype)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from spiking_fullsubnet_amd import _lib
+    L = _lib.lib()
+    assert L.sfsn_device_count() >= 1
+    return L
+
+
+def run_scan(hip, zin, w_hh, bias, alpha, beta, shared, h0=None, c0=None, want_mem=True):
+    """x.W_ih^T [T,R,G*H] numpy -> spikes, membrane, spikes_i8, hT, cT (numpy) through sfsn_gsn_layer_scan.
+    The ABI's input term includes bias_ih (forget-gate bias when shared, both gate biases otherwise): added here."""
+    from spiking_fullsubnet_amd._lib import ScanSegment, check
+    from spiking_fullsubnet_amd.engine import pack_w3
+    T, R, GH = zin.shape
+    H = bias.shape[0] // 2
+    zin = (zin + bias[:GH]).astype(np.float32)
+    HP = (H + 63) // 64 * 64
+    pk, dq = pack_w3(w_hh)
+    t = dict(zin=_t(zin), pk=_t(pk), dq=_t(dq), bias=_t(bias), alpha=_t(alpha), beta=_t(beta),
+             h=_t(np.zeros((R, H), np.float32) if h0 is None else h0), c=_t(np.zeros((R, H), np.float32) if c0 is None else c0),
+             spk=torch.empty((T, R, H), device=DEV), s8=torch.zeros((T, R, HP), dtype=torch.int8, device=DEV),
+             mem=torch.empty((T, R, H), device=DEV) if want_mem else None)
+    seg = (ScanSegment * 1)()
+    s = seg[0]
+    s.zin, s.w_hh, s.w_dq, s.bias, s.bn_alpha, s.bn_beta = _p(t["zin"]), _p(t["pk"]), _p(t["dq"]), _p(t["bias"]), _p(t["alpha"]), _p(t["beta"])
+    s.h_state, s.c_state, s.spikes_f32, s.spikes_i8, s.membrane, s.R = _p(t["h"]), _p(t["c"]), _p(t["spk"]), _p(t["s8"]), _p(t["mem"]), R
+    check(hip.sfsn_gsn_layer_scan(seg, 1, T, H, int(shared), None), "scan")
+    torch.cuda.synchronize()
+    return (t["spk"].cpu().numpy(), t["mem"].cpu().numpy() if want_mem else None, t["s8"].cpu().numpy(), t["h"].cpu().numpy(),
+            t["c"].cpu().numpy())
+
+
+def make_layer(rng, I, H, shared, bn):
+    sd = {}
+    rw._cell(rng, "", I, H, shared, bn, sd)
+    from spiking_fullsubnet_amd.engine import fold_batchnorm
+    if bn:
+        alpha, beta = fold_batchnorm(sd["batchnorm.weight"], sd["batchnorm.bias"], sd["batchnorm.running_mean"], sd["batchnorm.running_var"])
+        bnp = (sd["batchnorm.weight"], sd["batchnorm.bias"], sd["batchnorm.running_mean"], sd["batchnorm.running_var"])
+    else:
+        alpha, beta, bnp = np.ones(H, np.float32), np.zeros(H, np.float32), None
+    return sd, alpha, beta, bnp
+
+
+SCAN_SHAPES = [  # I, H, R, T, shared, bn
+    (12, 32, 5, 40, True, True), (9, 16, 4, 30, False, False), (20, 48, 19, 25, False, True), (38, 160, 33, 30, True, True),
+    (38, 224, 16, 40, True, True), (64, 240, 7, 30, True, True), (30, 256, 18, 20, True, False), (64, 320, 35, 30, True, True),
+    (94, 128, 16, 24, True, True), (24, 192, 9, 16, False, True),
+]
+
+
+@pytest.mark.parametrize("I,H,R,T,shared,bn", SCAN_SHAPES)
+def test_scan_free_running_vs_oracle(hip, I, H, R, T, shared, bn):
+    """sfsn_gsn_layer_scan vs the oracle's gsn_layer on identical zin-equivalent inputs (causal rule)."""
+    rng = np.random.default_rng(I * 1000 + H)
+    sd, alpha, beta, bnp = make_layer(rng, I, H, shared, bn)
+    x = rng.standard_normal((T, R, I)).astype(np.float32)
+    h0 = (rng.random((R, H)) > 0.5).astype(np.float32)
+    c0 = rng.standard_normal((R, H)).astype(np.float32)
+    o = Oracle("f32")
+    zin = o.linear(x, sd["weight_ih"])  # x . W_ih^T, correctly rounded
+    ref_spk, ref_mem, ref_h, ref_c = o.gsn_layer(x, sd["weight_ih"], sd["weight_hh"], sd["bias_ih"], bn=bnp, shared=shared, h0=h0, c0=c0)
+    spk, mem, s8, hT, cT = run_scan(hip, zin, sd["weight_hh"], sd["bias_ih"], alpha, beta, shared, h0, c0)
+    t_valid, st = parity.check_chain(spk, ref_spk, np.abs(ref_mem) < parity.TAU, np.full(R, T), f"scan H={H}", mem, ref_mem)
+    assert st["spike_agreement"] > 0.999, st
+    np.testing.assert_array_equal(s8[:, :, :H], spk.astype(np.int8))  # int8 copy == fp32 spikes
+    assert not s8[:, :, H:].any()
+    ok = t_valid == T
+    np.testing.assert_array_equal(hT[ok], ref_h[ok])
+    np.testing.assert_array_equal(hT, spk[-1])
+    np.testing.assert_allclose(cT[ok], ref_c[ok], atol=parity.MEM_ATOL, rtol=parity.MEM_RTOL)
+
+
+def test_scan_teacher_forced_single_steps(hip):
+    """Each step started from the ORACLE's state (T=1 launches): membranes within 1e-5 + 2e-6*|c| per step and spikes
+    equal wherever the oracle membrane is outside the +-TAU band -- no error can accumulate along the chain."""
+    rng = np.random.default_rng(7)
+    I, H, R, T = 38, 224, 16, 12
+    sd, alpha, beta, bnp = make_layer(rng, I, H, True, True)
+    x = rng.standard_normal((T, R, I)).astype(np.float32)
+    o = Oracle("f32")
+    zin = o.linear(x, sd["weight_ih"])
+    ref_spk, ref_mem, _, _ = o.gsn_layer(x, sd["weight_ih"], sd["weight_hh"], sd["bias_ih"], bn=bnp)
+    h, c = np.zeros((R, H), np.float32), np.zeros((R, H), np.float32)
+    for t in range(T):
+        spk, mem, _, hT, cT = run_scan(hip, zin[t:t + 1], sd["weight_hh"], sd["bias_ih"], alpha, beta, True, h, c)
+        err = np.abs(mem[0].astype(np.float64) - ref_mem[t])
+        assert (err <= 1e-5 + 2e-6 * np.abs(ref_mem[t])).all(), (t, err.max())
+        far = np.abs(ref_mem[t]) >= parity.TAU
+        np.testing.assert_array_equal(spk[0][far], ref_spk[t][far])
+        h, c = ref_spk[t], ref_mem[t]
+
+
+def test_scan_multi_segment_and_chunked_state_carry(hip):
+    """Three segments of different R in one launch == three single launches; two half-length launches carrying
+    (h, c) == one full launch, bit for bit (state in/out contract of StackedGSU, efficient_spiking_neuron.py:50-62)."""
+    from spiking_fullsubnet_amd._lib import ScanSegment, check
+    from spiking_fullsubnet_amd.engine import pack_w3
+    rng = np.random.default_rng(3)
+    H, T = 160, 22
+    Rs = [40, 9, 17]
+    layers = [make_layer(rng, 8, H, True, True) for _ in Rs]
+    zins = [rng.standard_normal((T, R, H)).astype(np.float32) for R in Rs]
+    singles = [run_scan(hip, z, l[0]["weight_hh"], l[0]["bias_ih"], l[1], l[2], True) for z, l in zip(zins, layers)]
+    keep, seg = [], (ScanSegment * 3)()
+    outs = []
+    for i, (R, z, l) in enumerate(zip(Rs, zins, layers)):
+        pk, dq = pack_w3(l[0]["weight_hh"])
+        ts = [_t((z + l[0]["bias_ih"][:H]).astype(np.float32)), _t(pk), _t(dq), _t(l[0]["bias_ih"]), _t(l[1]), _t(l[2]), torch.zeros((R, H), device=DEV), torch.zeros((R, H), device=DEV),
+              torch.empty((T, R, H), device=DEV), torch.zeros((T, R, (H + 63) // 64 * 64), dtype=torch.int8, device=DEV)]
+        keep.append(ts)
+        s = seg[i]
+        s.zin, s.w_hh, s.w_dq, s.bias, s.bn_alpha, s.bn_beta, s.h_state, s.c_state, s.spikes_f32, s.spikes_i8 = [_p(x) for x in ts]
+        s.membrane, s.R = None, R
+        outs.append(ts[8])
+    check(hip.sfsn_gsn_layer_scan(seg, 3, T, H, 1, None), "scan3")
+    torch.cuda.synchronize()
+    for o3, s1 in zip(outs, singles):
+        np.testing.assert_array_equal(o3.cpu().numpy(), s1[0])
+    z, l = zins[0], layers[0]
+    a = run_scan(hip, z[:9], l[0]["weight_hh"], l[0]["bias_ih"], l[1], l[2], True)
+    b = run_scan(hip, z[9:], l[0]["weight_hh"], l[0]["bias_ih"], l[1], l[2], True, a[3], a[4])
+    np.testing.assert_array_equal(np.concatenate([a[0], b[0]]), singles[0][0])
+    np.testing.assert_array_equal(b[4], singles[0][4])
+
+
+@pytest.mark.parametrize("M,K,N", [(50, 32, 24), (333, 224, 224), (100, 160, 64), (64, 320, 320), (47, 224, 40), (200, 224, 192),
+                                   (31, 48, 6), (90, 240, 64)])
+def test_spike_proj_matches_exact_product(hip, M, K, N):
+    """sfsn_spike_proj == sum of the selected fp32 weights, to one rounding of the digit-quantised weights."""
+    from spiking_fullsubnet_amd._lib import check
+    from spiking_fullsubnet_amd.engine import pack_w3, unpack_w3
+    rng = np.random.default_rng(M + K + N)
+    w = rng.uniform(-0.1, 0.1, (N, K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    s = (rng.random((M, K)) > 0.6)
+    KP = (K + 63) // 64 * 64
+    s8 = np.zeros((M, KP), np.int8)
+    s8[:, :K] = s
+    pk, dq = pack_w3(w)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    ts = [_t(s8), _t(pk), _t(dq), _t(bias)]
+    check(hip.sfsn_spike_proj(_p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]), _p(y), M, K, N, N, None), "spike_proj")
+    torch.cuda.synchronize()
+    wq = unpack_w3(pk, dq, N, K).astype(np.float64)
+    exact_q = (s.astype(np.float64) @ wq.T).astype(np.float32) + bias  # what the kernel computes, one rounding each
+    np.testing.assert_array_equal(y.cpu().numpy(), exact_q)
+    exact = s.astype(np.float64) @ w.astype(np.float64).T + bias
+    np.testing.assert_allclose(y.cpu().numpy(), exact, atol=2e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("M,K,N", [(100, 38, 224), (77, 94, 160), (64, 158, 224), (130, 64, 320), (33, 12, 32), (40, 64, 240)])
+def test_input_proj_f32(hip, M, K, N):
+    from spiking_fullsubnet_amd._lib import check
+    rng = np.random.default_rng(M * K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = rng.uniform(-0.1, 0.1, (N, K)).astype(np.float32)
+    z = torch.full((M, N), float("nan"), device=DEV)
+    ts = [_t(x), _t(w)]
+    bias = rng.standard_normal(N).astype(np.float32)
+    ts.append(_t(bias))
+    check(hip.sfsn_input_proj_f32(_p(ts[0]), _p(ts[1]), _p(ts[2]), _p(z), M, K, N, N, None), "input_proj")
+    torch.cuda.synchronize()
+    exact = x.astype(np.float64) @ w.astype(np.float64).T + bias
+    np.testing.assert_allclose(z.cpu().numpy(), exact, atol=3e-6, rtol=1e-5)  # k-ordered fp32 fma chain, K <= 160
+
+
+MODEL_CASES = [
+    ("live_tiny.npz", "live", rw.LIVE_TINY, 11), ("live_tiny_2spk.npz", "live", rw.LIVE_TINY_2SPK, 12),
+    ("live_tiny_unshared.npz", "live", rw.LIVE_TINY_UNSHARED, 13), ("live_m.npz", "live", rw.LIVE_M, 21),
+    ("frozen_tiny.npz", "frozen", rw.FROZEN_TINY, 31), ("frozen_s_zoo.npz", "frozen", rw.FROZEN_S, None),
+]
+
+
+def build_module(front, kw, sd):
+    import spiking_fullsubnet_amd as pkg
+    m = (pkg.SpikingFullSubNet if front == "live" else pkg.Separator)(**kw)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m.eval().to(DEV)
+
+
+def hip_result(model, stft, want_membrane=True):
+    res = model.forward_stft(_t(stft), want_membrane=want_membrane)
+    torch.cuda.synchronize()
+    out = dict(enh_stft=res["enh_stft"].cpu().numpy(), enh_mag=res["enh_mag"].cpu().numpy(),
+               fb_all=[a.cpu().numpy() for a in res["fb_all"]], sb_all=[[a.cpu().numpy() for a in l] for l in res["sb_all"]])
+    if want_membrane:
+        out["mem"] = {("fb", l): m.cpu().numpy() for l, m in enumerate(res["fb_mem"])}
+        for g, mems in enumerate(res["sb_mem"]):
+            out["mem"].update({(f"sb{g}", l): m.cpu().numpy() for l, m in enumerate(mems)})
+    return out
+
+
+def case_setup(fname, front, kw, seed):
+    gold = load(fname)
+    if front == "live":
+        spec, sd = omodel.spec_from_live_kwargs(kw), rw.live_state_dict(kw, seed)
+    else:
+        spec = omodel.spec_from_frozen_kwargs(kw)
+        sd = {k[3:]: v for k, v in gold.items() if k.startswith("sd/")} if seed is None else rw.frozen_state_dict(kw, seed)
+    return gold, spec, sd
+
+
+@pytest.mark.parametrize("fname,front,kw,seed", MODEL_CASES, ids=[c[0][:-4] for c in MODEL_CASES])
+def test_module_vs_reference_golden(fname, front, kw, seed):
+    """Drop-in module on the golden STFT vs the reference's recorded outputs: every layer input, spike tensor,
+    projection, the enhanced spectrum (<= 1e-4 rel, parity.REL) and, from the waveform, enh_y / enh_mag."""
+    gold, spec, sd = case_setup(fname, front, kw, seed)
+    model = build_module(front, kw, sd)
+    out = hip_result(model, gold["stft"])
+    stats = parity.check_model(out, gold, spec, tag=fname + ":")
+    for st in stats:
+        assert st["spike_agreement"] > 0.995, st
+    clean = all(st["diverged"] == 0 for st in stats)
+    outs = model(_t(gold["wave"]))
+    torch.cuda.synchronize()
+    assert outs[0].shape == gold["enh_y"].shape
+    if clean:
+        B, S, F, T = out["enh_mag"].shape
+        if "enh_mag" in gold:
+            np.testing.assert_allclose(out["enh_mag"].reshape(B * S, F, T), gold["enh_mag"], rtol=parity.REL, atol=parity.ATOL)
+            np.testing.assert_allclose(outs[1].cpu().numpy(), gold["enh_mag"], rtol=2e-4, atol=1e-4)  # includes the device STFT
+        np.testing.assert_allclose(outs[0].cpu().numpy(), gold["enh_y"], rtol=1e-3, atol=2e-5)          # device STFT + iSTFT
+    if "synops" in gold and clean:
+        assert omodel.compute_synops(out["fb_all"], out["sb_all"], spec["shared"]) == pytest.approx(float(gold["synops"]), rel=1e-6)
+
+
+@pytest.mark.parametrize("front,kw,seed,B,T", [("live", rw.LIVE_M, 5, 3, 60), ("frozen", rw.FROZEN_S, 6, 2, 50),
+                                                ("live", rw.LIVE_TINY_2SPK, 8, 5, 33)])
+def test_module_vs_oracle_seeded(front, kw, seed, B, T):
+    """Same seeded synthetic input through the HIP path and the CPU oracle (sizes the oracle finishes in seconds)."""
+    sd = rw.live_state_dict(kw, seed) if front == "live" else rw.frozen_state_dict(kw, seed)
+    spec = omodel.spec_from_live_kwargs(kw) if front == "live" else omodel.spec_from_frozen_kwargs(kw)
+    wave = torch.from_numpy(rw.synth_wave(B, T, seed, modulated=True))
+    stft = torch.stft(wave, 512, 128, 512, window=torch.hann_window(512), return_complex=True, pad_mode="constant").numpy()
+    ora = omodel.forward_from_stft(spec, sd, stft, "f32", want_membrane=True)
+    out = hip_result(build_module(front, kw, sd), stft)
+    stats = parity.check_model(out, parity.gold_from_oracle(ora), spec, tag="oracle:")
+    for st in stats:
+        assert st["spike_agreement"] > 0.99, st
+    if front == "frozen":  # Laplace means themselves
+        assert np.isfinite(out["enh_mag"]).all()
+
+
+def test_full_size_properties():
+    """BASELINE.json config 3 (live M, B=64, T=1000): properties that do not need the oracle at full size.
+    (i) run-to-run bit stability; (ii) batch independence: clips 5..12 computed alone == inside the batch, bit for bit;
+    (iii) sub-sampled oracle check: 2 clips x first 120 frames against the CPU oracle (the model is causal in T)."""
+    kw, seed, B, T = rw.LIVE_M, 21, 64, 1000
+    sd = rw.live_state_dict(kw, seed)
+    model = build_module("live", kw, sd)
+    wave = torch.from_numpy(rw.synth_wave(B, T, 0)).to(DEV)
+    stft = model.stft(wave)
+    assert stft.shape == (B, 257, T)
+    r1 = model.forward_stft(stft)
+    r2 = model.forward_stft(stft)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(r1["enh_stft"]), torch.view_as_real(r2["enh_stft"]))
+    for a, b in zip(r1["sb_all"][0], r2["sb_all"][0]):
+        assert torch.equal(a, b)
+    sub = model.forward_stft(stft[5:13].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(sub["enh_stft"]), torch.view_as_real(r1["enh_stft"][5:13]))
+    assert torch.equal(sub["fb_all"][2], r1["fb_all"][2][:, 5:13])
+    # oracle on clips 0,1 x 120 frames: causal model => the prefix of the long run must match the short oracle run
+    Tc = 120
+    spec = omodel.spec_from_live_kwargs(kw)
+    ora = omodel.forward_from_stft(spec, sd, stft[:2, :, :Tc].cpu().numpy(), "f32", want_membrane=True)
+    out = dict(enh_stft=r1["enh_stft"][:2, :, :, :Tc].cpu().numpy(), fb_all=[a[:Tc, :2].cpu().numpy() for a in r1["fb_all"]], sb_all=[])
+    for g, lst in enumerate(r1["sb_all"]):
+        N = spec_units(spec, g)
+        out["sb_all"].append([a[:Tc, :2 * N].cpu().numpy() for a in lst])
+    stats = parity.check_model(out, parity.gold_from_oracle(ora), spec, tag="full-size prefix:")
+    for st in stats:
+        assert st["spike_agreement"] > 0.99, st
+    rates = [float(a.mean()) for a in r1["fb_all"][1:3]]
+    assert all(0.02 < r < 0.98 for r in rates), rates  # the synthetic model is alive, not saturated
+
+
+def spec_units(spec, g):
+    return (spec["cutoffs"][g + 1] - spec["cutoffs"][g]) // spec["ctr"][g]
+
+
+def test_errors_match_reference_behaviour():
+    """ValueError for an indivisible band (modeling:283-287), AssertionError for a non-2D input (:426), loud failure on CPU."""
+    import spiking_fullsubnet_amd as pkg
+    bad = dict(rw.LIVE_TINY, freq_cutoffs=[0, 30, 128, 256])
+    m = pkg.SpikingFullSubNet(**bad).eval().to(DEV)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 2048, device=DEV))
+    m = pkg.SpikingFullSubNet(**rw.LIVE_TINY).eval().to(DEV)
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, 1, 2048, device=DEV))
+    with pytest.raises(RuntimeError):
+        pkg.SpikingFullSubNet(**rw.LIVE_TINY).eval()(torch.zeros(1, 2048))
+    with pytest.raises(RuntimeError):
+        pkg.SpikingFullSubNet(**rw.LIVE_TINY).to(DEV).train()(torch.zeros(1, 2048, device=DEV))
