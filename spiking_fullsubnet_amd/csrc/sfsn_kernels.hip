@@ -49,6 +49,7 @@ struct ScanSegDev {
 struct ScanParams {
     ScanSegDev seg[SFSN_MAX_SEGMENTS];
     int nseg, T, H, NT;  // NT = H / 16 output tiles per gate
+    int rpw;             // rows per workgroup (16, 8 or 4): fewer rows per CU = less HBM traffic per CU per step
 };
 
 __device__ __forceinline__ float recombine3(int a0, int a1, int a2) {
@@ -57,71 +58,83 @@ __device__ __forceinline__ float recombine3(int a0, int a1, int a2) {
     return __builtin_fmaf((float)a2, 65536.0f, (float)(a1 * 256 + a0));
 }
 
-// ---- input-term prefetch hidden from the compiler's s_waitcnt bookkeeping ------------------------------------
-// hipcc merges control-flow paths conservatively and ends up draining vmcnt (to 0, or to a count that includes the
-// spike stores issued a few hundred cycles earlier) before every use of a prefetched register: measured 1.36 us
-// per step instead of 0.83.  The loads are therefore issued from inline asm (invisible to the scoreboard) and
-// waited for by an explicit COUNTED s_waitcnt whose statement names every destination register as "+v", which
-// pins all consumers behind it (cdna_hip_programming.md 5.7, form ii).
-__device__ __forceinline__ void prefetch16(v4f& dst, const float* src) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
-}
-template <int COUNT, int NREG>
-__device__ __forceinline__ void wait_prefetch(const v4f* zc) {
-    v4f* z = const_cast<v4f*>(zc);
-    static_assert(COUNT <= 63, "vmcnt is a 6-bit field");
-    if constexpr (NREG == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(z[0]) : "n"(COUNT));
-    if constexpr (NREG == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(z[0]), "+v"(z[1]) : "n"(COUNT));
-    if constexpr (NREG == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]) : "n"(COUNT));
-    if constexpr (NREG == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]) : "n"(COUNT));
-    if constexpr (NREG == 5)
-        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]) : "n"(COUNT));
-    static_assert(NREG >= 1 && NREG <= 5, "extend wait_prefetch");
+// ---- input-term prefetch: LDS-DMA ring, hidden from the compiler's s_waitcnt bookkeeping -------------------------
+// What the profile showed: vmcnt retires in order and counts STORES too, and a spike store takes about a microsecond
+// to retire here, so any wait for a prefetched register that was issued after a store stalls the step for the store
+// (1.36 us per step instead of 0.83; with only loads or only stores in the queue the same kernel ran at 0.31 us of
+// memory time).  hipcc on top of that merges control-flow paths conservatively and drains to vmcnt(0).  Hence:
+//   * the input term travels global -> LDS by DMA (global_load_lds_dwordx4: no VGPR destination, so the prefetch
+//     depth costs no registers) into a per-wave ring RING_D steps deep, issued from inline asm the compiler's
+//     scoreboard does not see;
+//   * the consumer waits with ONE explicit, COUNTED s_waitcnt per step: everything issued after the DMA it needs
+//     (RING_D-1 steps of DMAs and spike stores) may stay in flight, so only stores RING_D-1 steps old are ever
+//     waited for (cdna_hip_programming.md 5.7 / T3+T4: counted vmcnt, never 0 in the main loop).
+// The LDS destination of a DMA is wave-uniform base (M0) + lane*16: each lane later reads back exactly the 16 bytes
+// it requested.  Destinations are kept below 64 KiB (the ring is the first thing in the LDS allocation).
+__device__ __forceinline__ void dma16_to_lds(unsigned lds_dst_uniform, const float* src) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_dst_uniform)
+        : "memory");
 }
 
-// ---- the scan body for a wave that owns NTL (compile-time) output tiles -------------------------------------
-// Straight-line code per step: no per-tile or per-row branch.  Rows past R are CLAMPED duplicates of row R-1: they
-// run the same instruction sequence on the same data, produce bit-identical values and store them to the same
-// addresses as the original (a benign duplicate write), so a step is one basic block the scheduler can interleave
-// and every s_waitcnt sits on the straight path.
-//
-// Global traffic of a step:
-//   * the input term of step t+1 is prefetched at the top of step t (prefetch16 / wait_prefetch above);
-//   * the spikes of step t-1 are FLUSHED from the LDS hidden-state buffer (which holds them all as int8) at the top
-//     of step t by all threads of the workgroup, each thread owning FL 4-neuron chunks: whole rows go out as full,
-//     contiguous cache lines (fp32: 16 B per lane, int8: 4 B per lane).  Storing the accumulator fragments directly
-//     (64 B per row per tile) made every store a partial-line write; those took longer than a step to retire and
-//     the in-order vmcnt queue stalled the prefetch behind them (measured 1.4 us per step vs 0.8 without stores).
-template <int KS, int NW, int OUT>
-struct ScanFlush {
-    static constexpr int LDH = KS * 64 + 16;
-    static constexpr int HP = KS * 64;
-    static constexpr int CHUNKS = 16 * (HP / 4);                       // 4-neuron chunks of the padded 16 x HP tile
-    static constexpr int FL = (CHUNKS + NW * 64 - 1) / (NW * 64);      // chunks per thread
+template <int G, int KS, int NW, int TPW, int OUT>
+struct ScanCfg {
+    static constexpr int LDH = KS * 64 + 32;  // +32 B row pad: the ds_read_b128 lane groups of a B fragment hit distinct banks
+    static constexpr int HP = KS * 64;        // padded hidden size
+    static constexpr int NC = 3 + G;          // per-neuron constant vectors: (bias_g - bias_f), alpha, beta, dq[G]
+    static constexpr int SLOT = NW * TPW * G * 1024;  // bytes of one ring slot (every wave: TPW tiles x G gates x 1 KiB)
+    static constexpr int RING_D = (4 * SLOT <= 65536) ? 4 : ((3 * SLOT <= 65536) ? 3 : 2);
+    static_assert(RING_D * SLOT <= 65536 || RING_D == 2, "ring too large");
+    static constexpr int RING_OFF = 0, HBUF_OFF = RING_D * SLOT, CST_OFF = HBUF_OFF + 2 * 16 * LDH;
+    static constexpr int LDS_BYTES = CST_OFF + NC * HP * 4;
+    // flush geometry: all threads of the workgroup write the previous step's spikes from the LDS hidden-state buffer
+    static constexpr int CHUNKS = 16 * (HP / 4);                    // 4-neuron chunks of the padded 16 x HP tile
+    static constexpr int FL = (CHUNKS + NW * 64 - 1) / (NW * 64);   // chunks per thread
     static constexpr int NSTF = ((OUT & 1) ? 1 : 0) + ((OUT & 2) ? 1 : 0);  // stores per chunk
-    int off_f32[FL], off_i8[FL], off_lds[FL];
+};
 
-    __device__ __forceinline__ void init(int tid, int row0, int R, int H) {
+// Spikes of one step, LDS (int8, all 16 rows x H) -> global.  Whole rows go out as full contiguous cache lines (fp32:
+// 16 B per lane, int8: 4 B per lane).  Storing the accumulator fragments directly (64 B per row per tile) made every
+// store a partial-line write and was measurably slower.  Surplus threads / pad columns / rows past R duplicate a real
+// chunk: same data to the same address, so the instruction count per thread is constant (the counted wait needs that).
+template <class C>
+struct ScanFlush {
+    int off_f32[C::FL], off_i8[C::FL], off_lds[C::FL];
+    int nact;  // wave-uniform: how many of my FL chunk slots are real (the others fall past rpw rows and are skipped)
+    __device__ __forceinline__ void init(int tid, int row0, int R, int H, int nthreads, int rpw) {
+        const int chunks = rpw * (C::HP / 4);  // multiple of 64: a wave is active or idle as a whole in every slot
+        const int tid0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+        nact = 0;
 #pragma unroll
-        for (int k = 0; k < FL; ++k) {
-            const int c = (tid + k * NW * 64) % CHUNKS;  // surplus threads duplicate a chunk (same data, same address)
-            const int rr = c / (HP / 4);
-            int j4 = (c - rr * (HP / 4)) * 4;
-            if (j4 > H - 4) j4 = H - 4;    // pad columns duplicate the row's last real chunk
-            const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;  // rows past R duplicate row R-1 (LDS holds the same values)
-            off_lds[k] = rr * LDH + j4;
+        for (int k = 0; k < C::FL; ++k) {
+            if (tid0 + k * nthreads < chunks) nact = k + 1;
+            const int c = (tid + k * nthreads) % chunks;
+            const int rr = c / (C::HP / 4);
+            int j4 = (c - rr * (C::HP / 4)) * 4;
+            if (j4 > H - 4) j4 = H - 4;  // pad columns duplicate the row's last real chunk (same data, same address)
+            const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;  // rows past R duplicate row R-1
+            off_lds[k] = rr * C::LDH + j4;
             off_f32[k] = rsrc * H + j4;
-            off_i8[k] = rsrc * HP + j4;
+            off_i8[k] = rsrc * C::HP + j4;
         }
     }
-    // spikes of step ts (held in hsrc) -> global
+    template <int OUT>
     __device__ __forceinline__ void run(const int8_t* hsrc, float* __restrict__ spikes_f32, int8_t* __restrict__ spikes_i8, int ts,
                                         int R, int H) const {
-        if constexpr (NSTF > 0) {
+        if constexpr (C::NSTF > 0) {
+            if (OUT & 256) ts = 0;  // (bit 8: timing experiment, fixed frame)
             float* pf = spikes_f32 + (size_t)ts * R * H;
-            int8_t* p8 = spikes_i8 + (size_t)ts * R * HP;
+            int8_t* p8 = spikes_i8 + (size_t)ts * R * C::HP;
 #pragma unroll
-            for (int k = 0; k < FL; ++k) {
+            for (int k = 0; k < C::FL; ++k) {
+                if (k >= nact) break;  // wave-uniform
                 const unsigned pk = *reinterpret_cast<const unsigned*>(hsrc + off_lds[k]);
                 if (OUT & 2) *reinterpret_cast<unsigned*>(p8 + off_i8[k]) = pk;
                 if (OUT & 1) {
@@ -133,29 +146,56 @@ struct ScanFlush {
     }
 };
 
-template <int G, int KS, int NW, int OUT, int NTL>
+// s_waitcnt vmcnt(N) for a wave-uniform runtime N in a small range: the instruction takes an immediate.
+template <int BASE, int STRIDE, int MAXK>
+__device__ __forceinline__ void wait_vmcnt_affine(int k) {
+    // waits for vmcnt <= BASE + k*STRIDE (clamped to the 6-bit field); k in [0, MAXK]
+#define SFSN_WAIT_CASE(K)                                                                           \
+    if constexpr (K <= MAXK)                                                                        \
+        if (k == K) {                                                                               \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BASE + K * STRIDE) > 63 ? 63 : (BASE + K * STRIDE)) : "memory"); \
+            return;                                                                                 \
+        }
+    SFSN_WAIT_CASE(0) SFSN_WAIT_CASE(1) SFSN_WAIT_CASE(2) SFSN_WAIT_CASE(3) SFSN_WAIT_CASE(4) SFSN_WAIT_CASE(5)
+#undef SFSN_WAIT_CASE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- the scan body for a wave that owns NTL (compile-time) output tiles -------------------------------------
+// Straight-line code per step: no per-tile or per-row branch.  Rows past R are CLAMPED duplicates of row R-1: they
+// run the same instruction sequence on the same data, produce bit-identical values and store them to the same
+// addresses as the original (a benign duplicate write), so a step is one basic block the scheduler can interleave.
+template <int G, int KS, int NW, int TPW, int OUT, int NTL>
 __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const int8_t* __restrict__ w_hh,
                                           float* __restrict__ spikes_f32, int8_t* __restrict__ spikes_i8,
                                           float* __restrict__ membrane, float* __restrict__ h_state, float* __restrict__ c_state,
-                                          const float (*cst)[KS * 64], int8_t (*hbuf)[16 * (KS * 64 + 16)], int T, int H, int NT,
-                                          int R, int row0, int rowc, int n, int q, int tid, int wave) {
-    constexpr int LDH = KS * 64 + 16;
-    using Flush = ScanFlush<KS, NW, OUT>;
-    Flush fl;
-    fl.init(tid, row0, R, H);
+                                          char* smem, int T, int H, int NT, int R, int row0, int rowc, int n, int q, int tid,
+                                          int wave, int rpw) {
+    using C = ScanCfg<G, KS, NW, TPW, OUT>;
+    constexpr int LDH = C::LDH, HP = C::HP, D = C::RING_D;
+    int8_t* hbuf = reinterpret_cast<int8_t*>(smem + C::HBUF_OFF);
+    const float(*cst)[HP] = reinterpret_cast<const float(*)[HP]>(smem + C::CST_OFF);
+    ScanFlush<C> fl;
+    fl.init(tid, row0, R, H, NW * 64, rpw);
     const int lane = tid & 63;
     if constexpr (NTL == 0) {
         // a wave without tiles still flushes its share of the spikes and keeps the workgroup's barrier count
         for (int t = 0; t < T; ++t) {
-            if (t > 0) fl.run(hbuf[t & 1], spikes_f32, spikes_i8, t - 1, R, H);
+            if (t > 0) fl.template run<OUT>(hbuf + (t & 1) * 16 * LDH, spikes_f32, spikes_i8, t - 1, R, H);
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();
         }
-        if (T > 0) fl.run(hbuf[T & 1], spikes_f32, spikes_i8, T - 1, R, H);
+        if (T > 0) fl.template run<OUT>(hbuf + (T & 1) * 16 * LDH, spikes_f32, spikes_i8, T - 1, R, H);
         return;
     } else {
         const int ldz = G * H;
-        constexpr int NMEM = (OUT & 4) ? NTL : 0;  // membrane stores per step (test output, accumulator layout)
+        constexpr int A = NTL * G;                   // DMAs per step
+        constexpr int NMEM = (OUT & 4) ? NTL : 0;    // membrane stores per step (test output, accumulator layout)
+        // VMEM operations issued after the DMA of data-step t and before the wait of compute-step t (program order per
+        // step: DMAs, flush stores, WAIT, membrane stores), with f = nact * NSTF flush stores per step for this wave:
+        //     (D-1) * (A + f + NMEM) + f  =  (D-1)*(A+NMEM)  +  nact * (D*NSTF)
+        constexpr int CBASE = (D - 1) * (A + NMEM), CSTRIDE = D * C::NSTF;
+
         // register-resident recurrent weights (int8 digits in MFMA A-fragment order) and membrane state
         v4i W[NTL][G][KS][3];
         v4f c[NTL];
@@ -175,59 +215,73 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
                     }
             c[i] = *reinterpret_cast<const v4f*>(c_state + (size_t)rowc * H + col[i]);
         }
-        // input term for t = 0 (zA: even t, zB: odd t -- ping-pong so that a prefetch is consumed a step later
-        // without a register copy)
-        v4f zA[NTL][G], zB[NTL][G];
-#pragma unroll
-        for (int i = 0; i < NTL; ++i)
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                zA[i][g] = zB[i][g] = v4f{0, 0, 0, 0};
-                if (T > 0) zA[i][g] = *reinterpret_cast<const v4f*>(zin + (size_t)rowc * ldz + g * H + col[i]);
-            }
-        // Drain every prologue load HERE, once: otherwise the compiler's conservative scoreboard re-waits for the
-        // weight registers with vmcnt(0) inside the loop, which also drains the in-flight stores of the previous step.
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-
-        // FIRST = the peeled step 0: nothing to flush (hc is the initial state) and its input term was loaded and
-        // drained in the prologue, so no wait either.
-        auto step = [&](const v4f (&z)[NTL][G], v4f (&zn)[NTL][G], const int8_t* hc, int8_t* hn, int t, int tn, auto first)
-                        __attribute__((always_inline)) {
-            constexpr bool FIRST = decltype(first)::value;
-            const float* zt = zin + (size_t)tn * R * ldz;
+        // my ring region: slot s, tile i, gate g at ring_base + s*SLOT + (i*G + g)*1024 (+ lane*16 for my bytes)
+        const unsigned ring_base = (unsigned)(C::RING_OFF + wave * (TPW * G * 1024));
+        const char* ring_rd = smem + ring_base + lane * 16;
+        auto issue = [&](int slot, int td) __attribute__((always_inline)) {
+            const float* zt = zin + ((size_t)((OUT & 128) ? 0 : td) * R + rowc) * ldz;  // (bit 7: timing experiment, fixed frame)
 #pragma unroll
             for (int i = 0; i < NTL; ++i)
 #pragma unroll
                 for (int g = 0; g < G; ++g)
-                    if (!(OUT & 8)) prefetch16(zn[i][g], zt + rowc * ldz + g * H + col[i]);
+                    dma16_to_lds(__builtin_amdgcn_readfirstlane(ring_base + slot * C::SLOT + (i * G + g) * 1024), zt + g * H + col[i]);
+        };
+        // prologue: the first D-1 steps' input terms, then drain EVERYTHING (weights, state, DMAs) once
+        for (int s0 = 0; s0 < D - 1; ++s0) issue(s0, s0 < T ? s0 : (T > 0 ? T - 1 : 0));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // tell the compiler's scoreboard too (its own loads above are done)
+
+        // FIRST = the peeled step 0: nothing to flush (the LDS buffer holds the initial state, not an output)
+        auto step = [&](int t, auto first) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first)::value;
+            const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
+            int8_t* hn = hbuf + ((t & 1) ^ 1) * 16 * LDH;
+            {   // input term of step t+D-1 -> ring (clamped past the end: a harmless re-read of the last frame)
+                const int td = (t + D - 1 < T) ? t + D - 1 : T - 1;
+                issue((t + D - 1) % D, td);
+            }
             v4i b[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(hc + n * LDH + ks * 64 + q * 16);
-            if constexpr (!FIRST) {
-                // spikes of step t-1 (= hc) -> global
-                fl.run(hc, spikes_f32, spikes_i8, t - 1, R, H);
-                // This step's input term was requested one step ago.  vmcnt retires in order and counts stores too, so
-                // the wait is COUNTED: what was issued after those loads -- last step's membrane stores, the loads and
-                // the flush stores just issued -- may stay in flight; only stores a full step old are waited for.
-                if (!(OUT & 8)) wait_prefetch<NMEM + NTL * G + Flush::FL * Flush::NSTF, NTL * G>(&z[0][0]);
-            }
+            const char* zslot = ring_rd + (t % D) * C::SLOT;
 #pragma unroll
             for (int i = 0; i < NTL; ++i) {
                 const int cc = col[i];
-                v4f pre[G];
+                v4i acc[G][3];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
-                        a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][0], b[ks], a0, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][1], b[ks], a1, 0, 0, 0);
-                        a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][2], b[ks], a2, 0, 0, 0);
+                        if constexpr (OUT & 16) {  // timing experiment: no MFMAs (cheap stand-in keeps W and b live)
+                            a0 += W[i][g][ks][0] ^ b[ks];
+                        } else {
+                            a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][0], b[ks], a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][1], b[ks], a1, 0, 0, 0);
+                            a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][2], b[ks], a2, 0, 0, 0);
+                        }
                     }
+                    acc[g][0] = a0; acc[g][1] = a1; acc[g][2] = a2;
+                }
+                if (i == 0) {
+                    // under the first tile's MFMA latency: spikes of step t-1 (= hc) -> global ...
+                    if constexpr (!FIRST) fl.template run<OUT>(hc, spikes_f32, spikes_i8, t - 1, R, H);
+                    // ... then the counted wait for this step's input term (see the comment block above).  The first D
+                    // steps have a shorter queue than the steady state the count assumes: they drain completely.
+                    if (t < D || CBASE + fl.nact * CSTRIDE > 63) {  // (vmcnt is a 6-bit field; the test variants may exceed it)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else {
+                        wait_vmcnt_affine<CBASE, CSTRIDE, C::FL>(fl.nact);
+                    }
+                }
+                v4f pre[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const v4f z = *reinterpret_cast<const v4f*>(zslot + (i * G + g) * 1024);
                     const v4f dq = *reinterpret_cast<const v4f*>(&cst[3 + g][cc]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)  // dq is a power of two: fma(rec, dq, z) == z + rec*dq with ONE rounding
-                        pre[g][r] = __builtin_fmaf(recombine3(a0[r], a1[r], a2[r]), dq[r], z[i][g][r]);
+                        pre[g][r] = __builtin_fmaf(recombine3(acc[g][0][r], acc[g][1][r], acc[g][2][r]), dq[r], z[r]);
                 }
                 const v4f alpha = *reinterpret_cast<const v4f*>(&cst[1][cc]);
                 const v4f beta = *reinterpret_cast<const v4f*>(&cst[2][cc]);
@@ -241,6 +295,10 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
                 }
                 v4f cy;
                 unsigned pk = 0;
+                if constexpr (OUT & 32) {  // timing experiment: no epilogue math
+                    cy = c[i];
+                    pk = (acc[0][0][0] ^ acc[0][1][1] ^ acc[0][2][2] ^ __float_as_uint(pre[0][0])) & 0x01010101u;
+                } else
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // f = sigmoid(pre_f) with the hardware exp2 / rcp (~1 ulp each)
@@ -255,23 +313,20 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
                 if (OUT & 4) *reinterpret_cast<v4f*>(membrane + ((size_t)t * R + rowc) * H + cc) = cy;
             }
             // h_t complete in hn before anyone reads it; hc is free for the next step's writes.  Only LDS traffic has
-            // to drain here -- global stores stay in flight across the barrier.
+            // to drain here -- global stores and DMAs stay in flight across the barrier.
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0), vmcnt/expcnt untouched
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(OUT & 64)) __builtin_amdgcn_s_barrier();  // (bit 6: timing experiment without the barrier)
         };
 
-        if (T > 0) step(zA, zB, hbuf[0], hbuf[1], 0, (1 < T) ? 1 : 0, std::true_type{});
+        if (T > 0) step(0, std::true_type{});
 #pragma unroll 1
-        for (int t = 1; t < T; t += 2) {
-            step(zB, zA, hbuf[1], hbuf[0], t, (t + 1 < T) ? t + 1 : t, std::false_type{});
-            if (t + 1 < T) step(zA, zB, hbuf[0], hbuf[1], t + 1, (t + 2 < T) ? t + 2 : t + 1, std::false_type{});
-        }
+        for (int t = 1; t < T; ++t) step(t, std::false_type{});
 
-        // the last step's (unused) prefetch is invisible to the compiler: drain it before its registers are reused
+        // DMAs past the end are invisible to the compiler: drain before the LDS / registers are reused
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (T > 0) fl.run(hbuf[T & 1], spikes_f32, spikes_i8, T - 1, R, H);
+        if (T > 0) fl.template run<OUT>(hbuf + (T & 1) * 16 * LDH, spikes_f32, spikes_i8, T - 1, R, H);
         // final state (duplicate rows write the same values to the same place)
-        const int8_t* hl = hbuf[T & 1];  // h_{T-1} (or the untouched initial state when T == 0)
+        const int8_t* hl = hbuf + (T & 1) * 16 * LDH;  // h_{T-1} (or the untouched initial state when T == 0)
 #pragma unroll
         for (int i = 0; i < NTL; ++i) {
             *reinterpret_cast<v4f*>(c_state + (size_t)rowc * H + col[i]) = c[i];
@@ -286,14 +341,15 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
 // KS = 64-wide k steps; NW = waves per workgroup; TPW = tiles owned by the first (NT - NW*(TPW-1)) waves, the
 // rest own TPW-1 (tiles are dealt round-robin, so the four SIMDs carry equal MFMA load and no wave computes a
 // tile that does not exist).  OUT bit 0: fp32 spikes, bit 1: int8 spikes, bit 2: membranes -- compile-time so that
-// the stores are straight-line code.
+// the stores are straight-line code.  LDS (dynamic, one allocation): [input-term ring][hidden state x2][constants].
 template <int G, int KS, int NW, int TPW, int OUT>
 __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
-    constexpr int LDH = KS * 64 + 16;  // +16 B row pad: the 16 rows of a B fragment land on distinct LDS banks
-    constexpr int HP = KS * 64;        // padded hidden size
-    constexpr int NC = 3 + G;          // per-neuron constant vectors: (bias_g - bias_f), alpha, beta, dq[G]
-    __shared__ __attribute__((aligned(16))) int8_t hbuf[2][16 * LDH];
-    __shared__ __attribute__((aligned(16))) float cst[NC][HP];
+    using C = ScanCfg<G, KS, NW, TPW, OUT>;
+    constexpr int LDH = C::LDH, HP = C::HP;
+    extern __shared__ __attribute__((aligned(16))) char scan_smem[];
+    char* smem = scan_smem;
+    int8_t* hbuf = reinterpret_cast<int8_t*>(smem + C::HBUF_OFF);
+    float(*cst)[HP] = reinterpret_cast<float(*)[HP]>(smem + C::CST_OFF);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -306,8 +362,12 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
         if ((int)blockIdx.x >= p.seg[i].tile0) s = i;
     const ScanSegDev sg = p.seg[s];
     const int H = p.H, NT = p.NT, T = p.T, R = sg.R;
-    const int row0 = ((int)blockIdx.x - sg.tile0) * 16;
-    const int rowc = (row0 + n < R) ? row0 + n : R - 1;
+    // A workgroup owns rpw rows; MFMA columns n >= rpw are clamped duplicates of column n % rpw (same data, same
+    // results, same addresses).  Fewer rows per workgroup = more CUs busy and less HBM traffic per CU per step: one CU
+    // sustains only ~10-13 B/clk of HBM streaming, which at 16 rows x 224 neurons (32 KB per step) IS the step time.
+    const int rpw = p.rpw;
+    const int row0 = ((int)blockIdx.x - sg.tile0) * rpw;
+    const int rowc = (row0 + (n & (rpw - 1)) < R) ? row0 + (n & (rpw - 1)) : R - 1;
 
     // per-neuron constants -> LDS; zero the hidden-state buffers (pads must read as 0 spikes)
     for (int j = tid; j < HP; j += NW * 64) {
@@ -318,26 +378,26 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
 #pragma unroll
         for (int g = 0; g < G; ++g) cst[3 + g][j] = in ? sg.w_dq[g * H + j] : 0.0f;
     }
-    for (int i = tid; i < 2 * 16 * LDH / 4; i += NW * 64) reinterpret_cast<int*>(&hbuf[0][0])[i] = 0;
+    for (int i = tid; i < 2 * 16 * LDH / 4; i += NW * 64) reinterpret_cast<int*>(hbuf)[i] = 0;
     __syncthreads();
     // initial hidden state h_{-1} -> hbuf[0] as int8 (all threads cooperate; 4 neurons per thread-iteration)
     for (int idx = tid; idx < 16 * (H / 4); idx += NW * 64) {
         const int rr = idx / (H / 4), j4 = (idx - rr * (H / 4)) * 4;
-        const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;
+        const int rsrc = (row0 + (rr & (rpw - 1)) < R) ? row0 + (rr & (rpw - 1)) : R - 1;
         const v4f h = *reinterpret_cast<const v4f*>(sg.h_state + (size_t)rsrc * H + j4);
         const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
                             (h.w > 0.5f ? 0x1000000u : 0u);
-        *reinterpret_cast<unsigned*>(&hbuf[0][rr * LDH + j4]) = pk;
+        *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
     }
     __syncthreads();
 
     const int n_hi = NT - NW * (TPW - 1);  // waves [0, n_hi) own TPW tiles, the others TPW-1
     if (wave < n_hi)
-        scan_body<G, KS, NW, OUT, TPW>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state, cst, hbuf,
-                                       T, H, NT, R, row0, rowc, n, q, tid, wave);
+        scan_body<G, KS, NW, TPW, OUT, TPW>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state, smem, T,
+                                            H, NT, R, row0, rowc, n, q, tid, wave, rpw);
     else
-        scan_body<G, KS, NW, OUT, TPW - 1>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state, cst,
-                                           hbuf, T, H, NT, R, row0, rowc, n, q, tid, wave);
+        scan_body<G, KS, NW, TPW, OUT, TPW - 1>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state,
+                                                smem, T, H, NT, R, row0, rowc, n, q, tid, wave, rpw);
 }
 
 // =====================================================================================================
@@ -738,27 +798,56 @@ extern "C" int sfsn_device_count(void) {
     return n;
 }
 
+template <int G, int KS, int NW, int TPW, int OUT>
+static int launch_scan_variant(const ScanParams& p, int tiles, hipStream_t st) {
+    using C = ScanCfg<G, KS, NW, TPW, OUT>;
+    auto kern = gsn_scan_kernel<G, KS, NW, TPW, OUT>;
+    if (C::LDS_BYTES > 64 * 1024) {
+        static bool raised = false;  // idempotent attribute; a benign race between threads sets it twice at worst
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) !=
+                hipSuccess)
+                return SFSN_EHIP;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NW * 64), C::LDS_BYTES, st, p);
+    return hip_ok(hipGetLastError());
+}
+
 template <int G, int KS, int NW, int TPW>
 static int launch_scan(const ScanParams& p, int tiles, int out, hipStream_t st) {
     // output sets compiled: int8 only (downstream products need it), fp32 + int8 (module API), + membranes (tests)
     switch (out) {
-        case 2: hipLaunchKernelGGL((gsn_scan_kernel<G, KS, NW, TPW, 2>), dim3(tiles), dim3(NW * 64), 0, st, p); break;
-        case 3: hipLaunchKernelGGL((gsn_scan_kernel<G, KS, NW, TPW, 3>), dim3(tiles), dim3(NW * 64), 0, st, p); break;
-        case 7: hipLaunchKernelGGL((gsn_scan_kernel<G, KS, NW, TPW, 7>), dim3(tiles), dim3(NW * 64), 0, st, p); break;
+        case 2: return launch_scan_variant<G, KS, NW, TPW, 2>(p, tiles, st);
+        case 3: return launch_scan_variant<G, KS, NW, TPW, 3>(p, tiles, st);
+        case 7: return launch_scan_variant<G, KS, NW, TPW, 7>(p, tiles, st);
 #ifdef SFSN_TIMING_EXPERIMENTS  // wrong-result variants for bottleneck attribution only (scripts/exp_scan.sh)
-        case 0: hipLaunchKernelGGL((gsn_scan_kernel<G, KS, NW, TPW, 0>), dim3(tiles), dim3(NW * 64), 0, st, p); break;
-        case 8: hipLaunchKernelGGL((gsn_scan_kernel<G, KS, NW, TPW, 8>), dim3(tiles), dim3(NW * 64), 0, st, p); break;
-        case 11: hipLaunchKernelGGL((gsn_scan_kernel<G, KS, NW, TPW, 11>), dim3(tiles), dim3(NW * 64), 0, st, p); break;
+        case 19: return launch_scan_variant<G, KS, NW, TPW, 19>(p, tiles, st);
+        case 35: return launch_scan_variant<G, KS, NW, TPW, 35>(p, tiles, st);
+        case 51: return launch_scan_variant<G, KS, NW, TPW, 51>(p, tiles, st);
+        case 67: return launch_scan_variant<G, KS, NW, TPW, 67>(p, tiles, st);
+        case 131: return launch_scan_variant<G, KS, NW, TPW, 131>(p, tiles, st);
+        case 259: return launch_scan_variant<G, KS, NW, TPW, 259>(p, tiles, st);
+        case 387: return launch_scan_variant<G, KS, NW, TPW, 387>(p, tiles, st);
 #endif
         default: return SFSN_EUNSUPPORTED;
     }
-    return hip_ok(hipGetLastError());
 }
 
 extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, int T, int H, int shared, void* stream) {
     if (!segs || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0) return SFSN_EINVAL;
     if (H % 16 != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     ScanParams p;
+    // rows per workgroup: as few as it takes to spread the launch over ~all 256 CUs (see the kernel comment)
+    int rows_total = 0;
+    for (int i = 0; i < n_segs; ++i) rows_total += segs[i].R > 0 ? segs[i].R : 0;
+    int rpw = 16;
+    while (rpw > 4 && (rows_total + rpw - 1) / rpw < 200) rpw >>= 1;
+#ifdef SFSN_TIMING_EXPERIMENTS
+    if (const char* e = getenv("SFSN_SCAN_RPW")) rpw = atoi(e);
+#endif
+    p.rpw = rpw;
     int tiles = 0;
     // the set of outputs must be the same for every segment of a launch (it selects the kernel variant);
     // the int8 spikes are always produced (every consumer of a scan in this library reads them)
@@ -777,7 +866,7 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
         d.zin = s.zin; d.w_hh = s.w_hh; d.w_dq = s.w_dq; d.bias = s.bias; d.bn_alpha = s.bn_alpha; d.bn_beta = s.bn_beta;
         d.h_state = s.h_state; d.c_state = s.c_state; d.spikes_f32 = s.spikes_f32; d.spikes_i8 = s.spikes_i8;
         d.membrane = s.membrane; d.R = s.R; d.tile0 = tiles;
-        tiles += (s.R + 15) / 16;
+        tiles += (s.R + rpw - 1) / rpw;
     }
     p.nseg = n_segs; p.T = T; p.H = H; p.NT = H / 16;
 #ifdef SFSN_TIMING_EXPERIMENTS

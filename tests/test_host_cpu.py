@@ -1,0 +1,181 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every symbol include/sfsn.h declares,
+weight packing (pure host integer work) is exact to its stated bound, BatchNorm folding is ATen-exact, the drop-in
+modules keep the reference's state-dict contract and fail loudly without a GPU, and the clip sharding / all-gather
+is correct on a world_size-2 gloo group."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import refweights as rw
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from spiking_fullsubnet_amd import _lib
+    _lib.build()
+    L = _lib.lib()
+    header = open(os.path.join(ROOT, "include", "sfsn.h")).read()
+    declared = set(re.findall(r"\b(sfsn_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.sfsn_abi_version() == 1
+    assert L.sfsn_strerror(-4).decode().startswith("Number of frequency bins")
+
+
+def test_no_device_means_loud_failure_not_fallback():
+    """Without a GPU every launch returns SFSN_EHIP (-> RuntimeError); nothing silently computes on the CPU."""
+    from spiking_fullsubnet_amd import _lib
+    import spiking_fullsubnet_amd as pkg
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = _lib.lib()
+    assert L.sfsn_device_count() == 0
+    m = pkg.SpikingFullSubNet(**rw.LIVE_TINY).eval()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(1, 4096))
+    with pytest.raises(RuntimeError):
+        pkg.Engine(m._spec(), {k: v.numpy() for k, v in m.state_dict().items()}, "cpu")
+
+
+@pytest.mark.parametrize("n,k", [(224, 224), (320, 320), (40, 224), (6, 48), (160, 38), (17, 65)])
+def test_w3_pack_roundtrip_bound(n, k):
+    """|W - W~| <= dq/2 per row (<= one fp32 ulp of the row's largest binade), dq a power of two, digits in int8,
+    zero padding, and exactness for weights already on the 24-bit grid."""
+    from spiking_fullsubnet_amd.engine import pack_w3, unpack_w3
+    rng = np.random.default_rng(n * 1000 + k)
+    w = (rng.standard_normal((n, k)) * rng.uniform(1e-3, 3.0, (n, 1))).astype(np.float32)
+    w[0, :] = 0.0
+    pk, dq = pack_w3(w)
+    assert pk.dtype == np.int8 and pk.size == 3 * ((n + 15) // 16) * ((k + 63) // 64) * 1024
+    w2 = unpack_w3(pk, dq, n, k)
+    assert (np.abs(w2.astype(np.float64) - w) <= dq[:n, None].astype(np.float64) / 2 + 1e-30).all()
+    m, e = np.frexp(dq[:n])
+    assert (m == 0.5).all()                                            # powers of two
+    assert (np.abs(w).max(1) <= dq[:n].astype(np.float64) * 8355711).all()   # digits cannot overflow
+    assert (dq[n:] == 0).all()
+    grid = (np.round(w / dq[:n, None]) * dq[:n, None]).astype(np.float32)  # already representable -> exact
+    pk2, dq2 = pack_w3(grid)
+    np.testing.assert_array_equal(unpack_w3(pk2, dq2, n, k), grid)
+
+
+def test_w3_pack_rejects_nonfinite():
+    from spiking_fullsubnet_amd.engine import pack_w3
+    w = np.ones((4, 4), np.float32)
+    w[1, 2] = np.inf
+    with pytest.raises(ValueError):
+        pack_w3(w)
+
+
+def test_fold_batchnorm_is_aten_exact():
+    """alpha/beta reproduce torch's CPU eval BatchNorm1d bit for bit (the oracle restates the same form)."""
+    from spiking_fullsubnet_amd.engine import fold_batchnorm
+    torch.manual_seed(0)
+    C = 224
+    bn = torch.nn.BatchNorm1d(C).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, .5); bn.running_var.uniform_(.3, 1.5); bn.weight.normal_(1, .2); bn.bias.normal_(0, .3)
+    x = torch.randn(257, C)
+    y = bn(x).detach().numpy()
+    a, b = fold_batchnorm(bn.weight.detach().numpy(), bn.bias.detach().numpy(), bn.running_mean.numpy(), bn.running_var.numpy())
+    y2 = (x.numpy().astype(np.float64) * a.astype(np.float64) + b.astype(np.float64)).astype(np.float32)  # fma
+    np.testing.assert_array_equal(y, y2)
+
+
+def test_state_dict_contract_live_and_frozen(golden_dir):
+    """Same keys / shapes as the reference modules: synthetic reference-named dicts and the zoo checkpoint load strict."""
+    import spiking_fullsubnet_amd as pkg
+    for kw, seed in ((rw.LIVE_M, 1), (rw.LIVE_TINY_UNSHARED, 2), (rw.LIVE_TINY_2SPK, 3)):
+        m = pkg.SpikingFullSubNet(**kw)
+        sd = rw.live_state_dict(kw, seed)
+        assert set(m.state_dict().keys()) == set(sd.keys())
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    g = np.load(os.path.join(golden_dir, "frozen_s_zoo.npz"))
+    s = pkg.Separator(**rw.FROZEN_S)
+    zoo = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    assert len(zoo) == 72
+    s.load_state_dict(zoo, strict=True)
+    assert sum(p.numel() for p in s.parameters()) == 520920  # trainable parameters of baseline_s
+
+
+def test_constructor_rejections_match_reference():
+    import spiking_fullsubnet_amd as pkg
+    with pytest.raises(NotImplementedError):
+        pkg.SpikingFullSubNet(**dict(rw.LIVE_TINY, sequence_model="GRU"))       # modeling:47
+    with pytest.raises(AssertionError):
+        pkg.SpikingFullSubNet(**dict(rw.LIVE_TINY, freq_cutoffs=[0, 32, 256]))  # modeling:197
+    with pytest.raises(NotImplementedError):
+        pkg.Separator(**dict(rw.FROZEN_TINY, sequence_model="LSTM"))            # model_low_freq:70
+    with pytest.raises(NotImplementedError):
+        pkg.Separator(**dict(rw.FROZEN_TINY, norm_type="forgetting_norm"))      # model_low_freq:227-231
+
+
+def test_reference_init_is_reproduced():
+    """Same RNG consumption order as the reference constructors: torch.manual_seed(s); Model(**kw) gives the same
+    initial weights (checked against values recorded from the reference: U(-1/sqrt(H), 1/sqrt(H)) cells first)."""
+    import spiking_fullsubnet_amd as pkg
+    torch.manual_seed(0)
+    m = pkg.SpikingFullSubNet(**rw.LIVE_TINY)
+    w = m.fb_model.sequence_model.layers[0].cell.weight_ih
+    assert w.shape == (48, 64) and float(w.detach().abs().max()) <= 1 / np.sqrt(48) + 1e-7
+    torch.manual_seed(0)
+    expect = torch.empty(48, 64).uniform_(-1 / np.sqrt(48), 1 / np.sqrt(48))
+    assert torch.equal(w.detach(), expect)  # first RNG draw of the constructor is the first cell's weight_ih
+
+
+def test_shard_bounds_partition():
+    from spiking_fullsubnet_amd.dist import shard_bounds
+    for n in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(8, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_clips, q):
+    import torch.distributed as dist
+    from spiking_fullsubnet_amd.dist import gather_clips, shard_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(n_clips * 3 * 5, dtype=torch.float32).reshape(n_clips, 3, 5)
+        lo, hi = shard_bounds(n_clips, rank, world)
+        out = gather_clips(full[lo:hi].clone(), n_clips)
+        q.put((rank, bool(torch.equal(out, full))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [8, 7])
+def test_gather_clips_world2_gloo(n_clips):
+    """N > 1 path on CPU: two gloo ranks shard the clips, all-gather and recover the batch in clip order (even and ragged)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
