@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layer-outputs", action="store_true", help="skip the fp32 spike tensors of the module API (reported in config)")
+    ap.add_argument("--sequential", action="store_true", help="disable the time-pipelined multi-stream schedule")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -85,8 +86,11 @@ def main():
     want_layers = not args.no_layer_outputs
     gathered = torch.empty((world * B, 1, 257, T), dtype=torch.float32, device=dev) if world > 1 else None
 
+    info = {}
+
     def step():
-        res = eng.forward_stft(stft, want_layers=want_layers)
+        res = eng.forward_stft(stft, want_layers=want_layers, pipeline=False if args.sequential else None)
+        info.update(pipelined=res["pipelined"], n_chunks=res["n_chunks"])
         if world > 1:
             dist.all_gather_into_tensor(gathered, res["enh_mag"])
         return res
@@ -117,19 +121,22 @@ def main():
         sb_ms = scan_ms.get("scan:sb")
         roofline = None
         if sb_ms:
-            bytes_per_launch = SB_SCAN_BYTES_PER_FRAME_PER_LAUNCH * B * T
+            # one launch of the scan kernel covers T / n_chunks frames of every clip (time-pipelined schedule)
+            frames_per_launch = B * T / info["n_chunks"]
+            bytes_per_launch = SB_SCAN_BYTES_PER_FRAME_PER_LAUNCH * frames_per_launch
             achieved = bytes_per_launch / (sb_ms["mean_ms"] * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
-                if tj.get("B") == B and tj.get("T") == T:
-                    traffic = tj.get("sb_scan_hbm_bytes_per_launch")
+                if tj.get("B") == B and tj.get("T") == T:  # measured on one whole-sequence launch; scale to this launch's frames
+                    traffic = int(tj.get("sb_scan_hbm_bytes_per_launch") / info["n_chunks"])
             roofline = dict(bound="hbm", kernel="gsn_scan_kernel<G=1,TPW=2,KS=4,NW=8> (sub-band groups, one launch per layer)",
                             achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
                             traffic=traffic, launch_ms=round(sb_ms["mean_ms"], 4), launches=sb_ms["n"],
                             algorithmic_bytes_per_launch=int(bytes_per_launch),
-                            per_step_us=round(1e3 * sb_ms["mean_ms"] / T, 3),
+                            per_step_us=round(1e3 * sb_ms["mean_ms"] / (T / info["n_chunks"]), 3),
+                            frames_per_launch=int(frames_per_launch), schedule=("time-pipelined x%d chunks on %d streams" % (info["n_chunks"], 4)) if info["pipelined"] else "sequential",
                             other_kernels_ms={k: round(v["mean_ms"], 4) for k, v in scan_ms.items() if k != "scan:sb"})
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -91,7 +91,9 @@ int sfsn_w3_unpack(const int8_t* packed, const float* dq, int n_out, int k_in, f
  * sqrt(var + eps), beta = fma(-mean, alpha, bias); identity = (1, 0) when bn=False).
  * The hidden state h lives in LDS as int8, the membrane c in registers, W_hh in registers as packed int8
  * digits for the whole scan; one workgroup owns 16 rows.  All segments of one launch must request the same set
- * of optional outputs (it selects the compiled kernel variant).
+ * of optional outputs (it selects the compiled kernel variant).  T is the number of frames of THIS launch: a long
+ * sequence may be scanned in chunks (pointers advanced by the caller, h_state / c_state carrying the state), which is
+ * how independent layers / models are pipelined over time on separate streams, and how streaming inference works.
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct sfsn_scan_segment {
     const float* zin;      /* [T][R][G*H] input term incl. bias (see above), G = 1 shared / 2 unshared      */
@@ -109,7 +111,7 @@ typedef struct sfsn_scan_segment {
 } sfsn_scan_segment;
 
 int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs /* host array */, int n_segs, int T, int H, int shared,
-                        void* stream);
+                        int rows_per_wg /* 16, 8, 4, or 0 = choose so that the launch covers ~all CUs */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Time-parallel products.
@@ -154,7 +156,7 @@ typedef struct sfsn_feature_group {
 
 int sfsn_features(const float* stft_ri /* [B][F][T][2] */, const float* fb_tbf /* [T][B][FB], NULL if unused */,
                   int B, int F, int T, int FB, float fdrc, const sfsn_feature_group* groups /* host */, int n_groups,
-                  void* stream);
+                  int t0, int nt /* frames [t0, t0+nt) are produced; tensors are indexed by absolute frame */, void* stream);
 
 /* Per-clip means for offline_laplace_norm (FROZEN:162-164: mean over all non-batch dims of the gathered,
  * un-normalised group tensor).  mu_out [n_groups][B].  Two launches: row sums of mag / fb, then the
@@ -178,7 +180,7 @@ typedef struct sfsn_df_group {
 
 int sfsn_deepfilter(const float* stft_ri /* [B][F][T][2] */, int B, int F, int T, int S,
                     const sfsn_df_group* groups /* host */, int n_groups, float* enh_ri /* [B][S][F][T][2] */,
-                    float* enh_mag /* [B][S][F][T], nullable */, void* stream);
+                    float* enh_mag /* [B][S][F][T], nullable */, int t0, int nt /* frames [t0, t0+nt) */, void* stream);
 
 #ifdef __cplusplus
 }

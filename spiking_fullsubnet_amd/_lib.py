@@ -72,17 +72,17 @@ def lib() -> ctypes.CDLL:
     L.sfsn_w3_unpack.restype = _I
     L.sfsn_w3_unpack.argtypes = [_P, _P, _I, _I, _P]
     L.sfsn_gsn_layer_scan.restype = _I
-    L.sfsn_gsn_layer_scan.argtypes = [ctypes.POINTER(ScanSegment), _I, _I, _I, _I, _P]
+    L.sfsn_gsn_layer_scan.argtypes = [ctypes.POINTER(ScanSegment), _I, _I, _I, _I, _I, _P]
     L.sfsn_input_proj_f32.restype = _I
     L.sfsn_input_proj_f32.argtypes = [_P, _P, _P, _P, _I, _I, _I, _I, _P]
     L.sfsn_spike_proj.restype = _I
     L.sfsn_spike_proj.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]
     L.sfsn_features.restype = _I
-    L.sfsn_features.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _P]
+    L.sfsn_features.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _I, _I, _P]
     L.sfsn_laplace_means.restype = _I
     L.sfsn_laplace_means.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _P, _P, _P]
     L.sfsn_deepfilter.restype = _I
-    L.sfsn_deepfilter.argtypes = [_P, _I, _I, _I, _I, ctypes.POINTER(DfGroup), _I, _P, _P, _P]
+    L.sfsn_deepfilter.argtypes = [_P, _I, _I, _I, _I, ctypes.POINTER(DfGroup), _I, _P, _P, _I, _I, _P]
     if L.sfsn_abi_version() != 1:
         raise ImportError(f"{LIB_PATH}: ABI version {L.sfsn_abi_version()} != 1; rebuild")
     _lib = L

@@ -71,29 +71,43 @@ __device__ __forceinline__ float recombine3(int a0, int a1, int a2) {
 //     waited for (cdna_hip_programming.md 5.7 / T3+T4: counted vmcnt, never 0 in the main loop).
 // The LDS destination of a DMA is wave-uniform base (M0) + lane*16: each lane later reads back exactly the 16 bytes
 // it requested.  Destinations are kept below 64 KiB (the ring is the first thing in the LDS allocation).
-__device__ __forceinline__ void dma16_to_lds(unsigned lds_dst_uniform, const float* src) {
+__device__ __forceinline__ void dma16_to_lds(unsigned lds_dst_uniform, const float* base_uniform, unsigned byte_off) {
+    // saddr form: 64-bit wave-uniform base in SGPRs + 32-bit per-lane byte offset (no 64-bit VALU address arithmetic).
+    // The "s" operands must be PROVABLY uniform for the compiler: readfirstlane both halves of the pointer.
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base_uniform);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned long long base = ((unsigned long long)hi << 32) | lo;
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(src), "s"(lds_dst_uniform)
+        : "v"(byte_off), "s"(base), "s"(lds_dst_uniform)
         : "memory");
 }
 
-template <int G, int KS, int NW, int TPW, int OUT>
+template <int G, int KS, int NW, int TPW, int OUT, int LP>
 struct ScanCfg {
     static constexpr int LDH = KS * 64 + 32;  // +32 B row pad: the ds_read_b128 lane groups of a B fragment hit distinct banks
     static constexpr int HP = KS * 64;        // padded hidden size
     static constexpr int NC = 3 + G;          // per-neuron constant vectors: (bias_g - bias_f), alpha, beta, dq[G]
-    static constexpr int SLOT = NW * TPW * G * 1024;  // bytes of one ring slot (every wave: TPW tiles x G gates x 1 KiB)
-    static constexpr int RING_D = (4 * SLOT <= 65536) ? 4 : ((3 * SLOT <= 65536) ? 3 : 2);
-    static_assert(RING_D * SLOT <= 65536 || RING_D == 2, "ring too large");
-    static constexpr int RING_OFF = 0, HBUF_OFF = RING_D * SLOT, CST_OFF = HBUF_OFF + 2 * 16 * LDH;
-    static constexpr int LDS_BYTES = CST_OFF + NC * HP * 4;
+    static constexpr int NTMAX = (NW * TPW < KS * 4) ? NW * TPW : KS * 4;  // output tiles per gate (NT <= H/16 <= 4 KS)
+    static constexpr int SLOT = NTMAX * G * 1024;  // bytes of one ring slot: 1 KiB per (tile, gate), indexed by tile id
+    static constexpr int HBUF_BYTES = 2 * 16 * LDH, CST_BYTES = NC * HP * 4;
+    // LP = 1: the least-significant digit plane of W_hh lives in LDS instead of registers (H = 320: 100 KB), which
+    // brings the per-wave weight registers from 300 down to 120 and lets 8 waves (2 per SIMD) share the CU.
+    static constexpr int WPLANE_BYTES = LP ? G * NTMAX * KS * 1024 : 0;
+    static constexpr int FIXED = HBUF_BYTES + CST_BYTES + WPLANE_BYTES;
+    static constexpr int LDS_CAP = 160 * 1024;
+    static constexpr int RING_D = (4 * SLOT <= 65536 && 4 * SLOT + FIXED <= LDS_CAP)   ? 4
+                                  : (3 * SLOT <= 65536 && 3 * SLOT + FIXED <= LDS_CAP) ? 3
+                                                                                        : 2;
+    static_assert(RING_D * SLOT <= 65536 && RING_D * SLOT + FIXED <= LDS_CAP, "LDS budget");
+    static constexpr int RING_OFF = 0, HBUF_OFF = RING_D * SLOT, CST_OFF = HBUF_OFF + HBUF_BYTES, WPLANE_OFF = CST_OFF + CST_BYTES;
+    static constexpr int LDS_BYTES = WPLANE_OFF + WPLANE_BYTES;
     // flush geometry: all threads of the workgroup write the previous step's spikes from the LDS hidden-state buffer
     static constexpr int CHUNKS = 16 * (HP / 4);                    // 4-neuron chunks of the padded 16 x HP tile
     static constexpr int FL = (CHUNKS + NW * 64 - 1) / (NW * 64);   // chunks per thread
@@ -165,16 +179,18 @@ __device__ __forceinline__ void wait_vmcnt_affine(int k) {
 // Straight-line code per step: no per-tile or per-row branch.  Rows past R are CLAMPED duplicates of row R-1: they
 // run the same instruction sequence on the same data, produce bit-identical values and store them to the same
 // addresses as the original (a benign duplicate write), so a step is one basic block the scheduler can interleave.
-template <int G, int KS, int NW, int TPW, int OUT, int NTL>
+template <int G, int KS, int NW, int TPW, int OUT, int LP, int NTL>
 __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const int8_t* __restrict__ w_hh,
                                           float* __restrict__ spikes_f32, int8_t* __restrict__ spikes_i8,
                                           float* __restrict__ membrane, float* __restrict__ h_state, float* __restrict__ c_state,
                                           char* smem, int T, int H, int NT, int R, int row0, int rowc, int n, int q, int tid,
                                           int wave, int rpw) {
-    using C = ScanCfg<G, KS, NW, TPW, OUT>;
+    using C = ScanCfg<G, KS, NW, TPW, OUT, LP>;
     constexpr int LDH = C::LDH, HP = C::HP, D = C::RING_D;
+    constexpr int NPR = 3 - LP;  // digit planes kept in registers (planes LP..2); plane 0 is in LDS when LP = 1
     int8_t* hbuf = reinterpret_cast<int8_t*>(smem + C::HBUF_OFF);
     const float(*cst)[HP] = reinterpret_cast<const float(*)[HP]>(smem + C::CST_OFF);
+    const char* wplane = smem + C::WPLANE_OFF;
     ScanFlush<C> fl;
     fl.init(tid, row0, R, H, NW * 64, rpw);
     const int lane = tid & 63;
@@ -197,34 +213,39 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
         constexpr int CBASE = (D - 1) * (A + NMEM), CSTRIDE = D * C::NSTF;
 
         // register-resident recurrent weights (int8 digits in MFMA A-fragment order) and membrane state
-        v4i W[NTL][G][KS][3];
+        v4i W[NTL][G][KS][NPR];
         v4f c[NTL];
-        int col[NTL];  // first neuron of my 4-neuron group in tile i
+        int col[NTL];          // first neuron of my 4-neuron group in tile i
+        unsigned zoff[NTL];    // byte offset of my 16 input-term bytes of tile i within a frame (gate 0)
+        unsigned wl_off[NTL];  // LDS byte offset of my fragment of tile i, k-step 0, in the LDS digit plane
 #pragma unroll
         for (int i = 0; i < NTL; ++i) {
             const int ct = wave + NW * i;
             col[i] = ct * 16 + q * 4;
+            zoff[i] = (unsigned)(rowc * ldz + col[i]) * 4u;
+            wl_off[i] = (unsigned)((ct * KS) * 64 + lane) * 16u;
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const size_t tile = (size_t)d * (G * NT) + (size_t)g * NT + ct;
+                    for (int d = 0; d < NPR; ++d) {
+                        const size_t tile = (size_t)(d + LP) * (G * NT) + (size_t)g * NT + ct;
                         W[i][g][ks][d] = *reinterpret_cast<const v4i*>(w_hh + ((tile * KS + ks) * 64 + lane) * 16);
                     }
             c[i] = *reinterpret_cast<const v4f*>(c_state + (size_t)rowc * H + col[i]);
         }
-        // my ring region: slot s, tile i, gate g at ring_base + s*SLOT + (i*G + g)*1024 (+ lane*16 for my bytes)
-        const unsigned ring_base = (unsigned)(C::RING_OFF + wave * (TPW * G * 1024));
+        // ring: slot s, tile ct, gate g at s*SLOT + (ct*G + g)*1024 (+ lane*16 for my bytes)
+        const unsigned ring_base = (unsigned)(C::RING_OFF + wave * (G * 1024));
         const char* ring_rd = smem + ring_base + lane * 16;
         auto issue = [&](int slot, int td) __attribute__((always_inline)) {
-            const float* zt = zin + ((size_t)((OUT & 128) ? 0 : td) * R + rowc) * ldz;  // (bit 7: timing experiment, fixed frame)
+            const float* zt = zin + (size_t)((OUT & 128) ? 0 : td) * R * ldz;  // wave-uniform (bit 7: timing experiment)
 #pragma unroll
             for (int i = 0; i < NTL; ++i)
 #pragma unroll
                 for (int g = 0; g < G; ++g)
-                    dma16_to_lds(__builtin_amdgcn_readfirstlane(ring_base + slot * C::SLOT + (i * G + g) * 1024), zt + g * H + col[i]);
+                    dma16_to_lds(__builtin_amdgcn_readfirstlane(ring_base + slot * C::SLOT + (NW * i * G + g) * 1024), zt,
+                                 zoff[i] + (unsigned)(g * H) * 4u);
         };
         // prologue: the first D-1 steps' input terms, then drain EVERYTHING (weights, state, DMAs) once
         for (int s0 = 0; s0 < D - 1; ++s0) issue(s0, s0 < T ? s0 : (T > 0 ? T - 1 : 0));
@@ -255,6 +276,11 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
                     for (int ks = 0; ks < KS; ++ks) {
                         if constexpr (OUT & 16) {  // timing experiment: no MFMAs (cheap stand-in keeps W and b live)
                             a0 += W[i][g][ks][0] ^ b[ks];
+                        } else if constexpr (LP == 1) {
+                            const v4i w0 = *reinterpret_cast<const v4i*>(wplane + wl_off[i] + (unsigned)((g * NT * KS + ks) * 1024));
+                            a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, b[ks], a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][0], b[ks], a1, 0, 0, 0);
+                            a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][1], b[ks], a2, 0, 0, 0);
                         } else {
                             a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][0], b[ks], a0, 0, 0, 0);
                             a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][1], b[ks], a1, 0, 0, 0);
@@ -277,7 +303,7 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
                 v4f pre[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const v4f z = *reinterpret_cast<const v4f*>(zslot + (i * G + g) * 1024);
+                    const v4f z = *reinterpret_cast<const v4f*>(zslot + (NW * i * G + g) * 1024);
                     const v4f dq = *reinterpret_cast<const v4f*>(&cst[3 + g][cc]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)  // dq is a power of two: fma(rec, dq, z) == z + rec*dq with ONE rounding
@@ -342,9 +368,9 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
 // rest own TPW-1 (tiles are dealt round-robin, so the four SIMDs carry equal MFMA load and no wave computes a
 // tile that does not exist).  OUT bit 0: fp32 spikes, bit 1: int8 spikes, bit 2: membranes -- compile-time so that
 // the stores are straight-line code.  LDS (dynamic, one allocation): [input-term ring][hidden state x2][constants].
-template <int G, int KS, int NW, int TPW, int OUT>
+template <int G, int KS, int NW, int TPW, int OUT, int LP>
 __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
-    using C = ScanCfg<G, KS, NW, TPW, OUT>;
+    using C = ScanCfg<G, KS, NW, TPW, OUT, LP>;
     constexpr int LDH = C::LDH, HP = C::HP;
     extern __shared__ __attribute__((aligned(16))) char scan_smem[];
     char* smem = scan_smem;
@@ -379,6 +405,11 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
         for (int g = 0; g < G; ++g) cst[3 + g][j] = in ? sg.w_dq[g * H + j] : 0.0f;
     }
     for (int i = tid; i < 2 * 16 * LDH / 4; i += NW * 64) reinterpret_cast<int*>(hbuf)[i] = 0;
+    if constexpr (LP == 1) {  // digit plane 0 of W_hh (the first G*NT*KS KiB of the packed array) -> LDS, once
+        v4i* dst = reinterpret_cast<v4i*>(smem + C::WPLANE_OFF);
+        const v4i* src = reinterpret_cast<const v4i*>(sg.w_hh);
+        for (int i = tid; i < G * NT * KS * 64; i += NW * 64) dst[i] = src[i];
+    }
     __syncthreads();
     // initial hidden state h_{-1} -> hbuf[0] as int8 (all threads cooperate; 4 neurons per thread-iteration)
     for (int idx = tid; idx < 16 * (H / 4); idx += NW * 64) {
@@ -393,10 +424,10 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
 
     const int n_hi = NT - NW * (TPW - 1);  // waves [0, n_hi) own TPW tiles, the others TPW-1
     if (wave < n_hi)
-        scan_body<G, KS, NW, TPW, OUT, TPW>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state, smem, T,
+        scan_body<G, KS, NW, TPW, OUT, LP, TPW>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state, smem, T,
                                             H, NT, R, row0, rowc, n, q, tid, wave, rpw);
     else
-        scan_body<G, KS, NW, TPW, OUT, TPW - 1>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state,
+        scan_body<G, KS, NW, TPW, OUT, LP, TPW - 1>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state,
                                                 smem, T, H, NT, R, row0, rowc, n, q, tid, wave, rpw);
 }
 
@@ -559,6 +590,7 @@ struct FeatGroupDev {
 struct FeatParams {
     FeatGroupDev g[SFSN_MAX_GROUPS];
     int ng, B, F, T, FB;
+    int t0, t1;  // frames [t0, t1) are produced
     float fdrc;
 };
 
@@ -584,13 +616,14 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
     const int nf = p.F - 1, T = p.T, B = p.B, FB = p.FB;
     float* magT = smem;                        // [nf][33]
     float* fbT = smem + (size_t)nf * 33;       // [32][FB]
-    const int b = blockIdx.y, t0 = blockIdx.x * FEAT_TT;
+    const int b = blockIdx.y, t0 = p.t0 + blockIdx.x * FEAT_TT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tend = p.t1;
 
     for (int idx = tid; idx < nf * FEAT_TT; idx += 256) {
         const int f = idx >> 5, tt = idx & 31, t = t0 + tt;
         float v = 0.0f;
-        if (t < T) {
+        if (t < tend) {
             const float2 c = *reinterpret_cast<const float2*>(stft + (((size_t)b * p.F + f) * T + t) * 2);
             v = compress_mag(c.x, c.y, p.fdrc);
         }
@@ -599,7 +632,7 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
     if (fb) {
         for (int idx = tid; idx < FEAT_TT * FB; idx += 256) {
             const int tt = idx / FB, f = idx - tt * FB, t = t0 + tt;
-            fbT[idx] = t < T ? fb[((size_t)t * B + b) * FB + f] : 0.0f;
+            fbT[idx] = t < tend ? fb[((size_t)t * B + b) * FB + f] : 0.0f;
         }
     }
     __syncthreads();
@@ -609,7 +642,7 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
         const int rows = FEAT_TT * g.N;
         for (int idx = wave; idx < rows; idx += 4) {
             const int tt = idx / g.N, k = idx - tt * g.N, t = t0 + tt;
-            if (t >= T) continue;  // wave-uniform
+            if (t >= tend) continue;  // wave-uniform
             float v[4];
             float sum = 0.0f;
 #pragma unroll
@@ -710,6 +743,7 @@ struct DfGroupDev {
 struct DfParams {
     DfGroupDev g[SFSN_MAX_GROUPS];
     int ng, B, F, T, S, fcov;  // fcov = first bin not covered by any group
+    int t0, t1;                // frames [t0, t1) are produced
 };
 
 // grid (ceil(T/32), B), 256 threads; LDS: one unit's projection tile [32][P+1].
@@ -717,8 +751,9 @@ __global__ __launch_bounds__(256) void deepfilter_kernel(const float* __restrict
                                                           float* __restrict__ enh, float* __restrict__ mag) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int B = p.B, F = p.F, T = p.T, S = p.S;
-    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    const int b = blockIdx.y, t0 = p.t0 + blockIdx.x * 32;
     const int tid = threadIdx.x, tt = tid & 31, fs = tid >> 5, t = t0 + tt;
+    const int tend = p.t1;
 
     for (int gi = 0; gi < p.ng; ++gi) {
         const DfGroupDev g = p.g[gi];
@@ -727,10 +762,10 @@ __global__ __launch_bounds__(256) void deepfilter_kernel(const float* __restrict
             __syncthreads();
             for (int idx = tid; idx < 32 * P; idx += 256) {
                 const int r = idx / P, c = idx - r * P, tr = t0 + r;
-                smem[r * LDP + c] = tr < T ? g.proj[((size_t)tr * B * g.N + (size_t)b * g.N + k) * P + c] : 0.0f;
+                smem[r * LDP + c] = tr < tend ? g.proj[((size_t)tr * B * g.N + (size_t)b * g.N + k) * P + c] : 0.0f;
             }
             __syncthreads();
-            if (t < T) {
+            if (t < tend) {
                 const float* pr = smem + tt * LDP;
                 for (int fci = fs; fci < g.fc; fci += 8) {
                     const int f = g.lo + k * g.fc + fci;
@@ -759,7 +794,7 @@ __global__ __launch_bounds__(256) void deepfilter_kernel(const float* __restrict
         }
     }
     // bins no group covers (at least the Nyquist bin) pass through untouched (MODEL:461-470)
-    if (t < T)
+    if (t < tend)
         for (int f = p.fcov + fs; f < F; f += 8) {
             const float2 xv = *reinterpret_cast<const float2*>(stft + (((size_t)b * F + f) * T + t) * 2);
             for (int s = 0; s < S; ++s) {
@@ -798,10 +833,10 @@ extern "C" int sfsn_device_count(void) {
     return n;
 }
 
-template <int G, int KS, int NW, int TPW, int OUT>
+template <int G, int KS, int NW, int TPW, int OUT, int LP>
 static int launch_scan_variant(const ScanParams& p, int tiles, hipStream_t st) {
-    using C = ScanCfg<G, KS, NW, TPW, OUT>;
-    auto kern = gsn_scan_kernel<G, KS, NW, TPW, OUT>;
+    using C = ScanCfg<G, KS, NW, TPW, OUT, LP>;
+    auto kern = gsn_scan_kernel<G, KS, NW, TPW, OUT, LP>;
     if (C::LDS_BYTES > 64 * 1024) {
         static bool raised = false;  // idempotent attribute; a benign race between threads sets it twice at worst
         if (!raised) {
@@ -815,27 +850,28 @@ static int launch_scan_variant(const ScanParams& p, int tiles, hipStream_t st) {
     return hip_ok(hipGetLastError());
 }
 
-template <int G, int KS, int NW, int TPW>
+template <int G, int KS, int NW, int TPW, int LP>
 static int launch_scan(const ScanParams& p, int tiles, int out, hipStream_t st) {
     // output sets compiled: int8 only (downstream products need it), fp32 + int8 (module API), + membranes (tests)
     switch (out) {
-        case 2: return launch_scan_variant<G, KS, NW, TPW, 2>(p, tiles, st);
-        case 3: return launch_scan_variant<G, KS, NW, TPW, 3>(p, tiles, st);
-        case 7: return launch_scan_variant<G, KS, NW, TPW, 7>(p, tiles, st);
+        case 2: return launch_scan_variant<G, KS, NW, TPW, 2, LP>(p, tiles, st);
+        case 3: return launch_scan_variant<G, KS, NW, TPW, 3, LP>(p, tiles, st);
+        case 7: return launch_scan_variant<G, KS, NW, TPW, 7, LP>(p, tiles, st);
 #ifdef SFSN_TIMING_EXPERIMENTS  // wrong-result variants for bottleneck attribution only (scripts/exp_scan.sh)
-        case 19: return launch_scan_variant<G, KS, NW, TPW, 19>(p, tiles, st);
-        case 35: return launch_scan_variant<G, KS, NW, TPW, 35>(p, tiles, st);
-        case 51: return launch_scan_variant<G, KS, NW, TPW, 51>(p, tiles, st);
-        case 67: return launch_scan_variant<G, KS, NW, TPW, 67>(p, tiles, st);
-        case 131: return launch_scan_variant<G, KS, NW, TPW, 131>(p, tiles, st);
-        case 259: return launch_scan_variant<G, KS, NW, TPW, 259>(p, tiles, st);
-        case 387: return launch_scan_variant<G, KS, NW, TPW, 387>(p, tiles, st);
+        case 19: return launch_scan_variant<G, KS, NW, TPW, 19, LP>(p, tiles, st);
+        case 35: return launch_scan_variant<G, KS, NW, TPW, 35, LP>(p, tiles, st);
+        case 51: return launch_scan_variant<G, KS, NW, TPW, 51, LP>(p, tiles, st);
+        case 67: return launch_scan_variant<G, KS, NW, TPW, 67, LP>(p, tiles, st);
+        case 131: return launch_scan_variant<G, KS, NW, TPW, 131, LP>(p, tiles, st);
+        case 259: return launch_scan_variant<G, KS, NW, TPW, 259, LP>(p, tiles, st);
+        case 387: return launch_scan_variant<G, KS, NW, TPW, 387, LP>(p, tiles, st);
 #endif
         default: return SFSN_EUNSUPPORTED;
     }
 }
 
-extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, int T, int H, int shared, void* stream) {
+extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, int T, int H, int shared, int rows_per_wg,
+                                   void* stream) {
     if (!segs || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0) return SFSN_EINVAL;
     if (H % 16 != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     ScanParams p;
@@ -843,7 +879,13 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
     int rows_total = 0;
     for (int i = 0; i < n_segs; ++i) rows_total += segs[i].R > 0 ? segs[i].R : 0;
     int rpw = 16;
-    while (rpw > 4 && (rows_total + rpw - 1) / rpw < 200) rpw >>= 1;
+    if (rows_per_wg == 16 || rows_per_wg == 8 || rows_per_wg == 4) {
+        rpw = rows_per_wg;
+    } else if (rows_per_wg != 0) {
+        return SFSN_EINVAL;
+    } else {
+        while (rpw > 4 && (rows_total + rpw - 1) / rpw < 200) rpw >>= 1;
+    }
 #ifdef SFSN_TIMING_EXPERIMENTS
     if (const char* e = getenv("SFSN_SCAN_RPW")) rpw = atoi(e);
 #endif
@@ -878,18 +920,18 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
     // more waves per SIMD overlap one wave's epilogue VALU with another's MFMAs and hide LDS / VMEM latency.
     int NW, TPW;
     if (shared) {
-        NW = H <= 256 ? 16 : 4;  // H = 320: 300 weight registers per wave need the whole 512-entry file (1 wave / SIMD)
+        NW = H <= 256 ? 16 : 8;  // H = 320: one digit plane in LDS, two in registers (120 per wave), 2 waves per SIMD
     } else {
         NW = H <= 128 ? 16 : 8;
         if (H > 256) return SFSN_EUNSUPPORTED;  // 2 gates x 320^2 x 3 digits does not fit one CU's register file
     }
     TPW = (NT + NW - 1) / NW;
-#define SCAN_CASE(G_, KS_, NW_, TPW_) \
-    if (KS == KS_ && NW == NW_ && TPW == TPW_) return launch_scan<G_, KS_, NW_, TPW_>(p, tiles, out, st);
+#define SCAN_CASE(G_, KS_, NW_, TPW_, LP_) \
+    if (KS == KS_ && NW == NW_ && TPW == TPW_) return launch_scan<G_, KS_, NW_, TPW_, LP_>(p, tiles, out, st);
     if (shared) {
-        SCAN_CASE(1, 1, 16, 1) SCAN_CASE(1, 2, 16, 1) SCAN_CASE(1, 3, 16, 1) SCAN_CASE(1, 4, 16, 1) SCAN_CASE(1, 5, 4, 5)
+        SCAN_CASE(1, 1, 16, 1, 0) SCAN_CASE(1, 2, 16, 1, 0) SCAN_CASE(1, 3, 16, 1, 0) SCAN_CASE(1, 4, 16, 1, 0) SCAN_CASE(1, 5, 8, 3, 1)
     } else {
-        SCAN_CASE(2, 1, 16, 1) SCAN_CASE(2, 2, 16, 1) SCAN_CASE(2, 3, 8, 2) SCAN_CASE(2, 4, 8, 2)
+        SCAN_CASE(2, 1, 16, 1, 0) SCAN_CASE(2, 2, 16, 1, 0) SCAN_CASE(2, 3, 8, 2, 0) SCAN_CASE(2, 4, 8, 2, 0)
     }
 #undef SCAN_CASE
     return SFSN_EUNSUPPORTED;
@@ -951,7 +993,10 @@ extern "C" int sfsn_input_proj_f32(const float* x, const float* w, const float* 
 }
 
 static int fill_feat(FeatParams& p, const sfsn_feature_group* groups, int n_groups, int B, int F, int T, int FB, float fdrc,
-                     bool need_x) {
+                     bool need_x, int t0 = 0, int nt = -1) {
+    if (nt < 0) nt = T;
+    if (t0 < 0 || nt <= 0 || t0 + nt > T) return SFSN_EINVAL;
+    p.t0 = t0; p.t1 = t0 + nt;
     if (!groups || n_groups <= 0 || n_groups > SFSN_MAX_GROUPS || B <= 0 || F < 2 || T <= 0 || FB < 0) return SFSN_EINVAL;
     const int nf = F - 1;
     p.ng = n_groups; p.B = B; p.F = F; p.T = T; p.FB = FB; p.fdrc = fdrc;
@@ -971,10 +1016,10 @@ static int fill_feat(FeatParams& p, const sfsn_feature_group* groups, int n_grou
 }
 
 extern "C" int sfsn_features(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc,
-                             const sfsn_feature_group* groups, int n_groups, void* stream) {
+                             const sfsn_feature_group* groups, int n_groups, int t0, int nt, void* stream) {
     if (!stft_ri) return SFSN_EINVAL;
     FeatParams p;
-    int rc = fill_feat(p, groups, n_groups, B, F, T, FB, fdrc, true);
+    int rc = fill_feat(p, groups, n_groups, B, F, T, FB, fdrc, true, t0, nt);
     if (rc != SFSN_OK) return rc;
     for (int i = 0; i < n_groups; ++i)
         if (groups[i].ctr_fb > 0 && !fb_tbf) return SFSN_EINVAL;
@@ -986,7 +1031,7 @@ extern "C" int sfsn_features(const float* stft_ri, const float* fb_tbf, int B, i
                                 (int)lds) != hipSuccess)
             return SFSN_EHIP;
     }
-    hipLaunchKernelGGL(features_kernel, dim3((T + FEAT_TT - 1) / FEAT_TT, B), dim3(256), lds, st, stft_ri, fb_tbf, p);
+    hipLaunchKernelGGL(features_kernel, dim3((nt + FEAT_TT - 1) / FEAT_TT, B), dim3(256), lds, st, stft_ri, fb_tbf, p);
     return hip_ok(hipGetLastError());
 }
 
@@ -1004,11 +1049,12 @@ extern "C" int sfsn_laplace_means(const float* stft_ri, const float* fb_tbf, int
 }
 
 extern "C" int sfsn_deepfilter(const float* stft_ri, int B, int F, int T, int S, const sfsn_df_group* groups, int n_groups,
-                               float* enh_ri, float* enh_mag, void* stream) {
+                               float* enh_ri, float* enh_mag, int t0, int nt, void* stream) {
     if (!stft_ri || !enh_ri || !groups || n_groups <= 0 || n_groups > SFSN_MAX_GROUPS || B <= 0 || F < 2 || T <= 0 || S <= 0)
         return SFSN_EINVAL;
+    if (t0 < 0 || nt <= 0 || t0 + nt > T) return SFSN_EINVAL;
     DfParams p;
-    p.ng = n_groups; p.B = B; p.F = F; p.T = T; p.S = S;
+    p.ng = n_groups; p.B = B; p.F = F; p.T = T; p.S = S; p.t0 = t0; p.t1 = t0 + nt;
     int lo = 0, maxP = 1;
     for (int i = 0; i < n_groups; ++i) {
         const sfsn_df_group& g = groups[i];
@@ -1028,6 +1074,6 @@ extern "C" int sfsn_deepfilter(const float* stft_ri, int B, int F, int T, int S,
                                 (int)lds) != hipSuccess)
             return SFSN_EHIP;
     }
-    hipLaunchKernelGGL(deepfilter_kernel, dim3((T + 31) / 32, B), dim3(256), lds, st, stft_ri, p, enh_ri, enh_mag);
+    hipLaunchKernelGGL(deepfilter_kernel, dim3((nt + 31) / 32, B), dim3(256), lds, st, stft_ri, p, enh_ri, enh_mag);
     return hip_ok(hipGetLastError());
 }

@@ -185,6 +185,9 @@ class Engine:
                              spec.sb_proj_size(g), spec.ln_sb, self.device) for g in range(spec.n_groups)]
         self._ws: Dict[tuple, dict] = {}
         self.timers: Optional[dict] = None  # set to {} to record HIP events around each launch group (bench.py)
+        self._stream_objs: Dict[int, torch.cuda.Stream] = {}
+        self._side: List[torch.cuda.Stream] = []
+        self.pipeline_chunk = 128  # frames per chunk of the time-pipelined schedule (live front-end); 0 disables it
 
     # ---------------------------------------------------------------------------------------------
     def _stream(self):
@@ -193,24 +196,30 @@ class Engine:
     class _Timed:
         """HIP events on the launch stream around a group of launches; no-op unless ``engine.timers`` is a dict."""
 
-        def __init__(self, eng, tag):
-            self.eng, self.tag = eng, tag
+        def __init__(self, eng, tag, stream):
+            self.eng, self.tag, self.stream = eng, tag, stream
 
         def __enter__(self):
             if self.eng.timers is not None:
                 self.e0 = torch.cuda.Event(enable_timing=True)
                 self.e1 = torch.cuda.Event(enable_timing=True)
-                self.e0.record(torch.cuda.current_stream(self.eng.device))
+                self.e0.record(self.eng._tstream(self.stream))
             return self
 
         def __exit__(self, *exc):
             if self.eng.timers is not None:
-                self.e1.record(torch.cuda.current_stream(self.eng.device))
+                self.e1.record(self.eng._tstream(self.stream))
                 self.eng.timers.setdefault(self.tag, []).append((self.e0, self.e1))
             return False
 
-    def timed(self, tag):
-        return Engine._Timed(self, tag)
+    def timed(self, tag, st=None):
+        return Engine._Timed(self, tag, st)
+
+    def _tstream(self, st):
+        """torch stream object for a raw stream handle handed to the C ABI (None = current stream)."""
+        if st is None:
+            return torch.cuda.current_stream(self.device)
+        return self._stream_objs.get(st.value, torch.cuda.current_stream(self.device))
 
     def timer_summary(self) -> dict:
         """{tag: {mean_ms, n}} per launch group (one group = the launches of one call site in one forward)."""
@@ -231,68 +240,67 @@ class Engine:
             ws = self._ws[key] = make()
         return ws
 
-    def _run_stack(self, seqs: List[_Seq], xs: List[torch.Tensor], T: int, want_layers: bool, want_membrane: bool, tag: str):
-        """One or several independent sequence models sharing (H, L): SequenceModel.forward modeling:81-125.
-
-        xs[i] is the normalised time-major input [T, R_i, I_i].  Returns (proj list, all_layer_outputs lists, membranes).
-        """
-        L, st, spec = self.lib, self._stream(), self.spec
-        H, G, nl = seqs[0].H, seqs[0].cells[0].G, len(seqs[0].cells)
-        HP = (H + 63) // 64 * 64
-        dev = self.device
-        Rs = [x.shape[1] for x in xs]
-        ws = self._workspace((tag, T, tuple(Rs)), lambda: dict(
-            zin=[torch.empty((T, R, G * H), dtype=torch.float32, device=dev) for R in Rs],
-            s8=[[torch.zeros((T, R, HP), dtype=torch.int8, device=dev) for R in Rs] for _ in range(2)]))
-        outs = [[x] for x in xs]
-        mems = [[] for _ in xs]
-        for l in range(nl):
-            # ---- input term zin = (layer input) . W_ih^T, time-parallel
-            tm = self.timed(("inproj:" if l == 0 else "spikeproj_in:") + tag)
-            tm.__enter__()
-            for i, (seq, x, R) in enumerate(zip(seqs, xs, Rs)):
-                cell, z, M = seq.cells[l], ws["zin"][i], T * R
-                if l == 0:
-                    for g in range(G):
-                        check(L.sfsn_input_proj_f32(_ptr(x), ctypes.c_void_p(cell.w_ih_f32.data_ptr() + g * H * seq.I * 4),
-                                                    ctypes.c_void_p(cell.bias.data_ptr() + g * H * 4),
-                                                    ctypes.c_void_p(z.data_ptr() + g * H * 4), M, seq.I, H, G * H, st), "sfsn_input_proj_f32")
-                else:
-                    s_prev = ws["s8"][(l - 1) & 1][i]
-                    for g in range(G):
+    # ---- per-stage launch helpers: every one works on the frame range [t0, t0+nt) and on an explicit stream, so
+    #      that the same code serves the sequential path (one chunk, current stream) and the time-pipelined path ----
+    def _stage_input(self, seqs, l, srcs, zins, t0, nt, st, tag):
+        """zin (chunk-local, [nt, R, G*H]) = layer input . W_ih^T + bias_ih.  srcs: x (l = 0, full [T,R,I] fp32) or the
+        previous layer's int8 spikes (l >= 1, full [T,R,HP])."""
+        L = self.lib
+        with self.timed(("inproj:" if l == 0 else "spikeproj_in:") + tag, st):
+            for seq, src, z in zip(seqs, srcs, zins):
+                cell, H, G, R = seq.cells[l], seq.H, seq.cells[l].G, src.shape[1]
+                M = nt * R
+                for g in range(G):
+                    zp = ctypes.c_void_p(z.data_ptr() + g * H * 4)
+                    bp = ctypes.c_void_p(cell.bias.data_ptr() + g * H * 4)
+                    if l == 0:
+                        check(L.sfsn_input_proj_f32(ctypes.c_void_p(src.data_ptr() + t0 * R * seq.I * 4),
+                                                    ctypes.c_void_p(cell.w_ih_f32.data_ptr() + g * H * seq.I * 4), bp, zp, M, seq.I, H,
+                                                    G * H, st), "sfsn_input_proj_f32")
+                    else:
                         pk, dq = cell.w_ih_q[g]
-                        check(L.sfsn_spike_proj(_ptr(s_prev), _ptr(pk), _ptr(dq), ctypes.c_void_p(cell.bias.data_ptr() + g * H * 4),
-                                                ctypes.c_void_p(z.data_ptr() + g * H * 4), M, H, H, G * H, st), "sfsn_spike_proj")
-            tm.__exit__()
-            # ---- the recurrent scan, all segments in one launch
-            segs = (ScanSegment * len(seqs))()
-            keep = []
-            for i, (seq, R) in enumerate(zip(seqs, Rs)):
-                cell = seq.cells[l]
-                h0 = torch.zeros((R, H), dtype=torch.float32, device=dev)  # states start at zero, modeling:100-106
-                c0 = torch.zeros((R, H), dtype=torch.float32, device=dev)
-                spk = torch.empty((T, R, H), dtype=torch.float32, device=dev) if want_layers else None
-                mem = torch.empty((T, R, H), dtype=torch.float32, device=dev) if want_membrane else None
-                s8 = ws["s8"][l & 1][i]
-                keep += [h0, c0]
-                sg = segs[i]
-                sg.zin, sg.w_hh, sg.w_dq, sg.bias = _ptr(ws["zin"][i]), _ptr(cell.w_hh_q), _ptr(cell.w_hh_dq), _ptr(cell.bias)
-                sg.bn_alpha, sg.bn_beta, sg.h_state, sg.c_state = _ptr(cell.alpha), _ptr(cell.beta), _ptr(h0), _ptr(c0)
-                sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.R = _ptr(spk), _ptr(s8), _ptr(mem), R
-                outs[i].append(spk)
-                mems[i].append(mem)
-            with self.timed("scan:" + tag):
-                check(L.sfsn_gsn_layer_scan(segs, len(seqs), T, H, int(spec.shared), st), "sfsn_gsn_layer_scan")
-        # ---- projection (nn.Linear on the last layer's spikes)
-        projs = []
-        with self.timed("proj:" + tag):
-            for i, (seq, R) in enumerate(zip(seqs, Rs)):
-                y = torch.empty((T, R, seq.P), dtype=torch.float32, device=dev)
-                check(L.sfsn_spike_proj(_ptr(ws["s8"][(nl - 1) & 1][i]), _ptr(seq.proj_q), _ptr(seq.proj_dq), _ptr(seq.proj_b), _ptr(y),
-                                        T * R, H, seq.P, seq.P, st), "sfsn_spike_proj(proj)")
-                projs.append(y)
-                outs[i].append(y)
-        return projs, outs, mems
+                        check(L.sfsn_spike_proj(ctypes.c_void_p(src.data_ptr() + t0 * R * src.shape[2]), _ptr(pk), _ptr(dq), bp, zp, M,
+                                                H, H, G * H, st), "sfsn_spike_proj")
+
+    def _stage_scan(self, seqs, l, zins, states, spks, s8s, mems, t0, nt, st, tag, rpw):
+        L, spec = self.lib, self.spec
+        H = seqs[0].H
+        HP = (H + 63) // 64 * 64
+        segs = (ScanSegment * len(seqs))()
+        for i, seq in enumerate(seqs):
+            cell, sg, R = seq.cells[l], segs[i], s8s[i].shape[1]
+            sg.zin, sg.w_hh, sg.w_dq, sg.bias = _ptr(zins[i]), _ptr(cell.w_hh_q), _ptr(cell.w_hh_dq), _ptr(cell.bias)
+            sg.bn_alpha, sg.bn_beta, sg.h_state, sg.c_state = _ptr(cell.alpha), _ptr(cell.beta), _ptr(states[i][0]), _ptr(states[i][1])
+            sg.spikes_f32 = None if spks[i] is None else ctypes.c_void_p(spks[i].data_ptr() + t0 * R * H * 4)
+            sg.membrane = None if mems[i] is None else ctypes.c_void_p(mems[i].data_ptr() + t0 * R * H * 4)
+            sg.spikes_i8 = ctypes.c_void_p(s8s[i].data_ptr() + t0 * R * HP)
+            sg.R = R
+        with self.timed("scan:" + tag, st):
+            check(L.sfsn_gsn_layer_scan(segs, len(seqs), nt, H, int(spec.shared), rpw, st), "sfsn_gsn_layer_scan")
+
+    def _stage_proj(self, seqs, s8s, projs, t0, nt, st, tag):
+        L = self.lib
+        with self.timed("proj:" + tag, st):
+            for seq, s8, y in zip(seqs, s8s, projs):
+                R = s8.shape[1]
+                check(L.sfsn_spike_proj(ctypes.c_void_p(s8.data_ptr() + t0 * R * s8.shape[2]), _ptr(seq.proj_q), _ptr(seq.proj_dq),
+                                        _ptr(seq.proj_b), ctypes.c_void_p(y.data_ptr() + t0 * R * seq.P * 4), nt * R, seq.H, seq.P, seq.P,
+                                        st), "sfsn_spike_proj(proj)")
+
+    def _alloc_stack(self, seqs, Rs, T, nt_max, want_layers, want_membrane, tag):
+        """Per-forward tensors of a stack of sequence models sharing (H, L): API outputs are fresh, scratch is cached."""
+        dev, H, G, nl = self.device, seqs[0].H, seqs[0].cells[0].G, len(seqs[0].cells)
+        HP = (H + 63) // 64 * 64
+        ws = self._workspace((tag, T, nt_max, tuple(Rs)), lambda: dict(
+            zin=[[torch.empty((nt_max, R, G * H), dtype=torch.float32, device=dev) for R in Rs] for _ in range(nl)],
+            s8=[[torch.zeros((T, R, HP), dtype=torch.int8, device=dev) for R in Rs] for _ in range(nl)]))
+        f32 = dict(dtype=torch.float32, device=dev)
+        return dict(
+            zin=ws["zin"], s8=ws["s8"],
+            states=[[(torch.zeros((R, H), **f32), torch.zeros((R, H), **f32)) for R in Rs] for _ in range(nl)],  # zero init, modeling:100-106
+            spk=[[torch.empty((T, R, H), **f32) if want_layers else None for R in Rs] for _ in range(nl)],
+            mem=[[torch.empty((T, R, H), **f32) if want_membrane else None for R in Rs] for _ in range(nl)],
+            proj=[torch.empty((T, R, seq.P), **f32) for seq, R in zip(seqs, Rs)])
 
     def _feature_groups(self, which: str, xs, mu):
         spec = self.spec
@@ -324,9 +332,23 @@ class Engine:
                 g.norm = _lib.NORM_NONE
         return arr
 
-    def forward_stft(self, stft: torch.Tensor, want_layers: bool = True, want_membrane: bool = False) -> dict:
+    def _handle(self, stream: torch.cuda.Stream):
+        self._stream_objs[stream.cuda_stream] = stream
+        return ctypes.c_void_p(stream.cuda_stream)
+
+    def forward_stft(self, stft: torch.Tensor, want_layers: bool = True, want_membrane: bool = False, pipeline: Optional[bool] = None) -> dict:
         """complex64 [B, n_fft/2+1, T] on the device -> dict(enh_stft [B,S,F,T] complex64, enh_mag [B,S,F,T],
-        fb_all, sb_all (the reference's all_layer_outputs lists; spike entries are None when want_layers=False))."""
+        fb_all, sb_all (the reference's all_layer_outputs lists; spike entries are None when want_layers=False)).
+
+        Schedule.  The four recurrent scans of a model (full-band layer 1/2, sub-band layer 1/2) are each a chain of T
+        dependent steps that occupies only a fraction of the chip, and layer l+1 / the sub-band model need frame t of
+        their producer only at frame t.  With ``pipeline`` (default: live front-end and T >= 2 chunks) the sequence is
+        cut into chunks of ``pipeline_chunk`` frames and the stages run as a software pipeline on separate HIP streams
+        chained by events -- stage s works on chunk c while stage s+1 works on chunk c-1 -- with the scan state carried in
+        the ABI's h_state / c_state buffers.  Results are bit-identical to the sequential schedule (same kernels, same
+        arithmetic; tested).  The frozen front-end's utterance-level Laplace mean needs the whole full-band output, so
+        only its two layer pairs overlap.
+        """
         spec, L = self.spec, self.lib
         want_layers = want_layers or want_membrane  # membranes are a test output of the fp32-spike kernel variant
         if stft.device != self.device or stft.dtype != torch.complex64 or stft.dim() != 3:
@@ -339,41 +361,114 @@ class Engine:
             if (hi - lo) % c != 0:
                 raise ValueError(f"Number of frequency bins must be divisible by the center frequency.GOT: ctr_freq={c}, "
                                  f"upper_cutoff_freq={hi}, lower_cutoff_freq={lo}")
-        st, dev = self._stream(), self.device
+        dev = self.device
+        main = torch.cuda.current_stream(dev)
         ri = torch.view_as_real(stft.contiguous())  # [B, F, T, 2] float32 view, no copy
         f32 = dict(dtype=torch.float32, device=dev)
-        # ---------------- full-band model
+        chunk = self.pipeline_chunk
+        if pipeline is None:
+            pipeline = chunk > 0 and T >= 2 * chunk
+        nt_max = chunk if pipeline else T
+        bounds = [(t0, min(nt_max, T - t0)) for t0 in range(0, T, nt_max)]
+        S, ng = spec.num_spks, spec.n_groups
+        nl_fb, nl_sb = spec.fb_layers, spec.sb_layers
+
+        # ---------------- tensors
         x_fb = torch.empty((T, B, spec.fb_in), **f32)
-        mu_fb = None
-        scratch = None
-        if spec.laplace:
-            mu_fb = torch.empty((1, B), **f32)
-            scratch = torch.empty((B * (F - 1 + spec.fb_proj),), **f32)
-            check(L.sfsn_laplace_means(_ptr(ri), None, B, F, T, 0, spec.fdrc, self._feature_groups("fb", [x_fb], mu_fb), 1,
-                                       _ptr(mu_fb), _ptr(scratch), st), "sfsn_laplace_means(fb)")
-        with self.timed("features:fb"):
-            check(L.sfsn_features(_ptr(ri), None, B, F, T, 0, spec.fdrc, self._feature_groups("fb", [x_fb], mu_fb), 1, st), "sfsn_features(fb)")
-        fb_projs, fb_outs, fb_mems = self._run_stack([self.fb], [x_fb], T, want_layers, want_membrane, "fb")
-        fb_proj = fb_projs[0]  # [T, B, FB]
-        # ---------------- sub-band models
-        xs = [torch.empty((T, B * spec.units(g), spec.sb_input_size(g)), **f32) for g in range(spec.n_groups)]
-        mu_sb = None
-        if spec.laplace:
-            mu_sb = torch.empty((spec.n_groups, B), **f32)
-            check(L.sfsn_laplace_means(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, self._feature_groups("sb", None, None),
-                                       spec.n_groups, _ptr(mu_sb), _ptr(scratch), st), "sfsn_laplace_means(sb)")
-        with self.timed("features:sb"):
-            check(L.sfsn_features(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, self._feature_groups("sb", xs, mu_sb),
-                                  spec.n_groups, st), "sfsn_features(sb)")
-        sb_projs, sb_outs, sb_mems = self._run_stack(self.sb, xs, T, want_layers, want_membrane, "sb")
-        # ---------------- deep filter + reconstruction
-        S = spec.num_spks
+        xs = [torch.empty((T, B * spec.units(g), spec.sb_input_size(g)), **f32) for g in range(ng)]
+        fb = self._alloc_stack([self.fb], [B], T, nt_max, want_layers, want_membrane, "fb")
+        sb = self._alloc_stack(self.sb, [x.shape[1] for x in xs], T, nt_max, want_layers, want_membrane, "sb")
         enh = torch.empty((B, S, F, T), dtype=torch.complex64, device=dev)
         enh_mag = torch.empty((B, S, F, T), **f32)
-        dfg = (DfGroup * spec.n_groups)()
-        for g in range(spec.n_groups):
-            dfg[g].proj, dfg[g].n_units, dfg[g].fc, dfg[g].df = _ptr(sb_projs[g]), spec.units(g), spec.ctr[g], spec.df[g]
-        with self.timed("deepfilter"):
-            check(L.sfsn_deepfilter(_ptr(ri), B, F, T, S, dfg, spec.n_groups, _ptr(torch.view_as_real(enh)), _ptr(enh_mag), st), "sfsn_deepfilter")
-        return dict(enh_stft=enh, enh_mag=enh_mag, fb_all=fb_outs[0], sb_all=sb_outs, fb_mem=fb_mems[0], sb_mem=sb_mems,
-                    mu_fb=mu_fb, mu_sb=mu_sb)
+        enh_ri = torch.view_as_real(enh)
+        dfg = (DfGroup * ng)()
+        for g in range(ng):
+            dfg[g].proj, dfg[g].n_units, dfg[g].fc, dfg[g].df = _ptr(sb["proj"][g]), spec.units(g), spec.ctr[g], spec.df[g]
+        mu_fb = mu_sb = scratch = None
+        if spec.laplace:
+            mu_fb, mu_sb = torch.empty((1, B), **f32), torch.empty((ng, B), **f32)
+            scratch = torch.empty((B * (F - 1 + spec.fb_proj),), **f32)
+        fg_fb = self._feature_groups("fb", [x_fb], mu_fb)
+        fg_sb = self._feature_groups("sb", xs, mu_sb)
+        fb_proj = fb["proj"][0]
+
+        # ---------------- streams: one per stage when pipelined, the current stream otherwise
+        n_stage = nl_fb + nl_sb
+        if pipeline:
+            while len(self._side) < n_stage:
+                self._side.append(torch.cuda.Stream(device=dev))
+            streams = self._side[:n_stage]
+            fork = torch.cuda.Event()
+            fork.record(main)
+            for s_ in streams:
+                s_.wait_event(fork)
+            rpw_fb, rpw_sb = 4, 16  # leave CUs for the time-parallel kernels of the other stages
+        else:
+            streams = [main] * n_stage
+            rpw_fb = rpw_sb = 0
+        hs = [self._handle(s_) for s_ in streams]
+        hmain = self._handle(main)
+
+        def fb_stage(l, t0, nt):
+            st = hs[l]
+            if l == 0:
+                with self.timed("features:fb", st):
+                    check(L.sfsn_features(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, t0, nt, st), "sfsn_features(fb)")
+                self._stage_input([self.fb], 0, [x_fb], fb["zin"][0], t0, nt, st, "fb")
+            else:
+                self._stage_input([self.fb], l, fb["s8"][l - 1], fb["zin"][l], t0, nt, st, "fb")
+            self._stage_scan([self.fb], l, fb["zin"][l], fb["states"][l], fb["spk"][l], fb["s8"][l], fb["mem"][l], t0, nt, st, "fb", rpw_fb)
+            if l == nl_fb - 1:
+                self._stage_proj([self.fb], fb["s8"][l], fb["proj"], t0, nt, st, "fb")
+
+        def sb_stage(l, t0, nt):
+            st = hs[nl_fb + l]
+            if l == 0:
+                with self.timed("features:sb", st):
+                    check(L.sfsn_features(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, fg_sb, ng, t0, nt, st), "sfsn_features(sb)")
+                self._stage_input(self.sb, 0, xs, sb["zin"][0], t0, nt, st, "sb")
+            else:
+                self._stage_input(self.sb, l, sb["s8"][l - 1], sb["zin"][l], t0, nt, st, "sb")
+            self._stage_scan(self.sb, l, sb["zin"][l], sb["states"][l], sb["spk"][l], sb["s8"][l], sb["mem"][l], t0, nt, st, "sb", rpw_sb)
+            if l == nl_sb - 1:
+                self._stage_proj(self.sb, sb["s8"][l], sb["proj"], t0, nt, st, "sb")
+                with self.timed("deepfilter", st):
+                    check(L.sfsn_deepfilter(_ptr(ri), B, F, T, S, dfg, ng, _ptr(enh_ri), _ptr(enh_mag), t0, nt, st), "sfsn_deepfilter")
+
+        def chain(stage_fn, n_layers, first_stream_idx, gate_events):
+            """Run the chunks through n_layers stages; stage l of chunk c waits for stage l-1 of chunk c (event) and, being on
+            one stream per stage, for its own chunk c-1.  gate_events[c] (optional) gates stage 0 of chunk c."""
+            last = []
+            for c, (t0, nt) in enumerate(bounds):
+                ev = gate_events[c] if gate_events else None
+                for l in range(n_layers):
+                    s_ = streams[first_stream_idx + l]
+                    if pipeline and ev is not None:
+                        s_.wait_event(ev)
+                    stage_fn(l, t0, nt)
+                    if pipeline:
+                        ev = torch.cuda.Event()
+                        ev.record(s_)
+                last.append(ev)
+            return last
+
+        if spec.laplace:
+            check(L.sfsn_laplace_means(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, _ptr(mu_fb), _ptr(scratch), hs[0]), "sfsn_laplace_means(fb)")
+            fb_done = chain(fb_stage, nl_fb, 0, None)
+            if pipeline:
+                streams[nl_fb].wait_event(fb_done[-1])
+            check(L.sfsn_laplace_means(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, fg_sb, ng, _ptr(mu_sb), _ptr(scratch),
+                                       hs[nl_fb]), "sfsn_laplace_means(sb)")
+            sb_done = chain(sb_stage, nl_sb, nl_fb, None)
+        else:
+            fb_done = chain(fb_stage, nl_fb, 0, None)
+            sb_done = chain(sb_stage, nl_sb, nl_fb, fb_done if pipeline else None)
+        if pipeline:
+            main.wait_event(sb_done[-1])
+            main.wait_event(fb_done[-1])
+
+        def outs(x, d, i):
+            return [x] + [d["spk"][l][i] for l in range(len(d["spk"]))] + [d["proj"][i]]
+        return dict(enh_stft=enh, enh_mag=enh_mag, fb_all=outs(x_fb, fb, 0), sb_all=[outs(xs[g], sb, g) for g in range(ng)],
+                    fb_mem=[fb["mem"][l][0] for l in range(nl_fb)], sb_mem=[[sb["mem"][l][g] for l in range(nl_sb)] for g in range(ng)],
+                    mu_fb=mu_fb, mu_sb=mu_sb, pipelined=bool(pipeline), n_chunks=len(bounds))

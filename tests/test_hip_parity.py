@@ -58,7 +58,7 @@ def run_scan(hip, zin, w_hh, bias, alpha, beta, shared, h0=None, c0=None, want_m
     s = seg[0]
     s.zin, s.w_hh, s.w_dq, s.bias, s.bn_alpha, s.bn_beta = _p(t["zin"]), _p(t["pk"]), _p(t["dq"]), _p(t["bias"]), _p(t["alpha"]), _p(t["beta"])
     s.h_state, s.c_state, s.spikes_f32, s.spikes_i8, s.membrane, s.R = _p(t["h"]), _p(t["c"]), _p(t["spk"]), _p(t["s8"]), _p(t["mem"]), R
-    check(hip.sfsn_gsn_layer_scan(seg, 1, T, H, int(shared), None), "scan")
+    check(hip.sfsn_gsn_layer_scan(seg, 1, T, H, int(shared), 0, None), "scan")
     torch.cuda.synchronize()
     return (t["spk"].cpu().numpy(), t["mem"].cpu().numpy() if want_mem else None, t["s8"].cpu().numpy(), t["h"].cpu().numpy(),
             t["c"].cpu().numpy())
@@ -147,7 +147,7 @@ def test_scan_multi_segment_and_chunked_state_carry(hip):
         s.zin, s.w_hh, s.w_dq, s.bias, s.bn_alpha, s.bn_beta, s.h_state, s.c_state, s.spikes_f32, s.spikes_i8 = [_p(x) for x in ts]
         s.membrane, s.R = None, R
         outs.append(ts[8])
-    check(hip.sfsn_gsn_layer_scan(seg, 3, T, H, 1, None), "scan3")
+    check(hip.sfsn_gsn_layer_scan(seg, 3, T, H, 1, 8, None), "scan3")
     torch.cuda.synchronize()
     for o3, s1 in zip(outs, singles):
         np.testing.assert_array_equal(o3.cpu().numpy(), s1[0])
@@ -309,6 +309,25 @@ def test_full_size_properties():
         assert st["spike_agreement"] > 0.99, st
     rates = [float(a.mean()) for a in r1["fb_all"][1:3]]
     assert all(0.02 < r < 0.98 for r in rates), rates  # the synthetic model is alive, not saturated
+
+
+@pytest.mark.parametrize("front,kw,seed", [("live", rw.LIVE_M, 5), ("frozen", rw.FROZEN_S, 6), ("live", rw.LIVE_TINY_UNSHARED, 7)])
+def test_pipelined_schedule_is_bit_identical(front, kw, seed):
+    """The time-pipelined multi-stream schedule (chunks carried through h_state / c_state) == the sequential schedule, bit for bit."""
+    sd = rw.live_state_dict(kw, seed) if front == "live" else rw.frozen_state_dict(kw, seed)
+    model = build_module(front, kw, sd)
+    wave = torch.from_numpy(rw.synth_wave(3, 300, seed)).to(DEV)
+    stft = torch.stft(wave, 512, 128, 512, window=torch.hann_window(512, device=DEV), return_complex=True, pad_mode="constant")
+    eng = model.engine()
+    eng.pipeline_chunk = 96  # 300 frames -> chunks of 96, 96, 96, 12
+    a = eng.forward_stft(stft, pipeline=False)
+    b = eng.forward_stft(stft, pipeline=True)
+    torch.cuda.synchronize()
+    assert b["pipelined"] and b["n_chunks"] == 4 and not a["pipelined"]
+    assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(b["enh_stft"]))
+    assert torch.equal(a["enh_mag"], b["enh_mag"])
+    for x, y in zip(a["fb_all"] + sum(a["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])):
+        assert torch.equal(x, y)
 
 
 def spec_units(spec, g):
