@@ -187,7 +187,8 @@ class Engine:
         self.timers: Optional[dict] = None  # set to {} to record HIP events around each launch group (bench.py)
         self._stream_objs: Dict[int, torch.cuda.Stream] = {}
         self._side: List[torch.cuda.Stream] = []
-        self.pipeline_chunk = 128  # frames per chunk of the time-pipelined schedule (live front-end); 0 disables it
+        self.pipeline_chunk = 128  # frames per chunk of the time-pipelined schedule
+        self.pipeline_default = False  # opt-in until the stages own disjoint CU sets
 
     # ---------------------------------------------------------------------------------------------
     def _stream(self):
@@ -367,7 +368,7 @@ class Engine:
         f32 = dict(dtype=torch.float32, device=dev)
         chunk = self.pipeline_chunk
         if pipeline is None:
-            pipeline = chunk > 0 and T >= 2 * chunk
+            pipeline = self.pipeline_default and chunk > 0 and T >= 2 * chunk
         nt_max = chunk if pipeline else T
         bounds = [(t0, min(nt_max, T - t0)) for t0 in range(0, T, nt_max)]
         S, ng = spec.num_spks, spec.n_groups
