@@ -577,6 +577,242 @@ __global__ __launch_bounds__(512) void input_proj_kernel(const float* __restrict
 }
 
 // =====================================================================================================
+// Fast paths of the two time-parallel products (N % 4 == 0, ldy % 4 == 0): a workgroup takes 64 rows at a time,
+// every wave keeps its W tiles in registers, the accumulator fragments are staged through LDS and leave as whole,
+// contiguous rows (full cache lines).  The direct fragment store of the generic kernels writes 64 B per row per tile
+// -- partial-line writes, measured ~3x slower on the 745 MB sub-band input term.
+// =====================================================================================================
+#define GEMM_MB 4  // 16-row tiles per workgroup iteration
+
+// Both kernels are software pipelined over 64-row super tiles: the next tile's left operand is requested from HBM
+// (coalesced, one pass, into registers) before the current tile is computed, and parked in the second LDS buffer
+// after it -- the HBM latency hides under the MFMA phase, and no wave re-reads what another already fetched.
+template <int TPW, int KS>
+__global__ __launch_bounds__(512) void spike_proj_fast_kernel(const int8_t* __restrict__ s, const int8_t* __restrict__ w,
+                                                               const float* __restrict__ dq, const float* __restrict__ bias,
+                                                               float* __restrict__ y, int M, int N, int ldy, int NT, int NWN) {
+    extern __shared__ __attribute__((aligned(16))) char gemm_smem_c[];
+    constexpr int KP = KS * 64;
+    constexpr int SROW = KP + 16;                     // +16 B: the 16 rows of a B fragment hit distinct banks
+    constexpr int SBUF = 64 * SROW;                   // one spike tile
+    constexpr int NV = (64 * KP / 16 + 511) / 512;    // 16-byte vectors per thread per tile
+    int8_t* sbuf = reinterpret_cast<int8_t*>(gemm_smem_c);            // [2][64][SROW]
+    float* obuf = reinterpret_cast<float*>(gemm_smem_c + 2 * SBUF);   // [64][N + 4]
+    const int NP = N + 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int MW = 8 / NWN;
+    const int cg = wave % NWN, mw = wave / NWN;
+    const bool worker = mw < MW;
+
+    v4i W[TPW][KS][3];
+    v4f dqv[TPW], bv[TPW];
+    int col[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int ct = cg + NWN * i;
+        const bool have = worker && ct < NT;
+        col[i] = have ? ct * 16 + q * 4 : -1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const size_t tile = (size_t)d * NT + (have ? ct : 0);
+                W[i][ks][d] = *reinterpret_cast<const v4i*>(w + ((tile * KS + ks) * 64 + lane) * 16);
+            }
+        dqv[i] = *reinterpret_cast<const v4f*>(dq + (have ? col[i] : 0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[i][r] = (bias && have && col[i] + r < N) ? bias[col[i] + r] : 0.0f;
+    }
+
+    const int NS = (M + 63) >> 6;  // 64-row super tiles
+    const int n4 = N >> 2;
+    v4i pre[NV];
+    auto fetch = [&](int st) __attribute__((always_inline)) {  // rows are contiguous: the tile is one 64*KP-byte block
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int v = tid + j * 512;
+            size_t byte = (size_t)st * 64 * KP + (size_t)v * 16;
+            const size_t last = (size_t)M * KP - 16;
+            if (byte > last) byte = last;  // clamp the ragged last tile (those rows are never stored)
+            if (v < 64 * KP / 16) pre[j] = *reinterpret_cast<const v4i*>(s + byte);
+        }
+    };
+    auto park = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int v = tid + j * 512;
+            if (v < 64 * KP / 16) {
+                const int r = v / (KP / 16), c16 = v - r * (KP / 16);
+                *reinterpret_cast<v4i*>(sbuf + buf * SBUF + r * SROW + c16 * 16) = pre[j];
+            }
+        }
+    };
+    int cur = 0;
+    if ((int)blockIdx.x < NS) {
+        fetch(blockIdx.x);
+        park(0);
+    }
+    __syncthreads();
+    for (int st = blockIdx.x; st < NS; st += gridDim.x) {
+        const int m0 = st * 64;
+        const int nxt = st + gridDim.x;
+        if (nxt < NS) fetch(nxt);
+        if (worker) {
+            for (int mi = mw; mi < GEMM_MB; mi += MW) {
+                const int8_t* sr = sbuf + cur * SBUF + (mi * 16 + n) * SROW + q * 16;
+                v4i b[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(sr + ks * 64);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    if (col[i] < 0) continue;
+                    v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][ks][0], b[ks], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][ks][1], b[ks], a1, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][ks][2], b[ks], a2, 0, 0, 0);
+                    }
+                    v4f o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = recombine3(a0[r], a1[r], a2[r]) * dqv[i][r] + bv[i][r];
+                    if (col[i] + 3 < N) {
+                        *reinterpret_cast<v4f*>(&obuf[(mi * 16 + n) * NP + col[i]]) = o;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col[i] + r < N) obuf[(mi * 16 + n) * NP + col[i] + r] = o[r];
+                    }
+                }
+            }
+        }
+        // Park the prefetched tile BEFORE issuing this tile's stores: the wait for the prefetch then covers only loads
+        // (vmcnt retires in order -- parking after the store loop drained every store of the tile first, each iteration).
+        if (nxt < NS) park(cur ^ 1);
+        cur ^= 1;
+        __syncthreads();
+        const int rows = (M - m0 < 64) ? M - m0 : 64;
+        for (int idx = tid; idx < rows * n4; idx += 512) {
+            const int r = idx / n4, c4 = idx - r * n4;
+            *reinterpret_cast<v4f*>(y + (size_t)(m0 + r) * ldy + c4 * 4) = *reinterpret_cast<const v4f*>(&obuf[r * NP + c4 * 4]);
+        }
+        __syncthreads();
+    }
+}
+
+template <int TPW, int KC>
+__global__ __launch_bounds__(512) void input_proj_fast_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ z, int M, int K, int N,
+                                                               int ldz, int NT, int NWN) {
+    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+    constexpr int KQ = KC * 16;        // padded K
+    constexpr int KPAD = KQ + 4;       // +4 floats: the 16 rows of a B fragment (ds_read_b128) land on distinct banks
+    constexpr int XBUF = 64 * KPAD;
+    constexpr int NV = (64 * KQ + 511) / 512;  // floats per thread per tile
+    float* xbuf = gemm_smem;               // [2][64][KPAD]
+    float* obuf = gemm_smem + 2 * XBUF;    // [64][N + 4]
+    const int NP = N + 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int MW = 8 / NWN;
+    const int cg = wave % NWN, mw = wave / NWN;
+    const bool worker = mw < MW;
+
+    float W[TPW][KC][4];
+    v4f bv[TPW];
+    int col[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int ct = cg + NWN * i;
+        const bool have = worker && ct < NT;
+        col[i] = have ? ct * 16 + q * 4 : -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[i][r] = (bias && have && col[i] + r < N) ? bias[col[i] + r] : 0.0f;
+        const int wr = ct * 16 + n;
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = c * 16 + q * 4 + e;
+                W[i][c][e] = (have && wr < N && k < K) ? w[(size_t)wr * K + k] : 0.0f;
+            }
+    }
+    const int NS = (M + 63) >> 6;
+    const int n4 = N >> 2;
+    float pre[NV];
+    int pr[NV], pk[NV];  // (row, k) of my elements within a tile: fixed
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int e = tid + j * 512;
+        pr[j] = e / KQ;
+        pk[j] = e - pr[j] * KQ;
+    }
+    auto fetch = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            int row = st * 64 + pr[j];
+            if (row > M - 1) row = M - 1;
+            pre[j] = (pr[j] < 64 && pk[j] < K) ? x[(size_t)row * K + pk[j]] : 0.0f;
+        }
+    };
+    auto park = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (pr[j] < 64) xbuf[buf * XBUF + pr[j] * KPAD + pk[j]] = pre[j];
+    };
+    int cur = 0;
+    if ((int)blockIdx.x < NS) {
+        fetch(blockIdx.x);
+        park(0);
+    }
+    __syncthreads();
+    for (int st = blockIdx.x; st < NS; st += gridDim.x) {
+        const int m0 = st * 64;
+        const int nxt = st + gridDim.x;
+        if (nxt < NS) fetch(nxt);
+        if (worker) {
+            for (int mi = mw; mi < GEMM_MB; mi += MW) {
+                v4f b[KC];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) b[c] = *reinterpret_cast<const v4f*>(&xbuf[cur * XBUF + (mi * 16 + n) * KPAD + c * 16 + q * 4]);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    if (col[i] < 0) continue;
+                    v4f acc = {0, 0, 0, 0};
+#pragma unroll
+                    for (int c = 0; c < KC; ++c)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[i][c][e], b[c][e], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] += bv[i][r];
+                    if (col[i] + 3 < N) {
+                        *reinterpret_cast<v4f*>(&obuf[(mi * 16 + n) * NP + col[i]]) = acc;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col[i] + r < N) obuf[(mi * 16 + n) * NP + col[i] + r] = acc[r];
+                    }
+                }
+            }
+        }
+        // Park the prefetched tile BEFORE issuing this tile's stores: the wait for the prefetch then covers only loads
+        // (vmcnt retires in order -- parking after the store loop drained every store of the tile first, each iteration).
+        if (nxt < NS) park(cur ^ 1);
+        cur ^= 1;
+        __syncthreads();
+        const int rows = (M - m0 < 64) ? M - m0 : 64;
+        for (int idx = tid; idx < rows * n4; idx += 512) {
+            const int r = idx / n4, c4 = idx - r * n4;
+            *reinterpret_cast<v4f*>(z + (size_t)(m0 + r) * ldz + c4 * 4) = *reinterpret_cast<const v4f*>(&obuf[r * NP + c4 * 4]);
+        }
+        __syncthreads();
+    }
+}
+
+// =====================================================================================================
 // feature prologue
 // =====================================================================================================
 struct FeatGroupDev {
@@ -603,10 +839,20 @@ __device__ __forceinline__ float compress_mag(float re, float im, float fdrc) {
     return fdrc == 0.5f ? sqrtf(m) : powf(m, fdrc);  // ATen evaluates pow(x, 0.5) as sqrt
 }
 
+// Wave-wide sum, result broadcast to every lane.  DPP row shifts / broadcasts (VALU speed) instead of
+// __shfl_xor, which lowers to ds_bpermute_b32 (an LDS round trip per step: the LayerNorm rows were latency bound).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    auto dpp_add = [](float x, auto ctrl, auto rmask) __attribute__((always_inline)) {
+        const int shifted = __builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, true);
+        return x + __int_as_float(shifted);
+    };
+    v = dpp_add(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
+    v = dpp_add(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
+    v = dpp_add(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
+    v = dpp_add(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8  -> lane 15 of a row = row sum
+    v = dpp_add(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1,3
+    v = dpp_add(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2,3 -> lane 63 = total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // grid (ceil(T/32), B), 256 threads.  LDS: mag tile [nf][33] + full-band tile [32][FB].
@@ -954,6 +1200,25 @@ extern "C" int sfsn_spike_proj(const int8_t* s, const int8_t* w_packed, const fl
     int grid = (MT + MW - 1) / MW;
     if (grid > 2048) grid = 2048;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)2 * 64 * (KS * 64 + 16) + (size_t)64 * (N + 4) * sizeof(float);
+    const bool fast = (N % 4 == 0) && (ldy % 4 == 0) && M >= 64 && lds <= 150 * 1024;
+    if (fast) {
+        int fgrid = (M + 63) / 64;
+        if (fgrid > 512) fgrid = 512;
+#define SPF_CASE(TPW_, KS_)                                                                                              \
+    if (TPW == TPW_ && KS == KS_) {                                                                                      \
+        auto kern = spike_proj_fast_kernel<TPW_, KS_>;                                                                   \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) \
+            return SFSN_EHIP;                                                                                            \
+        hipLaunchKernelGGL(kern, dim3(fgrid), dim3(512), lds, st, s, w_packed, w_dq, bias, y, M, N, ldy, NT, NWN);       \
+        return hip_ok(hipGetLastError());                                                                                \
+    }
+        SPF_CASE(1, 1) SPF_CASE(1, 2) SPF_CASE(1, 3) SPF_CASE(1, 4) SPF_CASE(1, 5)
+        SPF_CASE(2, 1) SPF_CASE(2, 2) SPF_CASE(2, 3) SPF_CASE(2, 4) SPF_CASE(2, 5)
+        SPF_CASE(3, 1) SPF_CASE(3, 2) SPF_CASE(3, 3) SPF_CASE(3, 4) SPF_CASE(3, 5)
+#undef SPF_CASE
+    }
 #define SP_CASE(TPW_, KS_)                                                                                          \
     if (TPW == TPW_ && KS == KS_) {                                                                                 \
         hipLaunchKernelGGL((spike_proj_kernel<TPW_, KS_>), dim3(grid), dim3(512), 0, st, s, w_packed, w_dq, bias, y, M, N, \
@@ -979,15 +1244,32 @@ extern "C" int sfsn_input_proj_f32(const float* x, const float* w, const float* 
     int grid = (MT + MW - 1) / MW;
     if (grid > 2048) grid = 2048;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int KCB = KC <= 3 ? 3 : (KC <= 6 ? 6 : 12);
+    const int KCB = KC <= 3 ? 3 : (KC <= 6 ? 6 : (KC <= 10 ? 10 : 12));
+    const size_t flds = ((size_t)2 * 64 * (KCB * 16 + 4) + (size_t)64 * (N + 4)) * sizeof(float);
+    if ((N % 4 == 0) && (ldz % 4 == 0) && M >= 64 && flds <= 150 * 1024) {
+        int fgrid = (M + 63) / 64;
+        if (fgrid > 512) fgrid = 512;
+#define IPF_CASE(TPW_, KC_)                                                                                               \
+    if (TPW == TPW_ && KCB == KC_) {                                                                                      \
+        auto kern = input_proj_fast_kernel<TPW_, KC_>;                                                                    \
+        if (flds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) \
+            return SFSN_EHIP;                                                                                             \
+        hipLaunchKernelGGL(kern, dim3(fgrid), dim3(512), flds, st, x, w, bias, z, M, K, N, ldz, NT, NWN);                 \
+        return hip_ok(hipGetLastError());                                                                                 \
+    }
+        IPF_CASE(1, 3) IPF_CASE(1, 6) IPF_CASE(1, 10) IPF_CASE(1, 12) IPF_CASE(2, 3) IPF_CASE(2, 6) IPF_CASE(2, 10) IPF_CASE(2, 12)
+        IPF_CASE(3, 3) IPF_CASE(3, 6) IPF_CASE(3, 10) IPF_CASE(3, 12)
+#undef IPF_CASE
+    }
 #define IP_CASE(TPW_, KC_)                                                                                           \
     if (TPW == TPW_ && KCB == KC_) {                                                                                 \
         hipLaunchKernelGGL((input_proj_kernel<TPW_, KC_>), dim3(grid), dim3(512), 0, st, x, w, bias, z, M, K, N, ldz, NT, \
                            NWN);                                                                                     \
         return hip_ok(hipGetLastError());                                                                            \
     }
-    IP_CASE(1, 3) IP_CASE(1, 6) IP_CASE(1, 12) IP_CASE(2, 3) IP_CASE(2, 6) IP_CASE(2, 12) IP_CASE(3, 3) IP_CASE(3, 6)
-    IP_CASE(3, 12)
+    IP_CASE(1, 3) IP_CASE(1, 6) IP_CASE(1, 10) IP_CASE(1, 12) IP_CASE(2, 3) IP_CASE(2, 6) IP_CASE(2, 10) IP_CASE(2, 12)
+    IP_CASE(3, 3) IP_CASE(3, 6) IP_CASE(3, 10) IP_CASE(3, 12)
 #undef IP_CASE
     return SFSN_EUNSUPPORTED;
 }
