@@ -27,6 +27,9 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # HIP maps streams onto this many hardware queues (default 4): the pipelined
+# schedule runs four scans + the time-parallel kernels concurrently and must not multiplex them onto shared queues
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
@@ -51,7 +54,10 @@ def main():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layer-outputs", action="store_true", help="skip the fp32 spike tensors of the module API (reported in config)")
-    ap.add_argument("--sequential", action="store_true", help="disable the time-pipelined multi-stream schedule")
+    ap.add_argument("--sequential", action="store_true", help="force the sequential single-stream schedule")
+    ap.add_argument("--pipeline", action="store_true", help="force the time-pipelined multi-stream schedule")
+    ap.add_argument("--time-all", action="store_true", help="HIP-event time every launch group, not only the dominant kernel")
+    ap.add_argument("--chunk", type=int, default=0, help="frames per pipeline chunk (default: engine default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,13 +89,15 @@ def main():
     stft = model.stft(wave).contiguous()  # untimed: the STFT is the edge of the path
     assert stft.shape == (B, 257, T)
     eng = model.engine()
+    if args.chunk:
+        eng.pipeline_chunk = args.chunk
     want_layers = not args.no_layer_outputs
     gathered = torch.empty((world * B, 1, 257, T), dtype=torch.float32, device=dev) if world > 1 else None
 
     info = {}
 
     def step():
-        res = eng.forward_stft(stft, want_layers=want_layers, pipeline=False if args.sequential else None)
+        res = eng.forward_stft(stft, want_layers=want_layers, pipeline=False if args.sequential else (True if args.pipeline else None))
         info.update(pipelined=res["pipelined"], n_chunks=res["n_chunks"])
         if world > 1:
             dist.all_gather_into_tensor(gathered, res["enh_mag"])
@@ -98,6 +106,7 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.timers = {}  # HIP events around the scan launches, on the launch stream (engine.py)
+    eng.timer_tags = None if args.time_all else {"scan:sb"}  # each timed group costs ~10 us of launch gap
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

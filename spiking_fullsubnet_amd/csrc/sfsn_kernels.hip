@@ -213,6 +213,11 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
         constexpr int CBASE = (D - 1) * (A + NMEM), CSTRIDE = D * C::NSTF;
 
         // register-resident recurrent weights (int8 digits in MFMA A-fragment order) and membrane state
+        // RP4 (OUT bit 9, used when the workgroup owns 4 rows): only MFMA columns 0..3 carry rows, so the 4 x 4 values
+        // a lane group holds are re-dealt ONE per lane (DPP row shifts with a bank mask: no LDS, 3 moves per accumulator)
+        // and the whole epilogue runs on a quarter of the values: lane (n, q) finishes neuron 4q + n/4 of row n%4.
+        constexpr bool RP4 = (OUT & 512) != 0;
+        const int r4 = n >> 2, row4 = n & 3;
         v4i W[NTL][G][KS][NPR];
         v4f c[NTL];
         int col[NTL];          // first neuron of my 4-neuron group in tile i
@@ -233,7 +238,11 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
                         const size_t tile = (size_t)(d + LP) * (G * NT) + (size_t)g * NT + ct;
                         W[i][g][ks][d] = *reinterpret_cast<const v4i*>(w_hh + ((tile * KS + ks) * 64 + lane) * 16);
                     }
-            c[i] = *reinterpret_cast<const v4f*>(c_state + (size_t)rowc * H + col[i]);
+            if constexpr (RP4) {
+                c[i] = v4f{c_state[(size_t)rowc * H + col[i] + r4], 0, 0, 0};
+            } else {
+                c[i] = *reinterpret_cast<const v4f*>(c_state + (size_t)rowc * H + col[i]);
+            }
         }
         // ring: slot s, tile ct, gate g at s*SLOT + (ct*G + g)*1024 (+ lane*16 for my bytes)
         const unsigned ring_base = (unsigned)(C::RING_OFF + wave * (G * 1024));
@@ -300,6 +309,33 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
                         wait_vmcnt_affine<CBASE, CSTRIDE, C::FL>(fl.nact);
                     }
                 }
+                if constexpr (RP4) {
+                    auto pick = [&](const v4i& a) __attribute__((always_inline)) {  // element r4 of lane (row4, q)
+                        int v = a[0];
+                        v = __builtin_amdgcn_update_dpp(v, a[1], 0x114, 0xf, 0x2, false);  // row_shr:4  -> lanes 4..7
+                        v = __builtin_amdgcn_update_dpp(v, a[2], 0x118, 0xf, 0x4, false);  // row_shr:8  -> lanes 8..11
+                        v = __builtin_amdgcn_update_dpp(v, a[3], 0x11C, 0xf, 0x8, false);  // row_shr:12 -> lanes 12..15
+                        return v;
+                    };
+                    const int cj = cc + r4;  // my neuron
+                    float pre1[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float rec = recombine3(pick(acc[g][0]), pick(acc[g][1]), pick(acc[g][2]));
+                        // the DMA put lane (row, q)'s 16 bytes at lane*16: mine are element r4 of lane (row4, q)
+                        const float z = *reinterpret_cast<const float*>(smem + ring_base + (t % D) * C::SLOT + (NW * i * G + g) * 1024 +
+                                                                        ((q * 16 + row4) * 16 + r4 * 4));
+                        pre1[g] = __builtin_fmaf(rec, cst[3 + g][cj], z);
+                    }
+                    const float pre_g1 = (G == 2) ? pre1[G - 1] : pre1[0] + cst[0][cj];
+                    const float f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre1[0] * -1.44269504088896341f));
+                    const float m = __builtin_fmaf(f, c[i][0] - pre_g1, pre_g1);
+                    const float y = __builtin_fmaf(m, cst[1][cj], cst[2][cj]);
+                    c[i][0] = y;
+                    hn[row4 * LDH + cj] = (y >= 0.0f) ? 1 : 0;
+                    if (OUT & 4) membrane[((size_t)t * R + rowc) * H + cj] = y;
+                    continue;
+                }
                 v4f pre[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -355,6 +391,11 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
         const int8_t* hl = hbuf + (T & 1) * 16 * LDH;  // h_{T-1} (or the untouched initial state when T == 0)
 #pragma unroll
         for (int i = 0; i < NTL; ++i) {
+            if constexpr (RP4) {
+                c_state[(size_t)rowc * H + col[i] + r4] = c[i][0];
+                h_state[(size_t)rowc * H + col[i] + r4] = (float)hl[row4 * LDH + col[i] + r4];
+                continue;
+            }
             *reinterpret_cast<v4f*>(c_state + (size_t)rowc * H + col[i]) = c[i];
             const unsigned pk = *reinterpret_cast<const unsigned*>(hl + n * LDH + col[i]);
             const v4f h = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)((pk >> 24) & 1u)};
@@ -1100,6 +1141,9 @@ template <int G, int KS, int NW, int TPW, int LP>
 static int launch_scan(const ScanParams& p, int tiles, int out, hipStream_t st) {
     // output sets compiled: int8 only (downstream products need it), fp32 + int8 (module API), + membranes (tests)
     switch (out) {
+        case 514: return launch_scan_variant<G, KS, NW, TPW, 514, LP>(p, tiles, st);
+        case 515: return launch_scan_variant<G, KS, NW, TPW, 515, LP>(p, tiles, st);
+        case 519: return launch_scan_variant<G, KS, NW, TPW, 519, LP>(p, tiles, st);
         case 2: return launch_scan_variant<G, KS, NW, TPW, 2, LP>(p, tiles, st);
         case 3: return launch_scan_variant<G, KS, NW, TPW, 3, LP>(p, tiles, st);
         case 7: return launch_scan_variant<G, KS, NW, TPW, 7, LP>(p, tiles, st);
@@ -1165,6 +1209,7 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
     // Waves per workgroup: as many as the per-wave share of W allows registers for (16 waves -> 128 VGPRs, 8 -> 256):
     // more waves per SIMD overlap one wave's epilogue VALU with another's MFMAs and hide LDS / VMEM latency.
     int NW, TPW;
+    if (rpw == 4 && out <= 7) out |= 512;  // repacked-epilogue variant (see scan_body)
     if (shared) {
         NW = H <= 256 ? 16 : 8;  // H = 320: one digit plane in LDS, two in registers (120 per wave), 2 waves per SIMD
     } else {

@@ -11,6 +11,7 @@ Reference call stack replaced: ``SpikingFullSubNet.forward`` modeli
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -185,10 +186,12 @@ class Engine:
                              spec.sb_proj_size(g), spec.ln_sb, self.device) for g in range(spec.n_groups)]
         self._ws: Dict[tuple, dict] = {}
         self.timers: Optional[dict] = None  # set to {} to record HIP events around each launch group (bench.py)
+        self.timer_tags = None  # optional set of tags to time (each timed group costs ~10 us of launch gap)
         self._stream_objs: Dict[int, torch.cuda.Stream] = {}
         self._side: List[torch.cuda.Stream] = []
         self.pipeline_chunk = 128  # frames per chunk of the time-pipelined schedule
         self.pipeline_default = False  # opt-in until the stages own disjoint CU sets
+        self.pipeline_two_phase = bool(int(os.environ.get('SFSN_TWO_PHASE', '1')))
 
     # ---------------------------------------------------------------------------------------------
     def _stream(self):
@@ -201,14 +204,15 @@ class Engine:
             self.eng, self.tag, self.stream = eng, tag, stream
 
         def __enter__(self):
-            if self.eng.timers is not None:
+            self.on = self.eng.timers is not None and (self.eng.timer_tags is None or self.tag in self.eng.timer_tags)
+            if self.on:
                 self.e0 = torch.cuda.Event(enable_timing=True)
                 self.e1 = torch.cuda.Event(enable_timing=True)
                 self.e0.record(self.eng._tstream(self.stream))
             return self
 
         def __exit__(self, *exc):
-            if self.eng.timers is not None:
+            if self.on:
                 self.e1.record(self.eng._tstream(self.stream))
                 self.eng.timers.setdefault(self.tag, []).append((self.e0, self.e1))
             return False
@@ -288,6 +292,19 @@ class Engine:
                                         _ptr(seq.proj_b), ctypes.c_void_p(y.data_ptr() + t0 * R * seq.P * 4), nt * R, seq.H, seq.P, seq.P,
                                         st), "sfsn_spike_proj(proj)")
 
+    def _zero_states(self, Rs, H, nl):
+        flat = torch.zeros((2 * nl * sum(Rs) * H,), dtype=torch.float32, device=self.device)
+        out, pos = [], 0
+        for _ in range(nl):
+            row = []
+            for R in Rs:
+                h = flat[pos:pos + R * H].view(R, H)
+                c = flat[pos + R * H:pos + 2 * R * H].view(R, H)
+                pos += 2 * R * H
+                row.append((h, c))
+            out.append(row)
+        return out
+
     def _alloc_stack(self, seqs, Rs, T, nt_max, want_layers, want_membrane, tag):
         """Per-forward tensors of a stack of sequence models sharing (H, L): API outputs are fresh, scratch is cached."""
         dev, H, G, nl = self.device, seqs[0].H, seqs[0].cells[0].G, len(seqs[0].cells)
@@ -298,7 +315,7 @@ class Engine:
         f32 = dict(dtype=torch.float32, device=dev)
         return dict(
             zin=ws["zin"], s8=ws["s8"],
-            states=[[(torch.zeros((R, H), **f32), torch.zeros((R, H), **f32)) for R in Rs] for _ in range(nl)],  # zero init, modeling:100-106
+            states=self._zero_states(Rs, H, nl),  # zero init, modeling:100-106 (one fill kernel for all of them)
             spk=[[torch.empty((T, R, H), **f32) if want_layers else None for R in Rs] for _ in range(nl)],
             mem=[[torch.empty((T, R, H), **f32) if want_membrane else None for R in Rs] for _ in range(nl)],
             proj=[torch.empty((T, R, seq.P), **f32) for seq, R in zip(seqs, Rs)])
@@ -332,6 +349,58 @@ class Engine:
             else:
                 g.norm = _lib.NORM_NONE
         return arr
+
+    _hip = None
+
+    def _masked_stream(self, cus: List[int]) -> torch.cuda.Stream:
+        """A HIP stream restricted to the given compute units (hipExtStreamCreateWithCUMask), wrapped for torch.  The
+        four recurrent scans of the pipelined schedule each get their own CUs and the time-parallel kernels the rest, so
+        that a 2000-block GEMM cannot flood the chip and starve a 52-workgroup scan (or vice versa)."""
+        if Engine._hip is None:
+            Engine._hip = ctypes.CDLL("libamdhip64.so")
+            Engine._hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+            Engine._hip.hipExtStreamCreateWithCUMask.restype = ctypes.c_int
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        words = (n_cu + 31) // 32
+        mask = (ctypes.c_uint32 * words)()
+        for c in cus:
+            mask[c // 32] |= (1 << (c % 32))
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = Engine._hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), words, mask)
+        if rc != 0 or not h.value:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+        return torch.cuda.ExternalStream(h.value, device=self.device)
+
+    def _pipeline_streams(self, n_fb: int, n_sb: int, fb_tiles: int, sb_tiles: int):
+        """(scan streams per stage, G streams per stage): disjoint CU sets, created once per geometry."""
+        key = (n_fb, n_sb, fb_tiles, sb_tiles)
+        if getattr(self, "_pipe_key", None) != key:
+            # CU ids are (32-bit mask word w, bit b) = w*32 + b; measured on MI355X (scripts/exp_cumask.py): a mask word
+            # is one XCD, and masks are honoured when every word enables a contiguous bit range.  Pools are therefore bit
+            # COLUMNS: the same range of CUs in every XCD -- each pool spans all eight L2s.
+            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            words = n_cu // 32
+            def columns(b0, b1, w0=0, w1=None):
+                return [w * 32 + b for w in range(w0, words if w1 is None else w1) for b in range(b0, b1)]
+            pools, col = [], 0
+            for tiles in [fb_tiles] * n_fb + [sb_tiles] * n_sb:
+                ncol = -(-tiles // words)  # bit columns needed: ceil(tiles / XCDs)
+                pools.append(columns(col, col + ncol))
+                col += ncol
+            if col > 24:
+                raise NotImplementedError("pipelined schedule: the scans would leave fewer than a quarter of the CUs to the other kernels")
+            g_pool = columns(col, 32)
+            if os.environ.get("SFSN_PLAIN_STREAMS"):  # diagnostic: no CU partitioning
+                self._pipe_scan = [torch.cuda.Stream(device=self.device) for _ in pools]
+                self._pipe_g = [torch.cuda.Stream(device=self.device) for _ in pools]
+                self._pipe_key = key
+                return self._pipe_scan, self._pipe_g
+            self._pipe_scan = [self._masked_stream(p) for p in pools]
+            self._pipe_g = [self._masked_stream(g_pool) for _ in pools]  # same CU pool, one queue per stage (a stage's
+            # time-parallel kernels wait for its own scan; a shared queue would serialise all four stages)
+            self._pipe_key = key
+        return self._pipe_scan, self._pipe_g
 
     def _handle(self, stream: torch.cuda.Stream):
         self._stream_objs[stream.cuda_stream] = stream
@@ -393,80 +462,92 @@ class Engine:
         fg_sb = self._feature_groups("sb", xs, mu_sb)
         fb_proj = fb["proj"][0]
 
-        # ---------------- streams: one per stage when pipelined, the current stream otherwise
+        # ---------------- streams: sequential = the current stream; pipelined = per stage one scan stream (own CUs) and one
+        #                  stream for its time-parallel kernels (shared CU pool), chained by events
         n_stage = nl_fb + nl_sb
         if pipeline:
-            while len(self._side) < n_stage:
-                self._side.append(torch.cuda.Stream(device=dev))
-            streams = self._side[:n_stage]
+            rpw_fb, rpw_sb = 16, 16
+            fb_tiles = (B + rpw_fb - 1) // rpw_fb
+            sb_tiles = sum((x.shape[1] + rpw_sb - 1) // rpw_sb for x in xs)
+            sstreams, gstreams = self._pipeline_streams(nl_fb, nl_sb, fb_tiles, sb_tiles)
             fork = torch.cuda.Event()
             fork.record(main)
-            for s_ in streams:
+            for s_ in sstreams + gstreams:
                 s_.wait_event(fork)
-            rpw_fb, rpw_sb = 4, 16  # leave CUs for the time-parallel kernels of the other stages
         else:
-            streams = [main] * n_stage
+            sstreams = gstreams = [main] * n_stage
             rpw_fb = rpw_sb = 0
-        hs = [self._handle(s_) for s_ in streams]
-        hmain = self._handle(main)
+        hS = [self._handle(s_) for s_ in sstreams]
+        hG = [self._handle(s_) for s_ in gstreams]
 
-        def fb_stage(l, t0, nt):
-            st = hs[l]
-            if l == 0:
-                with self.timed("features:fb", st):
-                    check(L.sfsn_features(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, t0, nt, st), "sfsn_features(fb)")
-                self._stage_input([self.fb], 0, [x_fb], fb["zin"][0], t0, nt, st, "fb")
-            else:
-                self._stage_input([self.fb], l, fb["s8"][l - 1], fb["zin"][l], t0, nt, st, "fb")
-            self._stage_scan([self.fb], l, fb["zin"][l], fb["states"][l], fb["spk"][l], fb["s8"][l], fb["mem"][l], t0, nt, st, "fb", rpw_fb)
-            if l == nl_fb - 1:
-                self._stage_proj([self.fb], fb["s8"][l], fb["proj"], t0, nt, st, "fb")
+        def link(src, dst):
+            """dst waits for everything enqueued on src so far (no-op on the sequential path)."""
+            if pipeline and src is not dst:
+                ev = torch.cuda.Event()
+                ev.record(src)
+                dst.wait_event(ev)
 
-        def sb_stage(l, t0, nt):
-            st = hs[nl_fb + l]
-            if l == 0:
-                with self.timed("features:sb", st):
-                    check(L.sfsn_features(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, fg_sb, ng, t0, nt, st), "sfsn_features(sb)")
-                self._stage_input(self.sb, 0, xs, sb["zin"][0], t0, nt, st, "sb")
-            else:
-                self._stage_input(self.sb, l, sb["s8"][l - 1], sb["zin"][l], t0, nt, st, "sb")
-            self._stage_scan(self.sb, l, sb["zin"][l], sb["states"][l], sb["spk"][l], sb["s8"][l], sb["mem"][l], t0, nt, st, "sb", rpw_sb)
-            if l == nl_sb - 1:
-                self._stage_proj(self.sb, sb["s8"][l], sb["proj"], t0, nt, st, "sb")
-                with self.timed("deepfilter", st):
-                    check(L.sfsn_deepfilter(_ptr(ri), B, F, T, S, dfg, ng, _ptr(enh_ri), _ptr(enh_mag), t0, nt, st), "sfsn_deepfilter")
-
-        def chain(stage_fn, n_layers, first_stream_idx, gate_events):
-            """Run the chunks through n_layers stages; stage l of chunk c waits for stage l-1 of chunk c (event) and, being on
-            one stream per stage, for its own chunk c-1.  gate_events[c] (optional) gates stage 0 of chunk c."""
-            last = []
+        # per-chunk completion events of the producers the next model / layer gates on
+        def run_model(seqs, d, xs_, first, feat_fn, tag, rpw, post_fn, gate_events):
+            nl = len(seqs[0].cells)
+            done = []
             for c, (t0, nt) in enumerate(bounds):
-                ev = gate_events[c] if gate_events else None
-                for l in range(n_layers):
-                    s_ = streams[first_stream_idx + l]
-                    if pipeline and ev is not None:
-                        s_.wait_event(ev)
-                    stage_fn(l, t0, nt)
+                for l in range(nl):
+                    si = first + l
+                    g, sc = gstreams[si], sstreams[si]
+                    if l == 0:
+                        if pipeline and gate_events is not None:
+                            g.wait_event(gate_events[c])
+                        feat_fn(t0, nt, hG[si])
+                        self._stage_input(seqs, 0, xs_, d["zin"][0], t0, nt, hG[si], tag)
+                    else:
+                        link(sstreams[si - 1], g)  # previous layer's scan of this chunk
+                        self._stage_input(seqs, l, d["s8"][l - 1], d["zin"][l], t0, nt, hG[si], tag)
+                    link(g, sc)
+                    self._stage_scan(seqs, l, d["zin"][l], d["states"][l], d["spk"][l], d["s8"][l], d["mem"][l], t0, nt, hS[si], tag, rpw)
                     if pipeline:
-                        ev = torch.cuda.Event()
-                        ev.record(s_)
-                last.append(ev)
-            return last
+                        link(sc, g)  # the chunk-local zin buffer is reused by the next chunk's input product
+                    if l == nl - 1:
+                        self._stage_proj(seqs, d["s8"][l], d["proj"], t0, nt, hG[si], tag)
+                        if post_fn is not None:
+                            post_fn(t0, nt, hG[si])
+                        if pipeline:
+                            ev = torch.cuda.Event()
+                            ev.record(g)
+                            done.append(ev)
+            return done
+
+        def feat_fb(t0, nt, st):
+            with self.timed("features:fb", st):
+                check(L.sfsn_features(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, t0, nt, st), "sfsn_features(fb)")
+
+        def feat_sb(t0, nt, st):
+            with self.timed("features:sb", st):
+                check(L.sfsn_features(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, fg_sb, ng, t0, nt, st), "sfsn_features(sb)")
+
+        def post_sb(t0, nt, st):
+            with self.timed("deepfilter", st):
+                check(L.sfsn_deepfilter(_ptr(ri), B, F, T, S, dfg, ng, _ptr(enh_ri), _ptr(enh_mag), t0, nt, st), "sfsn_deepfilter")
 
         if spec.laplace:
-            check(L.sfsn_laplace_means(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, _ptr(mu_fb), _ptr(scratch), hs[0]), "sfsn_laplace_means(fb)")
-            fb_done = chain(fb_stage, nl_fb, 0, None)
+            check(L.sfsn_laplace_means(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, _ptr(mu_fb), _ptr(scratch), hG[0]), "sfsn_laplace_means(fb)")
+        fb_done = run_model([self.fb], fb, [x_fb], 0, feat_fb, "fb", rpw_fb, None, None)
+        if spec.laplace:
+            # the utterance-level Laplace mean of the sub-band input needs the whole full-band output: no chunk overlap fb -> sb
             if pipeline:
-                streams[nl_fb].wait_event(fb_done[-1])
+                gstreams[nl_fb].wait_event(fb_done[-1])
             check(L.sfsn_laplace_means(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, fg_sb, ng, _ptr(mu_sb), _ptr(scratch),
-                                       hs[nl_fb]), "sfsn_laplace_means(sb)")
-            sb_done = chain(sb_stage, nl_sb, nl_fb, None)
+                                       hG[nl_fb]), "sfsn_laplace_means(sb)")
+            sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, None)
+        elif pipeline and self.pipeline_two_phase:
+            # full-band model first (its two layers overlapped), then the sub-band models (their two layers overlapped)
+            gstreams[nl_fb].wait_event(fb_done[-1])
+            sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, None)
         else:
-            fb_done = chain(fb_stage, nl_fb, 0, None)
-            sb_done = chain(sb_stage, nl_sb, nl_fb, fb_done if pipeline else None)
+            sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, fb_done if pipeline else None)
         if pipeline:
-            main.wait_event(sb_done[-1])
-            main.wait_event(fb_done[-1])
+            for s_ in sstreams + gstreams:
+                link(s_, main)
 
         def outs(x, d, i):
             return [x] + [d["spk"][l][i] for l in range(len(d["spk"]))] + [d["proj"][i]]
