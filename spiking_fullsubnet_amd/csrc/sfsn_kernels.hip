@@ -875,9 +875,13 @@ struct FeatParams {
 
 __device__ __forceinline__ int reflect_bin(int f, int nf) { return f < 0 ? -f : (f > nf - 1 ? 2 * (nf - 1) - f : f); }
 
+// |re + i im| without libm's range-scaling hypot (~25 instructions): STFT magnitudes of audio are nowhere near the
+// fp32 overflow / underflow of re^2 + im^2; v_sqrt_f32 is good to 1 ulp (parity tolerance is 1e-4 relative).
+__device__ __forceinline__ float fast_abs2(float re, float im) { return __builtin_amdgcn_sqrtf(__builtin_fmaf(re, re, im * im)); }
+
 __device__ __forceinline__ float compress_mag(float re, float im, float fdrc) {
-    const float m = hypotf(re, im);                  // torch.abs(complex)
-    return fdrc == 0.5f ? sqrtf(m) : powf(m, fdrc);  // ATen evaluates pow(x, 0.5) as sqrt
+    const float m = fast_abs2(re, im);                               // torch.abs(complex)
+    return fdrc == 0.5f ? __builtin_amdgcn_sqrtf(m) : powf(m, fdrc);  // ATen evaluates pow(x, 0.5) as sqrt
 }
 
 // Wave-wide sum, result broadcast to every lane.  DPP row shifts / broadcasts (VALU speed) instead of
@@ -926,51 +930,63 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
 
     for (int gi = 0; gi < p.ng; ++gi) {
         const FeatGroupDev g = p.g[gi];
-        const int rows = FEAT_TT * g.N;
-        for (int idx = wave; idx < rows; idx += 4) {
-            const int tt = idx / g.N, k = idx - tt * g.N, t = t0 + tt;
-            if (t >= tend) continue;  // wave-uniform
-            float v[4];
-            float sum = 0.0f;
+        // per-lane constants of this group: LayerNorm affine terms of my (up to 4) feature slots
+        float lw[4], lb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = lane + 64 * u;
+            const bool in = j < g.I && g.norm == SFSN_NORM_LAYERNORM;
+            lw[u] = in ? g.ln_w[j] : 0.0f;
+            lb[u] = in ? g.ln_b[j] : 0.0f;
+        }
+        const float inv_I = 1.0f / (float)g.I;
+        const float lap_den = g.norm == SFSN_NORM_LAPLACE ? g.mu[b] + 2.220446049250313e-16f : 1.0f;
+        for (int k = 0; k < g.N; ++k) {
+            // LDS offsets of my feature slots for unit k (independent of the frame): magnitude rows or full-band columns
+            int off[4];
+            bool is_fb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int j = lane + 64 * u;
-                v[u] = 0.0f;
-                if (j < g.I1) {
-                    v[u] = magT[reflect_bin(g.lo + k * g.ctr - g.nbr + j, nf) * 33 + tt];
-                } else if (j < g.I) {
-                    const int f = reflect_bin(g.lo + k * g.ctr_fb - g.nbr_fb + (j - g.I1), nf);
-                    v[u] = fbT[tt * FB + (f % FB)];
-                }
-                sum += v[u];
+                is_fb[u] = j >= g.I1;
+                if (j < g.I1)
+                    off[u] = reflect_bin(g.lo + k * g.ctr - g.nbr + j, nf) * 33;
+                else if (j < g.I)
+                    off[u] = reflect_bin(g.lo + k * g.ctr_fb - g.nbr_fb + (j - g.I1), nf) % FB;
+                else
+                    off[u] = -1;
             }
-            float* out = g.x + ((size_t)t * B * g.N + (size_t)b * g.N + k) * g.I;
-            if (g.norm == SFSN_NORM_LAYERNORM) {
-                const float mean = wave_sum(sum) / (float)g.I;
-                float ss = 0.0f;
+            for (int tt = wave; tt < FEAT_TT; tt += 4) {
+                const int t = t0 + tt;
+                if (t >= tend) break;  // wave-uniform
+                float v[4];
+                float sum = 0.0f;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float d = v[u] - mean;
-                    if (lane + 64 * u < g.I) ss += d * d;
+                    v[u] = off[u] < 0 ? 0.0f : (is_fb[u] ? fbT[tt * FB + off[u]] : magT[off[u] + tt]);
+                    sum += v[u];
                 }
-                const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)g.I + g.eps);
+                float* out = g.x + ((size_t)t * B * g.N + (size_t)b * g.N + k) * g.I;
+                if (g.norm == SFSN_NORM_LAYERNORM) {
+                    const float mean = wave_sum(sum) * inv_I;
+                    float ss = 0.0f;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = lane + 64 * u;
-                    if (j < g.I) out[j] = ((v[u] - mean) * rstd) * g.ln_w[j] + g.ln_b[j];
-                }
-            } else if (g.norm == SFSN_NORM_LAPLACE) {
-                const float den = g.mu[b] + 2.220446049250313e-16f;
+                    for (int u = 0; u < 4; ++u) {
+                        const float d = v[u] - mean;
+                        if (off[u] >= 0) ss += d * d;
+                    }
+                    const float rstd = __builtin_amdgcn_rsqf(wave_sum(ss) * inv_I + g.eps);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = lane + 64 * u;
-                    if (j < g.I) out[j] = v[u] / den;
-                }
-            } else {
+                    for (int u = 0; u < 4; ++u)
+                        if (off[u] >= 0) out[lane + 64 * u] = ((v[u] - mean) * rstd) * lw[u] + lb[u];
+                } else if (g.norm == SFSN_NORM_LAPLACE) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = lane + 64 * u;
-                    if (j < g.I) out[j] = v[u];
+                    for (int u = 0; u < 4; ++u)
+                        if (off[u] >= 0) out[lane + 64 * u] = v[u] / lap_den;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (off[u] >= 0) out[lane + 64 * u] = v[u];
                 }
             }
         }
@@ -1074,7 +1090,7 @@ __global__ __launch_bounds__(256) void deepfilter_kernel(const float* __restrict
                         }
                         const size_t o = (((size_t)b * S + s) * F + f) * T + t;
                         *reinterpret_cast<float2*>(enh + 2 * o) = make_float2(yr, yi);
-                        if (mag) mag[o] = hypotf(yr, yi);
+                        if (mag) mag[o] = fast_abs2(yr, yi);
                     }
                 }
             }
@@ -1087,7 +1103,7 @@ __global__ __launch_bounds__(256) void deepfilter_kernel(const float* __restrict
             for (int s = 0; s < S; ++s) {
                 const size_t o = (((size_t)b * S + s) * F + f) * T + t;
                 *reinterpret_cast<float2*>(enh + 2 * o) = xv;
-                if (mag) mag[o] = hypotf(xv.x, xv.y);
+                if (mag) mag[o] = fast_abs2(xv.x, xv.y);
             }
         }
 }
