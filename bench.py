@@ -48,8 +48,8 @@ SB_SCAN_BYTES_PER_FRAME_PER_LAUNCH = 29184 / 2
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="force the sequential single-stream schedule")
     ap.add_argument("--pipeline", action="store_true", help="force the time-pipelined multi-stream schedule")
     ap.add_argument("--time-all", action="store_true", help="HIP-event time every launch group, not only the dominant kernel")
+    ap.add_argument("--seq-chunk", type=int, default=0, help="frames per chunk of the single-stream schedule")
+    ap.add_argument("--rpw", type=str, default="", help="rows per scan workgroup 'fb,sb' (0 = auto)")
+    ap.add_argument("--inflight", type=int, default=6, help="forwards in flight on separate HIP streams (batch-level pipelining)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per pipeline chunk (default: engine default)")
     args = ap.parse_args()
 
@@ -91,38 +94,68 @@ def main():
     eng = model.engine()
     if args.chunk:
         eng.pipeline_chunk = args.chunk
+    if args.seq_chunk:
+        eng.seq_chunk = args.seq_chunk
     want_layers = not args.no_layer_outputs
     gathered = torch.empty((world * B, 1, 257, T), dtype=torch.float32, device=dev) if world > 1 else None
 
     info = {}
 
-    def step():
+    def forward():
         res = eng.forward_stft(stft, want_layers=want_layers, pipeline=False if args.sequential else (True if args.pipeline else None))
         info.update(pipelined=res["pipelined"], n_chunks=res["n_chunks"])
         if world > 1:
             dist.all_gather_into_tensor(gathered, res["enh_mag"])
         return res
 
-    for _ in range(args.warmup):
-        step()
-    eng.timers = {}  # HIP events around the scan launches, on the launch stream (engine.py)
-    eng.timer_tags = None if args.time_all else {"scan:sb"}  # each timed group costs ~10 us of launch gap
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def timed_region(step_fn, steps, warmup):
+        for _ in range(warmup):
+            step_fn()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    # ---- phase A (untimed for `value`): one forward at a time on one stream, the latency-optimal launch geometry.  The
+    #      dominant kernel runs alone here, so its HIP-event duration is the kernel's own (roofline), not a time share.
+    eng.rows_per_wg = (0, 0)
+    eng.timers, eng.timer_tags = {}, (None if args.time_all else {"scan:sb"})
+    ka = max(2, min(args.steps, 8))
+    dt_a = timed_region(forward, ka, min(args.warmup, 2) + 1)
     scan_ms = eng.timer_summary()
     eng.timers = None
+    single = dict(ms_per_step=round(1e3 * dt_a / ka, 4), value=round(world * B * T * ka / dt_a, 1), steps=ka)
+
+    # ---- phase B (THE timed region): `--inflight` forwards in flight on as many HIP streams -- batch-level pipelining of
+    #      independent batches, as a serving loop runs them.  The recurrent scans are latency-bound chains that occupy a
+    #      fraction of the CUs (16 rows per workgroup here, so that several scans fit side by side); the next batches'
+    #      scans and time-parallel kernels fill the rest of the chip.  Every step is one complete pass over one batch.
+    if args.inflight > 1:
+        eng.rows_per_wg = tuple(int(v) for v in args.rpw.split(",")) if args.rpw else (4, 16)
+        lanes = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
+        counter = [0]
+
+        def step():
+            s_ = lanes[counter[0] % len(lanes)]
+            counter[0] += 1
+            with torch.cuda.stream(s_):
+                return forward()
+    else:
+        if args.rpw:
+            eng.rows_per_wg = tuple(int(v) for v in args.rpw.split(","))
+        step = forward
+    dt = timed_region(step, args.steps, args.warmup)
 
     if rank == 0:
         frames = world * B * T * args.steps
@@ -140,12 +173,14 @@ def main():
                 tj = json.load(open(tpath))
                 if tj.get("B") == B and tj.get("T") == T:  # measured on one whole-sequence launch; scale to this launch's frames
                     traffic = int(tj.get("sb_scan_hbm_bytes_per_launch") / info["n_chunks"])
-            roofline = dict(bound="hbm", kernel="gsn_scan_kernel<G=1,TPW=2,KS=4,NW=8> (sub-band groups, one launch per layer)",
+            roofline = dict(bound="hbm", kernel="gsn_scan_kernel<G=1,KS=4,NW=16,TPW=1,OUT=fp32+int8 spikes,4-row repacked epilogue> (3 sub-band groups in one launch, one launch per layer)",
                             achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
                             traffic=traffic, launch_ms=round(sb_ms["mean_ms"], 4), launches=sb_ms["n"],
                             algorithmic_bytes_per_launch=int(bytes_per_launch),
                             per_step_us=round(1e3 * sb_ms["mean_ms"] / (T / info["n_chunks"]), 3),
                             frames_per_launch=int(frames_per_launch), schedule=("time-pipelined x%d chunks on %d streams" % (info["n_chunks"], 4)) if info["pipelined"] else "sequential",
+                            measured_in="phase A: single stream, one forward at a time (the kernel runs alone; in the timed region "
+                                        "several forwards share the chip and a launch's wall time is a time share, not the kernel's own)",
                             other_kernels_ms={k: round(v["mean_ms"], 4) for k, v in scan_ms.items() if k != "scan:sb"})
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -157,6 +192,8 @@ def main():
                     config=dict(workload="configs[2]: single MI355X, full model (full-band + 3 sub-band groups / 13 units), "
                                          "live baseline_m sizes, fp32 parity mode", clips_per_gpu=B, frames=T, bins=257,
                                 layer_outputs="api-faithful (fp32 spikes returned)" if want_layers else "skipped",
+                                in_flight=args.inflight, scan_rows_per_workgroup=list(eng.rows_per_wg),
+                                single_stream=single,
                                 parallelism=f"clip-sharded x{world}" + (" + RCCL all_gather(enh_mag)" if world > 1 else "")),
                     roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)

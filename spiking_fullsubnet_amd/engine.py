@@ -186,6 +186,8 @@ class Engine:
                              spec.sb_proj_size(g), spec.ln_sb, self.device) for g in range(spec.n_groups)]
         self._ws: Dict[tuple, dict] = {}
         self.timers: Optional[dict] = None  # set to {} to record HIP events around each launch group (bench.py)
+        self.seq_chunk = 0  # frames per chunk of the single-stream schedule (0 = whole sequence per launch)
+        self.rows_per_wg = (0, 0)  # (full-band, sub-band) rows per scan workgroup; 0 = let the library spread over all CUs
         self.timer_tags = None  # optional set of tags to time (each timed group costs ~10 us of launch gap)
         self._stream_objs: Dict[int, torch.cuda.Stream] = {}
         self._side: List[torch.cuda.Stream] = []
@@ -240,7 +242,7 @@ class Engine:
     def _workspace(self, key, make):
         ws = self._ws.get(key)
         if ws is None:
-            if len(self._ws) > 4:
+            if len(self._ws) > 8:
                 self._ws.clear()
             ws = self._ws[key] = make()
         return ws
@@ -309,7 +311,7 @@ class Engine:
         """Per-forward tensors of a stack of sequence models sharing (H, L): API outputs are fresh, scratch is cached."""
         dev, H, G, nl = self.device, seqs[0].H, seqs[0].cells[0].G, len(seqs[0].cells)
         HP = (H + 63) // 64 * 64
-        ws = self._workspace((tag, T, nt_max, tuple(Rs)), lambda: dict(
+        ws = self._workspace((tag, T, nt_max, tuple(Rs), torch.cuda.current_stream(dev).cuda_stream), lambda: dict(
             zin=[[torch.empty((nt_max, R, G * H), dtype=torch.float32, device=dev) for R in Rs] for _ in range(nl)],
             s8=[[torch.zeros((T, R, HP), dtype=torch.int8, device=dev) for R in Rs] for _ in range(nl)]))
         f32 = dict(dtype=torch.float32, device=dev)
@@ -438,7 +440,10 @@ class Engine:
         chunk = self.pipeline_chunk
         if pipeline is None:
             pipeline = self.pipeline_default and chunk > 0 and T >= 2 * chunk
-        nt_max = chunk if pipeline else T
+        # sequential schedule: optionally still cut the sequence into chunks (single stream): the chunk-sized input-term
+        # buffer is then produced and consumed while it is still in the 256 MB Infinity Cache instead of making a round
+        # trip through HBM (745 MB per sub-band layer at B=64, T=1000)
+        nt_max = chunk if pipeline else (self.seq_chunk if 0 < self.seq_chunk < T else T)
         bounds = [(t0, min(nt_max, T - t0)) for t0 in range(0, T, nt_max)]
         S, ng = spec.num_spks, spec.n_groups
         nl_fb, nl_sb = spec.fb_layers, spec.sb_layers
@@ -476,7 +481,7 @@ class Engine:
                 s_.wait_event(fork)
         else:
             sstreams = gstreams = [main] * n_stage
-            rpw_fb = rpw_sb = 0
+            rpw_fb, rpw_sb = self.rows_per_wg
         hS = [self._handle(s_) for s_ in sstreams]
         hG = [self._handle(s_) for s_ in gstreams]
 
