@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--rpw", type=str, default="", help="rows per scan workgroup 'fb,sb' (0 = auto)")
     ap.add_argument("--inflight", type=int, default=6, help="forwards in flight on separate HIP streams (batch-level pipelining)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per pipeline chunk (default: engine default)")
+    ap.add_argument("--streaming", action="store_true", help="BASELINE configs[4]: frame-by-frame session, per-call latency (own JSON line)")
+    ap.add_argument("--hop", type=int, default=1, help="frames per streaming call")
+    ap.add_argument("--no-graph", action="store_true", help="streaming: launch the kernels one by one instead of replaying the HIP graph")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,6 +95,8 @@ def main():
     stft = model.stft(wave).contiguous()  # untimed: the STFT is the edge of the path
     assert stft.shape == (B, 257, T)
     eng = model.engine()
+    if args.streaming:
+        return streaming_bench(args, model, dev, world, rank)
     if args.chunk:
         eng.pipeline_chunk = args.chunk
     if args.seq_chunk:
@@ -205,6 +210,44 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def streaming_bench(args, model, dev, world, rank):
+    """BASELINE.json configs[4]: B clips per GPU (default run: --batch 1), ``hop`` frames per call, state carried on the device;
+    per-call latency = host wall time from handing over the frame(s) to the enhanced frame(s) being complete (synchronised)."""
+    B = args.batch if args.batch != 64 else 1
+    hop, steps, warmup = args.hop, max(args.steps, 2000), max(args.warmup, 200)
+    sess = model.streaming(batch=B, hop=hop, graph=not args.no_graph)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    frames = (0.05 * torch.randn((steps + warmup, B, 257, hop, 2), generator=g)).to(dev)
+    frames = torch.view_as_complex(frames)
+    lat = []
+    for i in range(steps + warmup):
+        x = frames[i]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sess.step(x, copy=False)
+        torch.cuda.synchronize()
+        if i >= warmup:
+            lat.append(time.perf_counter() - t0)
+    lat = np.sort(np.asarray(lat)) * 1e6
+    # throughput of back-to-back calls without a host sync per call (the graph replays queue up)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        sess.step(frames[warmup + i], copy=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({
+            "metric": "streaming per-call latency p50 (BASELINE configs[4]: state carried on the device, hop frames per call)",
+            "value": round(float(lat[len(lat) // 2]), 1), "unit": "us", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(float(lat.mean()) / 1e3, 4), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (0.05*randn complex frames; seeded random weights, randomised BN stats)",
+            "config": {"workload": "configs[4]: streaming, live baseline_m sizes, fp32 parity mode", "clips_per_gpu": B, "hop_frames": hop,
+                       "hip_graph": not args.no_graph, "p99_us": round(float(lat[int(len(lat) * 0.99)]), 1),
+                       "min_us": round(float(lat[0]), 1), "unsynchronised_calls_per_s": round(steps / dt, 1),
+                       "real_time_factor_at_8ms_hop": round(8e3 * hop / float(lat[len(lat) // 2]), 1)}}))
 
 
 def cpu_baseline(kw, sd, stft):

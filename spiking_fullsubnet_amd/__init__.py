@@ -12,5 +12,6 @@ from . import _lib  # noqa: F401
 from .engine import Engine, PathSpec  # noqa: F401
 from .model_low_freq import Separator  # noqa: F401
 from .modeling_spiking_fullsubnet import SpikingFullSubNet  # noqa: F401
+from .streaming import StreamingSession  # noqa: F401
 
-__all__ = ["SpikingFullSubNet", "Separator", "Engine", "PathSpec"]
+__all__ = ["SpikingFullSubNet", "Separator", "Engine", "PathSpec", "StreamingSession"]

@@ -118,6 +118,13 @@ class _EngineMixin:
             self._engine_key = key
         return self._engine
 
+    def streaming(self, batch: int = 1, hop: int = 1, graph: bool = True):
+        """Frame-by-frame session on STFT frames (``streaming.StreamingSession``): state and deep-filter history stay on
+        the device between calls; one HIP-graph replay per hop.  Live front-end only."""
+        from .streaming import StreamingSession
+        self._check_mode()
+        return StreamingSession(self.engine(), batch=batch, hop=hop, graph=graph)
+
     def _check_mode(self):
         if self.training:
             raise RuntimeError(

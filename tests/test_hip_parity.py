@@ -359,6 +359,45 @@ def test_forwards_in_flight_on_separate_streams_are_independent():
             assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("kw,seed,B,hop,graph", [(rw.LIVE_TINY, 11, 2, 1, True), (rw.LIVE_M, 5, 1, 1, True), (rw.LIVE_M, 5, 3, 4, True),
+                                                  (rw.LIVE_TINY_2SPK, 12, 2, 3, False), (rw.LIVE_TINY_UNSHARED, 7, 1, 1, True)])
+def test_streaming_session_equals_offline_forward(kw, seed, B, hop, graph):
+    """BASELINE configs[4] (streaming, state carried, hop frames per call): the frame-by-frame session reproduces the offline
+    forward on the same clip bit for bit (the model is causal after the STFT), and a reset starts a new utterance.  (Offline forward vs
+    oracle / golden vectors: the tests above.)"""
+    model = build_module("live", kw, rw.live_state_dict(kw, seed))
+    T = 24 * hop if hop > 1 else 40
+    wave = torch.from_numpy(rw.synth_wave(B, T, seed)).to(DEV)
+    stft = torch.stft(wave, kw["n_fft"], kw["hop_length"], kw["win_length"], window=torch.hann_window(kw["win_length"], device=DEV),
+                      return_complex=True, pad_mode="constant")[..., :T].contiguous()
+    assert stft.shape[-1] == T
+    off = model.engine().forward_stft(stft, want_layers=False)
+    sess = model.streaming(batch=B, hop=hop, graph=graph)
+    for rep in range(2):
+        outs, mags = [], []
+        for t0 in range(0, T, hop):
+            e, m = sess.step(stft[..., t0:t0 + hop].contiguous())
+            outs.append(e)
+            mags.append(m)
+        assert sess.frames_done == T
+        e, m = torch.cat(outs, -1), torch.cat(mags, -1)
+        assert torch.equal(torch.view_as_real(e), torch.view_as_real(off["enh_stft"])), rep
+        assert torch.equal(m, off["enh_mag"])
+        sess.reset()
+
+
+def test_streaming_rejects_the_non_causal_front_end_and_bad_frames():
+    model = build_module("frozen", rw.FROZEN_TINY, rw.frozen_state_dict(rw.FROZEN_TINY, 31))
+    with pytest.raises(NotImplementedError):
+        model.streaming()
+    live = build_module("live", rw.LIVE_TINY, rw.live_state_dict(rw.LIVE_TINY, 11))
+    sess = live.streaming(batch=1, hop=2, graph=False)
+    with pytest.raises(RuntimeError):
+        sess.step(torch.zeros((1, rw.LIVE_TINY["n_fft"] // 2 + 1, 1), dtype=torch.complex64, device=DEV))
+    with pytest.raises(RuntimeError):
+        sess.step(torch.zeros((1, rw.LIVE_TINY["n_fft"] // 2 + 1, 2), dtype=torch.complex64))
+
+
 def spec_units(spec, g):
     return (spec["cutoffs"][g + 1] - spec["cutoffs"][g]) // spec["ctr"][g]
 
