@@ -182,6 +182,23 @@ int sfsn_deepfilter(const float* stft_ri /* [B][F][T][2] */, int B, int F, int T
                     const sfsn_df_group* groups /* host */, int n_groups, float* enh_ri /* [B][S][F][T][2] */,
                     float* enh_mag /* [B][S][F][T], nullable */, int t0, int nt /* frames [t0, t0+nt) */, void* stream);
 
+/* ----------------------------------------------------------------------------------------------------
+ * Spike counts -- the only thing the reference's energy proxy reads from the spike tensors:
+ * compute_synops (audiozen/metric.py:303-327) uses torch.gt(layer_output, 0).float().mean() per layer.  Counting the
+ * int8 spikes the scan already writes lets a caller that only wants SynOPs skip the fp32 spike tensors
+ * (spikes_f32 = NULL in sfsn_gsn_layer_scan): 4 B/spike of HBM writes and a 3-pass torch reduction less.
+ *     *count += #{ spikes_i8[i] != 0, i < n_bytes }       (exact integer; pad columns of the int8 layout are zero)
+ * One launch for up to SFSN_MAX_COUNT_TENSORS tensors.  `count` is accumulated (the caller zeroes it).
+ * ---------------------------------------------------------------------------------------------------- */
+#define SFSN_MAX_COUNT_TENSORS 16
+typedef struct sfsn_count_tensor {
+    const int8_t* spikes_i8;     /* device, 16-byte aligned, n_bytes % 16 == 0 */
+    unsigned long long n_bytes;
+    unsigned long long* count;   /* device */
+} sfsn_count_tensor;
+
+int sfsn_spike_count(const sfsn_count_tensor* tensors /* host */, int n_tensors, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,13 @@ class DfGroup(ctypes.Structure):
     _fields_ = [("proj", _P), ("n_units", _I), ("fc", _I), ("df", _I)]
 
 
+class CountTensor(ctypes.Structure):
+    _fields_ = [("spikes_i8", _P), ("n_bytes", ctypes.c_ulonglong), ("count", _P)]
+
+
+MAX_COUNT_TENSORS = 16
+
+
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (``make -C csrc``); hipcc cross-compiles without a GPU."""
     srcs = [os.path.join(CSRC, f) for f in ("sfsn_kernels.hip", "sfsn_pack.cpp")] + [
@@ -83,6 +90,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_laplace_means.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _P, _P, _P]
     L.sfsn_deepfilter.restype = _I
     L.sfsn_deepfilter.argtypes = [_P, _I, _I, _I, _I, ctypes.POINTER(DfGroup), _I, _P, _P, _I, _I, _P]
+    L.sfsn_spike_count.restype = _I
+    L.sfsn_spike_count.argtypes = [ctypes.POINTER(CountTensor), _I, _P]
     if L.sfsn_abi_version() != 1:
         raise ImportError(f"{LIB_PATH}: ABI version {L.sfsn_abi_version()} != 1; rebuild")
     _lib = L
@@ -91,7 +100,7 @@ def lib() -> ctypes.CDLL:
 
 EXPORTS = ("sfsn_abi_version", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
            "sfsn_w3_pack", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
-           "sfsn_laplace_means", "sfsn_deepfilter")
+           "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_spike_count")
 
 
 def check(rc: int, what: str = "") -> None:

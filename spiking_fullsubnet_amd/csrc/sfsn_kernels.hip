@@ -993,6 +993,39 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
     }
 }
 
+// ---- spike counts (SynOPs, audiozen/metric.py:303-327) ---------------------------------------------------------
+struct CountParams {
+    const int8_t* src[SFSN_MAX_COUNT_TENSORS];
+    unsigned long long* dst[SFSN_MAX_COUNT_TENSORS];
+    unsigned long long nvec[SFSN_MAX_COUNT_TENSORS];  // 16-byte vectors per tensor
+    int blk0[SFSN_MAX_COUNT_TENSORS + 1];             // first block of each tensor
+    int n;
+};
+
+// Spikes are bytes 0/1: popcount of a dword = number of spikes in it.  Each block streams 64 KB (256 threads x 16 x 16 B).
+__global__ __launch_bounds__(256) void spike_count_kernel(const CountParams p) {
+    int ti = 0;
+    while (ti + 1 < p.n && (int)blockIdx.x >= p.blk0[ti + 1]) ++ti;
+    const v4i* src = reinterpret_cast<const v4i*>(p.src[ti]);
+    const unsigned long long nvec = p.nvec[ti];
+    unsigned long long i = (unsigned long long)(blockIdx.x - p.blk0[ti]) * 4096 + threadIdx.x;
+    unsigned cnt = 0;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k, i += 256) {
+        if (i < nvec) {
+            const v4i v = src[i];
+            cnt += __builtin_popcount((unsigned)v.x) + __builtin_popcount((unsigned)v.y) + __builtin_popcount((unsigned)v.z) +
+                   __builtin_popcount((unsigned)v.w);
+        }
+    }
+    __shared__ unsigned part[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(p.dst[ti], (unsigned long long)(part[0] + part[1] + part[2] + part[3]));
+}
+
 // ---- Laplace means -----------------------------------------------------------------------------------
 // rs[b][f] = sum_t mag[b][f][t] (f < nf), then rs[b][nf + f'] = sum_t fb[t][b][f'].  One wave per row.
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ stft, const float* __restrict__ fb,
@@ -1388,6 +1421,25 @@ extern "C" int sfsn_laplace_means(const float* stft_ri, const float* fb_tbf, int
     const int rows = B * (F - 1 + FB);
     hipLaunchKernelGGL(rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, stft_ri, fb_tbf, scratch, B, F, T, FB, fdrc);
     hipLaunchKernelGGL(laplace_mu_kernel, dim3(n_groups, B), dim3(64), 0, st, scratch, p, mu_out);
+    return hip_ok(hipGetLastError());
+}
+
+extern "C" int sfsn_spike_count(const sfsn_count_tensor* tensors, int n_tensors, void* stream) {
+    if (!tensors || n_tensors <= 0 || n_tensors > SFSN_MAX_COUNT_TENSORS) return SFSN_EINVAL;
+    CountParams p;
+    p.n = n_tensors;
+    long long blocks = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        const sfsn_count_tensor& t = tensors[i];
+        if (!t.spikes_i8 || !t.count || t.n_bytes == 0 || (t.n_bytes & 15) || (reinterpret_cast<uintptr_t>(t.spikes_i8) & 15))
+            return SFSN_EINVAL;
+        p.src[i] = t.spikes_i8; p.dst[i] = t.count; p.nvec[i] = t.n_bytes / 16;
+        p.blk0[i] = (int)blocks;
+        blocks += (long long)((p.nvec[i] + 4095) / 4096);
+        if (blocks > 0x7fffffffLL) return SFSN_EUNSUPPORTED;
+    }
+    p.blk0[n_tensors] = (int)blocks;
+    hipLaunchKernelGGL(spike_count_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return hip_ok(hipGetLastError());
 }
 

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import DfGroup, FeatureGroup, ScanSegment, check
+from ._lib import CountTensor, DfGroup, FeatureGroup, ScanSegment, check
 
 
 @dataclass
@@ -158,6 +158,29 @@ def _pack_seq(sd: Dict[str, np.ndarray], prefix: str, spec: PathSpec, I: int, H:
         seq.ln_w = _dev(sd[prefix + "pre_layer_norm.weight"].astype(np.float32), device)
         seq.ln_b = _dev(sd[prefix + "pre_layer_norm.bias"].astype(np.float32), device)
     return seq
+
+
+class SpikeSummary:
+    """Stand-in for one fp32 spike tensor of ``all_layer_outputs`` when only its statistics are wanted
+    (``layer_outputs="counts"``): the exact number of spikes, counted on the device from the int8 spikes the scan writes,
+    plus the shape the tensor would have had.  ``metric.compute_synops`` / ``compute_neuronops`` accept it in place of
+    the tensor (audiozen/metric.py:303-340 read only ``gt(x, 0).float().mean()`` and ``size(-1)``)."""
+
+    def __init__(self, count: torch.Tensor, shape):
+        self.count, self.shape = count, torch.Size(shape)
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def numel(self) -> int:
+        return self.shape.numel()
+
+    def rate(self) -> torch.Tensor:
+        """fp32 firing rate = what ``torch.gt(x, 0).float().mean()`` estimates (here exact count / numel, rounded once)."""
+        return (self.count.to(torch.float64) / self.numel()).to(torch.float32)
+
+    def __repr__(self):
+        return f"SpikeSummary(shape={tuple(self.shape)})"
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -408,7 +431,21 @@ class Engine:
         self._stream_objs[stream.cuda_stream] = stream
         return ctypes.c_void_p(stream.cuda_stream)
 
-    def forward_stft(self, stft: torch.Tensor, want_layers: bool = True, want_membrane: bool = False, pipeline: Optional[bool] = None) -> dict:
+    def _count_spikes(self, s8_lists, shapes, st):
+        """One launch of sfsn_spike_count over every layer's int8 spike tensor -> list of SpikeSummary."""
+        n = len(s8_lists)
+        if n > _lib.MAX_COUNT_TENSORS:
+            raise NotImplementedError(f"more than {_lib.MAX_COUNT_TENSORS} spike tensors to count")
+        counts = torch.zeros((n,), dtype=torch.int64, device=self.device)
+        arr = (CountTensor * n)()
+        for i, t in enumerate(s8_lists):
+            arr[i].spikes_i8, arr[i].n_bytes, arr[i].count = t.data_ptr(), t.numel(), counts.data_ptr() + 8 * i
+        with self.timed("spike_count", st):
+            check(self.lib.sfsn_spike_count(arr, n, st), "sfsn_spike_count")
+        return [SpikeSummary(counts[i], shp) for i, shp in enumerate(shapes)]
+
+    def forward_stft(self, stft: torch.Tensor, want_layers: bool = True, want_membrane: bool = False, pipeline: Optional[bool] = None,
+                     want_counts: bool = False) -> dict:
         """complex64 [B, n_fft/2+1, T] on the device -> dict(enh_stft [B,S,F,T] complex64, enh_mag [B,S,F,T],
         fb_all, sb_all (the reference's all_layer_outputs lists; spike entries are None when want_layers=False)).
 
@@ -553,6 +590,17 @@ class Engine:
         if pipeline:
             for s_ in sstreams + gstreams:
                 link(s_, main)
+
+        if want_counts and not want_layers:
+            # SynOPs without the fp32 spike tensors: count the int8 spikes, one launch for all layers
+            tens = [fb["s8"][l][0] for l in range(nl_fb)] + [sb["s8"][l][g] for g in range(ng) for l in range(nl_sb)]
+            shapes = [(T, B, self.fb.H)] * nl_fb + [(T, xs[g].shape[1], self.sb[g].H) for g in range(ng) for _ in range(nl_sb)]
+            summ = self._count_spikes(tens, shapes, self._handle(main))
+            for l in range(nl_fb):
+                fb["spk"][l][0] = summ[l]
+            for g in range(ng):
+                for l in range(nl_sb):
+                    sb["spk"][l][g] = summ[nl_fb + g * nl_sb + l]
 
         def outs(x, d, i):
             return [x] + [d["spk"][l][i] for l in range(len(d["spk"]))] + [d["proj"][i]]

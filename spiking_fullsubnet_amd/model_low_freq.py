@@ -96,9 +96,9 @@ class Separator(_EngineMixin, nn.Module):
         return self._path_spec
 
     @torch.no_grad()
-    def forward_stft(self, complex_stft, want_layers=True, want_membrane=False):
+    def forward_stft(self, complex_stft, want_layers=True, want_membrane=False, want_counts=False):
         self._check_mode()
-        return self.engine().forward_stft(complex_stft, want_layers=want_layers, want_membrane=want_membrane)
+        return self.engine().forward_stft(complex_stft, want_layers=want_layers, want_membrane=want_membrane, want_counts=want_counts)
 
     @torch.no_grad()
     def forward(self, noisy_y):
@@ -111,7 +111,7 @@ class Separator(_EngineMixin, nn.Module):
         window = torch.hann_window(self.n_fft, device=noisy_y.device)
         stft = torch.stft(noisy_y, self.n_fft, self.hop_length, self.win_length, window=window, return_complex=True,
                           pad_mode="constant")
-        res = self.engine().forward_stft(stft)
+        res = self.engine().forward_stft(stft, **self._layer_kwargs())
         enhanced_stft = res["enh_stft"][:, 0]
         enhanced_y = torch.istft(enhanced_stft, n_fft=self.n_fft, hop_length=self.hop_length, win_length=self.win_length,
                                  window=torch.hann_window(self.win_length, device=noisy_y.device), length=noisy_y.size(-1))

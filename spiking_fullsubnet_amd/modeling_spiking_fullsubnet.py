@@ -102,6 +102,15 @@ class _EngineMixin:
 
     _engine = None
     _engine_key = None
+    # What forward() returns in place of the reference's fp32 spike tensors (entries 1..L of every all_layer_outputs list):
+    #   "tensors" (default, the reference's API), "counts" (SpikeSummary: exact spike counts + shape -- all that
+    #   metric.compute_synops / compute_neuronops read), "none" (None entries).
+    layer_outputs = "tensors"
+
+    def _layer_kwargs(self) -> dict:
+        if self.layer_outputs not in ("tensors", "counts", "none"):
+            raise ValueError(f"layer_outputs must be 'tensors', 'counts' or 'none', got {self.layer_outputs!r}")
+        return dict(want_layers=self.layer_outputs == "tensors", want_counts=self.layer_outputs == "counts")
 
     def _spec(self) -> PathSpec:  # pragma: no cover - provided by subclasses
         raise NotImplementedError
@@ -172,17 +181,17 @@ class SpikingFullSubNet(_EngineMixin, nn.Module):
         return torch.istft(spec, self.n_fft, self.hop_length, self.win_length, window=window, length=length)
 
     @torch.no_grad()
-    def forward_stft(self, noisy_cmp, want_layers=True, want_membrane=False):
+    def forward_stft(self, noisy_cmp, want_layers=True, want_membrane=False, want_counts=False):
         """The hot path alone: complex64 [B, 257, T] -> Engine.forward_stft result dict."""
         self._check_mode()
-        return self.engine().forward_stft(noisy_cmp, want_layers=want_layers, want_membrane=want_membrane)
+        return self.engine().forward_stft(noisy_cmp, want_layers=want_layers, want_membrane=want_membrane, want_counts=want_counts)
 
     @torch.no_grad()
     def forward(self, input):
         assert input.ndim == 2, f"Input tensor must be 2D, but got {input.ndim}D."
         self._check_mode()
         batch_size, sequence_length = input.shape
-        res = self.engine().forward_stft(self.stft(input))
+        res = self.engine().forward_stft(self.stft(input), **self._layer_kwargs())
         enh_stft = res["enh_stft"]  # [B, S, F, T]
         if self.num_spks > 1:
             enh_y = self.istft(enh_stft.reshape(batch_size * self.num_spks, *enh_stft.shape[2:]), length=sequence_length)

@@ -398,6 +398,54 @@ def test_streaming_rejects_the_non_causal_front_end_and_bad_frames():
         sess.step(torch.zeros((1, rw.LIVE_TINY["n_fft"] // 2 + 1, 2), dtype=torch.complex64))
 
 
+@pytest.mark.parametrize("front,kw,seed", [("live", rw.LIVE_M, 5), ("frozen", rw.FROZEN_S, 6), ("live", rw.LIVE_TINY_UNSHARED, 7)])
+def test_spike_counts_replace_the_fp32_spike_tensors(front, kw, seed):
+    """layer_outputs="counts": the device-side counts of the int8 spikes are exactly the sums of the fp32 spike tensors of the
+    default mode, the other outputs are bit-identical, and the SynOPs / NeuronOPs drop-ins give the same numbers either way."""
+    from spiking_fullsubnet_amd import SpikeSummary, metric
+    sd = rw.live_state_dict(kw, seed) if front == "live" else rw.frozen_state_dict(kw, seed)
+    model = build_module(front, kw, sd)
+    wave = torch.from_numpy(rw.synth_wave(3, 77, seed)).to(DEV)
+    full = model(wave)
+    model.layer_outputs = "counts"
+    lean = model(wave)
+    model.layer_outputs = "none"
+    bare = model(wave)
+    model.layer_outputs = "tensors"
+    torch.cuda.synchronize()
+    assert torch.equal(full[0], lean[0]) and torch.equal(full[1], lean[1]) and torch.equal(full[0], bare[0])
+    fb_f, sb_f, fb_c, sb_c = full[-2], full[-1], lean[-2], lean[-1]
+    n = 0
+    for a, b, c in zip([fb_f] + list(sb_f), [fb_c] + list(sb_c), [bare[-2]] + list(bare[-1])):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[-1], b[-1])
+        for x, y, z in zip(a[1:-1], b[1:-1], c[1:-1]):
+            assert isinstance(y, SpikeSummary) and z is None and tuple(y.shape) == tuple(x.shape)
+            assert int(y.count.item()) == int((x > 0).sum().item())
+            n += 1
+    assert n == 2 * (1 + len(sb_f))
+    shared = kw.get("shared_weights", True)
+    assert metric.compute_synops(fb_c, sb_c, shared) == pytest.approx(metric.compute_synops(fb_f, sb_f, shared), rel=1e-6)
+    assert metric.compute_neuronops(fb_c, sb_c) == metric.compute_neuronops(fb_f, sb_f)
+    oracle_syn = omodel.compute_synops([t.cpu().numpy() for t in fb_f], [[t.cpu().numpy() for t in l] for l in sb_f], shared)
+    assert metric.compute_synops(fb_c, sb_c, shared) == pytest.approx(oracle_syn, rel=1e-6)
+
+
+def test_spike_count_rejects_bad_arguments(hip):
+    from spiking_fullsubnet_amd._lib import CountTensor, SFSN_EINVAL
+    s = torch.ones((4, 64), dtype=torch.int8, device=DEV)
+    cnt = torch.zeros((1,), dtype=torch.int64, device=DEV)
+    arr = (CountTensor * 1)()
+    arr[0].spikes_i8, arr[0].n_bytes, arr[0].count = s.data_ptr(), s.numel(), cnt.data_ptr()
+    assert hip.sfsn_spike_count(arr, 1, None) == 0
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 256
+    arr[0].n_bytes = 250
+    assert hip.sfsn_spike_count(arr, 1, None) == SFSN_EINVAL
+    arr[0].n_bytes, arr[0].count = 256, None
+    assert hip.sfsn_spike_count(arr, 1, None) == SFSN_EINVAL
+    assert hip.sfsn_spike_count(arr, 0, None) == SFSN_EINVAL and hip.sfsn_spike_count(arr, 17, None) == SFSN_EINVAL
+
+
 def spec_units(spec, g):
     return (spec["cutoffs"][g + 1] - spec["cutoffs"][g]) // spec["ctr"][g]
 

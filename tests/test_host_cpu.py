@@ -128,6 +128,40 @@ def test_reference_init_is_reproduced():
     assert torch.equal(w.detach(), expect)  # first RNG draw of the constructor is the first cell's weight_ih
 
 
+@pytest.mark.parametrize("fname,shared", [("live_tiny.npz", True), ("live_m.npz", True), ("live_tiny_unshared.npz", False),
+                                          ("frozen_s_zoo.npz", True)])
+def test_metric_dropins_match_reference_values(golden_dir, fname, shared):
+    """metric.compute_synops / compute_neuronops on the reference's recorded layer outputs == the values the reference's own
+    audiozen.metric functions returned for them (recorded by tests/golden/make_golden.py), both from the fp32 spike tensors
+    and from SpikeSummary objects (exact counts + shapes, what layer_outputs="counts" returns)."""
+    import parity
+    from spiking_fullsubnet_amd import SpikeSummary, metric
+    gold = np.load(os.path.join(golden_dir, fname))
+    if "synops" not in gold:
+        pytest.skip("fixture without SynOPs")
+    prefixes = ["fb"] + sorted({k.split("/")[0] for k in gold.keys() if k.startswith("sb")}, key=lambda v: int(v[2:]))
+
+    def lists(summary):
+        out = []
+        for pre in prefixes:
+            ent = [torch.from_numpy(gold[f"{pre}/x"])]
+            l = 0
+            while f"{pre}/spikes_shape/{l}" in gold:
+                shape = tuple(int(v) for v in gold[f"{pre}/spikes_shape/{l}"])
+                spk = parity.unpack(gold[f"{pre}/spikes_packed/{l}"], shape)
+                ent.append(SpikeSummary(torch.tensor(int(spk.sum()), dtype=torch.int64), shape) if summary
+                           else torch.from_numpy(spk.astype(np.float32)))
+                l += 1
+            ent.append(torch.from_numpy(gold[f"{pre}/proj"]))
+            out.append(ent)
+        return out[0], out[1:]
+
+    for summary in (False, True):
+        fb, sb = lists(summary)
+        assert metric.compute_synops(fb, sb, shared_weights=shared) == pytest.approx(float(gold["synops"]), rel=1e-6)
+        assert metric.compute_neuronops(fb, sb) == float(gold["neuronops"])
+
+
 def test_shard_bounds_partition():
     from spiking_fullsubnet_amd.dist import shard_bounds
     for n in (0, 1, 7, 64, 512, 513):
