@@ -50,6 +50,7 @@ struct ScanParams {
     ScanSegDev seg[SFSN_MAX_SEGMENTS];
     int nseg, T, H, NT;  // NT = H / 16 output tiles per gate
     int rpw;             // rows per workgroup (16, 8 or 4): fewer rows per CU = less HBM traffic per CU per step
+    int prio;            // wave priority scheme (see gsn_scan_kernel)
 };
 
 __device__ __forceinline__ float recombine3(int a0, int a1, int a2) {
@@ -463,6 +464,15 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
     }
     __syncthreads();
 
+    {
+        int pr = 0;
+        if (p.prio == 1) pr = 3 - ((wave >> 2) & 3);
+        else if (p.prio == 2) pr = (wave >> 2) & 3;
+        else if (p.prio == 3) pr = 3 - (wave & 3);
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
     const int n_hi = NT - NW * (TPW - 1);  // waves [0, n_hi) own TPW tiles, the others TPW-1
     if (wave < n_hi)
         scan_body<G, KS, NW, TPW, OUT, LP, TPW>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state, smem, T,
@@ -853,6 +863,165 @@ __global__ __launch_bounds__(512) void input_proj_fast_kernel(const float* __res
     }
 }
 
+// ---- layer-0 input product on the bf16 matrix cores, fp32-accurate (3-way split) ------------------------------------
+// The fp32 MFMA (v_mfma_f32_16x16x4_f32, 256 FLOP/clk/CU) bounds input_proj_fast_kernel: 65 GFLOP per forward at B=64,
+// T=1000 is 0.41 ms of matrix-core time.  v_mfma_f32_16x16x32_bf16 is 16x faster per FLOP.  Every fp32 value splits
+// (round-to-nearest, v_cvt_pk_bf16_f32) into three bf16 pieces v = v1 + v2 + v3 with |v2| <= 2^-9 |v|, |v3| <= 2^-18 |v|
+// (the last residual has at most 8 significant bits and is exact).  Products of pieces are exact in fp32; the six products
+// x1w1, x1w2, x2w1, x1w3, x2w2, x3w1 carry x.w to 2^-26 |x||w| per term -- below half an fp32 ulp of the term -- and the
+// matrix core accumulates them in fp32.  The five small products go to their own accumulator (not swamped by the large
+// one; two independent MFMA chains) and are added once at the end.  6 MFMAs of 16 clk per 32 k instead of 8 of 32 clk.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16_rne(float a, float b) {
+    const v2f v = {a, b};
+    const bf2 p = __builtin_convertvector(v, bf2);  // v_cvt_pk_bf16_f32
+    return *reinterpret_cast<const unsigned*>(&p);
+}
+// (a, b) -> three packed bf16 pairs (low half = a's piece, high half = b's piece)
+__device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = pack_bf16_rne(a, b);
+    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pack_bf16_rne(ra, rb);
+    p3 = pack_bf16_rne(ra - __uint_as_float(p2 << 16), rb - __uint_as_float(p2 & 0xffff0000u));
+}
+
+template <int TPW, int KS>
+__global__ __launch_bounds__(512) void input_proj_bf3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ z, int M, int K, int N,
+                                                              int ldz, int NT, int NWN) {
+    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+    constexpr int KQ = KS * 32;          // padded K
+    constexpr int LDX = KQ + 8;          // bf16 elements per row: row stride = 16 B * odd -> conflict-free ds_read_b128
+    constexpr int PLANE = 64 * LDX / 2;  // dwords per piece plane
+    constexpr int NVP = (64 * KQ / 2 + 511) / 512;  // k-pairs per thread per tile
+    unsigned* xb = reinterpret_cast<unsigned*>(gemm_smem);  // [3][64][LDX] bf16
+    float* obuf = gemm_smem + 3 * PLANE;                    // [64][N + 4]
+    const int NP = N + 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int MW = 8 / NWN;
+    const int cg = wave % NWN, mw = wave / NWN;
+    const bool worker = mw < MW;
+
+    bf8 W[TPW][KS][3];
+    v4f bv[TPW];
+    int col[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int ct = cg + NWN * i;
+        const bool have = worker && ct < NT;
+        col[i] = have ? ct * 16 + q * 4 : -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[i][r] = (bias && have && col[i] + r < N) ? bias[col[i] + r] : 0.0f;
+        const int wr = ct * 16 + n;  // A fragment: lane holds 8 consecutive k of weight row wr
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            unsigned pw[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = ks * 32 + q * 8 + 2 * e;
+                const float a = (have && wr < N && k < K) ? w[(size_t)wr * K + k] : 0.0f;
+                const float b = (have && wr < N && k + 1 < K) ? w[(size_t)wr * K + k + 1] : 0.0f;
+                split3(a, b, pw[0][e], pw[1][e], pw[2][e]);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) W[i][ks][pl] = *reinterpret_cast<const bf8*>(pw[pl]);
+        }
+    }
+    const int NS = (M + 63) >> 6;
+    const int n4 = N >> 2;
+    v2f pre[NVP];
+    int pr[NVP], pk[NVP];  // (row, k) of my k-pairs within a tile: fixed
+#pragma unroll
+    for (int j = 0; j < NVP; ++j) {
+        const int e = tid + j * 512;
+        pr[j] = e / (KQ / 2);
+        pk[j] = (e - pr[j] * (KQ / 2)) * 2;
+    }
+    auto fetch = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NVP; ++j) {
+            int row = st * 64 + pr[j];
+            if (row > M - 1) row = M - 1;
+            const v2f zero = {0.0f, 0.0f};
+            pre[j] = (pr[j] < 64 && pk[j] < K) ? *reinterpret_cast<const v2f*>(x + (size_t)row * K + pk[j]) : zero;  // K is even
+        }
+    };
+    auto park = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NVP; ++j)
+            if (pr[j] < 64) {
+                unsigned p1, p2, p3;
+                split3(pre[j][0], pre[j][1], p1, p2, p3);
+                const int o = (pr[j] * LDX + pk[j]) >> 1;
+                xb[o] = p1;
+                xb[PLANE + o] = p2;
+                xb[2 * PLANE + o] = p3;
+            }
+    };
+    if ((int)blockIdx.x < NS) {
+        fetch(blockIdx.x);
+        park();
+    }
+    __syncthreads();
+    for (int st = blockIdx.x; st < NS; st += gridDim.x) {
+        const int m0 = st * 64;
+        const int nxt = st + gridDim.x;
+        if (nxt < NS) fetch(nxt);
+        if (worker) {
+            for (int mi = mw; mi < GEMM_MB; mi += MW) {
+                v4f hi[TPW], lo[TPW];
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) hi[i] = lo[i] = v4f{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const unsigned* src = xb + (((mi * 16 + n) * LDX + ks * 32 + q * 8) >> 1);
+                    const bf8 b1 = *reinterpret_cast<const bf8*>(src), b2 = *reinterpret_cast<const bf8*>(src + PLANE),
+                              b3 = *reinterpret_cast<const bf8*>(src + 2 * PLANE);
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) {
+                        if (col[i] < 0) continue;
+                        lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][2], b1, lo[i], 0, 0, 0);
+                        hi[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][0], b1, hi[i], 0, 0, 0);
+                        lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][1], b2, lo[i], 0, 0, 0);
+                        lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][0], b3, lo[i], 0, 0, 0);
+                        lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][1], b1, lo[i], 0, 0, 0);
+                        lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][0], b2, lo[i], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    if (col[i] < 0) continue;
+                    v4f acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = (hi[i][r] + lo[i][r]) + bv[i][r];
+                    if (col[i] + 3 < N) {
+                        *reinterpret_cast<v4f*>(&obuf[(mi * 16 + n) * NP + col[i]]) = acc;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col[i] + r < N) obuf[(mi * 16 + n) * NP + col[i] + r] = acc[r];
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every wave is done with the x pieces of this tile; obuf is complete
+        // park the prefetched tile BEFORE issuing this tile's stores (vmcnt retires in order: the wait for the prefetch
+        // would otherwise also wait for the stores)
+        if (nxt < NS) park();
+        const int rows = (M - m0 < 64) ? M - m0 : 64;
+        for (int idx = tid; idx < rows * n4; idx += 512) {
+            const int r = idx / n4, c4 = idx - r * n4;
+            *reinterpret_cast<v4f*>(z + (size_t)(m0 + r) * ldz + c4 * 4) = *reinterpret_cast<const v4f*>(&obuf[r * NP + c4 * 4]);
+        }
+        __syncthreads();
+    }
+}
+
 // =====================================================================================================
 // feature prologue
 // =====================================================================================================
@@ -1229,6 +1398,8 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
     if (const char* e = getenv("SFSN_SCAN_RPW")) rpw = atoi(e);
 #endif
     p.rpw = rpw;
+    p.prio = 0;
+    if (const char* e = getenv("SFSN_SCAN_PRIO")) p.prio = atoi(e);
     int tiles = 0;
     // the set of outputs must be the same for every segment of a launch (it selects the kernel variant);
     // the int8 spikes are always produced (every consumer of a scan in this library reads them)
@@ -1338,6 +1509,26 @@ extern "C" int sfsn_input_proj_f32(const float* x, const float* w, const float* 
     int grid = (MT + MW - 1) / MW;
     if (grid > 2048) grid = 2048;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const int KSB = K <= 64 ? 2 : (K <= 96 ? 3 : (K <= 160 ? 5 : 6));
+    const size_t blds = ((size_t)3 * 64 * (KSB * 32 + 8) * 2) + (size_t)64 * (N + 4) * sizeof(float);
+    static const bool no_bf3 = getenv("SFSN_INPROJ_F32") != nullptr;  // diagnostic: force the fp32-MFMA kernels
+    if (!no_bf3 && (K % 2 == 0) && K <= 192 && (N % 4 == 0) && (ldz % 4 == 0) && M >= 64 && TPW * KSB <= 12 && blds <= 150 * 1024 &&
+        (reinterpret_cast<uintptr_t>(x) & 7) == 0) {
+        int fgrid = (M + 63) / 64;
+        if (fgrid > 512) fgrid = 512;
+#define IPB_CASE(TPW_, KS_)                                                                                               \
+    if (TPW == TPW_ && KSB == KS_) {                                                                                      \
+        auto kern = input_proj_bf3_kernel<TPW_, KS_>;                                                                     \
+        if (blds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) \
+            return SFSN_EHIP;                                                                                             \
+        hipLaunchKernelGGL(kern, dim3(fgrid), dim3(512), blds, st, x, w, bias, z, M, K, N, ldz, NT, NWN);                 \
+        return hip_ok(hipGetLastError());                                                                                 \
+    }
+        IPB_CASE(1, 2) IPB_CASE(1, 3) IPB_CASE(1, 5) IPB_CASE(1, 6) IPB_CASE(2, 2) IPB_CASE(2, 3) IPB_CASE(2, 5)
+        IPB_CASE(3, 2) IPB_CASE(3, 3)
+#undef IPB_CASE
+    }
     const int KCB = KC <= 3 ? 3 : (KC <= 6 ? 6 : (KC <= 10 ? 10 : 12));
     const size_t flds = ((size_t)2 * 64 * (KCB * 16 + 4) + (size_t)64 * (N + 4)) * sizeof(float);
     if ((N % 4 == 0) && (ldz % 4 == 0) && M >= 64 && flds <= 150 * 1024) {
