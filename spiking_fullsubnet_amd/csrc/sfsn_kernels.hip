@@ -1310,6 +1310,106 @@ __global__ __launch_bounds__(256) void deepfilter_kernel(const float* __restrict
         }
 }
 
+// ---- pass-structured variant (every P a multiple of 4) --------------------------------------------------------------
+// A pass = a run of consecutive units of one group whose coefficient rows are contiguous in memory ([t][b*N + k][P]:
+// units k0..k0+U-1 of one (t, b) are U*P consecutive floats).  Per pass: the [32][U*P] coefficient tile is loaded with
+// 16-byte loads (a wave per row, eight rows in flight per wave), the noisy-spectrum tile [U*fc][32 + df - 1] once (the df
+// taps of an output then come from LDS instead of df global loads), one barrier pair, and all 256 threads have work
+// (U*fc bins x 32 frames).  baseline_m: 7 passes instead of 13 unit rounds, no runtime integer division per element.
+#define DF_MAX_PASSES 48
+struct DfPassParams {
+    DfParams base;
+    unsigned char pg[DF_MAX_PASSES], pk0[DF_MAX_PASSES], pnu[DF_MAX_PASSES];
+    int npass, ctile_floats;  // floats of LDS reserved for the coefficient tile (the X tile follows)
+};
+
+__global__ __launch_bounds__(256) void deepfilter_pass_kernel(const float* __restrict__ stft, const DfPassParams pp,
+                                                               float* __restrict__ enh, float* __restrict__ mag) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DfParams& p = pp.base;
+    const int B = p.B, F = p.F, T = p.T, S = p.S;
+    const int b = blockIdx.y, t0 = p.t0 + blockIdx.x * 32;
+    const int tid = threadIdx.x, tt = tid & 31, fs = tid >> 5, t = t0 + tt;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int tend = p.t1;
+    float* ct = smem;
+    float2* xt = reinterpret_cast<float2*>(smem + pp.ctile_floats);
+
+    for (int ps = 0; ps < pp.npass; ++ps) {
+        const DfGroupDev g = p.g[pp.pg[ps]];
+        const int k0 = pp.pk0[ps], U = pp.pnu[ps];
+        const int P = 2 * g.fc * g.df * S, UP = U * P, LD = UP + 1, Q = UP >> 2;
+        const int nb = U * g.fc, XW = 32 + g.df - 1;
+        __syncthreads();
+        // coefficient tile: row r = frame t0 + r, UP contiguous floats
+        for (int c4 = lane; c4 < Q; c4 += 64) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = wave + 4 * i, tr = t0 + r;
+                v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (tr < tend) v = *reinterpret_cast<const v4f*>(g.proj + ((size_t)tr * B * g.N + (size_t)b * g.N + k0) * P + 4 * c4);
+                float* d = ct + r * LD + 4 * c4;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            }
+        }
+        // noisy-spectrum tile (only when there is more than one tap): bins of the pass x frames [t0-(df-1), t0+32)
+        if (g.df > 1) {
+            const int fbase = g.lo + k0 * g.fc, tb = t0 - (g.df - 1);
+            for (int j = fs; j < nb; j += 8) {
+                const float* xrow = stft + ((size_t)b * F + fbase + j) * T * 2;
+                for (int c = tt; c < XW; c += 32) {
+                    const int ts = tb + c;
+                    float2 xv = make_float2(0.0f, 0.0f);
+                    if (ts >= 0 && ts < T) xv = *reinterpret_cast<const float2*>(xrow + 2 * (size_t)ts);
+                    xt[j * XW + c] = xv;
+                }
+            }
+        }
+        __syncthreads();
+        if (t < tend) {
+            const float* pr = ct + tt * LD;
+            int u = 0, fci = fs;
+            while (fci >= g.fc) { fci -= g.fc; ++u; }
+            for (int j = fs; j < nb; j += 8) {
+                const int f = g.lo + (k0 + u) * g.fc + fci;
+                const float* pu = pr + u * P;
+                for (int s_ = 0; s_ < S; ++s_) {
+                    float yr = 0.0f, yi = 0.0f;
+                    if (g.df > 1) {
+                        const float2* xr_ = xt + j * XW + tt;
+                        for (int d = 0; d < g.df; ++d) {
+                            const float2 xv = xr_[d];
+                            const float cr = pu[((0 * g.fc + fci) * g.df + d) * S + s_];
+                            const float ci = pu[((1 * g.fc + fci) * g.df + d) * S + s_];
+                            yr += xv.x * cr - xv.y * ci;
+                            yi += xv.x * ci + xv.y * cr;
+                        }
+                    } else {
+                        const float2 xv = *reinterpret_cast<const float2*>(stft + (((size_t)b * F + f) * T + t) * 2);
+                        const float cr = pu[(0 * g.fc + fci) * S + s_], ci = pu[(1 * g.fc + fci) * S + s_];
+                        yr += xv.x * cr - xv.y * ci;
+                        yi += xv.x * ci + xv.y * cr;
+                    }
+                    const size_t o = (((size_t)b * S + s_) * F + f) * T + t;
+                    *reinterpret_cast<float2*>(enh + 2 * o) = make_float2(yr, yi);
+                    if (mag) mag[o] = fast_abs2(yr, yi);
+                }
+                fci += 8;
+                while (fci >= g.fc) { fci -= g.fc; ++u; }
+            }
+        }
+    }
+    if (t < tend)
+        for (int f = p.fcov + fs; f < F; f += 8) {
+            const float2 xv = *reinterpret_cast<const float2*>(stft + (((size_t)b * F + f) * T + t) * 2);
+            for (int s_ = 0; s_ < S; ++s_) {
+                const size_t o = (((size_t)b * S + s_) * F + f) * T + t;
+                *reinterpret_cast<float2*>(enh + 2 * o) = xv;
+                if (mag) mag[o] = fast_abs2(xv.x, xv.y);
+            }
+        }
+}
+
 // =====================================================================================================
 // host side: argument checks, dispatch on compile-time shapes, launches
 // =====================================================================================================
@@ -1652,9 +1752,43 @@ extern "C" int sfsn_deepfilter(const float* stft_ri, int B, int F, int T, int S,
     }
     if (lo > F) return SFSN_EINVAL;
     p.fcov = lo;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {   // pass-structured kernel: every P a multiple of 4 (16-byte coefficient loads), tiles within 48 KB of LDS
+        static const bool no_pass = getenv("SFSN_DF_GENERIC") != nullptr;  // diagnostic: force the unit-by-unit kernel
+        DfPassParams pp;
+        pp.base = p;
+        pp.npass = 0;
+        bool ok = !no_pass;
+        int max_up = 0, max_x = 0;
+        for (int i = 0; i < n_groups && ok; ++i) {
+            const sfsn_df_group& g = groups[i];
+            const int P = 2 * g.fc * g.df * S;
+            if (P % 4 != 0 || P > 2048 || (reinterpret_cast<uintptr_t>(g.proj) & 15) != 0) { ok = false; break; }
+            int umax = 192 / P;  // <= 24.6 KB of coefficients per pass
+            if (umax < 1) umax = 1;
+            if (umax > 255) umax = 255;
+            const int np = (g.n_units + umax - 1) / umax, U = (g.n_units + np - 1) / np;
+            for (int k0 = 0; k0 < g.n_units; k0 += U) {
+                if (pp.npass >= DF_MAX_PASSES || k0 > 255 || i > 255) { ok = false; break; }
+                const int nu = (g.n_units - k0 < U) ? g.n_units - k0 : U;
+                pp.pg[pp.npass] = (unsigned char)i; pp.pk0[pp.npass] = (unsigned char)k0; pp.pnu[pp.npass] = (unsigned char)nu;
+                ++pp.npass;
+                if (nu * P > max_up) max_up = nu * P;
+                const int xw = g.df > 1 ? nu * g.fc * (32 + g.df - 1) * 2 : 0;
+                if (xw > max_x) max_x = xw;
+            }
+        }
+        if (ok) {
+            pp.ctile_floats = (32 * (max_up + 1) + 3) & ~3;
+            const size_t plds = ((size_t)pp.ctile_floats + max_x) * sizeof(float);
+            if (plds <= 48 * 1024) {
+                hipLaunchKernelGGL(deepfilter_pass_kernel, dim3((nt + 31) / 32, B), dim3(256), plds, st, stft_ri, pp, enh_ri, enh_mag);
+                return hip_ok(hipGetLastError());
+            }
+        }
+    }
     const size_t lds = (size_t)32 * (maxP + 1) * sizeof(float);
     if (lds > 150 * 1024) return SFSN_EUNSUPPORTED;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(deepfilter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
