@@ -1037,6 +1037,7 @@ struct FeatParams {
     FeatGroupDev g[SFSN_MAX_GROUPS];
     int ng, B, F, T, FB;
     int t0, t1;  // frames [t0, t1) are produced
+    int f_lo, f_cnt;  // magnitude bins [f_lo, f_lo + f_cnt) are the ones some group reads
     float fdrc;
 };
 
@@ -1069,25 +1070,94 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// grid (ceil(T/32), B), 256 threads.  LDS: mag tile [nf][33] + full-band tile [32][FB].
+// grid (ceil(T/32), B), 256 threads.  LDS: magnitude tile [f_cnt][33] + full-band tile [32][FB] + a gather table of the
+// current unit chunk + one staging segment per wave.
+//
+// A wave owns a frame.  For every unit of the chunk it gathers the row from the tiles (per-lane LDS offsets from the
+// table, built once per chunk by the whole workgroup), normalises it with two DPP wave reductions and parks it in its
+// staging segment; the units of one (frame, clip) are contiguous in x, so the segment then leaves as one contiguous run
+// (1.1-1.3 KB at baseline_m) with every lane storing -- rows of 38/94/158 floats written one by one were partial-line
+// writes 78 KB apart.  NU = ceil(I/64) feature slots per lane is a template parameter: no work for absent slots.
+#define FEAT_CHUNK 512  // floats per staging segment / gather-table entries: units per chunk = FEAT_CHUNK / I
+
+template <int NU>
+__device__ __forceinline__ void feat_chunk_rows(const FeatGroupDev& g, const float* magT, const float* fbT, const int* offs,
+                                                float* stage, int k0, int nk, int b, int B, int FB, int t0, int tend, int lane, int wave) {
+    float lw[NU], lb[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int j = lane + 64 * u;
+        const bool in = j < g.I && g.norm == SFSN_NORM_LAYERNORM;
+        lw[u] = in ? g.ln_w[j] : 0.0f;
+        lb[u] = in ? g.ln_b[j] : 0.0f;
+    }
+    const float inv_I = 1.0f / (float)g.I;
+    const float lap_den = g.norm == SFSN_NORM_LAPLACE ? g.mu[b] + 2.220446049250313e-16f : 1.0f;
+    const int seg = nk * g.I;
+    for (int tt = wave; tt < FEAT_TT; tt += 4) {
+        const int t = t0 + tt;
+        if (t >= tend) break;  // wave-uniform
+        for (int k = 0; k < nk; ++k) {
+            float v[NU];
+            bool have[NU];
+            float sum = 0.0f;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int j = lane + 64 * u;
+                have[u] = j < g.I;
+                const int o = have[u] ? offs[k * g.I + j] : 0;
+                v[u] = !have[u] ? 0.0f : (o < 0 ? fbT[tt * FB + (-1 - o)] : magT[o + tt]);
+                sum += v[u];
+            }
+            float y[NU];
+            if (g.norm == SFSN_NORM_LAYERNORM) {
+                const float mean = wave_sum(sum) * inv_I;
+                float ss = 0.0f;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const float d = v[u] - mean;
+                    if (have[u]) ss += d * d;
+                }
+                const float rstd = __builtin_amdgcn_rsqf(wave_sum(ss) * inv_I + g.eps);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) y[u] = ((v[u] - mean) * rstd) * lw[u] + lb[u];
+            } else if (g.norm == SFSN_NORM_LAPLACE) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) y[u] = v[u] / lap_den;
+            } else {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) y[u] = v[u];
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                if (have[u]) stage[k * g.I + lane + 64 * u] = y[u];
+        }
+        // LDS operations of one wave execute in order: the segment is complete when these reads are served
+        float* out = g.x + ((size_t)t * B * g.N + (size_t)b * g.N + k0) * g.I;
+        for (int i = lane; i < seg; i += 64) out[i] = stage[i];
+    }
+}
+
 __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ stft, const float* __restrict__ fb,
                                                         const FeatParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nf = p.F - 1, T = p.T, B = p.B, FB = p.FB;
-    float* magT = smem;                        // [nf][33]
-    float* fbT = smem + (size_t)nf * 33;       // [32][FB]
+    float* magT = smem;                                         // [f_cnt][33]
+    float* fbT = smem + (size_t)p.f_cnt * 33;                   // [32][FB]
+    int* offs = reinterpret_cast<int*>(fbT + FEAT_TT * (FB > 0 ? FB : 1));  // [FEAT_CHUNK]
     const int b = blockIdx.y, t0 = p.t0 + blockIdx.x * FEAT_TT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* stage = reinterpret_cast<float*>(offs + FEAT_CHUNK) + wave * FEAT_CHUNK;
     const int tend = p.t1;
 
-    for (int idx = tid; idx < nf * FEAT_TT; idx += 256) {
-        const int f = idx >> 5, tt = idx & 31, t = t0 + tt;
+    for (int idx = tid; idx < p.f_cnt * FEAT_TT; idx += 256) {
+        const int fr = idx >> 5, tt = idx & 31, t = t0 + tt;
         float v = 0.0f;
         if (t < tend) {
-            const float2 c = *reinterpret_cast<const float2*>(stft + (((size_t)b * p.F + f) * T + t) * 2);
+            const float2 c = *reinterpret_cast<const float2*>(stft + (((size_t)b * p.F + p.f_lo + fr) * T + t) * 2);
             v = compress_mag(c.x, c.y, p.fdrc);
         }
-        magT[f * 33 + tt] = v;
+        magT[fr * 33 + tt] = v;
     }
     if (fb) {
         for (int idx = tid; idx < FEAT_TT * FB; idx += 256) {
@@ -1095,69 +1165,24 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
             fbT[idx] = t < tend ? fb[((size_t)t * B + b) * FB + f] : 0.0f;
         }
     }
-    __syncthreads();
 
     for (int gi = 0; gi < p.ng; ++gi) {
         const FeatGroupDev g = p.g[gi];
-        // per-lane constants of this group: LayerNorm affine terms of my (up to 4) feature slots
-        float lw[4], lb[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = lane + 64 * u;
-            const bool in = j < g.I && g.norm == SFSN_NORM_LAYERNORM;
-            lw[u] = in ? g.ln_w[j] : 0.0f;
-            lb[u] = in ? g.ln_b[j] : 0.0f;
-        }
-        const float inv_I = 1.0f / (float)g.I;
-        const float lap_den = g.norm == SFSN_NORM_LAPLACE ? g.mu[b] + 2.220446049250313e-16f : 1.0f;
-        for (int k = 0; k < g.N; ++k) {
-            // LDS offsets of my feature slots for unit k (independent of the frame): magnitude rows or full-band columns
-            int off[4];
-            bool is_fb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = lane + 64 * u;
-                is_fb[u] = j >= g.I1;
-                if (j < g.I1)
-                    off[u] = reflect_bin(g.lo + k * g.ctr - g.nbr + j, nf) * 33;
-                else if (j < g.I)
-                    off[u] = reflect_bin(g.lo + k * g.ctr_fb - g.nbr_fb + (j - g.I1), nf) % FB;
-                else
-                    off[u] = -1;
+        const int kch = FEAT_CHUNK / g.I;  // units per chunk (>= 1: I <= 256)
+        for (int k0 = 0; k0 < g.N; k0 += kch) {
+            const int nk = (g.N - k0 < kch) ? g.N - k0 : kch;
+            __syncthreads();  // tiles loaded / previous chunk's table no longer read
+            // gather table of the chunk: entry >= 0 = offset of the bin's row in magT, < 0 = -1 - full-band column
+            for (int idx = tid; idx < nk * g.I; idx += 256) {
+                const int k = idx / g.I, j = idx - k * g.I, ku = k0 + k;
+                offs[idx] = j < g.I1 ? (reflect_bin(g.lo + ku * g.ctr - g.nbr + j, nf) - p.f_lo) * 33
+                                     : -1 - reflect_bin(g.lo + ku * g.ctr_fb - g.nbr_fb + (j - g.I1), nf) % FB;
             }
-            for (int tt = wave; tt < FEAT_TT; tt += 4) {
-                const int t = t0 + tt;
-                if (t >= tend) break;  // wave-uniform
-                float v[4];
-                float sum = 0.0f;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    v[u] = off[u] < 0 ? 0.0f : (is_fb[u] ? fbT[tt * FB + off[u]] : magT[off[u] + tt]);
-                    sum += v[u];
-                }
-                float* out = g.x + ((size_t)t * B * g.N + (size_t)b * g.N + k) * g.I;
-                if (g.norm == SFSN_NORM_LAYERNORM) {
-                    const float mean = wave_sum(sum) * inv_I;
-                    float ss = 0.0f;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float d = v[u] - mean;
-                        if (off[u] >= 0) ss += d * d;
-                    }
-                    const float rstd = __builtin_amdgcn_rsqf(wave_sum(ss) * inv_I + g.eps);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (off[u] >= 0) out[lane + 64 * u] = ((v[u] - mean) * rstd) * lw[u] + lb[u];
-                } else if (g.norm == SFSN_NORM_LAPLACE) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (off[u] >= 0) out[lane + 64 * u] = v[u] / lap_den;
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (off[u] >= 0) out[lane + 64 * u] = v[u];
-                }
-            }
+            __syncthreads();
+            if (g.I <= 64) feat_chunk_rows<1>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave);
+            else if (g.I <= 128) feat_chunk_rows<2>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave);
+            else if (g.I <= 192) feat_chunk_rows<3>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave);
+            else feat_chunk_rows<4>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave);
         }
     }
 }
@@ -1679,6 +1704,20 @@ static int fill_feat(FeatParams& p, const sfsn_feature_group* groups, int n_grou
         d.x = g.x; d.ln_w = g.ln_w; d.ln_b = g.ln_b; d.mu = g.mu; d.lo = g.lo; d.N = g.n_units; d.ctr = g.ctr; d.nbr = g.nbr;
         d.ctr_fb = g.ctr_fb; d.nbr_fb = g.nbr_fb; d.I1 = I1; d.I = I1 + I2; d.norm = g.norm; d.eps = g.ln_eps;
     }
+    // magnitude bins some group reads (reflected at both ends exactly as the kernel does): only those are loaded
+    int fmin = nf, fmax = -1;
+    for (int i = 0; i < n_groups; ++i) {
+        const sfsn_feature_group& g = groups[i];
+        const int ends[2] = {g.lo - g.nbr, g.lo + g.n_units * g.ctr - 1 + g.nbr};
+        for (int e = 0; e < 2; ++e) {
+            const int f = ends[e], r = f < 0 ? -f : (f > nf - 1 ? 2 * (nf - 1) - f : f);
+            const int c = f < 0 ? 0 : (f > nf - 1 ? nf - 1 : f);  // the unreflected part of the range reaches the edge
+            const int lo_ = r < c ? r : c, hi_ = r > c ? r : c;
+            if (lo_ < fmin) fmin = lo_;
+            if (hi_ > fmax) fmax = hi_;
+        }
+    }
+    p.f_lo = fmin; p.f_cnt = fmax - fmin + 1;
     return SFSN_OK;
 }
 
@@ -1690,7 +1729,7 @@ extern "C" int sfsn_features(const float* stft_ri, const float* fb_tbf, int B, i
     if (rc != SFSN_OK) return rc;
     for (int i = 0; i < n_groups; ++i)
         if (groups[i].ctr_fb > 0 && !fb_tbf) return SFSN_EINVAL;
-    const size_t lds = ((size_t)(F - 1) * 33 + (size_t)FEAT_TT * (FB > 0 ? FB : 1)) * sizeof(float);
+    const size_t lds = ((size_t)p.f_cnt * 33 + (size_t)FEAT_TT * (FB > 0 ? FB : 1) + 5 * FEAT_CHUNK) * sizeof(float);
     if (lds > 150 * 1024) return SFSN_EUNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (lds > 64 * 1024) {
