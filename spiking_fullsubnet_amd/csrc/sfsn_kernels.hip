@@ -1150,19 +1150,46 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
     float* stage = reinterpret_cast<float*>(offs + FEAT_CHUNK) + wave * FEAT_CHUNK;
     const int tend = p.t1;
 
-    for (int idx = tid; idx < p.f_cnt * FEAT_TT; idx += 256) {
-        const int fr = idx >> 5, tt = idx & 31, t = t0 + tt;
-        float v = 0.0f;
-        if (t < tend) {
-            const float2 c = *reinterpret_cast<const float2*>(stft + (((size_t)b * p.F + p.f_lo + fr) * T + t) * 2);
-            v = compress_mag(c.x, c.y, p.fdrc);
+    // Tile loads in batches of eight independent requests per thread (a load -> wait -> store loop costs one HBM round
+    // trip per iteration: 32 of them for 256 bins).  Frames past the end are clamped to a valid address and zeroed.
+    {
+        const int tt = tid & 31, t = t0 + tt;
+        const bool live = t < tend;
+        const int tc = live ? t : tend - 1;
+        const float* src = stft + (((size_t)b * p.F + p.f_lo) * T + tc) * 2;
+        for (int f0 = tid >> 5; f0 < p.f_cnt; f0 += 64) {  // this thread's bins: f0, f0+8, ..., f0+56
+            float2 c[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int fr = f0 + 8 * i;
+                if (fr > p.f_cnt - 1) fr = p.f_cnt - 1;
+                c[i] = *reinterpret_cast<const float2*>(src + (size_t)fr * T * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int fr = f0 + 8 * i;
+                if (fr < p.f_cnt) magT[fr * 33 + tt] = live ? compress_mag(c[i].x, c[i].y, p.fdrc) : 0.0f;
+            }
         }
-        magT[fr * 33 + tt] = v;
     }
     if (fb) {
-        for (int idx = tid; idx < FEAT_TT * FB; idx += 256) {
-            const int tt = idx / FB, f = idx - tt * FB, t = t0 + tt;
-            fbT[idx] = t < tend ? fb[((size_t)t * B + b) * FB + f] : 0.0f;
+        const int nfb = FEAT_TT * FB;
+        for (int i0 = tid; i0 < nfb; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int idx = i0 + 256 * i;
+                if (idx > nfb - 1) idx = nfb - 1;
+                const int tt = idx / FB, f = idx - tt * FB;
+                int t = t0 + tt;
+                if (t > tend - 1) t = tend - 1;
+                v[i] = fb[((size_t)t * B + b) * FB + f];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = i0 + 256 * i;
+                if (idx < nfb) fbT[idx] = (t0 + idx / FB < tend) ? v[i] : 0.0f;
+            }
         }
     }
 
