@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--time-all", action="store_true", help="HIP-event time every launch group, not only the dominant kernel")
     ap.add_argument("--seq-chunk", type=int, default=0, help="frames per chunk of the single-stream schedule")
     ap.add_argument("--rpw", type=str, default="", help="rows per scan workgroup 'fb,sb' (0 = auto)")
-    ap.add_argument("--inflight", type=int, default=6, help="forwards in flight on separate HIP streams (batch-level pipelining)")
+    ap.add_argument("--inflight", type=int, default=8, help="forwards in flight on separate HIP streams (batch-level pipelining)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per pipeline chunk (default: engine default)")
     ap.add_argument("--streaming", action="store_true", help="BASELINE configs[4]: frame-by-frame session, per-call latency (own JSON line)")
     ap.add_argument("--hop", type=int, default=1, help="frames per streaming call")
@@ -102,7 +102,7 @@ def main():
     if args.seq_chunk:
         eng.seq_chunk = args.seq_chunk
     want_layers = not args.no_layer_outputs
-    gathered = torch.empty((world * B, 1, 257, T), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = {}  # per HIP stream (lane): the all-gathered magnitudes of that lane's batch
 
     info = {}
 
@@ -110,7 +110,10 @@ def main():
         res = eng.forward_stft(stft, want_layers=want_layers, pipeline=False if args.sequential else (True if args.pipeline else None))
         info.update(pipelined=res["pipelined"], n_chunks=res["n_chunks"])
         if world > 1:
-            dist.all_gather_into_tensor(gathered, res["enh_mag"])
+            key = torch.cuda.current_stream(dev).cuda_stream
+            if key not in gathered:
+                gathered[key] = torch.empty((world * B, 1, 257, T), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(gathered[key], res["enh_mag"])
         return res
 
     def timed_region(step_fn, steps, warmup):
