@@ -10,7 +10,7 @@ All compute between ``stft`` and ``istft`` runs in hand-written gfx950 kernels b
 """
 from . import _lib  # noqa: F401
 from .engine import Engine, PathSpec, SpikeSummary  # noqa: F401
-from . import metric  # noqa: F401
+from . import checkpoint, metric  # noqa: F401
 from .model_low_freq import Separator  # noqa: F401
 from .modeling_spiking_fullsubnet import SpikingFullSubNet  # noqa: F401
 from .streaming import StreamingSession  # noqa: F401

@@ -198,10 +198,12 @@ def main():
     torch.set_num_threads(4)
     meta = dict(torch_version=torch.__version__, numpy_version=np.__version__)
 
-    out = {}
-    gsn_cases(neuron, out)
-    np.savez_compressed(os.path.join(HERE, "gsn_cells.npz"), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
-    print("gsn_cells.npz", len(out))
+    only = set(sys.argv[1:])  # e.g. `make_golden.py frozen_m_zoo` regenerates that fixture alone
+    if not only:
+        out = {}
+        gsn_cases(neuron, out)
+        np.savez_compressed(os.path.join(HERE, "gsn_cells.npz"), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
+        print("gsn_cells.npz", len(out))
 
     def live_case(fname, kw, seed, B, T, store_mem, wave_seed=0):
         sd = rw.live_state_dict(kw, seed)
@@ -221,10 +223,11 @@ def main():
         np.savez_compressed(os.path.join(HERE, fname), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
         print(fname, {k: v.shape for k, v in out.items() if k in ("stft", "enh_stft")})
 
-    live_case("live_tiny.npz", rw.LIVE_TINY, 11, 2, 24, True)
-    live_case("live_tiny_2spk.npz", rw.LIVE_TINY_2SPK, 12, 2, 20, True)
-    live_case("live_tiny_unshared.npz", rw.LIVE_TINY_UNSHARED, 13, 1, 20, True)
-    live_case("live_m.npz", rw.LIVE_M, 21, 1, 40, False)
+    if not only:
+        live_case("live_tiny.npz", rw.LIVE_TINY, 11, 2, 24, True)
+        live_case("live_tiny_2spk.npz", rw.LIVE_TINY_2SPK, 12, 2, 20, True)
+        live_case("live_tiny_unshared.npz", rw.LIVE_TINY_UNSHARED, 13, 1, 20, True)
+        live_case("live_m.npz", rw.LIVE_M, 21, 1, 40, False)
 
     def frozen_case(fname, kw, sd, B, T, store_mem, store_weights):
         model = frozen.Separator(**kw).eval()
@@ -244,10 +247,16 @@ def main():
         np.savez_compressed(os.path.join(HERE, fname), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
         print(fname)
 
-    frozen_case("frozen_tiny.npz", rw.FROZEN_TINY, rw.frozen_state_dict(rw.FROZEN_TINY, 31), 2, 24, True, False)
-    zoo = torch.load(f"{REF}/model_zoo/intel_ndns/spike_fsb/baseline_s/checkpoints/best/pytorch_model.bin", map_location="cpu")
-    zoo = {k: v.numpy() for k, v in zoo.items()}
-    frozen_case("frozen_s_zoo.npz", rw.FROZEN_S, zoo, 1, 126, False, True)
+    def zoo_weights(name):
+        zoo = torch.load(f"{REF}/model_zoo/intel_ndns/spike_fsb/{name}/checkpoints/best/pytorch_model.bin", map_location="cpu")
+        return {k: v.numpy() for k, v in zoo.items()}
+
+    if not only:
+        frozen_case("frozen_tiny.npz", rw.FROZEN_TINY, rw.frozen_state_dict(rw.FROZEN_TINY, 31), 2, 24, True, False)
+        frozen_case("frozen_s_zoo.npz", rw.FROZEN_S, zoo_weights("baseline_s"), 1, 126, False, True)
+    if not only or "frozen_m_zoo" in only:
+        # the trained baseline_m generator (the sizes bench.py runs: full-band 320, sub-band 224, deep-filter orders 5/3/1)
+        frozen_case("frozen_m_zoo.npz", rw.FROZEN_M, zoo_weights("baseline_m"), 1, 100, False, True)
 
 
 if __name__ == "__main__":

@@ -88,6 +88,8 @@ FROZEN_S = dict(  # model_zoo/intel_ndns/spike_fsb/baseline_s/baseline_s.toml [m
     norm_type="offline_laplace_norm", shared_weights=True, bn=True,
 )
 
+FROZEN_M = dict(FROZEN_S, fb_hidden_size=320, sb_hidden_size=224, sb_df_orders=[5, 3, 1])  # .../baseline_m/baseline_m.toml [model_g.args]
+
 FROZEN_TINY = dict(FROZEN_S, fb_hidden_size=48, sb_hidden_size=32, sb_df_orders=[2, 1, 3])
 
 

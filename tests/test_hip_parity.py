@@ -203,6 +203,7 @@ MODEL_CASES = [
     ("live_tiny.npz", "live", rw.LIVE_TINY, 11), ("live_tiny_2spk.npz", "live", rw.LIVE_TINY_2SPK, 12),
     ("live_tiny_unshared.npz", "live", rw.LIVE_TINY_UNSHARED, 13), ("live_m.npz", "live", rw.LIVE_M, 21),
     ("frozen_tiny.npz", "frozen", rw.FROZEN_TINY, 31), ("frozen_s_zoo.npz", "frozen", rw.FROZEN_S, None),
+    ("frozen_m_zoo.npz", "frozen", rw.FROZEN_M, None),
 ]
 
 

@@ -129,7 +129,7 @@ def test_reference_init_is_reproduced():
 
 
 @pytest.mark.parametrize("fname,shared", [("live_tiny.npz", True), ("live_m.npz", True), ("live_tiny_unshared.npz", False),
-                                          ("frozen_s_zoo.npz", True)])
+                                          ("frozen_s_zoo.npz", True), ("frozen_m_zoo.npz", True)])
 def test_metric_dropins_match_reference_values(golden_dir, fname, shared):
     """metric.compute_synops / compute_neuronops on the reference's recorded layer outputs == the values the reference's own
     audiozen.metric functions returned for them (recorded by tests/golden/make_golden.py), both from the fp32 spike tensors
@@ -160,6 +160,39 @@ def test_metric_dropins_match_reference_values(golden_dir, fname, shared):
         fb, sb = lists(summary)
         assert metric.compute_synops(fb, sb, shared_weights=shared) == pytest.approx(float(gold["synops"]), rel=1e-6)
         assert metric.compute_neuronops(fb, sb) == float(gold["neuronops"])
+
+
+def test_checkpoint_bridge_reads_the_reference_formats(golden_dir, tmp_path):
+    """accelerate-style checkpoint directories (pytorch_model.bin / model.safetensors, audiozen/trainer.py:225,238-242) load
+    strict into the drop-in modules; the trained zoo weights survive the round trip bit for bit; a frozen-named checkpoint
+    loads into a shape-compatible live module through the proj <-> fc_output_layer rename."""
+    import spiking_fullsubnet_amd as pkg
+    from safetensors.torch import save_file
+    from spiking_fullsubnet_amd import checkpoint
+    g = np.load(os.path.join(golden_dir, "frozen_m_zoo.npz"))
+    zoo = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    assert len(zoo) == 72 and sum(v.numel() for k, v in zoo.items() if "num_batches" not in k and "running" not in k) == 953704
+    d_bin, d_st = tmp_path / "best", tmp_path / "safe"
+    d_bin.mkdir(), d_st.mkdir()
+    torch.save(zoo, d_bin / "pytorch_model.bin")
+    torch.save({"junk": torch.zeros(1)}, d_bin / "pytorch_model_1.bin")  # the discriminator file must not be picked
+    save_file({("module." + k): v.contiguous() for k, v in zoo.items()}, str(d_st / "model.safetensors"))
+    for d in (d_bin, d_st, d_bin / "pytorch_model.bin"):
+        m = pkg.Separator(**rw.FROZEN_M)
+        missing, unexpected = checkpoint.load_checkpoint(m, str(d))
+        assert missing == [] and unexpected == []
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, zoo[k]), k
+    live_kw = dict(rw.LIVE_M, use_pre_layer_norm_fb=False, use_pre_layer_norm_sb=False)
+    live = pkg.SpikingFullSubNet(**live_kw)
+    missing, unexpected = checkpoint.load_checkpoint(live, str(d_bin))
+    assert missing == [] and unexpected == []
+    assert torch.equal(live.state_dict()["fb_model.proj.weight"], zoo["fb_model.fc_output_layer.weight"])
+    with pytest.raises(FileNotFoundError):
+        checkpoint.load_checkpoint(live, str(tmp_path / "nope"))
+    (tmp_path / "empty").mkdir()
+    with pytest.raises(FileNotFoundError):
+        checkpoint.find_weights_file(str(tmp_path / "empty"))
 
 
 def test_shard_bounds_partition():
