@@ -277,6 +277,45 @@ def test_module_vs_oracle_seeded(front, kw, seed, B, T):
         assert np.isfinite(out["enh_mag"]).all()
 
 
+@pytest.mark.parametrize("fname,kw", [("frozen_m_zoo.npz", rw.FROZEN_M), ("frozen_s_zoo.npz", rw.FROZEN_S)])
+def test_thirty_second_clip_sits_on_the_fp32_noise_floor(fname, kw):
+    """The recipes validate on 30 s clips = 3751 frames in one pass (dataloader.py:73-99).  Over thousands of steps
+    the strict causal rule of the short tests cannot hold for ANY pair of fp32 evaluations: slowly integrating neurons
+    accumulate rounding noise (measured with the trained baseline_s weights: |fp32 oracle - fp64 oracle| membranes 4e-7 at
+    t=0, 4.5e-4 at t=1000, first spike flip at t=2235; HIP vs fp32 oracle 5e-7, 5.7e-5, first flip at t=2320), and the
+    frozen front-end's utterance-level Laplace mean then carries one late full-band flip to every sub-band frame.  The
+    statement that can be made, with the TRAINED zoo weights (the seeded random models overflow over such lengths, in the
+    reference too): measured against the fp64 oracle, the HIP path is no further away than the fp32 oracle is -- per layer
+    in spike agreement and at the output in relative L2."""
+    T = 3751
+    gold = load(fname)
+    sd = {k[3:]: v for k, v in gold.items() if k.startswith("sd/")}
+    spec = omodel.spec_from_frozen_kwargs(kw)
+    wave = torch.from_numpy(rw.synth_wave(1, T, 17, modulated=True))
+    stft = torch.stft(wave, 512, 128, 512, window=torch.hann_window(512), return_complex=True, pad_mode="constant").numpy()
+    assert stft.shape[-1] == T
+    o32 = omodel.forward_from_stft(spec, sd, stft, "f32")
+    o64 = omodel.forward_from_stft(spec, sd, stft, "f64")
+    out = hip_result(build_module("frozen", kw, sd), stft, want_membrane=False)
+    assert np.isfinite(out["enh_stft"]).all()
+
+    def layers(res):
+        return [np.asarray(a) > 0.5 for a in res["fb_all"][1:-1]] + [np.asarray(a) > 0.5 for l in res["sb_all"] for a in l[1:-1]]
+
+    def first_flip(a, b):
+        d = (a != b).reshape(a.shape[0], -1).any(1)
+        return int(np.argmax(d)) if d.any() else T
+
+    for mine, f32, f64 in zip(layers(out), layers(o32), layers(o64)):
+        assert (mine == f64).mean() >= (f32 == f64).mean() - 0.02
+    # the full-band chain (nothing upstream but the input): the first disagreement with fp64 comes no earlier than fp32's own / 2
+    assert first_flip(layers(out)[0], layers(o64)[0]) >= first_flip(layers(o32)[0], layers(o64)[0]) // 2
+    ref64 = np.asarray(o64["enh_stft"])
+    floor = np.linalg.norm((np.asarray(o32["enh_stft"]) - ref64).ravel()) / np.linalg.norm(ref64.ravel())
+    mine = np.linalg.norm((out["enh_stft"] - ref64).ravel()) / np.linalg.norm(ref64.ravel())
+    assert mine <= 1.15 * floor + 1e-4, (mine, floor)
+
+
 def test_full_size_properties():
     """BASELINE.json config 3 (live M, B=64, T=1000): properties that do not need the oracle at full size.
     (i) run-to-run bit stability; (ii) batch independence: clips 5..12 computed alone == inside the batch, bit for bit;
