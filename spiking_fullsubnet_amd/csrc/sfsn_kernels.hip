@@ -50,7 +50,6 @@ struct ScanParams {
     ScanSegDev seg[SFSN_MAX_SEGMENTS];
     int nseg, T, H, NT;  // NT = H / 16 output tiles per gate
     int rpw;             // rows per workgroup (16, 8 or 4): fewer rows per CU = less HBM traffic per CU per step
-    int prio;            // wave priority scheme (see gsn_scan_kernel)
 };
 
 __device__ __forceinline__ float recombine3(int a0, int a1, int a2) {
@@ -464,15 +463,6 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
     }
     __syncthreads();
 
-    {
-        int pr = 0;
-        if (p.prio == 1) pr = 3 - ((wave >> 2) & 3);
-        else if (p.prio == 2) pr = (wave >> 2) & 3;
-        else if (p.prio == 3) pr = 3 - (wave & 3);
-        if (pr == 1) __builtin_amdgcn_s_setprio(1);
-        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-    }
     const int n_hi = NT - NW * (TPW - 1);  // waves [0, n_hi) own TPW tiles, the others TPW-1
     if (wave < n_hi)
         scan_body<G, KS, NW, TPW, OUT, LP, TPW>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state, smem, T,
@@ -1550,8 +1540,6 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
     if (const char* e = getenv("SFSN_SCAN_RPW")) rpw = atoi(e);
 #endif
     p.rpw = rpw;
-    p.prio = 0;
-    if (const char* e = getenv("SFSN_SCAN_PRIO")) p.prio = atoi(e);
     int tiles = 0;
     // the set of outputs must be the same for every segment of a launch (it selects the kernel variant);
     // the int8 spikes are always produced (every consumer of a scan in this library reads them)
