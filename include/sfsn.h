@@ -199,6 +199,21 @@ typedef struct sfsn_count_tensor {
 
 int sfsn_spike_count(const sfsn_count_tensor* tensors /* host */, int n_tensors, void* stream);
 
+/* ----------------------------------------------------------------------------------------------------
+ * The two edges of the path -- replace audiozen/acoustics/audio_feature.py:236-347 as the models call them
+ * (MODEL:429,473; FROZEN:568-572,612-617): torch.stft(y, n_fft, hop, n_fft, window, center=True, pad_mode="constant",
+ * return_complex=True) and torch.istft(X, n_fft, hop, n_fft, window, length=length).  n_fft = 512 (every reference config;
+ * SFSN_EUNSUPPORTED otherwise), n_fft % hop == 0, 4 hops per window at most.  `window` is the analysis/synthesis window on
+ * the device (n_fft floats; the reference passes torch.hann_window(n_fft)).
+ *   stft : frame t = samples [t*hop - n_fft/2, t*hop + n_fft/2), zero outside [0, L);  T must be 1 + L / hop
+ *   istft: y[m] = sum_t w[n - t*hop] * irfft(X[:, t])[n - t*hop] / sum_t w[n - t*hop]^2,  n = m + n_fft/2,  m < length
+ *          (imaginary parts of the DC and Nyquist bins are ignored, as by a complex-to-real transform)
+ * ---------------------------------------------------------------------------------------------------- */
+int sfsn_stft(const float* wave /* [B][L] */, int B, int L, int n_fft, int hop, const float* window,
+              float* stft_ri /* [B][n_fft/2+1][T][2] */, int T, void* stream);
+int sfsn_istft(const float* stft_ri /* [B][n_fft/2+1][T][2] */, int B, int T, int n_fft, int hop, const float* window,
+               float* wave /* [B][length] */, int length, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

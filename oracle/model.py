@@ -132,3 +132,43 @@ def compute_synops(fb_all, sb_all, shared_weights=True) -> float:
 def compute_neuronops(fb_all, sb_all) -> float:
     """audiozen/metric.py:330-340."""
     return float(sum(o.shape[-1] for o in fb_all) + sum(o.shape[-1] for outs in sb_all for o in outs))
+
+
+# ---- the two edges of the path (audiozen/acoustics/audio_feature.py:236-347) ---------------------------------------
+def hann_window(n: int) -> np.ndarray:
+    """torch.hann_window(n) (periodic), float32 as the reference builds it (audio_feature.py:269,337)."""
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n, dtype=np.float64) / n)).astype(np.float32)
+
+
+def stft(wave, n_fft: int = 512, hop: int = 128) -> np.ndarray:
+    """audio_feature.py:269-279 = torch.stft(y, n_fft, hop, n_fft, hann, center=True, pad_mode="constant", return_complex=True):
+    float [B, L] -> complex64 [B, n_fft/2+1, 1 + L // hop].  Frames in float64, rounded once."""
+    wave = np.asarray(wave, np.float64)
+    B, L = wave.shape
+    T = 1 + L // hop
+    pad = np.zeros((B, L + n_fft), np.float64)
+    pad[:, n_fft // 2:n_fft // 2 + L] = wave
+    win = hann_window(n_fft).astype(np.float64)
+    idx = np.arange(T)[:, None] * hop + np.arange(n_fft)[None, :]
+    frames = pad[:, idx] * win  # [B, T, n_fft]
+    return np.fft.rfft(frames, axis=-1).transpose(0, 2, 1).astype(np.complex64)
+
+
+def istft(spec, n_fft: int = 512, hop: int = 128, length=None) -> np.ndarray:
+    """audio_feature.py:337-345 = torch.istft(X, n_fft, hop, n_fft, hann, length=length): inverse real transform per frame
+    (imaginary parts of the DC / Nyquist bins ignored), synthesis window, overlap-add, division by the overlap-added
+    squared window, n_fft/2 samples trimmed at the front, `length` samples kept."""
+    spec = np.asarray(spec, np.complex128)
+    B, F, T = spec.shape
+    win = hann_window(n_fft).astype(np.float64)
+    frames = np.fft.irfft(spec.transpose(0, 2, 1), n=n_fft, axis=-1) * win  # [B, T, n_fft]
+    total = (T - 1) * hop + n_fft
+    y = np.zeros((B, total), np.float64)
+    env = np.zeros(total, np.float64)
+    for t in range(T):
+        y[:, t * hop:t * hop + n_fft] += frames[:, t]
+        env[t * hop:t * hop + n_fft] += win * win
+    if length is None:
+        length = (T - 1) * hop
+    sl = slice(n_fft // 2, n_fft // 2 + length)
+    return (y[:, sl] / env[sl]).astype(np.float32)

@@ -45,7 +45,7 @@ MAX_COUNT_TENSORS = 16
 
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (``make -C csrc``); hipcc cross-compiles without a GPU."""
-    srcs = [os.path.join(CSRC, f) for f in ("sfsn_kernels.hip", "sfsn_pack.cpp")] + [
+    srcs = [os.path.join(CSRC, f) for f in ("sfsn_kernels.hip", "sfsn_fft.hip", "sfsn_pack.cpp")] + [
         os.path.join(_HERE, "..", "include", "sfsn.h")]
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -92,6 +92,10 @@ def lib() -> ctypes.CDLL:
     L.sfsn_deepfilter.argtypes = [_P, _I, _I, _I, _I, ctypes.POINTER(DfGroup), _I, _P, _P, _I, _I, _P]
     L.sfsn_spike_count.restype = _I
     L.sfsn_spike_count.argtypes = [ctypes.POINTER(CountTensor), _I, _P]
+    L.sfsn_stft.restype = _I
+    L.sfsn_stft.argtypes = [_P, _I, _I, _I, _I, _P, _P, _I, _P]
+    L.sfsn_istft.restype = _I
+    L.sfsn_istft.argtypes = [_P, _I, _I, _I, _I, _P, _P, _I, _P]
     if L.sfsn_abi_version() != 1:
         raise ImportError(f"{LIB_PATH}: ABI version {L.sfsn_abi_version()} != 1; rebuild")
     _lib = L
@@ -100,7 +104,7 @@ def lib() -> ctypes.CDLL:
 
 EXPORTS = ("sfsn_abi_version", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
            "sfsn_w3_pack", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
-           "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_spike_count")
+           "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
 
 
 def check(rc: int, what: str = "") -> None:

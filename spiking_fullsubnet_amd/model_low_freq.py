@@ -108,11 +108,6 @@ class Separator(_EngineMixin, nn.Module):
             assert noisy_y.size(1) == 1, "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
             noisy_y = noisy_y.squeeze(1)
         self._check_mode()
-        window = torch.hann_window(self.n_fft, device=noisy_y.device)
-        stft = torch.stft(noisy_y, self.n_fft, self.hop_length, self.win_length, window=window, return_complex=True,
-                          pad_mode="constant")
-        res = self.engine().forward_stft(stft, **self._layer_kwargs())
-        enhanced_stft = res["enh_stft"][:, 0]
-        enhanced_y = torch.istft(enhanced_stft, n_fft=self.n_fft, hop_length=self.hop_length, win_length=self.win_length,
-                                 window=torch.hann_window(self.win_length, device=noisy_y.device), length=noisy_y.size(-1))
+        res = self.engine().forward_stft(self._stft(noisy_y), **self._layer_kwargs())
+        enhanced_y = self._istft(res["enh_stft"][:, 0], length=noisy_y.size(-1))
         return enhanced_y, res["enh_mag"][:, 0], res["fb_all"], res["sb_all"]

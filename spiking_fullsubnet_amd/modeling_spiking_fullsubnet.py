@@ -107,6 +107,31 @@ class _EngineMixin:
     #   metric.compute_synops / compute_neuronops read), "none" (None entries).
     layer_outputs = "tensors"
 
+    # The two edges of the path (audio_feature.py:236-347).  "device": the package's own STFT / inverse-STFT kernels (n_fft = 512,
+    # win_length = n_fft, 1..4 hops per window: every reference config); "torch": torch.stft / torch.istft (rocFFT).  With
+    # "device" a configuration the kernels do not cover falls back to torch -- that is the documented edge, not a CPU path.
+    spectral_backend = "device"
+
+    def _device_fft(self, t: torch.Tensor) -> bool:
+        n_fft, hop = self.n_fft, self.hop_length
+        return (self.spectral_backend == "device" and t.device.type == "cuda" and n_fft == 512 and self.win_length == n_fft
+                and n_fft % hop == 0 and n_fft // hop <= 4)
+
+    def _stft(self, y: torch.Tensor) -> torch.Tensor:
+        if self._device_fft(y) and y.dtype == torch.float32:
+            from . import spectral
+            return spectral.stft(y, self.n_fft, self.hop_length)
+        window = torch.hann_window(self.n_fft, device=y.device)
+        return torch.stft(y, self.n_fft, self.hop_length, self.win_length, window=window, return_complex=True, pad_mode="constant")
+
+    def _istft(self, spec: torch.Tensor, length=None) -> torch.Tensor:
+        if self._device_fft(spec) and spec.dtype == torch.complex64 and (length is None or 0 < length <= (spec.shape[-1] - 1) * self.hop_length
+                                                                         + self.n_fft // 2):
+            from . import spectral
+            return spectral.istft(spec, self.n_fft, self.hop_length, length=length)
+        window = torch.hann_window(self.n_fft, device=spec.device)
+        return torch.istft(spec, self.n_fft, self.hop_length, self.win_length, window=window, length=length)
+
     def _layer_kwargs(self) -> dict:
         if self.layer_outputs not in ("tensors", "counts", "none"):
             raise ValueError(f"layer_outputs must be 'tensors', 'counts' or 'none', got {self.layer_outputs!r}")
@@ -171,14 +196,12 @@ class SpikingFullSubNet(_EngineMixin, nn.Module):
     def _spec(self) -> PathSpec:
         return self._path_spec
 
-    # ---- the two edges of the path: plain torch.stft / torch.istft (audio_feature.py:236-347) -------------
+    # ---- the two edges of the path (audio_feature.py:236-347): see _EngineMixin.spectral_backend -------------
     def stft(self, y):
-        window = torch.hann_window(self.n_fft, device=y.device)
-        return torch.stft(y, self.n_fft, self.hop_length, self.win_length, window=window, return_complex=True, pad_mode="constant")
+        return self._stft(y)
 
     def istft(self, spec, length=None):
-        window = torch.hann_window(self.n_fft, device=spec.device)
-        return torch.istft(spec, self.n_fft, self.hop_length, self.win_length, window=window, length=length)
+        return self._istft(spec, length)
 
     @torch.no_grad()
     def forward_stft(self, noisy_cmp, want_layers=True, want_membrane=False, want_counts=False):

@@ -486,6 +486,61 @@ def test_spike_count_rejects_bad_arguments(hip):
     assert hip.sfsn_spike_count(arr, 0, None) == SFSN_EINVAL and hip.sfsn_spike_count(arr, 17, None) == SFSN_EINVAL
 
 
+@pytest.mark.parametrize("B,L", [(2, 128 * 39), (1, 1000), (3, 128 * 16), (2, 128 * 17 + 5), (1, 300), (64, 128 * 99)])
+def test_stft_istft_kernels_vs_oracle_and_torch(B, L):
+    """sfsn_stft / sfsn_istft vs the oracle's float64 restatement of audio_feature.py:236-347 and vs torch.stft / torch.istft on
+    the same device; ragged lengths (L not a multiple of the hop, T not a multiple of the 16-frame tile, clips shorter than a
+    window), and the analysis-synthesis round trip."""
+    from spiking_fullsubnet_amd import spectral
+    rng = np.random.default_rng(B * 1000 + L)
+    wave = (0.05 * rng.standard_normal((B, L))).astype(np.float32)
+    y = _t(wave)
+    X = spectral.stft(y, 512, 128)
+    torch.cuda.synchronize()
+    ref = omodel.stft(wave)
+    assert tuple(X.shape) == ref.shape == (B, 257, 1 + L // 128)
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(X.cpu().numpy(), ref, atol=3e-6 * scale, rtol=0)
+    win = torch.hann_window(512, device=DEV)
+    Xt = torch.stft(y, 512, 128, 512, window=win, return_complex=True, pad_mode="constant")
+    np.testing.assert_allclose(X.cpu().numpy(), Xt.cpu().numpy(), atol=3e-6 * scale, rtol=0)
+    # inverse on an arbitrary (not STFT-consistent) spectrum, incl. non-zero imaginary DC / Nyquist parts
+    T = X.shape[-1]
+    Z = (rng.standard_normal((B, 257, T)) + 1j * rng.standard_normal((B, 257, T))).astype(np.complex64)
+    for length in ((T - 1) * 128, max(1, (T - 1) * 128 - 37)):
+        if length < 1:
+            continue
+        yi = spectral.istft(_t(Z), 512, 128, length=length)
+        torch.cuda.synchronize()
+        refi = omodel.istft(Z, length=length)
+        assert tuple(yi.shape) == refi.shape == (B, length)
+        np.testing.assert_allclose(yi.cpu().numpy(), refi, atol=3e-6 * np.abs(refi).max(), rtol=0)
+        if length > 256:  # torch.istft refuses clips whose kept range touches a zero of the window envelope
+            yt = torch.istft(_t(Z), 512, 128, 512, window=win, length=length)
+            np.testing.assert_allclose(yi.cpu().numpy(), yt.cpu().numpy(), atol=3e-6 * np.abs(refi).max(), rtol=0)
+    if L % 128 == 0 and L >= 512:
+        back = spectral.istft(X, 512, 128, length=L).cpu().numpy()
+        np.testing.assert_allclose(back, wave, atol=2e-6, rtol=0)
+
+
+def test_stft_kernels_on_the_golden_edges_and_errors():
+    from spiking_fullsubnet_amd import spectral
+    for fname in ("live_m.npz", "frozen_m_zoo.npz", "live_tiny_2spk.npz"):
+        gold = load(fname)
+        X = spectral.stft(_t(gold["wave"]), 512, 128).cpu().numpy()
+        np.testing.assert_allclose(X, gold["stft"], atol=3e-6 * np.abs(gold["stft"]).max(), rtol=0)
+        enh = gold["enh_stft"]
+        y = spectral.istft(_t(enh.reshape(-1, *enh.shape[-2:])), 512, 128, length=gold["wave"].shape[-1]).cpu().numpy()
+        ref = gold["enh_y"].reshape(y.shape)
+        np.testing.assert_allclose(y, ref, atol=3e-6 * max(1e-3, np.abs(ref).max()), rtol=0)
+    with pytest.raises(NotImplementedError):
+        spectral.stft(torch.zeros((1, 4000), device=DEV), 256, 64)
+    with pytest.raises(RuntimeError):
+        spectral.stft(torch.zeros((1, 4000)), 512, 128)
+    with pytest.raises(ValueError):
+        spectral.istft(torch.zeros((1, 129, 10), dtype=torch.complex64, device=DEV), 512, 128)
+
+
 def spec_units(spec, g):
     return (spec["cutoffs"][g + 1] - spec["cutoffs"][g]) // spec["ctr"][g]
 

@@ -129,3 +129,17 @@ def test_fp32_vs_fp64_noise_floor_is_reported():
     r64 = omodel.forward_from_stft(spec, sd, gold["stft"], "f64")
     agree = [float(((a > .5) == (b > .5)).mean()) for a, b in zip(r32["fb_all"][1:-1], r64["fb_all"][1:-1])]
     assert min(agree) > 0.99
+
+
+@pytest.mark.parametrize("fname", ["live_tiny.npz", "live_m.npz", "frozen_s_zoo.npz", "frozen_m_zoo.npz"])
+def test_stft_and_istft_restatements_match_the_reference(golden_dir, fname):
+    """The edges of the path (audio_feature.py:236-347): the recorded waveform -> the STFT the reference computed from it, and
+    the recorded enhanced STFT -> the waveform the reference returned."""
+    gold = np.load(os.path.join(golden_dir, fname))
+    X = omodel.stft(gold["wave"])
+    assert X.shape == gold["stft"].shape
+    np.testing.assert_allclose(X, gold["stft"], atol=2e-6 * np.abs(gold["stft"]).max(), rtol=0)
+    enh = gold["enh_stft"]
+    y = omodel.istft(enh.reshape(-1, *enh.shape[-2:]), length=gold["wave"].shape[-1])
+    ref = gold["enh_y"].reshape(y.shape)
+    np.testing.assert_allclose(y, ref, atol=2e-6 * max(1e-3, np.abs(ref).max()), rtol=0)
