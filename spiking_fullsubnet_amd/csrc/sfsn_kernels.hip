@@ -1456,6 +1456,17 @@ __global__ __launch_bounds__(256) void deepfilter_pass_kernel(const float* __res
 // host side: argument checks, dispatch on compile-time shapes, launches
 // =====================================================================================================
 static inline int hip_ok(hipError_t e) { return e == hipSuccess ? SFSN_OK : SFSN_EHIP; }
+static int cu_count() {  // compute units of the current device (256 on MI355X); 256 if the query fails
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 extern "C" int sfsn_abi_version(void) { return SFSN_ABI_VERSION; }
@@ -1609,7 +1620,7 @@ extern "C" int sfsn_spike_proj(const int8_t* s, const int8_t* w_packed, const fl
     const bool fast = (N % 4 == 0) && (ldy % 4 == 0) && M >= 64 && lds <= 150 * 1024;
     if (fast) {
         int fgrid = (M + 63) / 64;
-        if (fgrid > 512) fgrid = 512;
+        { const int cap = cu_count() * (TPW == 1 ? 2 : 1); if (fgrid > cap) fgrid = cap; }  // resident workgroups only: the W tiles are loaded once per workgroup
 #define SPF_CASE(TPW_, KS_)                                                                                              \
     if (TPW == TPW_ && KS == KS_) {                                                                                      \
         auto kern = spike_proj_fast_kernel<TPW_, KS_>;                                                                   \
@@ -1655,7 +1666,7 @@ extern "C" int sfsn_input_proj_f32(const float* x, const float* w, const float* 
     if (!no_bf3 && (K % 2 == 0) && K <= 192 && (N % 4 == 0) && (ldz % 4 == 0) && M >= 64 && TPW * KSB <= 12 && blds <= 150 * 1024 &&
         (reinterpret_cast<uintptr_t>(x) & 7) == 0) {
         int fgrid = (M + 63) / 64;
-        if (fgrid > 512) fgrid = 512;
+        if (fgrid > cu_count()) fgrid = cu_count();  // one resident workgroup per CU: the W split is paid once per CU
 #define IPB_CASE(TPW_, KS_)                                                                                               \
     if (TPW == TPW_ && KSB == KS_) {                                                                                      \
         auto kern = input_proj_bf3_kernel<TPW_, KS_>;                                                                     \
