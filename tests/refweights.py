@@ -90,6 +90,10 @@ FROZEN_S = dict(  # model_zoo/intel_ndns/spike_fsb/baseline_s/baseline_s.toml [m
 
 FROZEN_M = dict(FROZEN_S, fb_hidden_size=320, sb_hidden_size=224, sb_df_orders=[5, 3, 1])  # .../baseline_m/baseline_m.toml [model_g.args]
 
+FROZEN_L = dict(FROZEN_S, fb_hidden_size=320, sb_hidden_size=256, freq_cutoffs=[32, 128, 192], sb_df_orders=[5, 3, 1, 1],
+                sb_num_center_freqs=[2, 4, 32, 64], sb_num_neighbor_freqs=[15, 15, 15, 15], fb_num_center_freqs=[2, 4, 32, 64],
+                fb_num_neighbor_freqs=[0, 0, 0, 0])  # recipes/.../spiking_fullsubnet_freeze_phase/baseline_l.toml (offline norm)
+
 FROZEN_TINY = dict(FROZEN_S, fb_hidden_size=48, sb_hidden_size=32, sb_df_orders=[2, 1, 3])
 
 

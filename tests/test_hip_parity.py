@@ -203,7 +203,7 @@ MODEL_CASES = [
     ("live_tiny.npz", "live", rw.LIVE_TINY, 11), ("live_tiny_2spk.npz", "live", rw.LIVE_TINY_2SPK, 12),
     ("live_tiny_unshared.npz", "live", rw.LIVE_TINY_UNSHARED, 13), ("live_m.npz", "live", rw.LIVE_M, 21),
     ("frozen_tiny.npz", "frozen", rw.FROZEN_TINY, 31), ("frozen_s_zoo.npz", "frozen", rw.FROZEN_S, None),
-    ("frozen_m_zoo.npz", "frozen", rw.FROZEN_M, None),
+    ("frozen_m_zoo.npz", "frozen", rw.FROZEN_M, None), ("frozen_l.npz", "frozen", rw.FROZEN_L, 33),
 ]
 
 
@@ -261,7 +261,7 @@ def test_module_vs_reference_golden(fname, front, kw, seed):
 
 
 @pytest.mark.parametrize("front,kw,seed,B,T", [("live", rw.LIVE_M, 5, 3, 60), ("frozen", rw.FROZEN_S, 6, 2, 50),
-                                                ("live", rw.LIVE_TINY_2SPK, 8, 5, 33)])
+                                                ("live", rw.LIVE_TINY_2SPK, 8, 5, 33), ("frozen", rw.FROZEN_L, 9, 2, 24)])
 def test_module_vs_oracle_seeded(front, kw, seed, B, T):
     """Same seeded synthetic input through the HIP path and the CPU oracle (sizes the oracle finishes in seconds)."""
     sd = rw.live_state_dict(kw, seed) if front == "live" else rw.frozen_state_dict(kw, seed)
