@@ -472,6 +472,121 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
                                                 smem, T, H, NT, R, row0, rowc, n, q, tid, wave, rpw);
 }
 
+// ---- streamed-weights scan: the shapes whose W_hh cannot live in one CU (unshared gates with H > 256: baseline_xl's
+// full-band layers, 2 x 320 x 320 x 3 B = 614 KB against 512 KB of registers + 160 KB of LDS) -------------------------
+// Same arithmetic as gsn_scan_kernel, bit for bit (same digit MFMAs, same epilogue), but every A fragment is fetched
+// from L2 each step (the packed planes are coalesced 1 KB fragments; every workgroup reads the same 600 KB, so they stay
+// in L2 / Infinity Cache).  A workgroup owns 16 rows; 8 waves share the output tiles; one barrier per step; inputs and
+// outputs go straight between global memory and the accumulator layout.  ~5 us per step: a functional path for a config
+// whose trained generator the reference does not even ship, not a tuned one.
+template <int G>
+__global__ __launch_bounds__(512) void gsn_scan_stream_kernel(const ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char scan_smem[];
+    constexpr int NW = 8, MAXT = (SFSN_MAX_HIDDEN / 16 + NW - 1) / NW;  // tiles per wave at most
+    const int H = p.H, NT = p.NT, T = p.T, KS = (H + 63) / 64, HP = KS * 64, LDH = HP + 32;
+    int8_t* hbuf = reinterpret_cast<int8_t*>(scan_smem);                       // [2][16][LDH]
+    float* cst = reinterpret_cast<float*>(scan_smem + 2 * 16 * LDH);            // [3 + G][HP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    int s = 0;
+    for (int i = 1; i < p.nseg; ++i)
+        if ((int)blockIdx.x >= p.seg[i].tile0) s = i;
+    const ScanSegDev sg = p.seg[s];
+    const int R = sg.R, row0 = ((int)blockIdx.x - sg.tile0) * 16;
+    const int rowc = (row0 + n < R) ? row0 + n : R - 1;
+    const int ldz = G * H;
+    for (int j = tid; j < HP; j += NW * 64) {
+        const bool in = j < H;
+        cst[0 * HP + j] = in ? sg.bias[H + j] - sg.bias[j] : 0.0f;
+        cst[1 * HP + j] = in ? sg.bn_alpha[j] : 0.0f;
+        cst[2 * HP + j] = in ? sg.bn_beta[j] : 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) cst[(3 + g) * HP + j] = in ? sg.w_dq[g * H + j] : 0.0f;
+    }
+    for (int i = tid; i < 2 * 16 * LDH / 4; i += NW * 64) reinterpret_cast<int*>(hbuf)[i] = 0;
+    __syncthreads();
+    for (int idx = tid; idx < 16 * (H / 4); idx += NW * 64) {
+        const int rr = idx / (H / 4), j4 = (idx - rr * (H / 4)) * 4;
+        const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;
+        const v4f h = *reinterpret_cast<const v4f*>(sg.h_state + (size_t)rsrc * H + j4);
+        const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
+                            (h.w > 0.5f ? 0x1000000u : 0u);
+        *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
+    }
+    v4f c[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int ct = wave + NW * i;
+        c[i] = ct < NT ? *reinterpret_cast<const v4f*>(sg.c_state + (size_t)rowc * H + ct * 16 + q * 4) : v4f{0, 0, 0, 0};
+    }
+    __syncthreads();
+    const size_t plane = (size_t)G * NT * KS * 1024;
+    for (int t = 0; t < T; ++t) {
+        const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
+        int8_t* hn = hbuf + ((t & 1) ^ 1) * 16 * LDH;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+            const int ct = wave + NW * i;
+            if (ct >= NT) break;  // wave-uniform
+            const int cc = ct * 16 + q * 4;
+            v4f z[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) z[g] = *reinterpret_cast<const v4f*>(sg.zin + ((size_t)t * R + rowc) * ldz + g * H + cc);
+            v4f pre[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+                const int8_t* wp = sg.w_hh + (((size_t)g * NT + ct) * KS * 64 + lane) * 16;
+                for (int ks = 0; ks < KS; ++ks) {
+                    const v4i b = *reinterpret_cast<const v4i*>(hc + n * LDH + ks * 64 + q * 16);
+                    const v4i w0 = *reinterpret_cast<const v4i*>(wp + (size_t)ks * 1024);
+                    const v4i w1 = *reinterpret_cast<const v4i*>(wp + (size_t)ks * 1024 + plane);
+                    const v4i w2 = *reinterpret_cast<const v4i*>(wp + (size_t)ks * 1024 + 2 * plane);
+                    a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, b, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, b, a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, b, a2, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre[g][r] = __builtin_fmaf(recombine3(a0[r], a1[r], a2[r]), cst[(3 + g) * HP + cc + r], z[g][r]);
+            }
+            v4f cy;
+            unsigned pk = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pre_g = (G == 2) ? pre[G - 1][r] : pre[0][r] + cst[cc + r];
+                const float f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre[0][r] * -1.44269504088896341f));
+                const float m = __builtin_fmaf(f, c[i][r] - pre_g, pre_g);
+                const float y = __builtin_fmaf(m, cst[1 * HP + cc + r], cst[2 * HP + cc + r]);
+                cy[r] = y;
+                pk |= (y >= 0.0f) ? (1u << (8 * r)) : 0u;
+            }
+            c[i] = cy;
+            *reinterpret_cast<unsigned*>(hn + n * LDH + cc) = pk;
+            if (row0 + n < R) {  // rows past R are computed (clamped duplicates) but not stored
+                *reinterpret_cast<unsigned*>(sg.spikes_i8 + ((size_t)t * R + rowc) * HP + cc) = pk;
+                if (sg.spikes_f32) {
+                    const v4f sp = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)(pk >> 24)};
+                    *reinterpret_cast<v4f*>(sg.spikes_f32 + ((size_t)t * R + rowc) * H + cc) = sp;
+                }
+                if (sg.membrane) *reinterpret_cast<v4f*>(sg.membrane + ((size_t)t * R + rowc) * H + cc) = cy;
+            }
+        }
+        __syncthreads();
+    }
+    const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int ct = wave + NW * i;
+        if (ct >= NT || row0 + n >= R) continue;
+        const int cc = ct * 16 + q * 4;
+        *reinterpret_cast<v4f*>(sg.c_state + (size_t)rowc * H + cc) = c[i];
+        const unsigned pk = *reinterpret_cast<const unsigned*>(hl + n * LDH + cc);
+        const v4f h = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)((pk >> 24) & 1u)};
+        *reinterpret_cast<v4f*>(sg.h_state + (size_t)rowc * H + cc) = h;
+    }
+}
+
 // =====================================================================================================
 // spike projection: y[m][n] = dq[n] * sum_k s[m][k] * Wq[n][k] (+ bias[n]);  s int8 0/1
 // Waves are dealt (column-tile group cg, row-tile lane mw); each wave keeps its W tiles in registers and
@@ -1540,10 +1655,12 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
     int rows_total = 0;
     for (int i = 0; i < n_segs; ++i) rows_total += segs[i].R > 0 ? segs[i].R : 0;
     int rpw = 16;
-    if (rows_per_wg == 16 || rows_per_wg == 8 || rows_per_wg == 4) {
-        rpw = rows_per_wg;
+    const bool streamed = !shared && H > 256;  // W_hh does not fit one CU: streamed-weights kernel, 16 rows per workgroup
+    if (rows_per_wg != 0 && rows_per_wg != 16 && rows_per_wg != 8 && rows_per_wg != 4) return SFSN_EINVAL;
+    if (streamed) {
+        rpw = 16;
     } else if (rows_per_wg != 0) {
-        return SFSN_EINVAL;
+        rpw = rows_per_wg;
     } else {
         while (rpw > 4 && (rows_total + rpw - 1) / rpw < 200) rpw >>= 1;
     }
@@ -1579,13 +1696,18 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     // Waves per workgroup: as many as the per-wave share of W allows registers for (16 waves -> 128 VGPRs, 8 -> 256):
     // more waves per SIMD overlap one wave's epilogue VALU with another's MFMAs and hide LDS / VMEM latency.
+    if (streamed) {
+        const int HPs = KS * 64;
+        const size_t lds = (size_t)2 * 16 * (HPs + 32) + (size_t)5 * HPs * 4;
+        hipLaunchKernelGGL(gsn_scan_stream_kernel<2>, dim3(tiles), dim3(512), lds, st, p);
+        return hip_ok(hipGetLastError());
+    }
     int NW, TPW;
     if (rpw == 4 && out <= 7) out |= 512;  // repacked-epilogue variant (see scan_body)
     if (shared) {
         NW = H <= 256 ? 16 : 8;  // H = 320: one digit plane in LDS, two in registers (120 per wave), 2 waves per SIMD
     } else {
         NW = H <= 128 ? 16 : 8;
-        if (H > 256) return SFSN_EUNSUPPORTED;  // 2 gates x 320^2 x 3 digits does not fit one CU's register file
     }
     TPW = (NT + NW - 1) / NW;
 #define SCAN_CASE(G_, KS_, NW_, TPW_, LP_) \

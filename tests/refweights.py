@@ -94,6 +94,8 @@ FROZEN_L = dict(FROZEN_S, fb_hidden_size=320, sb_hidden_size=256, freq_cutoffs=[
                 sb_num_center_freqs=[2, 4, 32, 64], sb_num_neighbor_freqs=[15, 15, 15, 15], fb_num_center_freqs=[2, 4, 32, 64],
                 fb_num_neighbor_freqs=[0, 0, 0, 0])  # recipes/.../spiking_fullsubnet_freeze_phase/baseline_l.toml (offline norm)
 
+FROZEN_XL = dict(FROZEN_M, shared_weights=False)  # .../spiking_fullsubnet_freeze_phase/baseline_xl.toml: separate gate weights
+
 FROZEN_TINY = dict(FROZEN_S, fb_hidden_size=48, sb_hidden_size=32, sb_df_orders=[2, 1, 3])
 
 

@@ -79,7 +79,7 @@ def make_layer(rng, I, H, shared, bn):
 SCAN_SHAPES = [  # I, H, R, T, shared, bn
     (12, 32, 5, 40, True, True), (9, 16, 4, 30, False, False), (20, 48, 19, 25, False, True), (38, 160, 33, 30, True, True),
     (38, 224, 16, 40, True, True), (64, 240, 7, 30, True, True), (30, 256, 18, 20, True, False), (64, 320, 35, 30, True, True),
-    (94, 128, 16, 24, True, True), (24, 192, 9, 16, False, True),
+    (94, 128, 16, 24, True, True), (24, 192, 9, 16, False, True), (64, 320, 21, 14, False, True), (20, 272, 5, 10, False, False),
 ]
 
 
@@ -204,6 +204,7 @@ MODEL_CASES = [
     ("live_tiny_unshared.npz", "live", rw.LIVE_TINY_UNSHARED, 13), ("live_m.npz", "live", rw.LIVE_M, 21),
     ("frozen_tiny.npz", "frozen", rw.FROZEN_TINY, 31), ("frozen_s_zoo.npz", "frozen", rw.FROZEN_S, None),
     ("frozen_m_zoo.npz", "frozen", rw.FROZEN_M, None), ("frozen_l.npz", "frozen", rw.FROZEN_L, 33),
+    ("frozen_xl.npz", "frozen", rw.FROZEN_XL, 34),
 ]
 
 

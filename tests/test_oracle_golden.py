@@ -70,7 +70,7 @@ CASES = [
     ("live_m.npz", "live", rw.LIVE_M, 21),
     ("frozen_tiny.npz", "frozen", rw.FROZEN_TINY, 31),
     ("frozen_s_zoo.npz", "frozen", rw.FROZEN_S, None), ("frozen_m_zoo.npz", "frozen", rw.FROZEN_M, None),
-    ("frozen_l.npz", "frozen", rw.FROZEN_L, 33),
+    ("frozen_l.npz", "frozen", rw.FROZEN_L, 33), ("frozen_xl.npz", "frozen", rw.FROZEN_XL, 34),
 ]
 
 
