@@ -196,6 +196,12 @@ def main():
                             measured_in="phase A: single stream, one forward at a time (the kernel runs alone; in the timed region "
                                         "several forwards share the chip and a launch's wall time is a time share, not the kernel's own)",
                             other_kernels_ms={k: round(v["mean_ms"], 4) for k, v in scan_ms.items() if k != "scan:sb"})
+            if traffic is not None and tj.get("forward_hbm_bytes") and want_layers:
+                # the whole job against the same roof: PMC-measured HBM bytes of one forward (all kernels) / time per step of
+                # the timed region (several forwards in flight)
+                jb = float(tj["forward_hbm_bytes"])
+                roofline["job"] = dict(hbm_bytes_per_step=int(jb), achieved=round(jb / (ms_per_step * 1e-3) / 1e9, 1), unit="GB/s",
+                                       frac=round(jb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(kw, sd, stft)

@@ -32,9 +32,25 @@ for k in f:
     out.append('"%s",%.0f,%.1f,%.0f,%.1f,%s' % (k.replace('"', ""), fs, 2 * fs * 1024 / 1e6, ws, ws * 1024 / 1e6,
                                                 ",".join("%.4g" % v if v != "" else "" for v in vals)))
 open(f"profiles/{rnd}_pmc_summary.csv", "w").write("\n".join(out) + "\n")
+# HBM traffic of one whole forward: every kernel's (2*FETCH + WRITE) per dispatch x its dispatches per forward
+def counts(fn):
+    c = collections.Counter()
+    seen = set()
+    for r in csv.DictReader(open(fn)):
+        key = (r["Kernel_Name"], r["Dispatch_Id"])
+        if key not in seen:
+            seen.add(key); c[r["Kernel_Name"]] += 1
+    return c
+cf = counts(f"{base}/pmc_FETCH_SIZE/p_counter_collection.csv")
+n_fwd = max(v for kk, v in cf.items() if "deepfilter" in kk)
+job = 0.0
+for kk, v in cf.items():
+    if any(t in kk for t in ("gsn_scan", "spike_proj", "input_proj", "features", "deepfilter", "rowsum", "laplace", "spike_count")):
+        job += (2 * f[kk].get("FETCH_SIZE", 0) + w.get(kk, {}).get("WRITE_SIZE", 0)) * 1024 * v / n_fwd
 k = [x for x in f if "gsn_scan_kernel<1, 4, 16" in x][0]
 tr = dict(B=64, T=1000, kernel=k, fetch_size_KiB=f[k]["FETCH_SIZE"], write_size_KiB=w[k]["WRITE_SIZE"],
           sb_scan_hbm_bytes_per_launch=int(2 * f[k]["FETCH_SIZE"] * 1024 + w[k]["WRITE_SIZE"] * 1024),
+          forward_hbm_bytes=int(job),
           note=f"2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per dispatch (gfx950 FETCH_SIZE half-count correction); source profiles/{rnd}_pmc_summary.csv")
 json.dump(tr, open("profiles/traffic.json", "w"), indent=1)
 rows = list(csv.DictReader(open(f"profiles/{rnd}_single_stream_kernel_stats.csv")))
