@@ -446,6 +446,12 @@ class Engine:
 
     def forward_stft(self, stft: torch.Tensor, want_layers: bool = True, want_membrane: bool = False, pipeline: Optional[bool] = None,
                      want_counts: bool = False) -> dict:
+        """See ``_forward_stft``; runs with this engine's device current (the C ABI launches on the calling thread's device)."""
+        with torch.cuda.device(self.device):
+            return self._forward_stft(stft, want_layers, want_membrane, pipeline, want_counts)
+
+    def _forward_stft(self, stft: torch.Tensor, want_layers: bool = True, want_membrane: bool = False, pipeline: Optional[bool] = None,
+                      want_counts: bool = False) -> dict:
         """complex64 [B, n_fft/2+1, T] on the device -> dict(enh_stft [B,S,F,T] complex64, enh_mag [B,S,F,T],
         fb_all, sb_all (the reference's all_layer_outputs lists; spike entries are None when want_layers=False)).
 

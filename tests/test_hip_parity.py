@@ -317,6 +317,24 @@ def test_thirty_second_clip_sits_on_the_fp32_noise_floor(fname, kw):
     assert mine <= 1.15 * floor + 1e-4, (mine, floor)
 
 
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 2), (1, 33), (5, 31)])
+def test_tiny_and_ragged_clip_shapes_vs_oracle(B, T):
+    """Edge shapes of the offline forward: a single frame, fewer frames than a deep-filter order, one frame past a 32-frame
+    tile, an odd batch -- live baseline_m sizes against the oracle (short clips: no divergence expected at all)."""
+    kw, seed = rw.LIVE_M, 14
+    sd = rw.live_state_dict(kw, seed)
+    spec = omodel.spec_from_live_kwargs(kw)
+    rng = np.random.default_rng(B * 100 + T)
+    stft = (0.3 * (rng.standard_normal((B, 257, T)) + 1j * rng.standard_normal((B, 257, T)))).astype(np.complex64)
+    ora = omodel.forward_from_stft(spec, sd, stft, "f32", want_membrane=True)
+    out = hip_result(build_module("live", kw, sd), stft)
+    stats = parity.check_model(out, parity.gold_from_oracle(ora), spec, tag=f"B{B}T{T}:")
+    assert all(st["spike_agreement"] > 0.999 for st in stats), stats
+    ref = np.asarray(ora["enh_stft"])
+    if all(st["diverged"] == 0 for st in stats):
+        np.testing.assert_allclose(out["enh_stft"], ref, rtol=parity.REL, atol=parity.ATOL + parity.REL * np.abs(ref).max())
+
+
 def test_full_size_properties():
     """BASELINE.json config 3 (live M, B=64, T=1000): properties that do not need the oracle at full size.
     (i) run-to-run bit stability; (ii) batch independence: clips 5..12 computed alone == inside the batch, bit for bit;
