@@ -1480,7 +1480,8 @@ struct DfPassParams {
     int npass, ctile_floats;  // floats of LDS reserved for the coefficient tile (the X tile follows)
 };
 
-__global__ __launch_bounds__(256) void deepfilter_pass_kernel(const float* __restrict__ stft, const DfPassParams pp,
+#define DFP_THREADS 512
+__global__ __launch_bounds__(DFP_THREADS) void deepfilter_pass_kernel(const float* __restrict__ stft, const DfPassParams pp,
                                                                float* __restrict__ enh, float* __restrict__ mag) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DfParams& p = pp.base;
@@ -1488,6 +1489,7 @@ __global__ __launch_bounds__(256) void deepfilter_pass_kernel(const float* __res
     const int b = blockIdx.y, t0 = p.t0 + blockIdx.x * 32;
     const int tid = threadIdx.x, tt = tid & 31, fs = tid >> 5, t = t0 + tt;
     const int lane = tid & 63, wave = tid >> 6;
+    constexpr int NWV = DFP_THREADS / 64, NFS = DFP_THREADS / 32;  // waves, bin slots
     const int tend = p.t1;
     float* ct = smem;
     float2* xt = reinterpret_cast<float2*>(smem + pp.ctile_floats);
@@ -1501,24 +1503,34 @@ __global__ __launch_bounds__(256) void deepfilter_pass_kernel(const float* __res
         // coefficient tile: row r = frame t0 + r, UP contiguous floats
         for (int c4 = lane; c4 < Q; c4 += 64) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = wave + 4 * i, tr = t0 + r;
+            for (int i = 0; i < 32 / NWV; ++i) {
+                const int r = wave + NWV * i, tr = t0 + r;
                 v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (tr < tend) v = *reinterpret_cast<const v4f*>(g.proj + ((size_t)tr * B * g.N + (size_t)b * g.N + k0) * P + 4 * c4);
                 float* d = ct + r * LD + 4 * c4;
                 d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
             }
         }
-        // noisy-spectrum tile (only when there is more than one tap): bins of the pass x frames [t0-(df-1), t0+32)
-        if (g.df > 1) {
-            const int fbase = g.lo + k0 * g.fc, tb = t0 - (g.df - 1);
-            for (int j = fs; j < nb; j += 8) {
-                const float* xrow = stft + ((size_t)b * F + fbase + j) * T * 2;
-                for (int c = tt; c < XW; c += 32) {
-                    const int ts = tb + c;
-                    float2 xv = make_float2(0.0f, 0.0f);
-                    if (ts >= 0 && ts < T) xv = *reinterpret_cast<const float2*>(xrow + 2 * (size_t)ts);
-                    xt[j * XW + c] = xv;
+        // noisy-spectrum tile: bins of the pass x frames [t0-(df-1), t0+32), eight independent requests per thread in flight
+        // (a load -> LDS-store loop pays one memory round trip per iteration: that was 70 % of this kernel's time)
+        {
+            const int fbase = g.lo + k0 * g.fc, tb = t0 - (g.df - 1), nx = nb * XW;
+            for (int e0 = tid; e0 < nx; e0 += DFP_THREADS * 8) {
+                float2 v[8];
+                bool ok[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int e = e0 + DFP_THREADS * i;
+                    if (e > nx - 1) e = nx - 1;
+                    const int j = e / XW, c = e - j * XW, ts = tb + c;
+                    ok[i] = ts >= 0 && ts < T;
+                    const int tsc = ts < 0 ? 0 : (ts > T - 1 ? T - 1 : ts);
+                    v[i] = *reinterpret_cast<const float2*>(stft + (((size_t)b * F + fbase + j) * T + tsc) * 2);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = e0 + DFP_THREADS * i;
+                    if (e < nx) xt[e] = ok[i] ? v[i] : make_float2(0.0f, 0.0f);
                 }
             }
         }
@@ -1527,23 +1539,16 @@ __global__ __launch_bounds__(256) void deepfilter_pass_kernel(const float* __res
             const float* pr = ct + tt * LD;
             int u = 0, fci = fs;
             while (fci >= g.fc) { fci -= g.fc; ++u; }
-            for (int j = fs; j < nb; j += 8) {
+            for (int j = fs; j < nb; j += NFS) {
                 const int f = g.lo + (k0 + u) * g.fc + fci;
                 const float* pu = pr + u * P;
                 for (int s_ = 0; s_ < S; ++s_) {
                     float yr = 0.0f, yi = 0.0f;
-                    if (g.df > 1) {
-                        const float2* xr_ = xt + j * XW + tt;
-                        for (int d = 0; d < g.df; ++d) {
-                            const float2 xv = xr_[d];
-                            const float cr = pu[((0 * g.fc + fci) * g.df + d) * S + s_];
-                            const float ci = pu[((1 * g.fc + fci) * g.df + d) * S + s_];
-                            yr += xv.x * cr - xv.y * ci;
-                            yi += xv.x * ci + xv.y * cr;
-                        }
-                    } else {
-                        const float2 xv = *reinterpret_cast<const float2*>(stft + (((size_t)b * F + f) * T + t) * 2);
-                        const float cr = pu[(0 * g.fc + fci) * S + s_], ci = pu[(1 * g.fc + fci) * S + s_];
+                    const float2* xr_ = xt + j * XW + tt;
+                    for (int d = 0; d < g.df; ++d) {
+                        const float2 xv = xr_[d];
+                        const float cr = pu[((0 * g.fc + fci) * g.df + d) * S + s_];
+                        const float ci = pu[((1 * g.fc + fci) * g.df + d) * S + s_];
                         yr += xv.x * cr - xv.y * ci;
                         yi += xv.x * ci + xv.y * cr;
                     }
@@ -1551,13 +1556,13 @@ __global__ __launch_bounds__(256) void deepfilter_pass_kernel(const float* __res
                     *reinterpret_cast<float2*>(enh + 2 * o) = make_float2(yr, yi);
                     if (mag) mag[o] = fast_abs2(yr, yi);
                 }
-                fci += 8;
+                fci += NFS;
                 while (fci >= g.fc) { fci -= g.fc; ++u; }
             }
         }
     }
     if (t < tend)
-        for (int f = p.fcov + fs; f < F; f += 8) {
+        for (int f = p.fcov + fs; f < F; f += NFS) {
             const float2 xv = *reinterpret_cast<const float2*>(stft + (((size_t)b * F + f) * T + t) * 2);
             for (int s_ = 0; s_ < S; ++s_) {
                 const size_t o = (((size_t)b * S + s_) * F + f) * T + t;
@@ -1961,7 +1966,7 @@ extern "C" int sfsn_deepfilter(const float* stft_ri, int B, int F, int T, int S,
                 pp.pg[pp.npass] = (unsigned char)i; pp.pk0[pp.npass] = (unsigned char)k0; pp.pnu[pp.npass] = (unsigned char)nu;
                 ++pp.npass;
                 if (nu * P > max_up) max_up = nu * P;
-                const int xw = g.df > 1 ? nu * g.fc * (32 + g.df - 1) * 2 : 0;
+                const int xw = nu * g.fc * (32 + g.df - 1) * 2;
                 if (xw > max_x) max_x = xw;
             }
         }
@@ -1969,7 +1974,7 @@ extern "C" int sfsn_deepfilter(const float* stft_ri, int B, int F, int T, int S,
             pp.ctile_floats = (32 * (max_up + 1) + 3) & ~3;
             const size_t plds = ((size_t)pp.ctile_floats + max_x) * sizeof(float);
             if (plds <= 48 * 1024) {
-                hipLaunchKernelGGL(deepfilter_pass_kernel, dim3((nt + 31) / 32, B), dim3(256), plds, st, stft_ri, pp, enh_ri, enh_mag);
+                hipLaunchKernelGGL(deepfilter_pass_kernel, dim3((nt + 31) / 32, B), dim3(DFP_THREADS), plds, st, stft_ri, pp, enh_ri, enh_mag);
                 return hip_ok(hipGetLastError());
             }
         }
