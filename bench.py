@@ -135,6 +135,19 @@ def main():
             dt = float(tmax.item())
         return dt
 
+    # ---- the roof as this box delivers it: a 1 GiB device-to-device copy (read + write), next to the 8 TB/s spec number
+    src_ = torch.empty((1 << 28,), dtype=torch.float32, device=dev)
+    dst_ = torch.empty_like(src_)
+    for _ in range(3):
+        dst_.copy_(src_)
+    torch.cuda.synchronize()
+    t_c = time.perf_counter()
+    for _ in range(10):
+        dst_.copy_(src_)
+    torch.cuda.synchronize()
+    copy_gbps = 10 * 2 * src_.numel() * 4 / (time.perf_counter() - t_c) / 1e9
+    del src_, dst_
+
     # ---- phase A (untimed for `value`): one forward at a time on one stream, the latency-optimal launch geometry.  The
     #      dominant kernel runs alone here, so its HIP-event duration is the kernel's own (roofline), not a time share.
     eng.rows_per_wg = (0, 0)
@@ -190,7 +203,7 @@ def main():
             roofline = dict(bound="hbm", kernel="gsn_scan_kernel<G=1,KS=4,NW=16,TPW=1,OUT=fp32+int8 spikes,4-row repacked epilogue> (3 sub-band groups in one launch, one launch per layer)",
                             achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
                             traffic=traffic, launch_ms=round(sb_ms["mean_ms"], 4), launches=sb_ms["n"],
-                            algorithmic_bytes_per_launch=int(bytes_per_launch),
+                            algorithmic_bytes_per_launch=int(bytes_per_launch), measured_copy_GBps=round(copy_gbps, 1),
                             per_step_us=round(1e3 * sb_ms["mean_ms"] / (T / info["n_chunks"]), 3),
                             frames_per_launch=int(frames_per_launch), schedule=("time-pipelined x%d chunks on %d streams" % (info["n_chunks"], 4)) if info["pipelined"] else "sequential",
                             measured_in="phase A: single stream, one forward at a time (the kernel runs alone; in the timed region "
@@ -274,7 +287,22 @@ def cpu_baseline(kw, sd, stft):
         if el > 12.0 or n >= 20:
             break
     frames = n * sample.shape[0] * Ts
-    return dict(value=round(frames / el, 1), unit="frames/s", cores=os.cpu_count(), kind="port",
+    # one core, for calibration: a smaller sample of the same batch, OpenMP pinned to one thread
+    single = cpu_model = None
+    try:
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        small = sample[:2, :, :32]
+        t1 = time.perf_counter()
+        omodel.forward_from_stft(spec, sd, small, "f32")
+        single = round(small.shape[0] * small.shape[2] / (time.perf_counter() - t1), 1)
+        gomp.omp_set_num_threads(os.cpu_count())
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), None)
+    except Exception:  # the baseline is reported, never required
+        pass
+    return dict(value=round(frames / el, 1), unit="frames/s", cores=os.cpu_count(), kind="port", single_core_value=single, cpu_model=cpu_model,
                 sample=f"{n} x (B={sample.shape[0]}, T={Ts} prefix of the same synthetic batch), {el:.1f} s of wall time, fp32 oracle "
                        f"(oracle/sfsn_oracle.c via oracle.model), OpenMP threads = all {os.cpu_count()} host cores",
                 reference_pytorch_cpu="3,265 frames/s for the reference's own PyTorch forward at B=64,T=1000 on 8 vCPU (BASELINE.md section 2, survey container)")
