@@ -335,6 +335,33 @@ def test_tiny_and_ragged_clip_shapes_vs_oracle(B, T):
         np.testing.assert_allclose(out["enh_stft"], ref, rtol=parity.REL, atol=parity.ATOL + parity.REL * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("fname,kw", [("frozen_m_zoo.npz", rw.FROZEN_M), ("frozen_s_zoo.npz", rw.FROZEN_S)])
+def test_config2_full_band_path_b32_t500(fname, kw):
+    """BASELINE.json configs[1]: B=32, T=500, the full-band path (R=32, I=64, H=320 / 240, two layers, projection 64), fp32 --
+    trained zoo weights, every full-band chain against the oracle under the strict causal rule."""
+    B, T = 32, 500
+    gold = load(fname)
+    sd = {k[3:]: v for k, v in gold.items() if k.startswith("sd/")}
+    spec = omodel.spec_from_frozen_kwargs(kw)
+    wave = torch.from_numpy(rw.synth_wave(B, T, 23, modulated=True))
+    stft = torch.stft(wave, 512, 128, 512, window=torch.hann_window(512), return_complex=True, pad_mode="constant").numpy()
+    ora = omodel.forward_from_stft(spec, sd, stft, "f32", want_membrane=True)
+    out = hip_result(build_module("frozen", kw, sd), stft)
+    g = parity.gold_from_oracle(ora)
+    t_valid = np.full(B, T)
+    parity.check_continuous(out["fb_all"][0], g["fb/x"], t_valid, "cfg2:fb/x")
+    for l in range(2):
+        shape = tuple(int(v) for v in g[f"fb/spikes_shape/{l}"])
+        ref, near = parity.unpack(g[f"fb/spikes_packed/{l}"], shape), parity.unpack(g[f"fb/near{parity.TAU:g}/{l}"], shape)
+        # membranes too for baseline_m; baseline_s has runaway neurons (|c| grows geometrically until it overflows, in the
+        # reference as well) whose membranes integrate rounding noise faster than any fixed relative tolerance: spikes only
+        mems = (out["mem"][("fb", l)], g[f"fb/membrane/{l}"]) if "_m_" in fname else (None, None)
+        t_valid, st = parity.check_chain(out["fb_all"][1 + l], ref, near, t_valid, f"cfg2:fb/L{l}", *mems)
+        assert st["spike_agreement"] > 0.99 and st["diverged"] <= 4, st  # a diverged row is one whose first flip the rule allowed
+    parity.check_continuous(out["fb_all"][-1], g["fb/proj"], t_valid, "cfg2:fb/proj")
+    assert (t_valid == T).mean() > 0.8  # nearly every clip's full-band chains run the 500 frames without a single spike flip
+
+
 def test_full_size_properties():
     """BASELINE.json config 3 (live M, B=64, T=1000): properties that do not need the oracle at full size.
     (i) run-to-run bit stability; (ii) batch independence: clips 5..12 computed alone == inside the batch, bit for bit;
