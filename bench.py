@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--rpw", type=str, default="", help="rows per scan workgroup 'fb,sb' (0 = auto)")
     ap.add_argument("--inflight", type=int, default=8, help="forwards in flight on separate HIP streams (batch-level pipelining)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per pipeline chunk (default: engine default)")
+    ap.add_argument("--no-saturated", action="store_true", help="skip the 4x-rows launch of the dominant kernel (roofline.saturated)")
     ap.add_argument("--streaming", action="store_true", help="BASELINE configs[4]: frame-by-frame session, per-call latency (own JSON line)")
     ap.add_argument("--hop", type=int, default=1, help="frames per streaming call")
     ap.add_argument("--no-graph", action="store_true", help="streaming: launch the kernels one by one instead of replaying the HIP graph")
@@ -158,6 +159,27 @@ def main():
     eng.timers = None
     single = dict(ms_per_step=round(1e3 * dt_a / ka, 4), value=round(world * B * T * ka / dt_a, 1), steps=ka)
 
+    # ---- the same kernel with the chip full (untimed for `value`): at B=64 a sub-band scan launch is 208 workgroups of 4 rows,
+    #      a latency-bound chain per workgroup; four times the rows (16 per workgroup, same 208 workgroups) shows what the
+    #      kernel moves per second when every CU has a full tile -- which is also how it runs in the timed region below,
+    #      where the scans of several forwards share the chip
+    saturated = None
+    if world == 1 and not args.no_saturated and B * 4 * T <= 256 * 1000:
+        stft4 = stft.repeat(4, 1, 1)
+        eng.timers, eng.timer_tags = {}, {"scan:sb"}
+        for _ in range(3):
+            eng.forward_stft(stft4, want_layers=want_layers, pipeline=False)
+        sat = eng.timer_summary().get("scan:sb")
+        eng.timers = None
+        eng._ws.clear()
+        del stft4
+        torch.cuda.empty_cache()
+        if sat:
+            ach = SB_SCAN_BYTES_PER_FRAME_PER_LAUNCH * 4 * B * T / (sat["min_ms"] * 1e-3) / 1e9
+            saturated = dict(clips=4 * B, launch_ms=round(sat["min_ms"], 4), achieved=round(ach, 1), unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4),
+                             note="same kernel, 4x the rows in one launch (16 rows per workgroup): not the bench workload, shown to separate "
+                                  "the kernel's efficiency from the occupancy of a B=64 launch")
+
     # ---- phase B (THE timed region): `--inflight` forwards in flight on as many HIP streams -- batch-level pipelining of
     #      independent batches, as a serving loop runs them.  The recurrent scans are latency-bound chains that occupy a
     #      fraction of the CUs (16 rows per workgroup here, so that several scans fit side by side); the next batches'
@@ -213,6 +235,8 @@ def main():
                 # the whole job against the same roof: PMC-measured HBM bytes of one forward (all kernels) / time per step of
                 # the timed region (several forwards in flight)
                 jb = float(tj["forward_hbm_bytes"])
+                if saturated:
+                    roofline["saturated"] = saturated
                 roofline["job"] = dict(hbm_bytes_per_step=int(jb), achieved=round(jb / (ms_per_step * 1e-3) / 1e9, 1), unit="GB/s",
                                        frac=round(jb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
         cpu = None
