@@ -113,6 +113,20 @@ typedef struct sfsn_scan_segment {
 int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs /* host array */, int n_segs, int T, int H, int shared,
                         int rows_per_wg /* 16, 8, 4, or 0 = choose so that the launch covers ~all CUs */, void* stream);
 
+/* Fused-input variant for layers >= 1 (their input is the previous layer's spikes): the input term is computed inside
+ * the scan from the int8 spikes and the packed input weights, so that sfsn_spike_proj's [T][R][H] fp32 result never makes
+ * its round trip through HBM.  Bit-identical to sfsn_spike_proj(bias = bias[0:H]) + sfsn_gsn_layer_scan.  Shared gate
+ * weights, 128 < H <= 256, 16 rows per workgroup (the geometry for a full chip); `zin` and `membrane` of the segments are
+ * ignored / must be NULL.  SFSN_EUNSUPPORTED for other shapes: the caller then uses the two-call form. */
+typedef struct sfsn_fused_input {
+    const int8_t* spikes_in; /* [T][R][pad64(H)] the previous layer's spikes_i8                           */
+    const int8_t* w_ih;      /* sfsn_w3_pack(W_ih [H][H])                                                  */
+    const float* w_ih_dq;    /* [pad16(H)]                                                                 */
+} sfsn_fused_input;
+
+int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs /* host */, const sfsn_fused_input* fin /* host, one per segment */,
+                              int n_segs, int T, int H, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Time-parallel products.
  * sfsn_input_proj_f32: z[m][n] = sum_k x[m][k] * w[n][k] (+ bias[n])  (NEURON:141-142 for layer 0: real-valued x)

@@ -27,6 +27,10 @@ class ScanSegment(ctypes.Structure):
                 ("h_state", _P), ("c_state", _P), ("spikes_f32", _P), ("spikes_i8", _P), ("membrane", _P), ("R", _I)]
 
 
+class FusedInput(ctypes.Structure):
+    _fields_ = [("spikes_in", _P), ("w_ih", _P), ("w_ih_dq", _P)]
+
+
 class FeatureGroup(ctypes.Structure):
     _fields_ = [("x", _P), ("ln_w", _P), ("ln_b", _P), ("mu", _P), ("lo", _I), ("n_units", _I), ("ctr", _I), ("nbr", _I),
                 ("ctr_fb", _I), ("nbr_fb", _I), ("norm", _I), ("ln_eps", _F)]
@@ -80,6 +84,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_w3_unpack.argtypes = [_P, _P, _I, _I, _P]
     L.sfsn_gsn_layer_scan.restype = _I
     L.sfsn_gsn_layer_scan.argtypes = [ctypes.POINTER(ScanSegment), _I, _I, _I, _I, _I, _P]
+    L.sfsn_gsn_layer_scan_fused.restype = _I
+    L.sfsn_gsn_layer_scan_fused.argtypes = [ctypes.POINTER(ScanSegment), ctypes.POINTER(FusedInput), _I, _I, _I, _P]
     L.sfsn_input_proj_f32.restype = _I
     L.sfsn_input_proj_f32.argtypes = [_P, _P, _P, _P, _I, _I, _I, _I, _P]
     L.sfsn_spike_proj.restype = _I
@@ -103,7 +109,7 @@ def lib() -> ctypes.CDLL:
 
 
 EXPORTS = ("sfsn_abi_version", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
-           "sfsn_w3_pack", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
+           "sfsn_w3_pack", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
            "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
 
 

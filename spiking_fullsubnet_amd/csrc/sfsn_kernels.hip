@@ -44,6 +44,10 @@ struct ScanSegDev {
     float* membrane;
     int R;
     int tile0;  // first workgroup (row tile) of this segment
+    // fused-input scan only: the previous layer's int8 spikes and this layer's packed input weights
+    const int8_t* spikes_in;
+    const int8_t* w_ih;
+    const float* w_ih_dq;
 };
 
 struct ScanParams {
@@ -470,6 +474,204 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
     else
         scan_body<G, KS, NW, TPW, OUT, LP, TPW - 1>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state,
                                                 smem, T, H, NT, R, row0, rowc, n, q, tid, wave, rpw);
+}
+
+// ---- fused-input scan (layers >= 1, shared gates, 128 < H <= 256, 16 rows per workgroup) -----------------------------------
+// With the chip full the scan is HBM-bound (PMC + scripts/exp_dupmfma.py: doubling its matrix work does not change the launch
+// time), and half of what it reads is the fp32 input term x.W_ih^T + b that sfsn_spike_proj wrote just before: 2 x 745 MB per
+// sub-band layer at B=64, T=1000.  For a layer whose input is the previous layer's spikes that term is the same kind of
+// product as the recurrent one, so this variant computes it in place: it reads the int8 spikes (4 KB per step instead of
+// 14 KB) and keeps BOTH weight matrices in the CU -- digit plane 0 of each in LDS (2 x NT*KS KB), planes 1 and 2 in
+// registers (8 waves x 2 tiles: 128 VGPRs).  24 instead of 12 MFMAs per tile and step; results bit-identical to
+// sfsn_spike_proj + sfsn_gsn_layer_scan (same exact integer products, same two roundings: fma(rec_ih, dq, b) then
+// fma(rec_hh, dq, .)).  Input spikes arrive through an LDS-DMA ring like the input term of the other variant (row chunks
+// rotated by the row index so that B-fragment reads spread over the banks), spikes leave through ScanFlush.
+template <int KS, int OUT, int NTL>
+__device__ __forceinline__ void fused_body(const ScanSegDev& sg, char* smem, int T, int H, int NT, int R, int row0, int rowc, int n,
+                                           int q, int tid, int wave) {
+    using C = ScanCfg<1, KS, 8, 2, OUT, 0>;  // geometry constants of the flush only (LDH, HP, FL, NSTF)
+    constexpr int LDH = C::LDH, HP = C::HP, D = 3, NW = 8, NCH = KS * 4;  // NCH = 16-byte chunks per input row
+    constexpr int SR_BYTES = 16 * HP;                                      // one ring slot: 16 rows of int8 spikes
+    constexpr int HBUF_OFF = D * SR_BYTES, CST_OFF = HBUF_OFF + 2 * 16 * LDH, WHH_OFF = CST_OFF + 6 * HP * 4;
+    const int WIH_OFF = WHH_OFF + NT * KS * 1024;
+    int8_t* hbuf = reinterpret_cast<int8_t*>(smem + HBUF_OFF);
+    const float(*cst)[HP] = reinterpret_cast<const float(*)[HP]>(smem + CST_OFF);  // b_f, b_g - b_f, alpha, beta, dq_hh, dq_ih
+    ScanFlush<C> fl;
+    fl.init(tid, row0, R, H, NW * 64, 16);
+    const int lane = tid & 63;
+    constexpr int CBASE = (D - 2) * 1, CSTRIDE = (D - 1) * C::NSTF;  // outstanding operations allowed at the end-of-step wait
+
+    v4i Whh[NTL][KS][2], Wih[NTL][KS][2];
+    v4f c[NTL];
+    int col[NTL];
+    unsigned wl_off[NTL];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        const int ct = wave + NW * i;
+        col[i] = ct * 16 + q * 4;
+        wl_off[i] = (unsigned)((ct * KS) * 64 + lane) * 16u;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const size_t tile = (size_t)(d + 1) * NT + ct;
+                Whh[i][ks][d] = *reinterpret_cast<const v4i*>(sg.w_hh + ((tile * KS + ks) * 64 + lane) * 16);
+                Wih[i][ks][d] = *reinterpret_cast<const v4i*>(sg.w_ih + ((tile * KS + ks) * 64 + lane) * 16);
+            }
+        c[i] = *reinterpret_cast<const v4f*>(sg.c_state + (size_t)rowc * H + col[i]);
+    }
+    // input-spike ring: DMA piece k = 64 chunks e = 64k + lane of the 16 x NCH chunks of a step; chunk e sits at LDS byte
+    // 16 e and holds global chunk (e % NCH - e / NCH) mod NCH of row e / NCH (a rotation by the row index).
+    const int piece = (wave & 3) < KS ? (wave & 3) : KS - 1;  // KS pieces; surplus waves repeat the last one (same bytes)
+    const int e = piece * 64 + lane, er = e / NCH, esl = e - er * NCH;
+    const int erow = (row0 + er < R) ? row0 + er : R - 1;
+    const unsigned src_off = (unsigned)(erow * HP + ((esl - er % NCH + NCH) % NCH) * 16);
+    const size_t frame = (size_t)R * HP;
+    auto issue = [&](int slot, int td) __attribute__((always_inline)) {
+        dma16_to_lds(__builtin_amdgcn_readfirstlane((unsigned)(slot * SR_BYTES + piece * 1024)), reinterpret_cast<const float*>(sg.spikes_in + (size_t)td * frame), src_off);
+    };
+    for (int s0 = 0; s0 < D - 1; ++s0) issue(s0, s0 < T ? s0 : (T > 0 ? T - 1 : 0));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    auto step = [&](int t, auto first) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first)::value;
+        const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
+        int8_t* hn = hbuf + ((t & 1) ^ 1) * 16 * LDH;
+        {
+            const int td = (t + D - 1 < T) ? t + D - 1 : T - 1;
+            issue((t + D - 1) % D, td);
+        }
+        v4i bh[KS], bs[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bh[ks] = *reinterpret_cast<const v4i*>(hc + n * LDH + ks * 64 + q * 16);
+        const char* sslot = smem + (t % D) * SR_BYTES + n * HP;
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+            const int cc = col[i];
+            v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4i w0 = *reinterpret_cast<const v4i*>(smem + WHH_OFF + wl_off[i] + (unsigned)(ks * 1024));
+                a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, bh[ks], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[i][ks][0], bh[ks], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[i][ks][1], bh[ks], a2, 0, 0, 0);
+            }
+            if (i == 0) {
+                // under the first tile's MFMA latency: spikes of step t-1 -> global; then this step's input spikes (every
+                // wave's piece of the slot landed before the barrier that ended the previous step, see below)
+                if constexpr (!FIRST) fl.template run<OUT>(hc, sg.spikes_f32, sg.spikes_i8, t - 1, R, H);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) bs[ks] = *reinterpret_cast<const v4i*>(sslot + ((ks * 4 + q + n) % NCH) * 16);
+            }
+            v4i e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0}, e2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4i w0 = *reinterpret_cast<const v4i*>(smem + WIH_OFF + wl_off[i] + (unsigned)(ks * 1024));
+                e0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, bs[ks], e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wih[i][ks][0], bs[ks], e1, 0, 0, 0);
+                e2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wih[i][ks][1], bs[ks], e2, 0, 0, 0);
+            }
+            const v4f bf = *reinterpret_cast<const v4f*>(&cst[0][cc]), db = *reinterpret_cast<const v4f*>(&cst[1][cc]);
+            const v4f alpha = *reinterpret_cast<const v4f*>(&cst[2][cc]), beta = *reinterpret_cast<const v4f*>(&cst[3][cc]);
+            const v4f dqh = *reinterpret_cast<const v4f*>(&cst[4][cc]), dqi = *reinterpret_cast<const v4f*>(&cst[5][cc]);
+            v4f cy;
+            unsigned pk = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = __builtin_fmaf(recombine3(e0[r], e1[r], e2[r]), dqi[r], bf[r]);   // = sfsn_spike_proj's rec*dq + bias
+                const float pre_f = __builtin_fmaf(recombine3(a0[r], a1[r], a2[r]), dqh[r], z);
+                const float pre_g = pre_f + db[r];
+                const float f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre_f * -1.44269504088896341f));
+                const float m = __builtin_fmaf(f, c[i][r] - pre_g, pre_g);
+                const float y = __builtin_fmaf(m, alpha[r], beta[r]);
+                cy[r] = y;
+                pk |= (y >= 0.0f) ? (1u << (8 * r)) : 0u;
+            }
+            c[i] = cy;
+            *reinterpret_cast<unsigned*>(hn + n * LDH + cc) = pk;
+        }
+        // The input-spike slot of step t+1 is read by EVERY wave but filled by several: each wave waits here for its own
+        // piece (issued at the top of step t-1; since then: one more DMA and two steps' flush stores), and the barrier
+        // makes all pieces visible to all.  (The input-term ring of the other scan variant needs no such rendezvous: there
+        // a wave reads only what it loaded itself.)
+        if (t < D || CBASE + fl.nact * CSTRIDE > 63) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            wait_vmcnt_affine<CBASE, CSTRIDE, C::FL>(fl.nact);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+    };
+    __builtin_amdgcn_s_barrier();  // the prologue's pieces (drained above by every wave) are now visible to all
+    if (T > 0) step(0, std::true_type{});
+#pragma unroll 1
+    for (int t = 1; t < T; ++t) step(t, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (T > 0) fl.template run<OUT>(hbuf + (T & 1) * 16 * LDH, sg.spikes_f32, sg.spikes_i8, T - 1, R, H);
+    const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        *reinterpret_cast<v4f*>(sg.c_state + (size_t)rowc * H + col[i]) = c[i];
+        const unsigned pk = *reinterpret_cast<const unsigned*>(hl + n * LDH + col[i]);
+        const v4f h = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)((pk >> 24) & 1u)};
+        *reinterpret_cast<v4f*>(sg.h_state + (size_t)rowc * H + col[i]) = h;
+    }
+}
+
+template <int KS, int OUT>
+__global__ __launch_bounds__(512) void gsn_scan_fused_kernel(const ScanParams p) {
+    using C = ScanCfg<1, KS, 8, 2, OUT, 0>;
+    constexpr int LDH = C::LDH, HP = C::HP, D = 3, NW = 8;
+    constexpr int HBUF_OFF = D * 16 * HP, CST_OFF = HBUF_OFF + 2 * 16 * LDH, WHH_OFF = CST_OFF + 6 * HP * 4;
+    extern __shared__ __attribute__((aligned(16))) char scan_smem[];
+    char* smem = scan_smem;
+    int8_t* hbuf = reinterpret_cast<int8_t*>(smem + HBUF_OFF);
+    float(*cst)[HP] = reinterpret_cast<float(*)[HP]>(smem + CST_OFF);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    int s = 0;
+    for (int i = 1; i < p.nseg; ++i)
+        if ((int)blockIdx.x >= p.seg[i].tile0) s = i;
+    const ScanSegDev sg = p.seg[s];
+    const int H = p.H, NT = p.NT, T = p.T, R = sg.R;
+    const int row0 = ((int)blockIdx.x - sg.tile0) * 16;
+    const int rowc = (row0 + n < R) ? row0 + n : R - 1;
+    for (int j = tid; j < HP; j += NW * 64) {
+        const bool in = j < H;
+        cst[0][j] = in ? sg.bias[j] : 0.0f;
+        cst[1][j] = in ? sg.bias[H + j] - sg.bias[j] : 0.0f;
+        cst[2][j] = in ? sg.bn_alpha[j] : 0.0f;
+        cst[3][j] = in ? sg.bn_beta[j] : 0.0f;
+        cst[4][j] = in ? sg.w_dq[j] : 0.0f;
+        cst[5][j] = in ? sg.w_ih_dq[j] : 0.0f;
+    }
+    for (int i = tid; i < 2 * 16 * LDH / 4; i += NW * 64) reinterpret_cast<int*>(hbuf)[i] = 0;
+    {   // digit plane 0 of both matrices -> LDS, once
+        v4i* d0 = reinterpret_cast<v4i*>(smem + WHH_OFF);
+        v4i* d1 = reinterpret_cast<v4i*>(smem + WHH_OFF + NT * KS * 1024);
+        const v4i* s0 = reinterpret_cast<const v4i*>(sg.w_hh);
+        const v4i* s1 = reinterpret_cast<const v4i*>(sg.w_ih);
+        for (int i = tid; i < NT * KS * 64; i += NW * 64) {
+            d0[i] = s0[i];
+            d1[i] = s1[i];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 16 * (H / 4); idx += NW * 64) {
+        const int rr = idx / (H / 4), j4 = (idx - rr * (H / 4)) * 4;
+        const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;
+        const v4f h = *reinterpret_cast<const v4f*>(sg.h_state + (size_t)rsrc * H + j4);
+        const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
+                            (h.w > 0.5f ? 0x1000000u : 0u);
+        *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
+    }
+    __syncthreads();
+    if (wave < NT - NW)  // waves [0, NT - 8) own two tiles, the others one (8 < NT <= 16)
+        fused_body<KS, OUT, 2>(sg, smem, T, H, NT, R, row0, rowc, n, q, tid, wave);
+    else
+        fused_body<KS, OUT, 1>(sg, smem, T, H, NT, R, row0, rowc, n, q, tid, wave);
 }
 
 // ---- streamed-weights scan: the shapes whose W_hh cannot live in one CU (unshared gates with H > 256: baseline_xl's
@@ -1723,6 +1925,48 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
         SCAN_CASE(2, 1, 16, 1, 0) SCAN_CASE(2, 2, 16, 1, 0) SCAN_CASE(2, 3, 8, 2, 0) SCAN_CASE(2, 4, 8, 2, 0)
     }
 #undef SCAN_CASE
+    return SFSN_EUNSUPPORTED;
+}
+
+extern "C" int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, int n_segs, int T, int H,
+                                         void* stream) {
+    if (!segs || !fin || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0) return SFSN_EINVAL;
+    if (H % 16 != 0 || H <= 128 || H > 256) return SFSN_EUNSUPPORTED;  // two output tiles per wave: 8 < H/16 <= 16
+    ScanParams p;
+    p.rpw = 16;
+    int tiles = 0;
+    const int out = 2 | (segs[0].spikes_f32 ? 1 : 0);
+    for (int i = 0; i < n_segs; ++i) {
+        const sfsn_scan_segment& s = segs[i];
+        if (!s.spikes_i8 || (s.spikes_f32 != nullptr) != ((out & 1) != 0) || s.membrane) return SFSN_EINVAL;
+        if (s.R <= 0 || !fin[i].spikes_in || !fin[i].w_ih || !fin[i].w_ih_dq || !s.w_hh || !s.w_dq || !s.bias || !s.bn_alpha ||
+            !s.bn_beta || !s.h_state || !s.c_state)
+            return SFSN_EINVAL;
+        if (!aligned16(fin[i].spikes_in) || !aligned16(fin[i].w_ih) || !aligned16(s.w_hh) || !aligned16(s.h_state) ||
+            !aligned16(s.c_state) || !aligned16(s.spikes_f32) || !aligned16(s.spikes_i8))
+            return SFSN_EINVAL;
+        ScanSegDev& d = p.seg[i];
+        d.zin = nullptr; d.w_hh = s.w_hh; d.w_dq = s.w_dq; d.bias = s.bias; d.bn_alpha = s.bn_alpha; d.bn_beta = s.bn_beta;
+        d.h_state = s.h_state; d.c_state = s.c_state; d.spikes_f32 = s.spikes_f32; d.spikes_i8 = s.spikes_i8;
+        d.membrane = nullptr; d.R = s.R; d.tile0 = tiles;
+        d.spikes_in = fin[i].spikes_in; d.w_ih = fin[i].w_ih; d.w_ih_dq = fin[i].w_ih_dq;
+        tiles += (s.R + 15) / 16;
+    }
+    p.nseg = n_segs; p.T = T; p.H = H; p.NT = H / 16;
+    const int KS = (H + 63) / 64, HP = KS * 64;
+    const int lds = 3 * 16 * HP + 2 * 16 * (HP + 32) + 6 * HP * 4 + 2 * p.NT * KS * 1024;
+    if (lds > 160 * 1024) return SFSN_EUNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define FUSED_CASE(KS_, OUT_)                                                                                              \
+    if (KS == KS_ && out == OUT_) {                                                                                        \
+        auto kern = gsn_scan_fused_kernel<KS_, OUT_>;                                                                      \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
+            return SFSN_EHIP;                                                                                              \
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, st, p);                                                      \
+        return hip_ok(hipGetLastError());                                                                                  \
+    }
+    FUSED_CASE(3, 2) FUSED_CASE(3, 3) FUSED_CASE(4, 2) FUSED_CASE(4, 3)
+#undef FUSED_CASE
     return SFSN_EUNSUPPORTED;
 }
 

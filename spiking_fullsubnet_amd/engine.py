@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CountTensor, DfGroup, FeatureGroup, ScanSegment, check
+from ._lib import CountTensor, DfGroup, FeatureGroup, FusedInput, ScanSegment, check
 
 
 @dataclass
@@ -211,6 +211,7 @@ class Engine:
         self.timers: Optional[dict] = None  # set to {} to record HIP events around each launch group (bench.py)
         self.seq_chunk = 0  # frames per chunk of the single-stream schedule (0 = whole sequence per launch)
         self.rows_per_wg = (0, 0)  # (full-band, sub-band) rows per scan workgroup; 0 = let the library spread over all CUs
+        self.fuse_input = True  # layers >= 1: input term inside the scan where the geometry allows it (see _fusable)
         self.timer_tags = None  # optional set of tags to time (each timed group costs ~10 us of launch gap)
         self._stream_objs: Dict[int, torch.cuda.Stream] = {}
         self._side: List[torch.cuda.Stream] = []
@@ -307,6 +308,32 @@ class Engine:
             sg.R = R
         with self.timed("scan:" + tag, st):
             check(L.sfsn_gsn_layer_scan(segs, len(seqs), nt, H, int(spec.shared), rpw, st), "sfsn_gsn_layer_scan")
+
+    def _fusable(self, seqs, rpw, want_membrane) -> bool:
+        """Layers >= 1 can take their input term inside the scan (sfsn_gsn_layer_scan_fused): shared gates, 128 < H <= 256,
+        16 rows per workgroup -- the launch geometry of a full chip, where the scan is HBM-bound and the saved round trip of
+        the fp32 input term is pure gain; with 4 rows per workgroup (one forward alone) the doubled MFMA work would cost more."""
+        return bool(self.fuse_input and self.spec.shared and 128 < seqs[0].H <= 256 and rpw == 16 and not want_membrane)
+
+    def _stage_scan_fused(self, seqs, l, states, spks, s8s, t0, nt, st, tag):
+        L = self.lib
+        H = seqs[0].H
+        HP = (H + 63) // 64 * 64
+        segs = (ScanSegment * len(seqs))()
+        fin = (FusedInput * len(seqs))()
+        for i, seq in enumerate(seqs):
+            cell, sg, R = seq.cells[l], segs[i], s8s[l][i].shape[1]
+            pk, dq = cell.w_ih_q[0]
+            sg.zin, sg.w_hh, sg.w_dq, sg.bias = None, _ptr(cell.w_hh_q), _ptr(cell.w_hh_dq), _ptr(cell.bias)
+            sg.bn_alpha, sg.bn_beta, sg.h_state, sg.c_state = _ptr(cell.alpha), _ptr(cell.beta), _ptr(states[i][0]), _ptr(states[i][1])
+            sg.spikes_f32 = None if spks[i] is None else ctypes.c_void_p(spks[i].data_ptr() + t0 * R * H * 4)
+            sg.membrane = None
+            sg.spikes_i8 = ctypes.c_void_p(s8s[l][i].data_ptr() + t0 * R * HP)
+            sg.R = R
+            fin[i].spikes_in = s8s[l - 1][i].data_ptr() + t0 * R * HP
+            fin[i].w_ih, fin[i].w_ih_dq = pk.data_ptr(), dq.data_ptr()
+        with self.timed("scan:" + tag, st):
+            check(L.sfsn_gsn_layer_scan_fused(segs, fin, len(seqs), nt, H, st), "sfsn_gsn_layer_scan_fused")
 
     def _stage_proj(self, seqs, s8s, projs, t0, nt, st, tag):
         L = self.lib
@@ -538,6 +565,7 @@ class Engine:
         # per-chunk completion events of the producers the next model / layer gates on
         def run_model(seqs, d, xs_, first, feat_fn, tag, rpw, post_fn, gate_events):
             nl = len(seqs[0].cells)
+            fused = self._fusable(seqs, rpw, want_membrane)
             done = []
             for c, (t0, nt) in enumerate(bounds):
                 for l in range(nl):
@@ -548,11 +576,16 @@ class Engine:
                             g.wait_event(gate_events[c])
                         feat_fn(t0, nt, hG[si])
                         self._stage_input(seqs, 0, xs_, d["zin"][0], t0, nt, hG[si], tag)
-                    else:
+                    elif fused:
                         link(sstreams[si - 1], g)  # previous layer's scan of this chunk
+                    else:
+                        link(sstreams[si - 1], g)
                         self._stage_input(seqs, l, d["s8"][l - 1], d["zin"][l], t0, nt, hG[si], tag)
                     link(g, sc)
-                    self._stage_scan(seqs, l, d["zin"][l], d["states"][l], d["spk"][l], d["s8"][l], d["mem"][l], t0, nt, hS[si], tag, rpw)
+                    if l > 0 and fused:
+                        self._stage_scan_fused(seqs, l, d["states"][l], d["spk"][l], d["s8"], t0, nt, hS[si], tag)
+                    else:
+                        self._stage_scan(seqs, l, d["zin"][l], d["states"][l], d["spk"][l], d["s8"][l], d["mem"][l], t0, nt, hS[si], tag, rpw)
                     if pipeline:
                         link(sc, g)  # the chunk-local zin buffer is reused by the next chunk's input product
                     if l == nl - 1:

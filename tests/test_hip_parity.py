@@ -587,6 +587,31 @@ def test_stft_kernels_on_the_golden_edges_and_errors():
         spectral.istft(torch.zeros((1, 129, 10), dtype=torch.complex64, device=DEV), 512, 128)
 
 
+@pytest.mark.parametrize("front,kw,seed", [("live", rw.LIVE_M, 5), ("frozen", rw.FROZEN_S, 6), ("frozen", rw.FROZEN_L, 9),
+                                           ("live", rw.LIVE_TINY_2SPK, 8)])
+def test_fused_input_scan_is_bit_identical(front, kw, seed):
+    """sfsn_gsn_layer_scan_fused (layers >= 1 compute x.W_ih^T + b inside the scan from the previous layer's int8 spikes) ==
+    sfsn_spike_proj + sfsn_gsn_layer_scan, bit for bit, for every tensor the module returns: hidden sizes 224 / 240 / 160 /
+    256 (four and three 64-wide k steps, 14 / 15 / 10 / 16 output tiles), ragged row counts, state carried over chunks."""
+    sd = rw.live_state_dict(kw, seed) if front == "live" else rw.frozen_state_dict(kw, seed)
+    model = build_module(front, kw, sd)
+    wave = torch.from_numpy(rw.synth_wave(3, 70, seed)).to(DEV)
+    stft = model._stft(wave)
+    eng = model.engine()
+    eng.rows_per_wg = (16, 16)
+    outs = []
+    for fuse, chunk in ((False, 0), (True, 0), (True, 32)):
+        eng.fuse_input, eng.seq_chunk = fuse, chunk
+        outs.append(eng.forward_stft(stft))
+        torch.cuda.synchronize()
+    eng.fuse_input, eng.seq_chunk, eng.rows_per_wg = True, 0, (0, 0)
+    a = outs[0]
+    for b in outs[1:]:
+        assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(b["enh_stft"]))
+        for x, y in zip(a["fb_all"] + sum(a["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])):
+            assert torch.equal(x, y)
+
+
 def spec_units(spec, g):
     return (spec["cutoffs"][g + 1] - spec["cutoffs"][g]) // spec["ctr"][g]
 
