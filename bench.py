@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--time-all", action="store_true", help="HIP-event time every launch group, not only the dominant kernel")
     ap.add_argument("--seq-chunk", type=int, default=0, help="frames per chunk of the single-stream schedule")
     ap.add_argument("--rpw", type=str, default="", help="rows per scan workgroup 'fb,sb' (0 = auto)")
-    ap.add_argument("--inflight", type=int, default=8, help="forwards in flight on separate HIP streams (batch-level pipelining)")
+    ap.add_argument("--inflight", type=int, default=12, help="forwards in flight on separate HIP streams (batch-level pipelining)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per pipeline chunk (default: engine default)")
     ap.add_argument("--no-saturated", action="store_true", help="skip the 4x-rows launch of the dominant kernel (roofline.saturated)")
     ap.add_argument("--streaming", action="store_true", help="BASELINE configs[4]: frame-by-frame session, per-call latency (own JSON line)")
