@@ -1960,8 +1960,12 @@ extern "C" int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs, const sf
 #define FUSED_CASE(KS_, OUT_)                                                                                              \
     if (KS == KS_ && out == OUT_) {                                                                                        \
         auto kern = gsn_scan_fused_kernel<KS_, OUT_>;                                                                      \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
-            return SFSN_EHIP;                                                                                              \
+        static int raised = 0; /* idempotent attribute, raised to the largest size seen (not a stream operation) */        \
+        if (lds > raised) {                                                                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
+                return SFSN_EHIP;                                                                                          \
+            raised = lds;                                                                                                  \
+        }                                                                                                                  \
         hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, st, p);                                                      \
         return hip_ok(hipGetLastError());                                                                                  \
     }
