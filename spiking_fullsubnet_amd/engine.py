@@ -266,7 +266,7 @@ class Engine:
     def _workspace(self, key, make):
         ws = self._ws.get(key)
         if ws is None:
-            if len(self._ws) > 8:
+            if len(self._ws) > 64:  # (tag, geometry, stream): a dozen forwards in flight hold two entries each
                 self._ws.clear()
             ws = self._ws[key] = make()
         return ws
