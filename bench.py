@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--rpw", type=str, default="", help="rows per scan workgroup 'fb,sb' (0 = auto)")
     ap.add_argument("--inflight", type=int, default=12, help="forwards in flight on separate HIP streams (batch-level pipelining)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per pipeline chunk (default: engine default)")
+    ap.add_argument("--no-phase-a", action="store_true", help="skip the single-stream phase (no roofline object): profiling runs of the timed region alone")
     ap.add_argument("--no-saturated", action="store_true", help="skip the 4x-rows launch of the dominant kernel (roofline.saturated)")
     ap.add_argument("--streaming", action="store_true", help="BASELINE configs[4]: frame-by-frame session, per-call latency (own JSON line)")
     ap.add_argument("--hop", type=int, default=1, help="frames per streaming call")
@@ -154,10 +155,14 @@ def main():
     eng.rows_per_wg = (0, 0)
     eng.timers, eng.timer_tags = {}, (None if args.time_all else {"scan:sb"})
     ka = max(2, min(args.steps, 8))
-    dt_a = timed_region(forward, ka, min(args.warmup, 2) + 1)
-    scan_ms = eng.timer_summary()
+    if args.no_phase_a:
+        scan_ms, single = {}, None
+        args.no_saturated = True
+    else:
+        dt_a = timed_region(forward, ka, min(args.warmup, 2) + 1)
+        scan_ms = eng.timer_summary()
+        single = dict(ms_per_step=round(1e3 * dt_a / ka, 4), value=round(world * B * T * ka / dt_a, 1), steps=ka)
     eng.timers = None
-    single = dict(ms_per_step=round(1e3 * dt_a / ka, 4), value=round(world * B * T * ka / dt_a, 1), steps=ka)
 
     # ---- the same kernel with the chip full (untimed for `value`): at B=64 a sub-band scan launch is 208 workgroups of 4 rows,
     #      a latency-bound chain per workgroup; four times the rows (16 per workgroup, same 208 workgroups) shows what the

@@ -14,5 +14,9 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_IN
   tag=$(echo $c | cut -d' ' -f1)
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$tag -o p -- python bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-saturated > $OUT/pmc_$tag.log 2>&1
 done
+# (4) HBM traffic of one forward as the timed region runs it (sub-band scans at 16 rows per workgroup, fused-input layer 2)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/job_$c -o p -- python bench.py --no-phase-a --inflight 1 --rpw 4,16 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/job_$c.log 2>&1
+done
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -1 $OUT/bench_default.json

@@ -41,12 +41,13 @@ def counts(fn):
         if key not in seen:
             seen.add(key); c[r["Kernel_Name"]] += 1
     return c
-cf = counts(f"{base}/pmc_FETCH_SIZE/p_counter_collection.csv")
+jf, jw = agg(f"{base}/job_FETCH_SIZE/p_counter_collection.csv"), agg(f"{base}/job_WRITE_SIZE/p_counter_collection.csv")
+cf = counts(f"{base}/job_FETCH_SIZE/p_counter_collection.csv")
 n_fwd = max(v for kk, v in cf.items() if "deepfilter" in kk)
 job = 0.0
 for kk, v in cf.items():
     if any(t in kk for t in ("gsn_scan", "spike_proj", "input_proj", "features", "deepfilter", "rowsum", "laplace", "spike_count")):
-        job += (2 * f[kk].get("FETCH_SIZE", 0) + w.get(kk, {}).get("WRITE_SIZE", 0)) * 1024 * v / n_fwd
+        job += (2 * jf[kk].get("FETCH_SIZE", 0) + jw.get(kk, {}).get("WRITE_SIZE", 0)) * 1024 * v / n_fwd
 k = [x for x in f if "gsn_scan_kernel<1, 4, 16" in x][0]
 tr = dict(B=64, T=1000, kernel=k, fetch_size_KiB=f[k]["FETCH_SIZE"], write_size_KiB=w[k]["WRITE_SIZE"],
           sb_scan_hbm_bytes_per_launch=int(2 * f[k]["FETCH_SIZE"] * 1024 + w[k]["WRITE_SIZE"] * 1024),
