@@ -604,12 +604,24 @@ def test_fused_input_scan_is_bit_identical(front, kw, seed):
         eng.fuse_input, eng.seq_chunk = fuse, chunk
         outs.append(eng.forward_stft(stft))
         torch.cuda.synchronize()
+    lean = []
+    for fuse in (False, True):  # the int8-only kernel variants (no fp32 spike tensors): counts mode
+        eng.fuse_input, eng.seq_chunk = fuse, 0
+        lean.append(eng.forward_stft(stft, want_layers=False, want_counts=True))
+        torch.cuda.synchronize()
     eng.fuse_input, eng.seq_chunk, eng.rows_per_wg = True, 0, (0, 0)
     a = outs[0]
     for b in outs[1:]:
         assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(b["enh_stft"]))
         for x, y in zip(a["fb_all"] + sum(a["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])):
             assert torch.equal(x, y)
+    for b in lean:
+        assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(b["enh_stft"]))
+        for x, y in zip(a["fb_all"] + sum(a["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])):
+            if torch.is_tensor(y):
+                assert torch.equal(x, y)
+            else:
+                assert int(y.count.item()) == int((x > 0).sum().item())
 
 
 def spec_units(spec, g):
