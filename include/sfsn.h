@@ -127,6 +127,18 @@ typedef struct sfsn_fused_input {
 int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs /* host */, const sfsn_fused_input* fin /* host, one per segment */,
                               int n_segs, int T, int H, void* stream);
 
+/* Layer-0 twin: the real-valued input product inside the scan (bf16 3-way split, bit-identical to sfsn_input_proj_f32 +
+ * sfsn_gsn_layer_scan).  Same restrictions as above plus: I even, I <= 64, R % 16 == 0, x 16-byte aligned.  All segments of
+ * a launch see the same LDS layout only if they share I: the slot size is taken from each segment's own I. */
+typedef struct sfsn_fused_x {
+    const float* x;    /* [T][R][I] the layer input (sfsn_features' output) */
+    const float* w_ih; /* [H][I] fp32 input weights, row-major              */
+    int I;
+} sfsn_fused_x;
+
+int sfsn_gsn_layer_scan_fused_x(const sfsn_scan_segment* segs /* host */, const sfsn_fused_x* fin /* host, one per segment */,
+                                int n_segs, int T, int H, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Time-parallel products.
  * sfsn_input_proj_f32: z[m][n] = sum_k x[m][k] * w[n][k] (+ bias[n])  (NEURON:141-142 for layer 0: real-valued x)

@@ -31,6 +31,10 @@ class FusedInput(ctypes.Structure):
     _fields_ = [("spikes_in", _P), ("w_ih", _P), ("w_ih_dq", _P)]
 
 
+class FusedX(ctypes.Structure):
+    _fields_ = [("x", _P), ("w_ih", _P), ("I", _I)]
+
+
 class FeatureGroup(ctypes.Structure):
     _fields_ = [("x", _P), ("ln_w", _P), ("ln_b", _P), ("mu", _P), ("lo", _I), ("n_units", _I), ("ctr", _I), ("nbr", _I),
                 ("ctr_fb", _I), ("nbr_fb", _I), ("norm", _I), ("ln_eps", _F)]
@@ -86,6 +90,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_gsn_layer_scan.argtypes = [ctypes.POINTER(ScanSegment), _I, _I, _I, _I, _I, _P]
     L.sfsn_gsn_layer_scan_fused.restype = _I
     L.sfsn_gsn_layer_scan_fused.argtypes = [ctypes.POINTER(ScanSegment), ctypes.POINTER(FusedInput), _I, _I, _I, _P]
+    L.sfsn_gsn_layer_scan_fused_x.restype = _I
+    L.sfsn_gsn_layer_scan_fused_x.argtypes = [ctypes.POINTER(ScanSegment), ctypes.POINTER(FusedX), _I, _I, _I, _P]
     L.sfsn_input_proj_f32.restype = _I
     L.sfsn_input_proj_f32.argtypes = [_P, _P, _P, _P, _I, _I, _I, _I, _P]
     L.sfsn_spike_proj.restype = _I
@@ -109,7 +115,7 @@ def lib() -> ctypes.CDLL:
 
 
 EXPORTS = ("sfsn_abi_version", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
-           "sfsn_w3_pack", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
+           "sfsn_w3_pack", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
            "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
 
 

@@ -48,6 +48,10 @@ struct ScanSegDev {
     const int8_t* spikes_in;
     const int8_t* w_ih;
     const float* w_ih_dq;
+    // fused real-valued input (layer 0): the feature rows and the fp32 input weights
+    const float* x_in;
+    const float* w_ih_f32;
+    int I;
 };
 
 struct ScanParams {
@@ -1329,6 +1333,243 @@ __global__ __launch_bounds__(512) void input_proj_bf3_kernel(const float* __rest
     }
 }
 
+// ---- fused real-valued input scan (layer 0 of a group with narrow feature rows: baseline_m group 0, 8 units x 38) ----------------
+// The layer-0 twin of gsn_scan_fused_kernel: the input term x.W_ih^T + b is computed inside the scan, here from the fp32
+// feature rows with the bf16 3-way split of input_proj_bf3_kernel (same six products per 32 k, same two accumulators, same
+// final (hi + lo) + b: bit-identical to sfsn_input_proj_f32 + sfsn_gsn_layer_scan).  W_ih pieces live in registers (I <= 64:
+// 2 tiles x 2 k-steps x 3 pieces x 4 VGPRs), W_hh as in the fused-input scan (plane 0 in LDS, 1-2 in registers).  The 16
+// feature rows of a step are one contiguous block (16 x I floats): it arrives by LDS-DMA, and the wave that fetched a piece
+// converts that same piece -- after its own wait, before the step barrier -- into the three bf16 planes the B fragments
+// are read from (double-buffered), so no extra rendezvous is needed.  Needs R % 16 == 0 (a block is copied flat).
+template <int KS, int OUT, int NTL>
+__device__ __forceinline__ void fusedx_body(const ScanSegDev& sg, char* smem, int T, int H, int NT, int R, int row0, int rowc, int n,
+                                            int q, int tid, int wave) {
+    using C = ScanCfg<1, KS, 8, 2, OUT, 0>;
+    constexpr int LDH = C::LDH, HP = C::HP, D = 3, NW = 8, KSB = 2, LDX = KSB * 32 + 8;
+    const int I = sg.I;
+    const int xbytes = 16 * I * 4;                              // one step's feature block
+    const int XSLOT = (xbytes + 1023) & ~1023;                  // ring slot (whole 1 KB DMA pieces)
+    constexpr int PL_BYTES = 16 * LDX * 2;                      // one bf16 plane of 16 rows
+    const int PLANES_OFF = D * XSLOT, HBUF_OFF = PLANES_OFF + 2 * 3 * PL_BYTES;
+    const int CST_OFF = HBUF_OFF + 2 * 16 * LDH, WHH_OFF = CST_OFF + 5 * HP * 4;
+    int8_t* hbuf = reinterpret_cast<int8_t*>(smem + HBUF_OFF);
+    const float(*cst)[HP] = reinterpret_cast<const float(*)[HP]>(smem + CST_OFF);  // b_f, b_g - b_f, alpha, beta, dq_hh
+    ScanFlush<C> fl;
+    fl.init(tid, row0, R, H, NW * 64, 16);
+    const int lane = tid & 63;
+    constexpr int CBASE = (D - 2) * 1, CSTRIDE = (D - 1) * C::NSTF;
+
+    v4i Whh[NTL][KS][2];
+    bf8 Wx[NTL][KSB][3];
+    v4f c[NTL];
+    int col[NTL];
+    unsigned wl_off[NTL];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        const int ct = wave + NW * i;
+        col[i] = ct * 16 + q * 4;
+        wl_off[i] = (unsigned)((ct * KS) * 64 + lane) * 16u;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const size_t tile = (size_t)(d + 1) * NT + ct;
+                Whh[i][ks][d] = *reinterpret_cast<const v4i*>(sg.w_hh + ((tile * KS + ks) * 64 + lane) * 16);
+            }
+        const int wr = ct * 16 + n;  // A fragment: lane holds 8 consecutive k of weight row wr (as input_proj_bf3_kernel)
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks) {
+            unsigned pw[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = ks * 32 + q * 8 + 2 * e;
+                const float a = (wr < H && k < I) ? sg.w_ih_f32[(size_t)wr * I + k] : 0.0f;
+                const float b = (wr < H && k + 1 < I) ? sg.w_ih_f32[(size_t)wr * I + k + 1] : 0.0f;
+                split3(a, b, pw[0][e], pw[1][e], pw[2][e]);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) Wx[i][ks][pl] = *reinterpret_cast<const bf8*>(pw[pl]);
+        }
+        c[i] = *reinterpret_cast<const v4f*>(sg.c_state + (size_t)rowc * H + col[i]);
+    }
+    // feature ring: DMA piece p = 64 16-byte chunks of the step's flat block; the wave that fetches piece p also converts it
+    const int nchunk = 4 * I;                                  // 16 * I floats / 4
+    const int npiece = (nchunk + 63) >> 6;
+    const int piece = (wave < npiece) ? wave : npiece - 1;     // surplus waves repeat the last piece (same bytes, same writes)
+    int chunk = piece * 64 + lane;
+    if (chunk > nchunk - 1) chunk = nchunk - 1;                // surplus lanes repeat the last chunk
+    const unsigned src_off = (unsigned)chunk * 16u;
+    const size_t frame = (size_t)R * I;                        // floats per step of this segment
+    const float* xbase = sg.x_in + (size_t)row0 * I;
+    // my four floats of the block: flat index 4 chunk + j -> (row, k) -> bf16 index in a plane
+    int poff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = 4 * chunk + j, rr = f / I, k = f - rr * I;
+        poff[j] = rr * LDX + k;
+    }
+    // the DMA of a surplus lane lands at its OWN lds slot (piece * 1024 + lane * 16) but carries the clamped chunk: read it there
+    const int my_lds = piece * 1024 + lane * 16;
+    auto issue = [&](int slot, int td) __attribute__((always_inline)) {
+        dma16_to_lds(__builtin_amdgcn_readfirstlane((unsigned)(slot * XSLOT + piece * 1024)), xbase + (size_t)td * frame, src_off);
+    };
+    auto convert = [&](int slot, int buf) __attribute__((always_inline)) {  // my piece of ring slot -> bf16 planes[buf]
+        const v4f v = *reinterpret_cast<const v4f*>(smem + slot * XSLOT + my_lds);
+        unsigned short* pl = reinterpret_cast<unsigned short*>(smem + PLANES_OFF + buf * 3 * PL_BYTES);
+        unsigned p1[2], p2[2], p3[2];
+        split3(v[0], v[1], p1[0], p2[0], p3[0]);
+        split3(v[2], v[3], p1[1], p2[1], p3[1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sh = (j & 1) * 16;
+            pl[poff[j]] = (unsigned short)(p1[j >> 1] >> sh);
+            pl[PL_BYTES / 2 + poff[j]] = (unsigned short)(p2[j >> 1] >> sh);
+            pl[2 * (PL_BYTES / 2) + poff[j]] = (unsigned short)(p3[j >> 1] >> sh);
+        }
+    };
+    for (int s0 = 0; s0 < D - 1; ++s0) issue(s0, s0 < T ? s0 : (T > 0 ? T - 1 : 0));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    convert(0, 0);  // step 0's features (my piece; the barrier below publishes everybody's)
+
+    auto step = [&](int t, auto first) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first)::value;
+        const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
+        int8_t* hn = hbuf + ((t & 1) ^ 1) * 16 * LDH;
+        {
+            const int td = (t + D - 1 < T) ? t + D - 1 : T - 1;
+            issue((t + D - 1) % D, td);
+        }
+        v4i bh[KS];
+        bf8 bx[KSB][3];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bh[ks] = *reinterpret_cast<const v4i*>(hc + n * LDH + ks * 64 + q * 16);
+        const char* pbase = smem + PLANES_OFF + (t & 1) * 3 * PL_BYTES + (n * LDX + q * 8) * 2;
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bx[ks][pl] = *reinterpret_cast<const bf8*>(pbase + pl * PL_BYTES + ks * 64);
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+            const int cc = col[i];
+            v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4i w0 = *reinterpret_cast<const v4i*>(smem + WHH_OFF + wl_off[i] + (unsigned)(ks * 1024));
+                a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, bh[ks], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[i][ks][0], bh[ks], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[i][ks][1], bh[ks], a2, 0, 0, 0);
+            }
+            if (i == 0) {
+                if constexpr (!FIRST) fl.template run<OUT>(hc, sg.spikes_f32, sg.spikes_i8, t - 1, R, H);
+            }
+            v4f hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KSB; ++ks) {  // the product sequence of input_proj_bf3_kernel, instruction for instruction
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wx[i][ks][2], bx[ks][0], lo, 0, 0, 0);
+                hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wx[i][ks][0], bx[ks][0], hi, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wx[i][ks][1], bx[ks][1], lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wx[i][ks][0], bx[ks][2], lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wx[i][ks][1], bx[ks][0], lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wx[i][ks][0], bx[ks][1], lo, 0, 0, 0);
+            }
+            const v4f bf = *reinterpret_cast<const v4f*>(&cst[0][cc]), db = *reinterpret_cast<const v4f*>(&cst[1][cc]);
+            const v4f alpha = *reinterpret_cast<const v4f*>(&cst[2][cc]), beta = *reinterpret_cast<const v4f*>(&cst[3][cc]);
+            const v4f dqh = *reinterpret_cast<const v4f*>(&cst[4][cc]);
+            v4f cy;
+            unsigned pk = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = (hi[r] + lo[r]) + bf[r];  // = input_proj_bf3_kernel's epilogue
+                const float pre_f = __builtin_fmaf(recombine3(a0[r], a1[r], a2[r]), dqh[r], z);
+                const float pre_g = pre_f + db[r];
+                const float f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre_f * -1.44269504088896341f));
+                const float m = __builtin_fmaf(f, c[i][r] - pre_g, pre_g);
+                const float y = __builtin_fmaf(m, alpha[r], beta[r]);
+                cy[r] = y;
+                pk |= (y >= 0.0f) ? (1u << (8 * r)) : 0u;
+            }
+            c[i] = cy;
+            *reinterpret_cast<unsigned*>(hn + n * LDH + cc) = pk;
+        }
+        // my piece of step t+1's features has landed after this wait; convert it into the other plane buffer (nobody reads
+        // that one during step t); the barrier publishes the planes and the new hidden state together
+        if (t < D || CBASE + fl.nact * CSTRIDE > 63) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            wait_vmcnt_affine<CBASE, CSTRIDE, C::FL>(fl.nact);
+        }
+        convert((t + 1) % D, (t + 1) & 1);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+    };
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    if (T > 0) step(0, std::true_type{});
+#pragma unroll 1
+    for (int t = 1; t < T; ++t) step(t, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (T > 0) fl.template run<OUT>(hbuf + (T & 1) * 16 * LDH, sg.spikes_f32, sg.spikes_i8, T - 1, R, H);
+    const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        *reinterpret_cast<v4f*>(sg.c_state + (size_t)rowc * H + col[i]) = c[i];
+        const unsigned pk = *reinterpret_cast<const unsigned*>(hl + n * LDH + col[i]);
+        const v4f h = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)((pk >> 24) & 1u)};
+        *reinterpret_cast<v4f*>(sg.h_state + (size_t)rowc * H + col[i]) = h;
+    }
+}
+
+template <int KS, int OUT>
+__global__ __launch_bounds__(512) void gsn_scan_fusedx_kernel(const ScanParams p) {
+    using C = ScanCfg<1, KS, 8, 2, OUT, 0>;
+    constexpr int LDH = C::LDH, HP = C::HP, D = 3, NW = 8, LDX = 2 * 32 + 8, PL_BYTES = 16 * LDX * 2;
+    extern __shared__ __attribute__((aligned(16))) char scan_smem[];
+    char* smem = scan_smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    int s = 0;
+    for (int i = 1; i < p.nseg; ++i)
+        if ((int)blockIdx.x >= p.seg[i].tile0) s = i;
+    const ScanSegDev sg = p.seg[s];
+    const int H = p.H, NT = p.NT, T = p.T, R = sg.R;
+    const int XSLOT = (16 * sg.I * 4 + 1023) & ~1023;
+    const int PLANES_OFF = D * XSLOT, HBUF_OFF = PLANES_OFF + 2 * 3 * PL_BYTES, CST_OFF = HBUF_OFF + 2 * 16 * LDH, WHH_OFF = CST_OFF + 5 * HP * 4;
+    int8_t* hbuf = reinterpret_cast<int8_t*>(smem + HBUF_OFF);
+    float(*cst)[HP] = reinterpret_cast<float(*)[HP]>(smem + CST_OFF);
+    const int row0 = ((int)blockIdx.x - sg.tile0) * 16;
+    const int rowc = row0 + n;  // R % 16 == 0: every row of the tile exists
+    for (int j = tid; j < HP; j += NW * 64) {
+        const bool in = j < H;
+        cst[0][j] = in ? sg.bias[j] : 0.0f;
+        cst[1][j] = in ? sg.bias[H + j] - sg.bias[j] : 0.0f;
+        cst[2][j] = in ? sg.bn_alpha[j] : 0.0f;
+        cst[3][j] = in ? sg.bn_beta[j] : 0.0f;
+        cst[4][j] = in ? sg.w_dq[j] : 0.0f;
+    }
+    for (int i = tid; i < 2 * 16 * LDH / 4; i += NW * 64) reinterpret_cast<int*>(hbuf)[i] = 0;
+    for (int i = tid; i < 2 * 3 * PL_BYTES / 4; i += NW * 64) reinterpret_cast<int*>(smem + PLANES_OFF)[i] = 0;  // k >= I stays zero
+    {
+        v4i* d0 = reinterpret_cast<v4i*>(smem + WHH_OFF);
+        const v4i* s0 = reinterpret_cast<const v4i*>(sg.w_hh);
+        for (int i = tid; i < NT * KS * 64; i += NW * 64) d0[i] = s0[i];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 16 * (H / 4); idx += NW * 64) {
+        const int rr = idx / (H / 4), j4 = (idx - rr * (H / 4)) * 4;
+        const v4f h = *reinterpret_cast<const v4f*>(sg.h_state + (size_t)(row0 + rr) * H + j4);
+        const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
+                            (h.w > 0.5f ? 0x1000000u : 0u);
+        *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
+    }
+    __syncthreads();
+    if (wave < NT - NW)
+        fusedx_body<KS, OUT, 2>(sg, smem, T, H, NT, R, row0, rowc, n, q, tid, wave);
+    else
+        fusedx_body<KS, OUT, 1>(sg, smem, T, H, NT, R, row0, rowc, n, q, tid, wave);
+}
+
 // =====================================================================================================
 // feature prologue
 // =====================================================================================================
@@ -1971,6 +2212,56 @@ extern "C" int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs, const sf
     }
     FUSED_CASE(3, 2) FUSED_CASE(3, 3) FUSED_CASE(4, 2) FUSED_CASE(4, 3)
 #undef FUSED_CASE
+    return SFSN_EUNSUPPORTED;
+}
+
+extern "C" int sfsn_gsn_layer_scan_fused_x(const sfsn_scan_segment* segs, const sfsn_fused_x* fin, int n_segs, int T, int H,
+                                           void* stream) {
+    if (!segs || !fin || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0) return SFSN_EINVAL;
+    if (H % 16 != 0 || H <= 128 || H > 256) return SFSN_EUNSUPPORTED;
+    ScanParams p;
+    p.rpw = 16;
+    int tiles = 0, imax = 0;
+    const int out = 2 | (segs[0].spikes_f32 ? 1 : 0);
+    for (int i = 0; i < n_segs; ++i) {
+        const sfsn_scan_segment& s = segs[i];
+        if (!s.spikes_i8 || (s.spikes_f32 != nullptr) != ((out & 1) != 0) || s.membrane) return SFSN_EINVAL;
+        if (s.R <= 0 || !fin[i].x || !fin[i].w_ih || !s.w_hh || !s.w_dq || !s.bias || !s.bn_alpha || !s.bn_beta || !s.h_state ||
+            !s.c_state)
+            return SFSN_EINVAL;
+        if (fin[i].I <= 0 || fin[i].I > 64 || fin[i].I % 2 != 0 || s.R % 16 != 0) return SFSN_EUNSUPPORTED;
+        if (!aligned16(fin[i].x) || !aligned16(s.w_hh) || !aligned16(s.h_state) || !aligned16(s.c_state) || !aligned16(s.spikes_f32) ||
+            !aligned16(s.spikes_i8))
+            return SFSN_EINVAL;
+        ScanSegDev& d = p.seg[i];
+        d.zin = nullptr; d.w_hh = s.w_hh; d.w_dq = s.w_dq; d.bias = s.bias; d.bn_alpha = s.bn_alpha; d.bn_beta = s.bn_beta;
+        d.h_state = s.h_state; d.c_state = s.c_state; d.spikes_f32 = s.spikes_f32; d.spikes_i8 = s.spikes_i8;
+        d.membrane = nullptr; d.R = s.R; d.tile0 = tiles;
+        d.spikes_in = nullptr; d.w_ih = nullptr; d.w_ih_dq = nullptr;
+        d.x_in = fin[i].x; d.w_ih_f32 = fin[i].w_ih; d.I = fin[i].I;
+        if (fin[i].I > imax) imax = fin[i].I;
+        tiles += s.R / 16;
+    }
+    p.nseg = n_segs; p.T = T; p.H = H; p.NT = H / 16;
+    const int KS = (H + 63) / 64, HP = KS * 64;
+    const int xslot = (16 * imax * 4 + 1023) & ~1023;
+    const int lds = 3 * xslot + 2 * 3 * 16 * 72 * 2 + 2 * 16 * (HP + 32) + 5 * HP * 4 + p.NT * KS * 1024;
+    if (lds > 160 * 1024) return SFSN_EUNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define FUSEDX_CASE(KS_, OUT_)                                                                                             \
+    if (KS == KS_ && out == OUT_) {                                                                                        \
+        auto kern = gsn_scan_fusedx_kernel<KS_, OUT_>;                                                                     \
+        static int raised = 0;                                                                                             \
+        if (lds > raised) {                                                                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
+                return SFSN_EHIP;                                                                                          \
+            raised = lds;                                                                                                  \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, st, p);                                                      \
+        return hip_ok(hipGetLastError());                                                                                  \
+    }
+    FUSEDX_CASE(3, 2) FUSEDX_CASE(3, 3) FUSEDX_CASE(4, 2) FUSEDX_CASE(4, 3)
+#undef FUSEDX_CASE
     return SFSN_EUNSUPPORTED;
 }
 

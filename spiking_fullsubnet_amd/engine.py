@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CountTensor, DfGroup, FeatureGroup, FusedInput, ScanSegment, check
+from ._lib import CountTensor, DfGroup, FeatureGroup, FusedInput, FusedX, ScanSegment, check
 
 
 @dataclass
@@ -211,7 +211,8 @@ class Engine:
         self.timers: Optional[dict] = None  # set to {} to record HIP events around each launch group (bench.py)
         self.seq_chunk = 0  # frames per chunk of the single-stream schedule (0 = whole sequence per launch)
         self.rows_per_wg = (0, 0)  # (full-band, sub-band) rows per scan workgroup; 0 = let the library spread over all CUs
-        self.fuse_input = True  # layers >= 1: input term inside the scan where the geometry allows it (see _fusable)
+        self.fuse_input = True  # input term inside the scan where the geometry allows it (see _fusable / _fusable_x)
+        self.launches: Dict[str, int] = {}  # launches per C-ABI scan entry point (tests assert which path ran)
         self.timer_tags = None  # optional set of tags to time (each timed group costs ~10 us of launch gap)
         self._stream_objs: Dict[int, torch.cuda.Stream] = {}
         self._side: List[torch.cuda.Stream] = []
@@ -315,6 +316,34 @@ class Engine:
         the fp32 input term is pure gain; with 4 rows per workgroup (one forward alone) the doubled MFMA work would cost more."""
         return bool(self.fuse_input and self.spec.shared and 128 < seqs[0].H <= 256 and rpw == 16 and not want_membrane)
 
+    def _fusable_x(self, seq, x, rpw, want_membrane) -> bool:
+        """Layer 0 of a group can take its real-valued input product inside the scan (sfsn_gsn_layer_scan_fused_x) when, on
+        top of _fusable's conditions, the feature rows are narrow (even I <= 64: W_ih pieces fit in registers) and the row
+        count is a multiple of 16 (a step's rows are copied as one flat block)."""
+        return bool(self.fuse_input and self.spec.shared and 128 < seq.H <= 256 and rpw == 16 and not want_membrane
+                    and seq.I % 2 == 0 and seq.I <= 64 and x.shape[1] % 16 == 0)
+
+    def _stage_scan_fused_x(self, seqs, xs_, states, spks, s8s, t0, nt, st, tag):
+        """Layer 0 of the given sequence models, input product inside the scan."""
+        L = self.lib
+        H = seqs[0].H
+        HP = (H + 63) // 64 * 64
+        segs = (ScanSegment * len(seqs))()
+        fin = (FusedX * len(seqs))()
+        for i, (seq, x) in enumerate(zip(seqs, xs_)):
+            cell, sg, R = seq.cells[0], segs[i], x.shape[1]
+            sg.zin, sg.w_hh, sg.w_dq, sg.bias = None, _ptr(cell.w_hh_q), _ptr(cell.w_hh_dq), _ptr(cell.bias)
+            sg.bn_alpha, sg.bn_beta, sg.h_state, sg.c_state = _ptr(cell.alpha), _ptr(cell.beta), _ptr(states[i][0]), _ptr(states[i][1])
+            sg.spikes_f32 = None if spks[i] is None else ctypes.c_void_p(spks[i].data_ptr() + t0 * R * H * 4)
+            sg.membrane = None
+            sg.spikes_i8 = ctypes.c_void_p(s8s[i].data_ptr() + t0 * R * HP)
+            sg.R = R
+            fin[i].x = x.data_ptr() + t0 * R * seq.I * 4
+            fin[i].w_ih, fin[i].I = cell.w_ih_f32.data_ptr(), seq.I
+        self.launches["fused_x"] = self.launches.get("fused_x", 0) + 1
+        with self.timed("scan:" + tag, st):
+            check(L.sfsn_gsn_layer_scan_fused_x(segs, fin, len(seqs), nt, H, st), "sfsn_gsn_layer_scan_fused_x")
+
     def _stage_scan_fused(self, seqs, l, states, spks, s8s, t0, nt, st, tag):
         L = self.lib
         H = seqs[0].H
@@ -332,6 +361,7 @@ class Engine:
             sg.R = R
             fin[i].spikes_in = s8s[l - 1][i].data_ptr() + t0 * R * HP
             fin[i].w_ih, fin[i].w_ih_dq = pk.data_ptr(), dq.data_ptr()
+        self.launches["fused"] = self.launches.get("fused", 0) + 1
         with self.timed("scan:" + tag, st):
             check(L.sfsn_gsn_layer_scan_fused(segs, fin, len(seqs), nt, H, st), "sfsn_gsn_layer_scan_fused")
 
@@ -575,7 +605,29 @@ class Engine:
                         if pipeline and gate_events is not None:
                             g.wait_event(gate_events[c])
                         feat_fn(t0, nt, hG[si])
-                        self._stage_input(seqs, 0, xs_, d["zin"][0], t0, nt, hG[si], tag)
+                        fx = [i for i in range(len(seqs)) if self._fusable_x(seqs[i], xs_[i], rpw, want_membrane)]
+                        rest = [i for i in range(len(seqs)) if i not in fx]
+                        pick = lambda lst, idx: [lst[i] for i in idx]
+                        if rest:
+                            self._stage_input(pick(seqs, rest), 0, pick(xs_, rest), pick(d["zin"][0], rest), t0, nt, hG[si], tag)
+                        link(g, sc)
+                        if fx:  # their input product happens inside the scan
+                            self._stage_scan_fused_x(pick(seqs, fx), pick(xs_, fx), pick(d["states"][0], fx), pick(d["spk"][0], fx),
+                                                     pick(d["s8"][0], fx), t0, nt, hS[si], tag)
+                        if rest:
+                            self._stage_scan(pick(seqs, rest), 0, pick(d["zin"][0], rest), pick(d["states"][0], rest), pick(d["spk"][0], rest),
+                                             pick(d["s8"][0], rest), pick(d["mem"][0], rest), t0, nt, hS[si], tag, rpw)
+                        if pipeline:
+                            link(sc, g)
+                        if nl == 1:
+                            self._stage_proj(seqs, d["s8"][0], d["proj"], t0, nt, hG[si], tag)
+                            if post_fn is not None:
+                                post_fn(t0, nt, hG[si])
+                            if pipeline:
+                                ev = torch.cuda.Event()
+                                ev.record(g)
+                                done.append(ev)
+                        continue
                     elif fused:
                         link(sstreams[si - 1], g)  # previous layer's scan of this chunk
                     else:

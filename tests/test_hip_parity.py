@@ -590,12 +590,13 @@ def test_stft_kernels_on_the_golden_edges_and_errors():
 @pytest.mark.parametrize("front,kw,seed", [("live", rw.LIVE_M, 5), ("frozen", rw.FROZEN_S, 6), ("frozen", rw.FROZEN_L, 9),
                                            ("live", rw.LIVE_TINY_2SPK, 8)])
 def test_fused_input_scan_is_bit_identical(front, kw, seed):
-    """sfsn_gsn_layer_scan_fused (layers >= 1 compute x.W_ih^T + b inside the scan from the previous layer's int8 spikes) ==
-    sfsn_spike_proj + sfsn_gsn_layer_scan, bit for bit, for every tensor the module returns: hidden sizes 224 / 240 / 160 /
+    """sfsn_gsn_layer_scan_fused (layers >= 1 compute x.W_ih^T + b inside the scan from the previous layer's int8 spikes) and
+    sfsn_gsn_layer_scan_fused_x (layer 0 of groups with narrow feature rows, from the fp32 features with the bf16 split) ==
+    sfsn_spike_proj / sfsn_input_proj_f32 + sfsn_gsn_layer_scan, bit for bit, for every tensor the module returns: hidden sizes 224 / 240 / 160 /
     256 (four and three 64-wide k steps, 14 / 15 / 10 / 16 output tiles), ragged row counts, state carried over chunks."""
     sd = rw.live_state_dict(kw, seed) if front == "live" else rw.frozen_state_dict(kw, seed)
     model = build_module(front, kw, sd)
-    wave = torch.from_numpy(rw.synth_wave(3, 70, seed)).to(DEV)
+    wave = torch.from_numpy(rw.synth_wave(4, 70, seed)).to(DEV)  # even batch: group 0's rows are a multiple of 16 (layer-0 fusion)
     stft = model._stft(wave)
     eng = model.engine()
     eng.rows_per_wg = (16, 16)
@@ -610,6 +611,8 @@ def test_fused_input_scan_is_bit_identical(front, kw, seed):
         lean.append(eng.forward_stft(stft, want_layers=False, want_counts=True))
         torch.cuda.synchronize()
     eng.fuse_input, eng.seq_chunk, eng.rows_per_wg = True, 0, (0, 0)
+    if kw is not rw.LIVE_TINY_2SPK:  # both fused entry points really ran (the tiny model's hidden size is below their range)
+        assert eng.launches.get("fused", 0) > 0 and eng.launches.get("fused_x", 0) > 0, eng.launches
     a = outs[0]
     for b in outs[1:]:
         assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(b["enh_stft"]))
