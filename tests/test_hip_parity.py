@@ -627,6 +627,34 @@ def test_fused_input_scan_is_bit_identical(front, kw, seed):
                 assert int(y.count.item()) == int((x > 0).sum().item())
 
 
+def test_full_size_fused_forwards_in_flight_equal_the_plain_forward():
+    """BASELINE configs[2] sizes (B=64, T=1000, live baseline_m) as bench.py's timed region runs them -- several forwards in
+    flight on separate streams, sub-band scans at 16 rows per workgroup with both fused-input scan variants -- against the
+    plain single-stream forward (no fusion, 4 rows per workgroup): every returned tensor bit for bit, for every lane."""
+    kw, seed = rw.LIVE_M, 21
+    model = build_module("live", kw, rw.live_state_dict(kw, seed))
+    eng = model.engine()
+    stft = model._stft(torch.from_numpy(rw.synth_wave(64, 1000, 3)).to(DEV))
+    eng.fuse_input, eng.rows_per_wg = False, (0, 0)
+    ref = eng.forward_stft(stft)
+    torch.cuda.synchronize()
+    eng.fuse_input, eng.rows_per_wg = True, (4, 16)
+    lanes = [torch.cuda.Stream(device=DEV) for _ in range(6)]
+    outs = []
+    for s_ in lanes:
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            outs.append(eng.forward_stft(stft))
+    torch.cuda.synchronize()
+    eng.rows_per_wg = (0, 0)
+    assert eng.launches.get("fused", 0) >= 6 and eng.launches.get("fused_x", 0) >= 6
+    for b in outs:
+        assert torch.equal(torch.view_as_real(ref["enh_stft"]), torch.view_as_real(b["enh_stft"]))
+        assert torch.equal(ref["enh_mag"], b["enh_mag"])
+        for x, y in zip(ref["fb_all"] + sum(ref["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])):
+            assert torch.equal(x, y)
+
+
 def spec_units(spec, g):
     return (spec["cutoffs"][g + 1] - spec["cutoffs"][g]) // spec["ctr"][g]
 
