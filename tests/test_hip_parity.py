@@ -655,6 +655,29 @@ def test_full_size_fused_forwards_in_flight_equal_the_plain_forward():
             assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("T", [1, 2, 3, 5])
+def test_fused_scans_on_very_short_sequences(T):
+    """Fewer frames than the fused scans' input ring is deep (3 slots): prologue clamping, first-steps drains and the final
+    flush, against the two-call form, bit for bit."""
+    kw, seed = rw.LIVE_M, 31
+    model = build_module("live", kw, rw.live_state_dict(kw, seed))
+    eng = model.engine()
+    rng = np.random.default_rng(T)
+    stft = _t((0.3 * (rng.standard_normal((2, 257, T)) + 1j * rng.standard_normal((2, 257, T)))).astype(np.complex64))
+    eng.rows_per_wg = (16, 16)
+    eng.fuse_input = False
+    a = eng.forward_stft(stft)
+    eng.fuse_input = True
+    n0 = dict(eng.launches)
+    b = eng.forward_stft(stft)
+    torch.cuda.synchronize()
+    eng.rows_per_wg = (0, 0)
+    assert eng.launches.get("fused", 0) > n0.get("fused", 0) and eng.launches.get("fused_x", 0) > n0.get("fused_x", 0)
+    assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(b["enh_stft"]))
+    for x, y in zip(a["fb_all"] + sum(a["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])):
+        assert torch.equal(x, y)
+
+
 def spec_units(spec, g):
     return (spec["cutoffs"][g + 1] - spec["cutoffs"][g]) // spec["ctr"][g]
 
