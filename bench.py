@@ -268,7 +268,8 @@ def streaming_bench(args, model, dev, world, rank):
     per-call latency = host wall time from handing over the frame(s) to the enhanced frame(s) being complete (synchronised)."""
     B = args.batch if args.batch != 64 else 1
     hop, steps, warmup = args.hop, max(args.steps, 2000), max(args.warmup, 200)
-    sess = model.streaming(batch=B, hop=hop, graph=not args.no_graph)
+    rpw = tuple(int(v) for v in args.rpw.split(",")) if args.rpw else None
+    sess = model.streaming(batch=B, hop=hop, graph=not args.no_graph, rows_per_wg=rpw)
     g = torch.Generator(device="cpu").manual_seed(3)
     frames = (0.05 * torch.randn((steps + warmup, B, 257, hop, 2), generator=g)).to(dev)
     frames = torch.view_as_complex(frames)

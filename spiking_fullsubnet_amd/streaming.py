@@ -28,7 +28,7 @@ from .engine import Engine, _ptr
 class StreamingSession:
     """``step(frames [B, F, hop] complex64) -> (enh_stft [B, S, F, hop], enh_mag [B, S, F, hop])`` with state carried."""
 
-    def __init__(self, engine: Engine, batch: int = 1, hop: int = 1, graph: bool = True):
+    def __init__(self, engine: Engine, batch: int = 1, hop: int = 1, graph: bool = True, rows_per_wg=None):
         spec = engine.spec
         if spec.laplace:
             raise NotImplementedError("the frozen front-end's offline Laplace normalisation (model_low_freq.py:147-169) needs the whole "
@@ -36,6 +36,7 @@ class StreamingSession:
         if batch < 1 or hop < 1:
             raise ValueError("batch and hop must be positive")
         self.eng, self.B, self.hop = engine, batch, hop
+        self.rows_per_wg = rows_per_wg  # (full-band, sub-band) rows per scan workgroup; None = the engine's setting
         dev = self.dev = engine.device
         self.F = spec.n_fft // 2 + 1
         self.D = D = max(spec.df) - 1  # frames of input history the deep filter reaches back
@@ -91,10 +92,16 @@ class StreamingSession:
             self.hist[:, :, :D].copy_(self._tmp[:, :, :D])
         self.hist[:, :, D:].copy_(self.inp)
         ri = torch.view_as_real(self.hist)
-        rpw_fb, rpw_sb = eng.rows_per_wg
+        # default: the engine's full-band setting, 16 rows per workgroup for the sub-band stack -- few rows per hop anyway, and
+        # that geometry lets layers >= 1 take their input product inside the scan (three launches less per hop)
+        rpw_fb, rpw_sb = (eng.rows_per_wg[0], 16) if self.rows_per_wg is None else self.rows_per_wg
 
         def model(seqs, d, xs, tag, rpw):
+            fused = eng._fusable(seqs, rpw, False)  # layers >= 1: input product inside the scan (three launches less per hop)
             for l in range(d["nl"]):
+                if l > 0 and fused:
+                    eng._stage_scan_fused(seqs, l, d["states"][l], [None] * len(seqs), d["s8"], D, hop, st, tag)
+                    continue
                 # chunk-local zin holds frames [D, D+hop) at rows [0, hop): sources are offset by D inside _stage_input
                 eng._stage_input(seqs, l, xs if l == 0 else d["s8"][l - 1], d["zin"][l], D, hop, st, tag)
                 eng._stage_scan(seqs, l, d["zin"][l], d["states"][l], [None] * len(seqs), d["s8"][l], [None] * len(seqs), D, hop, st, tag, rpw)
