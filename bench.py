@@ -153,7 +153,7 @@ def main():
     # ---- phase A (untimed for `value`): one forward at a time on one stream, the latency-optimal launch geometry.  The
     #      dominant kernel runs alone here, so its HIP-event duration is the kernel's own (roofline), not a time share.
     eng.rows_per_wg = (0, 0)
-    eng.timers, eng.timer_tags = {}, (None if args.time_all else {"scan:sb"})
+    eng.timers, eng.timer_tags = {}, (None if args.time_all else {"scan:sb", "scan:fb"})
     ka = max(2, min(args.steps, 8))
     if args.no_phase_a:
         scan_ms, single = {}, None
@@ -235,7 +235,14 @@ def main():
                             frames_per_launch=int(frames_per_launch), schedule=("time-pipelined x%d chunks on %d streams" % (info["n_chunks"], 4)) if info["pipelined"] else "sequential",
                             measured_in="phase A: single stream, one forward at a time (the kernel runs alone; in the timed region "
                                         "several forwards share the chip and a launch's wall time is a time share, not the kernel's own)",
-                            other_kernels_ms={k: round(v["mean_ms"], 4) for k, v in scan_ms.items() if k != "scan:sb"})
+                            other_kernels_ms={k: round(v["mean_ms"], 4) for k, v in scan_ms.items() if k not in ("scan:sb", "scan:fb")})
+            fb_ms = scan_ms.get("scan:fb")
+            if fb_ms:
+                # the other recurrent kernel: one launch per full-band layer, B rows x H=320 on B/4 CUs -- a pure dependency
+                # chain (its algorithmic traffic is ~1 % of the sub-band scan's): reported as time per step
+                roofline["full_band_scan"] = dict(kernel="gsn_scan_kernel<G=1,KS=5,NW=8,TPW=3,LP=1> (W_hh: two digit planes in registers, one in LDS)",
+                                                  launch_ms=round(fb_ms["mean_ms"], 4), per_step_us=round(1e3 * fb_ms["mean_ms"] / (T / info["n_chunks"]), 3),
+                                                  workgroups=(B + 3) // 4)
             if traffic is not None and tj.get("forward_hbm_bytes") and want_layers:
                 # the whole job against the same roof: PMC-measured HBM bytes of one forward (all kernels) / time per step of
                 # the timed region (several forwards in flight)
