@@ -76,13 +76,20 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  (SFSN_BENCH_BACKEND=gloo lets several ranks share one GPU: a plumbing check of the multi-rank
+    # code path on a single-GPU box, not a measurement.)
+    backend = os.environ.get("SFSN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     import refweights as rw
     import spiking_fullsubnet_amd as pkg
@@ -258,8 +265,10 @@ def main():
                     value=round(frames / dt, 1), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
                     data="synthetic (0.05*randn waveform -> Hann-512/128 STFT, resident in HBM; seeded random weights, randomised BN stats)",
-                    config=dict(workload="configs[2]: single MI355X, full model (full-band + 3 sub-band groups / 13 units), "
-                                         "live baseline_m sizes, fp32 parity mode", clips_per_gpu=B, frames=T, bins=257,
+                    config=dict(workload=("configs[2]: single MI355X" if world == 1 else
+                                          f"configs[3]: {world} x MI355X, clips sharded over ranks ({world * B} per step), configs[2] per GPU") +
+                                         ", full model (full-band + 3 sub-band groups / 13 units), live baseline_m sizes, fp32 parity mode",
+                                clips_per_gpu=B, frames=T, bins=257,
                                 layer_outputs="api-faithful (fp32 spikes returned)" if want_layers else "skipped",
                                 in_flight=(n_lanes if args.inflight > 1 else 1), scan_rows_per_workgroup=list(eng.rows_per_wg),
                                 single_stream=single,
