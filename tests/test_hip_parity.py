@@ -696,3 +696,46 @@ def test_errors_match_reference_behaviour():
         pkg.SpikingFullSubNet(**rw.LIVE_TINY).eval()(torch.zeros(1, 2048))
     with pytest.raises(RuntimeError):
         pkg.SpikingFullSubNet(**rw.LIVE_TINY).to(DEV).train()(torch.zeros(1, 2048, device=DEV))
+
+
+def test_fused_scan_entry_points_reject_what_they_do_not_cover(hip):
+    """sfsn_gsn_layer_scan_fused / _fused_x return SFSN_EUNSUPPORTED (the caller then uses the two-call form) or SFSN_EINVAL."""
+    from spiking_fullsubnet_amd._lib import FusedInput, FusedX, ScanSegment, SFSN_EINVAL, SFSN_EUNSUPPORTED
+    from spiking_fullsubnet_amd.engine import fold_batchnorm, pack_w3
+    rng = np.random.default_rng(0)
+
+    def segment(H, R, T):
+        w = rng.uniform(-0.1, 0.1, (H, H)).astype(np.float32)
+        pk, dq = pack_w3(w)
+        keep = [_t(pk), _t(dq), _t(rng.standard_normal(2 * H).astype(np.float32)), _t(np.ones(H, np.float32)), _t(np.zeros(H, np.float32)),
+                torch.zeros((R, H), device=DEV), torch.zeros((R, H), device=DEV),
+                torch.zeros((T, R, (H + 63) // 64 * 64), dtype=torch.int8, device=DEV),
+                torch.zeros((T, R, (H + 63) // 64 * 64), dtype=torch.int8, device=DEV), _t(rng.standard_normal((T, R, 38)).astype(np.float32)),
+                _t(rng.uniform(-0.1, 0.1, (H, 38)).astype(np.float32))]
+        sg = (ScanSegment * 1)()
+        sg[0].w_hh, sg[0].w_dq, sg[0].bias, sg[0].bn_alpha, sg[0].bn_beta = (_p(k) for k in keep[:5])
+        sg[0].h_state, sg[0].c_state, sg[0].spikes_i8, sg[0].R = _p(keep[5]), _p(keep[6]), _p(keep[7]), R
+        fi = (FusedInput * 1)()
+        fi[0].spikes_in, fi[0].w_ih, fi[0].w_ih_dq = keep[8].data_ptr(), keep[0].data_ptr(), keep[1].data_ptr()
+        fx = (FusedX * 1)()
+        fx[0].x, fx[0].w_ih, fx[0].I = keep[9].data_ptr(), keep[10].data_ptr(), 38
+        return sg, fi, fx, keep
+
+    sg, fi, fx, keep = segment(224, 32, 4)
+    assert hip.sfsn_gsn_layer_scan_fused(sg, fi, 1, 4, 224, None) == 0 and hip.sfsn_gsn_layer_scan_fused_x(sg, fx, 1, 4, 224, None) == 0
+    torch.cuda.synchronize()
+    for H in (64, 128, 320):  # outside 128 < H <= 256
+        s2, f2, x2, k2 = segment(H, 32, 2)
+        assert hip.sfsn_gsn_layer_scan_fused(s2, f2, 1, 2, H, None) == SFSN_EUNSUPPORTED
+        assert hip.sfsn_gsn_layer_scan_fused_x(s2, x2, 1, 2, H, None) == SFSN_EUNSUPPORTED
+    s3, f3, x3, k3 = segment(224, 24, 2)  # rows not a multiple of 16: only the real-valued variant minds
+    assert hip.sfsn_gsn_layer_scan_fused(s3, f3, 1, 2, 224, None) == 0
+    assert hip.sfsn_gsn_layer_scan_fused_x(s3, x3, 1, 2, 224, None) == SFSN_EUNSUPPORTED
+    fx[0].I = 37
+    assert hip.sfsn_gsn_layer_scan_fused_x(sg, fx, 1, 4, 224, None) == SFSN_EUNSUPPORTED
+    fx[0].I, fx[0].x = 38, None
+    assert hip.sfsn_gsn_layer_scan_fused_x(sg, fx, 1, 4, 224, None) == SFSN_EINVAL
+    fi[0].spikes_in = None
+    assert hip.sfsn_gsn_layer_scan_fused(sg, fi, 1, 4, 224, None) == SFSN_EINVAL
+    assert hip.sfsn_gsn_layer_scan_fused(sg, fi, 0, 4, 224, None) == SFSN_EINVAL
+    torch.cuda.synchronize()
