@@ -597,49 +597,41 @@ class Engine:
             nl = len(seqs[0].cells)
             fused = self._fusable(seqs, rpw, want_membrane)
             done = []
+            pick = lambda lst, idx: [lst[i] for i in idx]
+            # layer 0: groups whose real-valued input product can run inside the scan / the rest (input product first)
+            fx = [i for i in range(len(seqs)) if self._fusable_x(seqs[i], xs_[i], rpw, want_membrane)]
+            rest = [i for i in range(len(seqs)) if i not in fx]
             for c, (t0, nt) in enumerate(bounds):
                 for l in range(nl):
                     si = first + l
                     g, sc = gstreams[si], sstreams[si]
+                    # ---- what the scan of this layer consumes
                     if l == 0:
                         if pipeline and gate_events is not None:
                             g.wait_event(gate_events[c])
                         feat_fn(t0, nt, hG[si])
-                        fx = [i for i in range(len(seqs)) if self._fusable_x(seqs[i], xs_[i], rpw, want_membrane)]
-                        rest = [i for i in range(len(seqs)) if i not in fx]
-                        pick = lambda lst, idx: [lst[i] for i in idx]
                         if rest:
                             self._stage_input(pick(seqs, rest), 0, pick(xs_, rest), pick(d["zin"][0], rest), t0, nt, hG[si], tag)
-                        link(g, sc)
-                        if fx:  # their input product happens inside the scan
+                    else:
+                        link(sstreams[si - 1], g)  # previous layer's scan of this chunk
+                        if not fused:
+                            self._stage_input(seqs, l, d["s8"][l - 1], d["zin"][l], t0, nt, hG[si], tag)
+                    link(g, sc)
+                    # ---- the scan(s)
+                    if l == 0:
+                        if fx:
                             self._stage_scan_fused_x(pick(seqs, fx), pick(xs_, fx), pick(d["states"][0], fx), pick(d["spk"][0], fx),
                                                      pick(d["s8"][0], fx), t0, nt, hS[si], tag)
                         if rest:
                             self._stage_scan(pick(seqs, rest), 0, pick(d["zin"][0], rest), pick(d["states"][0], rest), pick(d["spk"][0], rest),
                                              pick(d["s8"][0], rest), pick(d["mem"][0], rest), t0, nt, hS[si], tag, rpw)
-                        if pipeline:
-                            link(sc, g)
-                        if nl == 1:
-                            self._stage_proj(seqs, d["s8"][0], d["proj"], t0, nt, hG[si], tag)
-                            if post_fn is not None:
-                                post_fn(t0, nt, hG[si])
-                            if pipeline:
-                                ev = torch.cuda.Event()
-                                ev.record(g)
-                                done.append(ev)
-                        continue
                     elif fused:
-                        link(sstreams[si - 1], g)  # previous layer's scan of this chunk
-                    else:
-                        link(sstreams[si - 1], g)
-                        self._stage_input(seqs, l, d["s8"][l - 1], d["zin"][l], t0, nt, hG[si], tag)
-                    link(g, sc)
-                    if l > 0 and fused:
                         self._stage_scan_fused(seqs, l, d["states"][l], d["spk"][l], d["s8"], t0, nt, hS[si], tag)
                     else:
                         self._stage_scan(seqs, l, d["zin"][l], d["states"][l], d["spk"][l], d["s8"][l], d["mem"][l], t0, nt, hS[si], tag, rpw)
                     if pipeline:
                         link(sc, g)  # the chunk-local zin buffer is reused by the next chunk's input product
+                    # ---- after the last layer: projection and whatever follows the model
                     if l == nl - 1:
                         self._stage_proj(seqs, d["s8"][l], d["proj"], t0, nt, hG[si], tag)
                         if post_fn is not None:
