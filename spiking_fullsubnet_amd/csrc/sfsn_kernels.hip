@@ -1628,19 +1628,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 // writes 78 KB apart.  NU = ceil(I/64) feature slots per lane is a template parameter: no work for absent slots.
 #define FEAT_CHUNK 512  // floats per staging segment / gather-table entries: units per chunk = FEAT_CHUNK / I
 
-template <int NU>
+template <int NU, int NORM>
 __device__ __forceinline__ void feat_chunk_rows(const FeatGroupDev& g, const float* magT, const float* fbT, const int* offs,
                                                 float* stage, int k0, int nk, int b, int B, int FB, int t0, int tend, int lane, int wave) {
     float lw[NU], lb[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int j = lane + 64 * u;
-        const bool in = j < g.I && g.norm == SFSN_NORM_LAYERNORM;
+        const bool in = j < g.I && NORM == SFSN_NORM_LAYERNORM;
         lw[u] = in ? g.ln_w[j] : 0.0f;
         lb[u] = in ? g.ln_b[j] : 0.0f;
     }
     const float inv_I = 1.0f / (float)g.I;
-    const float lap_den = g.norm == SFSN_NORM_LAPLACE ? g.mu[b] + 2.220446049250313e-16f : 1.0f;
+    const float lap_den = NORM == SFSN_NORM_LAPLACE ? g.mu[b] + 2.220446049250313e-16f : 1.0f;
     const int seg = nk * g.I;
     for (int tt = wave; tt < FEAT_TT; tt += 4) {
         const int t = t0 + tt;
@@ -1658,7 +1658,7 @@ __device__ __forceinline__ void feat_chunk_rows(const FeatGroupDev& g, const flo
                 sum += v[u];
             }
             float y[NU];
-            if (g.norm == SFSN_NORM_LAYERNORM) {
+            if constexpr (NORM == SFSN_NORM_LAYERNORM) {
                 const float mean = wave_sum(sum) * inv_I;
                 float ss = 0.0f;
 #pragma unroll
@@ -1669,7 +1669,7 @@ __device__ __forceinline__ void feat_chunk_rows(const FeatGroupDev& g, const flo
                 const float rstd = __builtin_amdgcn_rsqf(wave_sum(ss) * inv_I + g.eps);
 #pragma unroll
                 for (int u = 0; u < NU; ++u) y[u] = ((v[u] - mean) * rstd) * lw[u] + lb[u];
-            } else if (g.norm == SFSN_NORM_LAPLACE) {
+            } else if constexpr (NORM == SFSN_NORM_LAPLACE) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u) y[u] = v[u] / lap_den;
             } else {
@@ -1754,10 +1754,17 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
                                      : -1 - reflect_bin(g.lo + ku * g.ctr_fb - g.nbr_fb + (j - g.I1), nf) % FB;
             }
             __syncthreads();
-            if (g.I <= 64) feat_chunk_rows<1>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave);
-            else if (g.I <= 128) feat_chunk_rows<2>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave);
-            else if (g.I <= 192) feat_chunk_rows<3>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave);
-            else feat_chunk_rows<4>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave);
+#define FEAT_ROWS(NU_)                                                                                                             \
+    do {                                                                                                                           \
+        if (g.norm == SFSN_NORM_LAYERNORM) feat_chunk_rows<NU_, SFSN_NORM_LAYERNORM>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave); \
+        else if (g.norm == SFSN_NORM_LAPLACE) feat_chunk_rows<NU_, SFSN_NORM_LAPLACE>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave); \
+        else feat_chunk_rows<NU_, SFSN_NORM_NONE>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave);               \
+    } while (0)
+            if (g.I <= 64) FEAT_ROWS(1);
+            else if (g.I <= 128) FEAT_ROWS(2);
+            else if (g.I <= 192) FEAT_ROWS(3);
+            else FEAT_ROWS(4);
+#undef FEAT_ROWS
         }
     }
 }
