@@ -1,6 +1,6 @@
 # Bottleneck attribution for the scan kernels (wrong-result debug variants, built with -DSFSN_TIMING_EXPERIMENTS).
 cd $GRAFT_REPO_ROOT/spiking_fullsubnet_amd/csrc && cp libsfsn_hip.so /tmp/keep.so
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -DSFSN_TIMING_EXPERIMENTS -shared -o libsfsn_hip.so sfsn_kernels.hip sfsn_pack.cpp
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -DSFSN_TIMING_EXPERIMENTS -shared -o libsfsn_hip.so sfsn_kernels.hip sfsn_fft.hip sfsn_pack.cpp
 cd $GRAFT_REPO_ROOT
 for r in 16 8 4; do
 for v in 3 51; do
