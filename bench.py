@@ -27,8 +27,8 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # HIP maps streams onto this many hardware queues (default 4): the pipelined
-# schedule runs four scans + the time-parallel kernels concurrently and must not multiplex them onto shared queues
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # HIP maps streams onto this many hardware queues (default 4): the forwards in
+# flight each need their own, or independent batches serialise behind each other (12 lanes: 16 queues 37.3, 24 queues 38.2 M frames/s)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
