@@ -142,8 +142,11 @@ int sfsn_gsn_layer_scan_fused_x(const sfsn_scan_segment* segs /* host */, const 
 /* ------------------------------------------------------------------------------------------------------
  * Time-parallel products.
  * sfsn_input_proj_f32: z[m][n] = sum_k x[m][k] * w[n][k] (+ bias[n])  (NEURON:141-142 for layer 0: real-valued x)
- *     exact-fp32 MFMA (v_mfma_f32_16x16x4_f32); x [M][K], w [N][K] row-major fp32, z [M][ldz] (columns 0..N-1 written;
- *     ldz > N lets the two gate halves of an unshared cell land side by side).
+ *     fp32-accurate on the bf16 matrix cores: x and w are split (round to nearest) into three bf16 pieces each, the six
+ *     leading piece products are exact in fp32 and carry x.w to 2^-26 |x||w| per term, accumulation in fp32
+ *     (even K <= 192); v_mfma_f32_16x16x4_f32 (an exact k-ordered fmaf chain) for the other shapes.
+ *     x [M][K], w [N][K] row-major fp32, z [M][ldz] (columns 0..N-1 written; ldz > N lets the two gate halves of an
+ *     unshared cell land side by side).
  * sfsn_spike_proj:     y[m][n] = dq[n] * sum_k s[m][k] * Wq[n][k] (+ bias[n])
  *     s int8 0/1 [M][pad64(K)] as written by the scan; Wq/dq from sfsn_w3_pack(W [N][K]); y [M][N] fp32.
  *     Used for layer>=1 input products (bias NULL: NEURON:141) and the projection (nn.Linear MODEL:49-52,118;
