@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 1
+#define SFSN_ABI_VERSION 2 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -47,6 +47,9 @@ extern "C" {
 #define SFSN_MAX_GROUPS 8      /* sub-band groups per model                                                     */
 
 int sfsn_abi_version(void);
+/* First 16 hex digits of the sha256 of the sources this library was built from (include/sfsn.h, csrc/*): lets a binding
+ * refuse a stale build whose struct layouts or entry points no longer match the header it was written against. */
+const char* sfsn_source_hash(void);
 const char* sfsn_strerror(int code);
 /* Number of visible HIP devices (0 when there is none); never fails. */
 int sfsn_device_count(void);
@@ -138,6 +141,29 @@ typedef struct sfsn_fused_x {
 
 int sfsn_gsn_layer_scan_fused_x(const sfsn_scan_segment* segs /* host */, const sfsn_fused_x* fin /* host, one per segment */,
                                 int n_segs, int T, int H, void* stream);
+
+/* Layer-pipelined stack scan -- replaces StackedGSU.forward (NEURON:50-62) for ALL layers of a stack in ONE launch.
+ * The reference runs layer l over all T frames, then layer l+1 (NEURON:56-61); layer l+1 needs frame t of layer l only at
+ * frame t, so here every layer's rows get their own workgroups (weights resident for the whole launch) and the workgroups of
+ * layer l+1 trail their producers of layer l by a few frames: int8 spikes handed over through L2 with write-through stores and
+ * per-workgroup progress counters.  The critical path of a stack is one chain of T steps instead of n_layers chains, and the
+ * fp32 input term of layers >= 1 makes no round trip through HBM.  Bit-identical to sfsn_input_proj_f32 / sfsn_spike_proj +
+ * sfsn_gsn_layer_scan per layer.
+ *   segs[l * n_segs + i]: layer l of segment i, as for sfsn_gsn_layer_scan; `zin` is read for layer 0 (the input term incl.
+ *       bias, written before the launch).  For H > 256 (the two matrices of a layer >= 1 do not fit one CU) `zin` of layers >= 1
+ *       must point at a [T][R][H] scratch buffer: a third kind of workgroup computes the input term into it, frame by frame.
+ *       `membrane` must be NULL.  R of a segment is the same in every layer.
+ *   fin[l * n_segs + i]: packed input weights of layer l >= 1; spikes_in must equal segs[(l-1) * n_segs + i].spikes_i8.
+ *   rows_per_wg[l]: 4, 8 or 16 (NULL: 8 everywhere).  One workgroup occupies a CU: keep the sum over all layers of
+ *       ceil(R / rows_per_wg) within the device's CU count, or layers queue behind each other (correct, not pipelined).
+ *   lag: frames a consumer lets its producers run ahead before it (re)starts -- amortises its polls; 16-32 is a good value.
+ *   scratch: device memory, sfsn_stack_scratch_bytes(...) bytes, private to this launch until it completes.  Word 0 is an
+ *       error flag the caller may read back after the launch: non-zero = a bounded hand-off wait expired (results invalid).
+ * Shared gate weights only (SFSN_EUNSUPPORTED otherwise: use the per-layer calls). */
+size_t sfsn_stack_scratch_bytes(int n_layers, int n_segs, int rows_total);
+int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs /* host [n_layers][n_segs] */, const sfsn_fused_input* fin /* host, same shape;
+                        layer-0 entries ignored */, int n_layers, int n_segs, int T, int H, const int* rows_per_wg /* host [n_layers] */,
+                        int lag, void* scratch, size_t scratch_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Time-parallel products.

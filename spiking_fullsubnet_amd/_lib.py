@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
 NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE = 0, 1, 2
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
+ABI_VERSION = 2  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -51,13 +52,28 @@ class CountTensor(ctypes.Structure):
 MAX_COUNT_TENSORS = 16
 
 
+def _sources():
+    """The files the library is made of, in the order the Makefile hashes them (SRCS)."""
+    return [os.path.join(_HERE, "..", "include", "sfsn.h")] + [
+        os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_fft.hip", "sfsn_pack.cpp")]
+
+
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the sources; equals ``sfsn_source_hash()`` of a library built from them."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in _sources():
+        with open(s, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (``make -C csrc``); hipcc cross-compiles without a GPU."""
-    srcs = [os.path.join(CSRC, f) for f in ("sfsn_kernels.hip", "sfsn_fft.hip", "sfsn_pack.cpp")] + [
-        os.path.join(_HERE, "..", "include", "sfsn.h")]
+    srcs = _sources()
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
-        subprocess.run(["make", "-C", CSRC, "-s"] + (["-B"] if force else []), check=True)
+        subprocess.run(["make", "-C", CSRC, "-s", "-j4"] + (["-B"] if force else []), check=True)
     return LIB_PATH
 
 
@@ -75,6 +91,15 @@ def lib() -> ctypes.CDLL:
             "(or `make -C spiking_fullsubnet_amd/csrc`). There is no CPU or eager fallback for this path.")
     L = ctypes.CDLL(LIB_PATH)
     L.sfsn_abi_version.restype = _I
+    if L.sfsn_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {L.sfsn_abi_version()} != {ABI_VERSION}; rebuild (make -C {CSRC})")
+    # a stale build (sources edited after the last make) is refused, not called with mismatched struct layouts; file times
+    # do not survive a copy of the tree, so the check is a hash of the sources compiled into the library
+    if all(os.path.exists(s) for s in _sources()):
+        L.sfsn_source_hash.restype = ctypes.c_char_p
+        built, want = L.sfsn_source_hash().decode(), source_hash()
+        if built != want:
+            raise ImportError(f"{LIB_PATH} was built from other sources (hash {built}, tree {want}); rebuild: make -C {CSRC}")
     L.sfsn_strerror.restype = ctypes.c_char_p
     L.sfsn_strerror.argtypes = [_I]
     L.sfsn_device_count.restype = _I
@@ -92,6 +117,11 @@ def lib() -> ctypes.CDLL:
     L.sfsn_gsn_layer_scan_fused.argtypes = [ctypes.POINTER(ScanSegment), ctypes.POINTER(FusedInput), _I, _I, _I, _P]
     L.sfsn_gsn_layer_scan_fused_x.restype = _I
     L.sfsn_gsn_layer_scan_fused_x.argtypes = [ctypes.POINTER(ScanSegment), ctypes.POINTER(FusedX), _I, _I, _I, _P]
+    L.sfsn_stack_scratch_bytes.restype = ctypes.c_size_t
+    L.sfsn_stack_scratch_bytes.argtypes = [_I, _I, _I]
+    L.sfsn_gsn_stack_scan.restype = _I
+    L.sfsn_gsn_stack_scan.argtypes = [ctypes.POINTER(ScanSegment), ctypes.POINTER(FusedInput), _I, _I, _I, _I, ctypes.POINTER(_I), _I, _P,
+                                      ctypes.c_size_t, _P]
     L.sfsn_input_proj_f32.restype = _I
     L.sfsn_input_proj_f32.argtypes = [_P, _P, _P, _P, _I, _I, _I, _I, _P]
     L.sfsn_spike_proj.restype = _I
@@ -108,14 +138,15 @@ def lib() -> ctypes.CDLL:
     L.sfsn_stft.argtypes = [_P, _I, _I, _I, _I, _P, _P, _I, _P]
     L.sfsn_istft.restype = _I
     L.sfsn_istft.argtypes = [_P, _I, _I, _I, _I, _P, _P, _I, _P]
-    if L.sfsn_abi_version() != 1:
-        raise ImportError(f"{LIB_PATH}: ABI version {L.sfsn_abi_version()} != 1; rebuild")
+    if L.sfsn_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {L.sfsn_abi_version()} != {ABI_VERSION}; rebuild (make -C {CSRC})")
     _lib = L
     return L
 
 
-EXPORTS = ("sfsn_abi_version", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
-           "sfsn_w3_pack", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
+EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
+           "sfsn_w3_pack", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_stack_scratch_bytes", "sfsn_gsn_stack_scan",
+           "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
            "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
 
 

@@ -6,6 +6,12 @@
 
 #include "sfsn.h"
 
+#ifndef SFSN_SRC_HASH
+#define SFSN_SRC_HASH "unknown"
+#endif
+// first 16 hex digits of sha256 over the library's sources (Makefile: SRCS), checked by the Python binding at load time
+extern "C" const char* sfsn_source_hash(void) { return SFSN_SRC_HASH; }
+
 static inline int tiles16(int n) { return (n + 15) / 16; }
 static inline int steps64(int k) { return (k + 63) / 64; }
 

@@ -1,0 +1,570 @@
+// sfsn_scan_dev.h -- device code shared by the gfx950 scan kernels (sfsn_kernels.hip, sfsn_stack.hip).
+// gfx950 only; see sfsn_kernels.hip for the design notes.
+#ifndef SFSN_SCAN_DEV_H
+#define SFSN_SCAN_DEV_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "sfsn.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define SFSN_WAVE 64
+
+// =====================================================================================================
+// GSN layer scan
+// =====================================================================================================
+struct ScanSegDev {
+    const float* zin;
+    const int8_t* w_hh;
+    const float* w_dq;
+    const float* bias;
+    const float* bn_alpha;
+    const float* bn_beta;
+    float* h_state;
+    float* c_state;
+    float* spikes_f32;
+    int8_t* spikes_i8;
+    float* membrane;
+    int R;
+    int tile0;  // first workgroup (row tile) of this segment
+    // fused-input scan only: the previous layer's int8 spikes and this layer's packed input weights
+    const int8_t* spikes_in;
+    const int8_t* w_ih;
+    const float* w_ih_dq;
+    // fused real-valued input (layer 0): the feature rows and the fp32 input weights
+    const float* x_in;
+    const float* w_ih_f32;
+    int I;
+};
+
+struct ScanParams {
+    ScanSegDev seg[SFSN_MAX_SEGMENTS];
+    int nseg, T, H, NT;  // NT = H / 16 output tiles per gate
+    int rpw;             // rows per workgroup (16, 8 or 4): fewer rows per CU = less HBM traffic per CU per step
+};
+
+__device__ __forceinline__ float recombine3(int a0, int a1, int a2) {
+    // exact value (a2*65536 + a1*256 + a0) rounded ONCE to fp32: |a1*256 + a0| < 2^24 is exact as a float,
+    // |a2| < 2^16 is exact, the fma rounds the sum once.
+    return __builtin_fmaf((float)a2, 65536.0f, (float)(a1 * 256 + a0));
+}
+
+// ---- input-term prefetch: LDS-DMA ring, hidden from the compiler's s_waitcnt bookkeeping -------------------------
+// What the profile showed: vmcnt retires in order and counts STORES too, and a spike store takes about a microsecond
+// to retire here, so any wait for a prefetched register that was issued after a store stalls the step for the store
+// (1.36 us per step instead of 0.83; with only loads or only stores in the queue the same kernel ran at 0.31 us of
+// memory time).  hipcc on top of that merges control-flow paths conservatively and drains to vmcnt(0).  Hence:
+//   * the input term travels global -> LDS by DMA (global_load_lds_dwordx4: no VGPR destination, so the prefetch
+//     depth costs no registers) into a per-wave ring RING_D steps deep, issued from inline asm the compiler's
+//     scoreboard does not see;
+//   * the consumer waits with ONE explicit, COUNTED s_waitcnt per step: everything issued after the DMA it needs
+//     (RING_D-1 steps of DMAs and spike stores) may stay in flight, so only stores RING_D-1 steps old are ever
+//     waited for (cdna_hip_programming.md 5.7 / T3+T4: counted vmcnt, never 0 in the main loop).
+// The LDS destination of a DMA is wave-uniform base (M0) + lane*16: each lane later reads back exactly the 16 bytes
+// it requested.  Destinations are kept below 64 KiB (the ring is the first thing in the LDS allocation).
+template <bool SC1 = false>
+__device__ __forceinline__ void dma16_to_lds(unsigned lds_dst_uniform, const float* base_uniform, unsigned byte_off) {
+    // saddr form: 64-bit wave-uniform base in SGPRs + 32-bit per-lane byte offset (no 64-bit VALU address arithmetic).
+    // The "s" operands must be PROVABLY uniform for the compiler: readfirstlane both halves of the pointer.
+    // SC1: agent-scope load (bypasses this CU's L1) -- for data another workgroup of the SAME launch has published with
+    // write-through stores (the stack kernel's layer-to-layer hand-off, MI355X_MICROARCH.md "inter-workgroup visibility").
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base_uniform);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned long long base = ((unsigned long long)hi << 32) | lo;
+    unsigned keep;
+    if constexpr (SC1) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2 sc1\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(byte_off), "s"(base), "s"(lds_dst_uniform)
+            : "memory");
+    } else {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(byte_off), "s"(base), "s"(lds_dst_uniform)
+            : "memory");
+    }
+}
+
+// ---- layer-to-layer hand-off inside ONE launch (the stack kernel, sfsn_stack.hip) ---------------------------------------
+// A producer workgroup (layer l, some rows) publishes the number of frames whose int8 spikes (or input terms) are complete in
+// global memory in a 32-bit progress counter; the consumer workgroups of layer l+1 that own those rows start a frame only when
+// it is covered.  Visibility follows MI355X_MICROARCH.md: payload written with sc1 (write-through) stores, drained by the
+// writer's vmcnt before the sc1 counter store; consumer polls the counter with relaxed agent-scope loads and reads the payload
+// with sc1 loads (the LDS-DMA above).  Deadlock freedom: producers always have LOWER block indices than their consumers and
+// workgroups are dispatched in index order, so a resident consumer's producer is resident or finished; every spin is bounded
+// all the same (err word set, the launch completes with garbage and the host raises).
+struct StackLink {
+    const unsigned* in;  // first of n_in consecutive producer counters; nullptr = input not gated
+    int n_in;
+    unsigned* out;       // this workgroup's counter; nullptr = nothing to publish
+    unsigned* err;       // launch-wide error word (non-zero = a bounded spin expired)
+    int lag;             // frames a consumer lets its producer run ahead before it starts / resumes (amortises the polls)
+};
+
+#define SFSN_STACK_SPIN_LIMIT 400000  // x (s_sleep 32 + one L2 round trip) ~ 1 s
+
+// All waves of the workgroup call this at the same point (uniform decision).  Returns the number of frames published by ALL
+// producers (>= need on success), or -1 when the bounded spin expired.  `word` is an LDS int reserved for this purpose.
+__device__ __forceinline__ int stack_refresh(const StackLink& lk, int need, int T, int* word, int wave, int lane) {
+    if (wave == 0 && lane == 0) {
+        const int want = (need + lk.lag < T) ? need + lk.lag : T;
+        int v = 0;
+        for (unsigned spins = 0;; ++spins) {
+            v = 0x7fffffff;
+            for (int i = 0; i < lk.n_in; ++i) {
+                const int pi = (int)__hip_atomic_load(lk.in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = pi < v ? pi : v;
+            }
+            if (v >= want) break;
+            if (spins > SFSN_STACK_SPIN_LIMIT) {
+                __hip_atomic_store(lk.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = -1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        *reinterpret_cast<volatile int*>(word) = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    const int v = *reinterpret_cast<volatile int*>(word);
+    return v;
+}
+
+__device__ __forceinline__ void stack_publish(const StackLink& lk, int frames) {
+    __hip_atomic_store(lk.out, (unsigned)frames, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1
+}
+
+__device__ __forceinline__ void store16_sc1(void* base_uniform, unsigned byte_off, v4i data) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base_uniform);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned long long base = ((unsigned long long)hi << 32) | lo;
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(byte_off), "v"(data), "s"(base) : "memory");
+}
+
+template <int G, int KS, int NW, int TPW, int OUT, int LP>
+struct ScanCfg {
+    static constexpr int LDH = KS * 64 + 32;  // +32 B row pad: the ds_read_b128 lane groups of a B fragment hit distinct banks
+    static constexpr int HP = KS * 64;        // padded hidden size
+    static constexpr int NC = 3 + G;          // per-neuron constant vectors: (bias_g - bias_f), alpha, beta, dq[G]
+    static constexpr int NTMAX = (NW * TPW < KS * 4) ? NW * TPW : KS * 4;  // output tiles per gate (NT <= H/16 <= 4 KS)
+    static constexpr int SLOT = NTMAX * G * 1024;  // bytes of one ring slot: 1 KiB per (tile, gate), indexed by tile id
+    static constexpr int HBUF_BYTES = 2 * 16 * LDH, CST_BYTES = NC * HP * 4;
+    // LP = 1: the least-significant digit plane of W_hh lives in LDS instead of registers (H = 320: 100 KB), which
+    // brings the per-wave weight registers from 300 down to 120 and lets 8 waves (2 per SIMD) share the CU.
+    static constexpr int WPLANE_BYTES = LP ? G * NTMAX * KS * 1024 : 0;
+    static constexpr int FIXED = HBUF_BYTES + CST_BYTES + WPLANE_BYTES;
+    static constexpr int LDS_CAP = 160 * 1024;
+    static constexpr int RING_D = (4 * SLOT <= 65536 && 4 * SLOT + FIXED <= LDS_CAP)   ? 4
+                                  : (3 * SLOT <= 65536 && 3 * SLOT + FIXED <= LDS_CAP) ? 3
+                                                                                        : 2;
+    static_assert(RING_D * SLOT <= 65536 && RING_D * SLOT + FIXED <= LDS_CAP, "LDS budget");
+    static constexpr int RING_OFF = 0, HBUF_OFF = RING_D * SLOT, CST_OFF = HBUF_OFF + HBUF_BYTES, WPLANE_OFF = CST_OFF + CST_BYTES;
+    static constexpr int LDS_BYTES = WPLANE_OFF + WPLANE_BYTES;
+    // flush geometry: all threads of the workgroup write the previous step's spikes from the LDS hidden-state buffer
+    static constexpr int CHUNKS = 16 * (HP / 4);                    // 4-neuron chunks of the padded 16 x HP tile
+    static constexpr int FL = (CHUNKS + NW * 64 - 1) / (NW * 64);   // chunks per thread
+    static constexpr int NSTF = ((OUT & 1) ? 1 : 0) + ((OUT & 2) ? 1 : 0);  // stores per chunk
+};
+
+// Spikes of one step, LDS (int8, all 16 rows x H) -> global.  Whole rows go out as full contiguous cache lines (fp32:
+// 16 B per lane, int8: 4 B per lane).  Storing the accumulator fragments directly (64 B per row per tile) made every
+// store a partial-line write and was measurably slower.  Surplus threads / pad columns / rows past R duplicate a real
+// chunk: same data to the same address, so the instruction count per thread is constant (the counted wait needs that).
+template <class C>
+struct ScanFlush {
+    int off_f32[C::FL], off_i8[C::FL], off_lds[C::FL];
+    int nact;  // wave-uniform: how many of my FL chunk slots are real (the others fall past rpw rows and are skipped)
+    // write-through (sc1) form of the int8 rows, used when another workgroup of the same launch consumes them: 16 bytes per
+    // lane (4-byte sc1 stores are one fabric write each), threads [0, rpw * HP/16) take one chunk each
+    int o8_lds, nact8;
+    unsigned o8_glb;
+    __device__ __forceinline__ void init(int tid, int row0, int R, int H, int nthreads, int rpw) {
+        const int chunks = rpw * (C::HP / 4);  // multiple of 64: a wave is active or idle as a whole in every slot
+        const int tid0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+        nact = 0;
+#pragma unroll
+        for (int k = 0; k < C::FL; ++k) {
+            if (tid0 + k * nthreads < chunks) nact = k + 1;
+            const int c = (tid + k * nthreads) % chunks;
+            const int rr = c / (C::HP / 4);
+            int j4 = (c - rr * (C::HP / 4)) * 4;
+            if (j4 > H - 4) j4 = H - 4;  // pad columns duplicate the row's last real chunk (same data, same address)
+            const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;  // rows past R duplicate row R-1
+            off_lds[k] = rr * C::LDH + j4;
+            off_f32[k] = rsrc * H + j4;
+            off_i8[k] = rsrc * C::HP + j4;
+        }
+        {
+            const int chunks16 = rpw * (C::HP / 16);
+            nact8 = (tid0 < chunks16) ? 1 : 0;
+            const int c = tid < chunks16 ? tid : chunks16 - 1;  // surplus lanes of the last active wave duplicate the last chunk
+            const int rr = c / (C::HP / 16), j16 = (c - rr * (C::HP / 16)) * 16;
+            const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;
+            o8_lds = rr * C::LDH + j16;
+            o8_glb = (unsigned)(rsrc * C::HP + j16);
+        }
+    }
+    // stores this wave issues per flushed frame (the counted waits of the scan bodies need it)
+    template <int OUT, bool SC1>
+    __device__ __forceinline__ int stores_per_frame() const {
+        if constexpr (SC1) return nact * ((OUT & 1) ? 1 : 0) + ((OUT & 2) ? nact8 : 0);
+        return nact * C::NSTF;
+    }
+    template <int OUT, bool SC1 = false>
+    __device__ __forceinline__ void run(const int8_t* hsrc, float* __restrict__ spikes_f32, int8_t* __restrict__ spikes_i8, int ts,
+                                        int R, int H) const {
+        if constexpr (C::NSTF > 0) {
+            if (OUT & 256) ts = 0;  // (bit 8: timing experiment, fixed frame)
+            float* pf = spikes_f32 + (size_t)ts * R * H;
+            int8_t* p8 = spikes_i8 + (size_t)ts * R * C::HP;
+            if constexpr (SC1 && (OUT & 2)) {
+                if (nact8) store16_sc1(p8, o8_glb, *reinterpret_cast<const v4i*>(hsrc + o8_lds));  // wave-uniform branch
+            }
+            if constexpr (SC1 && !(OUT & 1)) return;
+#pragma unroll
+            for (int k = 0; k < C::FL; ++k) {
+                if (k >= nact) break;  // wave-uniform
+                const unsigned pk = *reinterpret_cast<const unsigned*>(hsrc + off_lds[k]);
+                if ((OUT & 2) && !SC1) *reinterpret_cast<unsigned*>(p8 + off_i8[k]) = pk;
+                if (OUT & 1) {
+                    const v4f sp = {(float)(pk & 0xffu), (float)((pk >> 8) & 0xffu), (float)((pk >> 16) & 0xffu), (float)(pk >> 24)};
+                    *reinterpret_cast<v4f*>(pf + off_f32[k]) = sp;
+                }
+            }
+        }
+    }
+};
+
+// s_waitcnt vmcnt(N) for a wave-uniform runtime N in a small range: the instruction takes an immediate.
+template <int BASE, int STRIDE, int MAXK>
+__device__ __forceinline__ void wait_vmcnt_affine(int k) {
+    // waits for vmcnt <= BASE + k*STRIDE (clamped to the 6-bit field); k in [0, MAXK]
+#define SFSN_WAIT_CASE(K)                                                                           \
+    if constexpr (K <= MAXK)                                                                        \
+        if (k == K) {                                                                               \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BASE + K * STRIDE) > 63 ? 63 : (BASE + K * STRIDE)) : "memory"); \
+            return;                                                                                 \
+        }
+    SFSN_WAIT_CASE(0) SFSN_WAIT_CASE(1) SFSN_WAIT_CASE(2) SFSN_WAIT_CASE(3) SFSN_WAIT_CASE(4) SFSN_WAIT_CASE(5)
+#undef SFSN_WAIT_CASE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Workgroup set-up shared by the scan kernels: per-neuron constants -> LDS, hidden-state buffers zeroed (pads must read as
+// 0 spikes), digit plane 0 of W_hh -> LDS when LP = 1, initial hidden state -> hbuf[0] as int8.  Ends with a barrier.
+template <int G, int KS, int NW, int TPW, int OUT, int LP>
+__device__ __forceinline__ void scan_prologue(const ScanSegDev& sg, char* smem, int tid, int H, int NT, int R, int row0, int rpw) {
+    using C = ScanCfg<G, KS, NW, TPW, OUT, LP>;
+    constexpr int LDH = C::LDH, HP = C::HP;
+    int8_t* hbuf = reinterpret_cast<int8_t*>(smem + C::HBUF_OFF);
+    float(*cst)[HP] = reinterpret_cast<float(*)[HP]>(smem + C::CST_OFF);
+    for (int j = tid; j < HP; j += NW * 64) {
+        const bool in = j < H;
+        cst[0][j] = in ? sg.bias[H + j] - sg.bias[j] : 0.0f;
+        cst[1][j] = in ? sg.bn_alpha[j] : 0.0f;
+        cst[2][j] = in ? sg.bn_beta[j] : 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) cst[3 + g][j] = in ? sg.w_dq[g * H + j] : 0.0f;
+    }
+    for (int i = tid; i < 2 * 16 * LDH / 4; i += NW * 64) reinterpret_cast<int*>(hbuf)[i] = 0;
+    if constexpr (LP == 1) {  // digit plane 0 of W_hh (the first G*NT*KS KiB of the packed array) -> LDS, once
+        v4i* dst = reinterpret_cast<v4i*>(smem + C::WPLANE_OFF);
+        const v4i* src = reinterpret_cast<const v4i*>(sg.w_hh);
+        for (int i = tid; i < G * NT * KS * 64; i += NW * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    // initial hidden state h_{-1} -> hbuf[0] as int8 (all threads cooperate; 4 neurons per thread-iteration)
+    for (int idx = tid; idx < 16 * (H / 4); idx += NW * 64) {
+        const int rr = idx / (H / 4), j4 = (idx - rr * (H / 4)) * 4;
+        const int rsrc = (row0 + (rr & (rpw - 1)) < R) ? row0 + (rr & (rpw - 1)) : R - 1;
+        const v4f h = *reinterpret_cast<const v4f*>(sg.h_state + (size_t)rsrc * H + j4);
+        const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
+                            (h.w > 0.5f ? 0x1000000u : 0u);
+        *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
+    }
+    __syncthreads();
+
+}
+
+// ---- the scan body for a wave that owns NTL (compile-time) output tiles -------------------------------------
+// Straight-line code per step: no per-tile or per-row branch.  Rows past R are CLAMPED duplicates of row R-1: they
+// run the same instruction sequence on the same data, produce bit-identical values and store them to the same
+// addresses as the original (a benign duplicate write), so a step is one basic block the scheduler can interleave.
+// FLG (the stack kernel, sfsn_stack.hip): bit 0 = the input term is produced by another workgroup of this launch (gated on
+// lk->in, read with sc1 loads); bit 1 = this layer's int8 spikes feed another workgroup of this launch (write-through stores,
+// progress published in lk->out).  `gate_word` is an LDS int (stack_refresh).
+template <int G, int KS, int NW, int TPW, int OUT, int LP, int NTL, int FLG = 0>
+__device__ __forceinline__ void scan_body(const float* __restrict__ zin, const int8_t* __restrict__ w_hh,
+                                          float* __restrict__ spikes_f32, int8_t* __restrict__ spikes_i8,
+                                          float* __restrict__ membrane, float* __restrict__ h_state, float* __restrict__ c_state,
+                                          char* smem, int T, int H, int NT, int R, int row0, int rowc, int n, int q, int tid,
+                                          int wave, int rpw, const StackLink* lk = nullptr, int* gate_word = nullptr) {
+    using C = ScanCfg<G, KS, NW, TPW, OUT, LP>;
+    constexpr int LDH = C::LDH, HP = C::HP, D = C::RING_D;
+    constexpr bool GATED = (FLG & 1) != 0, PUB = (FLG & 2) != 0;
+    int avail = 0;  // frames of the input term known to be published (GATED)
+    constexpr int NPR = 3 - LP;  // digit planes kept in registers (planes LP..2); plane 0 is in LDS when LP = 1
+    int8_t* hbuf = reinterpret_cast<int8_t*>(smem + C::HBUF_OFF);
+    const float(*cst)[HP] = reinterpret_cast<const float(*)[HP]>(smem + C::CST_OFF);
+    const char* wplane = smem + C::WPLANE_OFF;
+    ScanFlush<C> fl;
+    fl.init(tid, row0, R, H, NW * 64, rpw);
+    const int lane = tid & 63;
+    if constexpr (NTL == 0) {
+        // a wave without tiles still flushes its share of the spikes and keeps the workgroup's barrier count
+        for (int t = 0; t < T; ++t) {
+            if constexpr (GATED) {  // same decisions as the waves with tiles (avail is only ever updated in stack_refresh)
+                const int need = (t + D < T) ? t + D : T;
+                if (avail >= 0 && need > avail) avail = stack_refresh(*lk, need, T, gate_word, wave, lane);
+                if (avail < 0) break;  // a bounded spin expired: give up (uniform), the error word is set
+            }
+            if (t > 0) fl.template run<OUT, PUB>(hbuf + (t & 1) * 16 * LDH, spikes_f32, spikes_i8, t - 1, R, H);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (T > 0 && avail >= 0) fl.template run<OUT, PUB>(hbuf + (T & 1) * 16 * LDH, spikes_f32, spikes_i8, T - 1, R, H);
+        if constexpr (PUB) {  // every wave's stores of the last frames are complete before wave 0 publishes T
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    } else {
+        const int ldz = G * H;
+        constexpr int A = NTL * G;                   // DMAs per step
+        constexpr int NMEM = (OUT & 4) ? NTL : 0;    // membrane stores per step (test output, accumulator layout)
+        // VMEM operations issued after the DMA of data-step t and before the wait of compute-step t (program order per
+        // step: DMAs, flush stores, WAIT, membrane stores), with f = nact * NSTF flush stores per step for this wave:
+        //     (D-1) * (A + f + NMEM) + f  =  (D-1)*(A+NMEM)  +  nact * (D*NSTF)
+        constexpr int CBASE = (D - 1) * (A + NMEM), CSTRIDE = PUB ? D : D * C::NSTF;
+        const int nst = PUB ? fl.template stores_per_frame<OUT, true>() : fl.nact;  // multiplier of CSTRIDE
+        // (PUB: wave 0 also issues one 4-byte counter store per step, not counted: the wait is then stricter by the D-1
+        //  oldest operations behind the DMA it needs -- flush stores several steps old)
+
+        // register-resident recurrent weights (int8 digits in MFMA A-fragment order) and membrane state
+        // RP4 (OUT bit 9, used when the workgroup owns 4 rows): only MFMA columns 0..3 carry rows, so the 4 x 4 values
+        // a lane group holds are re-dealt ONE per lane (DPP row shifts with a bank mask: no LDS, 3 moves per accumulator)
+        // and the whole epilogue runs on a quarter of the values: lane (n, q) finishes neuron 4q + n/4 of row n%4.
+        constexpr bool RP4 = (OUT & 512) != 0;
+        const int r4 = n >> 2, row4 = n & 3;
+        v4i W[NTL][G][KS][NPR];
+        v4f c[NTL];
+        int col[NTL];          // first neuron of my 4-neuron group in tile i
+        unsigned zoff[NTL];    // byte offset of my 16 input-term bytes of tile i within a frame (gate 0)
+        unsigned wl_off[NTL];  // LDS byte offset of my fragment of tile i, k-step 0, in the LDS digit plane
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+            const int ct = wave + NW * i;
+            col[i] = ct * 16 + q * 4;
+            zoff[i] = (unsigned)(rowc * ldz + col[i]) * 4u;
+            wl_off[i] = (unsigned)((ct * KS) * 64 + lane) * 16u;
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int d = 0; d < NPR; ++d) {
+                        const size_t tile = (size_t)(d + LP) * (G * NT) + (size_t)g * NT + ct;
+                        W[i][g][ks][d] = *reinterpret_cast<const v4i*>(w_hh + ((tile * KS + ks) * 64 + lane) * 16);
+                    }
+            if constexpr (RP4) {
+                c[i] = v4f{c_state[(size_t)rowc * H + col[i] + r4], 0, 0, 0};
+            } else {
+                c[i] = *reinterpret_cast<const v4f*>(c_state + (size_t)rowc * H + col[i]);
+            }
+        }
+        // ring: slot s, tile ct, gate g at s*SLOT + (ct*G + g)*1024 (+ lane*16 for my bytes)
+        const unsigned ring_base = (unsigned)(C::RING_OFF + wave * (G * 1024));
+        const char* ring_rd = smem + ring_base + lane * 16;
+        auto issue = [&](int slot, int td) __attribute__((always_inline)) {
+            const float* zt = zin + (size_t)((OUT & 128) ? 0 : td) * R * ldz;  // wave-uniform (bit 7: timing experiment)
+#pragma unroll
+            for (int i = 0; i < NTL; ++i)
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    dma16_to_lds<GATED>(__builtin_amdgcn_readfirstlane(ring_base + slot * C::SLOT + (NW * i * G + g) * 1024), zt,
+                                        zoff[i] + (unsigned)(g * H) * 4u);
+        };
+        if constexpr (GATED) {  // the prologue and step 0 read frames [0, D)
+            const int need = D < T ? D : T;
+            avail = stack_refresh(*lk, need, T, gate_word, wave, lane);
+        }
+        // prologue: the first D-1 steps' input terms, then drain EVERYTHING (weights, state, DMAs) once
+        for (int s0 = 0; s0 < D - 1; ++s0) issue(s0, s0 < T ? s0 : (T > 0 ? T - 1 : 0));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // tell the compiler's scoreboard too (its own loads above are done)
+
+        // FIRST = the peeled step 0: nothing to flush (the LDS buffer holds the initial state, not an output)
+        auto step = [&](int t, auto first) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first)::value;
+            const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
+            int8_t* hn = hbuf + ((t & 1) ^ 1) * 16 * LDH;
+            {   // input term of step t+D-1 -> ring (clamped past the end: a harmless re-read of the last frame)
+                const int td = (t + D - 1 < T) ? t + D - 1 : T - 1;
+                issue((t + D - 1) % D, td);
+            }
+            v4i b[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(hc + n * LDH + ks * 64 + q * 16);
+            const char* zslot = ring_rd + (t % D) * C::SLOT;
+#pragma unroll
+            for (int i = 0; i < NTL; ++i) {
+                const int cc = col[i];
+                v4i acc[G][3];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        if constexpr (OUT & 16) {  // timing experiment: no MFMAs (cheap stand-in keeps W and b live)
+                            a0 += W[i][g][ks][0] ^ b[ks];
+                        } else if constexpr (LP == 1) {
+                            const v4i w0 = *reinterpret_cast<const v4i*>(wplane + wl_off[i] + (unsigned)((g * NT * KS + ks) * 1024));
+                            a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, b[ks], a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][0], b[ks], a1, 0, 0, 0);
+                            a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][1], b[ks], a2, 0, 0, 0);
+                        } else {
+                            a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][0], b[ks], a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][1], b[ks], a1, 0, 0, 0);
+                            a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[i][g][ks][2], b[ks], a2, 0, 0, 0);
+                        }
+                    }
+                    acc[g][0] = a0; acc[g][1] = a1; acc[g][2] = a2;
+                }
+                if (i == 0) {
+                    // under the first tile's MFMA latency: spikes of step t-1 (= hc) -> global ...
+                    if constexpr (!FIRST) fl.template run<OUT, PUB>(hc, spikes_f32, spikes_i8, t - 1, R, H);
+                    // ... then the counted wait for this step's input term (see the comment block above).  The first D
+                    // steps have a shorter queue than the steady state the count assumes: they drain completely.
+                    if (t < D || CBASE + nst * CSTRIDE > 63) {  // (vmcnt is a 6-bit field; the test variants may exceed it)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else {
+                        wait_vmcnt_affine<CBASE, CSTRIDE, C::FL + 1>(nst);
+                    }
+                }
+                if constexpr (RP4) {
+                    auto pick = [&](const v4i& a) __attribute__((always_inline)) {  // element r4 of lane (row4, q)
+                        int v = a[0];
+                        v = __builtin_amdgcn_update_dpp(v, a[1], 0x114, 0xf, 0x2, false);  // row_shr:4  -> lanes 4..7
+                        v = __builtin_amdgcn_update_dpp(v, a[2], 0x118, 0xf, 0x4, false);  // row_shr:8  -> lanes 8..11
+                        v = __builtin_amdgcn_update_dpp(v, a[3], 0x11C, 0xf, 0x8, false);  // row_shr:12 -> lanes 12..15
+                        return v;
+                    };
+                    const int cj = cc + r4;  // my neuron
+                    float pre1[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float rec = recombine3(pick(acc[g][0]), pick(acc[g][1]), pick(acc[g][2]));
+                        // the DMA put lane (row, q)'s 16 bytes at lane*16: mine are element r4 of lane (row4, q)
+                        const float z = *reinterpret_cast<const float*>(smem + ring_base + (t % D) * C::SLOT + (NW * i * G + g) * 1024 +
+                                                                        ((q * 16 + row4) * 16 + r4 * 4));
+                        pre1[g] = __builtin_fmaf(rec, cst[3 + g][cj], z);
+                    }
+                    const float pre_g1 = (G == 2) ? pre1[G - 1] : pre1[0] + cst[0][cj];
+                    const float f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre1[0] * -1.44269504088896341f));
+                    const float m = __builtin_fmaf(f, c[i][0] - pre_g1, pre_g1);
+                    const float y = __builtin_fmaf(m, cst[1][cj], cst[2][cj]);
+                    c[i][0] = y;
+                    hn[row4 * LDH + cj] = (y >= 0.0f) ? 1 : 0;
+                    if (OUT & 4) membrane[((size_t)t * R + rowc) * H + cj] = y;
+                    continue;
+                }
+                v4f pre[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const v4f z = *reinterpret_cast<const v4f*>(zslot + (NW * i * G + g) * 1024);
+                    const v4f dq = *reinterpret_cast<const v4f*>(&cst[3 + g][cc]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)  // dq is a power of two: fma(rec, dq, z) == z + rec*dq with ONE rounding
+                        pre[g][r] = __builtin_fmaf(recombine3(acc[g][0][r], acc[g][1][r], acc[g][2][r]), dq[r], z[r]);
+                }
+                const v4f alpha = *reinterpret_cast<const v4f*>(&cst[1][cc]);
+                const v4f beta = *reinterpret_cast<const v4f*>(&cst[2][cc]);
+                v4f pre_g;
+                if constexpr (G == 2) {
+                    pre_g = pre[1];
+                } else {
+                    const v4f db = *reinterpret_cast<const v4f*>(&cst[0][cc]);  // bias_g - bias_f
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pre_g[r] = pre[0][r] + db[r];
+                }
+                v4f cy;
+                unsigned pk = 0;
+                if constexpr (OUT & 32) {  // timing experiment: no epilogue math
+                    cy = c[i];
+                    pk = (acc[0][0][0] ^ acc[0][1][1] ^ acc[0][2][2] ^ __float_as_uint(pre[0][0])) & 0x01010101u;
+                } else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // f = sigmoid(pre_f) with the hardware exp2 / rcp (~1 ulp each)
+                    const float f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre[0][r] * -1.44269504088896341f));
+                    const float m = __builtin_fmaf(f, c[i][r] - pre_g[r], pre_g[r]);  // f*c + (1-f)*g
+                    const float y = __builtin_fmaf(m, alpha[r], beta[r]);              // eval BatchNorm, ATen form
+                    cy[r] = y;
+                    pk |= (y >= 0.0f) ? (1u << (8 * r)) : 0u;                           // Triangle.forward, NEURON:89
+                }
+                c[i] = cy;
+                *reinterpret_cast<unsigned*>(hn + n * LDH + cc) = pk;
+                if (OUT & 4) *reinterpret_cast<v4f*>(membrane + ((size_t)t * R + rowc) * H + cc) = cy;
+            }
+            // h_t complete in hn before anyone reads it; hc is free for the next step's writes.  Only LDS traffic has
+            // to drain here -- global stores and DMAs stay in flight across the barrier.
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0), vmcnt/expcnt untouched
+            if constexpr (!(OUT & 64)) __builtin_amdgcn_s_barrier();  // (bit 6: timing experiment without the barrier)
+        };
+
+        if (T > 0 && avail >= 0) step(0, std::true_type{});
+#pragma unroll 1
+        for (int t = 1; t < T; ++t) {
+            if constexpr (GATED) {  // step t issues the DMA of frame t+D-1
+                const int need = (t + D < T) ? t + D : T;
+                if (avail >= 0 && need > avail) avail = stack_refresh(*lk, need, T, gate_word, wave, lane);
+                if (avail < 0) break;  // a bounded spin expired: give up (uniform), the error word is set
+            }
+            if constexpr (PUB) {
+                // After the barrier that ended step t-1 every wave has passed its counted wait of step t-1, which covers the
+                // flush stores of steps <= t-1-D, i.e. frames <= t-2-D: t-1-D frames are complete in memory.
+                if (wave == 0 && lane == 0 && t - 1 - D > 0) stack_publish(*lk, t - 1 - D);
+            }
+            step(t, std::false_type{});
+        }
+
+        // DMAs past the end are invisible to the compiler: drain before the LDS / registers are reused
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (T > 0 && avail >= 0) fl.template run<OUT, PUB>(hbuf + (T & 1) * 16 * LDH, spikes_f32, spikes_i8, T - 1, R, H);
+        if constexpr (PUB) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (wave == 0 && lane == 0) stack_publish(*lk, T);  // (also after an expired spin: consumers must not wait for us)
+        }
+        // final state (duplicate rows write the same values to the same place)
+        const int8_t* hl = hbuf + (T & 1) * 16 * LDH;  // h_{T-1} (or the untouched initial state when T == 0)
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+            if constexpr (RP4) {
+                c_state[(size_t)rowc * H + col[i] + r4] = c[i][0];
+                h_state[(size_t)rowc * H + col[i] + r4] = (float)hl[row4 * LDH + col[i] + r4];
+                continue;
+            }
+            *reinterpret_cast<v4f*>(c_state + (size_t)rowc * H + col[i]) = c[i];
+            const unsigned pk = *reinterpret_cast<const unsigned*>(hl + n * LDH + col[i]);
+            const v4f h = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)((pk >> 24) & 1u)};
+            *reinterpret_cast<v4f*>(h_state + (size_t)rowc * H + col[i]) = h;
+        }
+    }
+}
+
+#endif

@@ -1,0 +1,647 @@
+// sfsn_stack.hip -- the layer-pipelined GSN stack scan for gfx950 (MI355X / CDNA4): sfsn_gsn_stack_scan.
+//
+// The reference runs a stack layer by layer (StackedGSU.forward, efficient_spiking_neuron.py:56-61: layer l over ALL T frames,
+// then layer l+1), but layer l+1 needs frame t of layer l only at frame t.  This kernel runs every layer of a stack in ONE
+// launch: each layer's rows are owned by their own workgroups (one per CU, weights resident for all T frames), and a
+// workgroup of layer l+1 trails its producers of layer l by a few frames.  The hand-off goes through L2 / Infinity Cache
+// with write-through (sc1) stores, a per-workgroup progress counter and sc1 loads (sfsn_scan_dev.h: StackLink; rules from
+// MI355X_MICROARCH.md "inter-workgroup visibility" and "hand-off price list").  The critical path of a stack is then one
+// chain of T dependent steps instead of L chains back to back, and the fp32 input term of layers >= 1 never exists in HBM.
+//
+// Roles (a role = one layer of one row segment = a contiguous range of workgroups; producers have lower block indices):
+//   ZIN    recurrent scan whose input term x.W_ih^T + b arrives as fp32 [T][R][H] -- layer 0 (written by the time-parallel
+//          input product before the launch) or a layer >= 1 fed by a PROJ role (H > 256);  = scan_body of sfsn_scan_dev.h
+//   FUSED  recurrent scan of a layer >= 1 that computes its input term itself from the previous layer's int8 spikes
+//          (shared gates, H <= 256: both weight matrices fit one CU)
+//   PROJ   the time-parallel input product S.W_ih^T + b of a layer >= 1 whose two matrices do not fit one CU together
+//          (H = 320, the full-band model): 16 rows per workgroup, no recurrence, feeds a ZIN role
+// Arithmetic is that of the per-layer kernels, instruction for instruction: results are bit-identical to
+// sfsn_spike_proj + sfsn_gsn_layer_scan (tested).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sfsn.h"
+#include "sfsn_scan_dev.h"
+
+#define STACK_MAX_ROLES 24
+#define STACK_ZIN 0
+#define STACK_FUSED 1
+#define STACK_PROJ 2
+
+struct StackRoleDev {
+    const int8_t* w_hh;
+    const float* w_dq;
+    const float* bias;
+    const float* bn_alpha;
+    const float* bn_beta;
+    float* h_state;
+    float* c_state;
+    float* spikes_f32;
+    int8_t* spikes_i8;
+    float* zin;               // ZIN: the input term (read); PROJ: the input term (written)
+    const int8_t* spikes_in;  // FUSED / PROJ: the previous layer's int8 spikes
+    const int8_t* w_ih;       // FUSED / PROJ: packed input weights
+    const float* w_ih_dq;
+    int R, block0, nblocks, kind, rpw;
+    int src;      // producer role (-1: the input is complete before the launch)
+    int src_rpw;  // rows per workgroup of the producer role
+    int pub;      // 1: another role of this launch consumes what this role writes
+};
+
+struct StackParams {
+    StackRoleDev role[STACK_MAX_ROLES];
+    unsigned* prog;  // [0] error word, [1 + block] frames published by that workgroup
+    int nroles, T, H, NT, lag;
+    int gate_off;    // byte offset of the gate word in the dynamic LDS allocation (behind every role's layout)
+};
+
+template <int KS>
+struct StackGeom {
+    static constexpr int NW = 8;
+    static constexpr int TPW = KS <= 2 ? 1 : (KS <= 4 ? 2 : 3);
+    static constexpr int LP = KS == 5 ? 1 : 0;
+    static constexpr int HP = KS * 64, LDH = HP + 32;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FUSED role: the fused-input scan of sfsn_kernels.hip (gsn_scan_fused_kernel) for any rows-per-workgroup, gated and
+// (optionally) publishing.  8 waves; wave w owns output tiles w and w + 8 (those that exist).  Digit plane 0 of W_hh and
+// W_ih in LDS, planes 1-2 in registers.  LDS: [input-spike ring D x SLOT][hbuf 2 x 16 x LDH][6 constants x HP][W_hh p0][W_ih p0].
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS>
+struct FusedLayout {
+    static constexpr int HP = KS * 64, LDH = HP + 32, D = 3, NCH = KS * 4;
+    __device__ __host__ static constexpr int slot_bytes(int rpw) { return ((rpw * HP + 1023) / 1024) * 1024; }
+    __device__ __host__ static constexpr int hbuf_off(int rpw) { return D * slot_bytes(rpw); }
+    __device__ __host__ static constexpr int cst_off(int rpw) { return hbuf_off(rpw) + 2 * 16 * LDH; }
+    __device__ __host__ static constexpr int whh_off(int rpw) { return cst_off(rpw) + 6 * HP * 4; }
+    __device__ __host__ static constexpr int bytes(int rpw, int NT) { return whh_off(rpw) + 2 * NT * KS * 1024; }
+};
+
+template <int KS, int OUT, int NTL, bool PUB>
+__device__ __forceinline__ void stack_fused_body(const StackRoleDev& rl, const StackLink& lk, char* smem, int* gate_word, int T, int H,
+                                                 int NT, int row0, int rowc, int n, int q, int tid, int wave) {
+    using C = ScanCfg<1, KS, 8, 2, OUT, 0>;  // geometry constants of the flush only (LDH, HP, FL, NSTF)
+    using L = FusedLayout<KS>;
+    constexpr int LDH = C::LDH, HP = C::HP, D = L::D, NW = 8, NCH = L::NCH;
+    const int rpw = rl.rpw, R = rl.R;
+    const int SLOT = L::slot_bytes(rpw);
+    const int WHH_OFF = L::whh_off(rpw), WIH_OFF = WHH_OFF + NT * KS * 1024;
+    int8_t* hbuf = reinterpret_cast<int8_t*>(smem + L::hbuf_off(rpw));
+    const float(*cst)[HP] = reinterpret_cast<const float(*)[HP]>(smem + L::cst_off(rpw));  // b_f, b_g - b_f, alpha, beta, dq_hh, dq_ih
+    ScanFlush<C> fl;
+    fl.init(tid, row0, R, H, NW * 64, rpw);
+    const int lane = tid & 63;
+    // operations allowed in flight at the end-of-step wait: one more DMA and the flush stores of two steps
+    constexpr int CBASE = (D - 2) * 1, CSTRIDE = (D - 1);
+    const int nst = fl.template stores_per_frame<OUT, PUB>();
+
+    v4i Whh[NTL > 0 ? NTL : 1][KS][2], Wih[NTL > 0 ? NTL : 1][KS][2];
+    v4f c[NTL > 0 ? NTL : 1];
+    int col[NTL > 0 ? NTL : 1];
+    unsigned wl_off[NTL > 0 ? NTL : 1];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        const int ct = wave + NW * i;
+        col[i] = ct * 16 + q * 4;
+        wl_off[i] = (unsigned)((ct * KS) * 64 + lane) * 16u;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const size_t tile = (size_t)(d + 1) * NT + ct;
+                Whh[i][ks][d] = *reinterpret_cast<const v4i*>(rl.w_hh + ((tile * KS + ks) * 64 + lane) * 16);
+                Wih[i][ks][d] = *reinterpret_cast<const v4i*>(rl.w_ih + ((tile * KS + ks) * 64 + lane) * 16);
+            }
+        c[i] = *reinterpret_cast<const v4f*>(rl.c_state + (size_t)rowc * H + col[i]);
+    }
+    // input-spike ring: a slot holds the rpw rows of a frame as rpw * NCH 16-byte chunks; chunk e = (row er, position esl)
+    // sits at LDS byte 16 e and holds global chunk (esl - er) mod NCH of that row (a rotation by the row index: the 16 rows
+    // of a B fragment then hit distinct banks).  DMA piece k = chunks [64 k, 64 k + 64); wave w fetches piece min(w, last).
+    const int nchunk = rpw * NCH;
+    const int npiece = (nchunk + 63) >> 6;
+    const int piece = wave < npiece ? wave : npiece - 1;
+    int e = piece * 64 + lane;
+    if (e > nchunk - 1) e = nchunk - 1;  // surplus lanes re-fetch the last chunk (into the slot's padding)
+    const int er = e / NCH, esl = e - er * NCH;
+    const int erow = (row0 + er < R) ? row0 + er : R - 1;
+    const unsigned src_off = (unsigned)(erow * HP + ((esl - er % NCH + NCH) % NCH) * 16);
+    const size_t frame = (size_t)R * HP;
+    auto issue = [&](int slot, int td) __attribute__((always_inline)) {
+        dma16_to_lds<true>(__builtin_amdgcn_readfirstlane((unsigned)(slot * SLOT + piece * 1024)),
+                           reinterpret_cast<const float*>(rl.spikes_in + (size_t)td * frame), src_off);
+    };
+    int avail = 0;
+    {   // the prologue and step 0 read frames [0, D)
+        const int need = D < T ? D : T;
+        avail = stack_refresh(lk, need, T, gate_word, wave, lane);
+    }
+    for (int s0 = 0; s0 < D - 1; ++s0) issue(s0, s0 < T ? s0 : (T > 0 ? T - 1 : 0));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    const int nr = n & (rpw - 1);  // MFMA columns n >= rpw are duplicates of column n % rpw (same data, same results)
+    auto step = [&](int t, auto first) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first)::value;
+        const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
+        int8_t* hn = hbuf + ((t & 1) ^ 1) * 16 * LDH;
+        {
+            const int td = (t + D - 1 < T) ? t + D - 1 : T - 1;
+            issue((t + D - 1) % D, td);
+        }
+        v4i bh[KS], bs[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bh[ks] = *reinterpret_cast<const v4i*>(hc + n * LDH + ks * 64 + q * 16);
+        const char* sslot = smem + (t % D) * SLOT + nr * HP;
+        if constexpr (NTL == 0) {
+            if constexpr (!FIRST) fl.template run<OUT, PUB>(hc, rl.spikes_f32, rl.spikes_i8, t - 1, R, H);
+        }
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+            const int cc = col[i];
+            v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4i w0 = *reinterpret_cast<const v4i*>(smem + WHH_OFF + wl_off[i] + (unsigned)(ks * 1024));
+                a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, bh[ks], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[i][ks][0], bh[ks], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[i][ks][1], bh[ks], a2, 0, 0, 0);
+            }
+            if (i == 0) {
+                // under the first tile's MFMA latency: spikes of step t-1 -> global; then this step's input spikes (every
+                // wave's piece of the slot landed before the barrier that ended the previous step)
+                if constexpr (!FIRST) fl.template run<OUT, PUB>(hc, rl.spikes_f32, rl.spikes_i8, t - 1, R, H);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) bs[ks] = *reinterpret_cast<const v4i*>(sslot + ((ks * 4 + q + nr) % NCH) * 16);
+            }
+            v4i e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0}, e2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4i w0 = *reinterpret_cast<const v4i*>(smem + WIH_OFF + wl_off[i] + (unsigned)(ks * 1024));
+                e0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, bs[ks], e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wih[i][ks][0], bs[ks], e1, 0, 0, 0);
+                e2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wih[i][ks][1], bs[ks], e2, 0, 0, 0);
+            }
+            const v4f bf = *reinterpret_cast<const v4f*>(&cst[0][cc]), db = *reinterpret_cast<const v4f*>(&cst[1][cc]);
+            const v4f alpha = *reinterpret_cast<const v4f*>(&cst[2][cc]), beta = *reinterpret_cast<const v4f*>(&cst[3][cc]);
+            const v4f dqh = *reinterpret_cast<const v4f*>(&cst[4][cc]), dqi = *reinterpret_cast<const v4f*>(&cst[5][cc]);
+            v4f cy;
+            unsigned pk = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = __builtin_fmaf(recombine3(e0[r], e1[r], e2[r]), dqi[r], bf[r]);   // = sfsn_spike_proj's rec*dq + bias
+                const float pre_f = __builtin_fmaf(recombine3(a0[r], a1[r], a2[r]), dqh[r], z);
+                const float pre_g = pre_f + db[r];
+                const float f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre_f * -1.44269504088896341f));
+                const float m = __builtin_fmaf(f, c[i][r] - pre_g, pre_g);
+                const float y = __builtin_fmaf(m, alpha[r], beta[r]);
+                cy[r] = y;
+                pk |= (y >= 0.0f) ? (1u << (8 * r)) : 0u;
+            }
+            c[i] = cy;
+            *reinterpret_cast<unsigned*>(hn + n * LDH + cc) = pk;
+        }
+        // each wave waits for its own piece of step t+1's slot (issued at the top of step t-1; since then: one more DMA and
+        // two steps' flush stores); the barrier makes all pieces and the new hidden state visible to all
+        if (t < D || CBASE + nst * CSTRIDE > 63) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            wait_vmcnt_affine<CBASE, CSTRIDE, 5>(nst);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+    };
+    __builtin_amdgcn_s_barrier();  // the prologue's pieces (drained above by every wave) are now visible to all
+    if (T > 0 && avail >= 0) step(0, std::true_type{});
+#pragma unroll 1
+    for (int t = 1; t < T; ++t) {
+        {   // step t issues the DMA of frame t+D-1
+            const int need = (t + D < T) ? t + D : T;
+            if (avail >= 0 && need > avail) avail = stack_refresh(lk, need, T, gate_word, wave, lane);
+            if (avail < 0) break;
+        }
+        if constexpr (PUB) {
+            // After the barrier that ended step t-1 every wave has passed the wait of step t-1, which covers the flush
+            // stores issued at steps <= t-3, i.e. frames <= t-4: t-3 frames are complete in memory.
+            if (wave == 0 && lane == 0 && t - 3 > 0) stack_publish(lk, t - 3);
+        }
+        step(t, std::false_type{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (T > 0 && avail >= 0) fl.template run<OUT, PUB>(hbuf + (T & 1) * 16 * LDH, rl.spikes_f32, rl.spikes_i8, T - 1, R, H);
+    if constexpr (PUB) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave == 0 && lane == 0) stack_publish(lk, T);
+    }
+    const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        *reinterpret_cast<v4f*>(rl.c_state + (size_t)rowc * H + col[i]) = c[i];
+        const unsigned pk = *reinterpret_cast<const unsigned*>(hl + n * LDH + col[i]);
+        const v4f h = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)((pk >> 24) & 1u)};
+        *reinterpret_cast<v4f*>(rl.h_state + (size_t)rowc * H + col[i]) = h;
+    }
+}
+
+template <int KS, int OUT, bool PUB>
+__device__ __forceinline__ void stack_fused_role(const StackRoleDev& rl, const StackLink& lk, char* smem, int* gate_word, int T, int H,
+                                                 int NT, int blk) {
+    using L = FusedLayout<KS>;
+    constexpr int LDH = L::LDH, HP = L::HP, NW = 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int rpw = rl.rpw, R = rl.R;
+    const int row0 = blk * rpw;
+    const int rowc = (row0 + (n & (rpw - 1)) < R) ? row0 + (n & (rpw - 1)) : R - 1;
+    int8_t* hbuf = reinterpret_cast<int8_t*>(smem + L::hbuf_off(rpw));
+    float(*cst)[HP] = reinterpret_cast<float(*)[HP]>(smem + L::cst_off(rpw));
+    for (int j = tid; j < HP; j += NW * 64) {
+        const bool in = j < H;
+        cst[0][j] = in ? rl.bias[j] : 0.0f;
+        cst[1][j] = in ? rl.bias[H + j] - rl.bias[j] : 0.0f;
+        cst[2][j] = in ? rl.bn_alpha[j] : 0.0f;
+        cst[3][j] = in ? rl.bn_beta[j] : 0.0f;
+        cst[4][j] = in ? rl.w_dq[j] : 0.0f;
+        cst[5][j] = in ? rl.w_ih_dq[j] : 0.0f;
+    }
+    for (int i = tid; i < 2 * 16 * LDH / 4; i += NW * 64) reinterpret_cast<int*>(hbuf)[i] = 0;
+    {   // digit plane 0 of both matrices -> LDS, once
+        v4i* d0 = reinterpret_cast<v4i*>(smem + L::whh_off(rpw));
+        v4i* d1 = reinterpret_cast<v4i*>(smem + L::whh_off(rpw) + NT * KS * 1024);
+        const v4i* s0 = reinterpret_cast<const v4i*>(rl.w_hh);
+        const v4i* s1 = reinterpret_cast<const v4i*>(rl.w_ih);
+        for (int i = tid; i < NT * KS * 64; i += NW * 64) {
+            d0[i] = s0[i];
+            d1[i] = s1[i];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 16 * (H / 4); idx += NW * 64) {
+        const int rr = idx / (H / 4), j4 = (idx - rr * (H / 4)) * 4;
+        const int rsrc = (row0 + (rr & (rpw - 1)) < R) ? row0 + (rr & (rpw - 1)) : R - 1;
+        const v4f h = *reinterpret_cast<const v4f*>(rl.h_state + (size_t)rsrc * H + j4);
+        const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
+                            (h.w > 0.5f ? 0x1000000u : 0u);
+        *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
+    }
+    __syncthreads();
+    if (wave + NW < NT)
+        stack_fused_body<KS, OUT, 2, PUB>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+    else if (wave < NT)
+        stack_fused_body<KS, OUT, 1, PUB>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+    else
+        stack_fused_body<KS, OUT, 0, PUB>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PROJ role: z[t][r][:] = (S[t][r][:] . W_ih^T) * dq + bias_f for 16 rows per workgroup, frame by frame behind its producers.
+// Same products as sfsn_spike_proj (three int8 digit MFMAs, one rounding in the recombination, rec * dq exact, + bias).
+// Digit plane 0 of W_ih in LDS, planes 1-2 in registers (8 waves x up to 3 tiles).  Output fragments leave as 16-byte
+// write-through stores.  LDS: [input-spike ring D x 16 x HP][bias, dq: 2 x HP floats][W_ih p0].
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS>
+struct ProjLayout {
+    static constexpr int HP = KS * 64, D = 3, NCH = KS * 4;
+    static constexpr int SLOT = 16 * HP;
+    static constexpr int CST_OFF = D * SLOT, W_OFF = CST_OFF + 2 * HP * 4;
+    __device__ __host__ static constexpr int bytes(int NT) { return W_OFF + NT * KS * 1024; }
+};
+
+template <int KS, int NTL>
+__device__ __forceinline__ void stack_proj_body(const StackRoleDev& rl, const StackLink& lk, char* smem, int* gate_word, int T, int H,
+                                                int NT, int row0, int rowc, int n, int q, int tid, int wave) {
+    using L = ProjLayout<KS>;
+    constexpr int HP = L::HP, D = L::D, NW = 8, NCH = L::NCH, SLOT = L::SLOT;
+    const int R = rl.R;
+    const float(*cst)[HP] = reinterpret_cast<const float(*)[HP]>(smem + L::CST_OFF);  // bias_f, dq_ih
+    const int lane = tid & 63;
+    constexpr int CBASE = (D - 2) * 1 + (D - 1) * NTL;  // one more DMA and two steps' output stores may stay in flight
+
+    v4i Wih[NTL > 0 ? NTL : 1][KS][2];
+    int col[NTL > 0 ? NTL : 1];
+    unsigned wl_off[NTL > 0 ? NTL : 1];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        const int ct = wave + NW * i;
+        col[i] = ct * 16 + q * 4;
+        wl_off[i] = (unsigned)((ct * KS) * 64 + lane) * 16u;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const size_t tile = (size_t)(d + 1) * NT + ct;
+                Wih[i][ks][d] = *reinterpret_cast<const v4i*>(rl.w_ih + ((tile * KS + ks) * 64 + lane) * 16);
+            }
+    }
+    constexpr int nchunk = 16 * NCH, npiece = (nchunk + 63) >> 6;  // = KS pieces of 1 KiB
+    const int piece = wave < npiece ? wave : npiece - 1;
+    const int e = piece * 64 + lane;
+    const int er = e / NCH, esl = e - er * NCH;
+    const int erow = (row0 + er < R) ? row0 + er : R - 1;
+    const unsigned src_off = (unsigned)(erow * HP + ((esl - er % NCH + NCH) % NCH) * 16);
+    const size_t frame = (size_t)R * HP;
+    auto issue = [&](int slot, int td) __attribute__((always_inline)) {
+        dma16_to_lds<true>(__builtin_amdgcn_readfirstlane((unsigned)(slot * SLOT + piece * 1024)),
+                           reinterpret_cast<const float*>(rl.spikes_in + (size_t)td * frame), src_off);
+    };
+    int avail = 0;
+    {
+        const int need = D < T ? D : T;
+        avail = stack_refresh(lk, need, T, gate_word, wave, lane);
+    }
+    for (int s0 = 0; s0 < D - 1; ++s0) issue(s0, s0 < T ? s0 : (T > 0 ? T - 1 : 0));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+
+    const unsigned zrow = (unsigned)(rowc * H) * 4u;
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        if (t > 0) {
+            const int need = (t + D < T) ? t + D : T;
+            if (avail >= 0 && need > avail) avail = stack_refresh(lk, need, T, gate_word, wave, lane);
+            // stores issued at steps <= t-3 are complete for every wave (see the wait below): frames [0, t-2)
+            if (wave == 0 && lane == 0 && t - 2 > 0) stack_publish(lk, t - 2);
+        }
+        if (avail < 0) break;
+        {
+            const int td = (t + D - 1 < T) ? t + D - 1 : T - 1;
+            issue((t + D - 1) % D, td);
+        }
+        v4i bs[KS];
+        const char* sslot = smem + (t % D) * SLOT + n * HP;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bs[ks] = *reinterpret_cast<const v4i*>(sslot + ((ks * 4 + q + n) % NCH) * 16);
+        float* zt = rl.zin + (size_t)t * R * H;
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+            const int cc = col[i];
+            v4i e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0}, e2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4i w0 = *reinterpret_cast<const v4i*>(smem + L::W_OFF + wl_off[i] + (unsigned)(ks * 1024));
+                e0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, bs[ks], e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wih[i][ks][0], bs[ks], e1, 0, 0, 0);
+                e2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wih[i][ks][1], bs[ks], e2, 0, 0, 0);
+            }
+            const v4f bf = *reinterpret_cast<const v4f*>(&cst[0][cc]), dqi = *reinterpret_cast<const v4f*>(&cst[1][cc]);
+            v4f z;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = __builtin_fmaf(recombine3(e0[r], e1[r], e2[r]), dqi[r], bf[r]);
+            v4i zi;
+            __builtin_memcpy(&zi, &z, 16);
+            store16_sc1(zt, zrow + (unsigned)cc * 4u, zi);  // rows past R are clamped duplicates (same value, same address)
+        }
+        // my piece of step t+1's slot was issued at the top of step t-1; since then: this step's DMA and 2 x NTL stores
+        if (t < D) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CBASE) : "memory");
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave == 0 && lane == 0) stack_publish(lk, T);
+}
+
+template <int KS>
+__device__ __forceinline__ void stack_proj_role(const StackRoleDev& rl, const StackLink& lk, char* smem, int* gate_word, int T, int H,
+                                                int NT, int blk) {
+    using L = ProjLayout<KS>;
+    constexpr int HP = L::HP, NW = 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int R = rl.R;
+    const int row0 = blk * 16;
+    const int rowc = (row0 + n < R) ? row0 + n : R - 1;
+    float(*cst)[HP] = reinterpret_cast<float(*)[HP]>(smem + L::CST_OFF);
+    for (int j = tid; j < HP; j += NW * 64) {
+        const bool in = j < H;
+        cst[0][j] = in ? rl.bias[j] : 0.0f;
+        cst[1][j] = in ? rl.w_ih_dq[j] : 0.0f;
+    }
+    {
+        v4i* d1 = reinterpret_cast<v4i*>(smem + L::W_OFF);
+        const v4i* s1 = reinterpret_cast<const v4i*>(rl.w_ih);
+        for (int i = tid; i < NT * KS * 64; i += NW * 64) d1[i] = s1[i];
+    }
+    __syncthreads();
+    const int ntl = (NT - wave + NW - 1) / NW;  // tiles wave, wave + 8, ... < NT
+    if (ntl >= 3)
+        stack_proj_body<KS, 3>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+    else if (ntl == 2)
+        stack_proj_body<KS, 2>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+    else if (ntl == 1)
+        stack_proj_body<KS, 1>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+    else
+        stack_proj_body<KS, 0>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ZIN role = scan_body (sfsn_scan_dev.h) with 8 waves, gated and / or publishing.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS, int OUT, int FLG>
+__device__ __forceinline__ void stack_zin_role(const StackRoleDev& rl, const StackLink& lk, char* smem, int* gate_word, int T, int H, int NT,
+                                               int blk) {
+    using G = StackGeom<KS>;
+    constexpr int NW = G::NW, TPW = G::TPW, LP = G::LP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int rpw = rl.rpw, R = rl.R;
+    const int row0 = blk * rpw;
+    const int rowc = (row0 + (n & (rpw - 1)) < R) ? row0 + (n & (rpw - 1)) : R - 1;
+    ScanSegDev sg;
+    sg.zin = rl.zin; sg.w_hh = rl.w_hh; sg.w_dq = rl.w_dq; sg.bias = rl.bias; sg.bn_alpha = rl.bn_alpha; sg.bn_beta = rl.bn_beta;
+    sg.h_state = rl.h_state; sg.c_state = rl.c_state; sg.spikes_f32 = rl.spikes_f32; sg.spikes_i8 = rl.spikes_i8; sg.membrane = nullptr;
+    sg.R = R;
+    scan_prologue<1, KS, NW, TPW, OUT, LP>(sg, smem, tid, H, NT, R, row0, rpw);
+    const int n_hi = NT - NW * (TPW - 1);  // waves [0, n_hi) own TPW tiles, the others TPW-1
+    if (wave < n_hi)
+        scan_body<1, KS, NW, TPW, OUT, LP, TPW, FLG>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, nullptr, sg.h_state, sg.c_state, smem, T, H,
+                                                     NT, R, row0, rowc, n, q, tid, wave, rpw, &lk, gate_word);
+    else
+        scan_body<1, KS, NW, TPW, OUT, LP, TPW - 1, FLG>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, nullptr, sg.h_state, sg.c_state, smem, T,
+                                                         H, NT, R, row0, rowc, n, q, tid, wave, rpw, &lk, gate_word);
+}
+
+// OUT: bit 0 fp32 spikes, bit 1 int8 spikes (always).  The 4-row repacked epilogue (bit 9) is selected per role from rpw.
+template <int KS, int OUT>
+__global__ __launch_bounds__(512) void gsn_stack_kernel(const StackParams p) {
+    // (no static __shared__ here: the LDS-DMA destinations of the scan bodies are absolute LDS addresses from offset 0)
+    extern __shared__ __attribute__((aligned(16))) char scan_smem[];
+    int* gate_word_p = reinterpret_cast<int*>(scan_smem + p.gate_off);
+    int ri = -1;
+    for (int i = 0; i < p.nroles; ++i)
+        if ((int)blockIdx.x >= p.role[i].block0 && (int)blockIdx.x < p.role[i].block0 + p.role[i].nblocks) ri = i;
+    if (ri < 0) return;  // padding block (role ranges start at multiples of 8: producer and consumer share an XCD)
+    const StackRoleDev& rl = p.role[ri];
+    const int blk = (int)blockIdx.x - rl.block0;
+    StackLink lk;
+    lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = p.prog; lk.lag = p.lag;
+    if (rl.pub) lk.out = p.prog + 1 + blockIdx.x;
+    const int my_rpw = rl.kind == STACK_PROJ ? 16 : rl.rpw;
+    if (rl.src >= 0) {  // the producer workgroups that own my rows
+        const StackRoleDev& sr = p.role[rl.src];
+        const int r0 = blk * my_rpw;
+        int r1 = r0 + my_rpw - 1;
+        if (r1 > rl.R - 1) r1 = rl.R - 1;
+        const int b0 = r0 / rl.src_rpw, b1 = r1 / rl.src_rpw;
+        lk.in = p.prog + 1 + sr.block0 + b0;
+        lk.n_in = b1 - b0 + 1;
+    }
+    const int T = p.T, H = p.H, NT = p.NT;
+    if (rl.kind == STACK_FUSED) {
+        if constexpr (KS <= 4) {
+            if (rl.pub)
+                stack_fused_role<KS, OUT, true>(rl, lk, scan_smem, gate_word_p, T, H, NT, blk);
+            else
+                stack_fused_role<KS, OUT, false>(rl, lk, scan_smem, gate_word_p, T, H, NT, blk);
+        }
+    } else if (rl.kind == STACK_PROJ) {
+        if constexpr (KS == 5) stack_proj_role<KS>(rl, lk, scan_smem, gate_word_p, T, H, NT, blk);
+    } else {
+        const bool rp4 = rl.rpw == 4;
+        const int flg = (rl.src >= 0 ? 1 : 0) | (rl.pub ? 2 : 0);
+#define ZIN_CASE(F)                                                                                       \
+    if (flg == F) {                                                                                       \
+        if (rp4)                                                                                          \
+            stack_zin_role<KS, OUT | 512, F>(rl, lk, scan_smem, gate_word_p, T, H, NT, blk);               \
+        else                                                                                              \
+            stack_zin_role<KS, OUT, F>(rl, lk, scan_smem, gate_word_p, T, H, NT, blk);                     \
+    }
+        if constexpr (KS == 5) {  // layer 0 publishes to a PROJ role; layers >= 1 are gated on one (the last one publishes nothing)
+            ZIN_CASE(0) ZIN_CASE(1) ZIN_CASE(2) ZIN_CASE(3)
+        } else {  // layers >= 1 are FUSED roles: a ZIN role is a layer 0
+            ZIN_CASE(0) ZIN_CASE(2)
+        }
+#undef ZIN_CASE
+    }
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" size_t sfsn_stack_scratch_bytes(int n_layers, int n_segs, int rows_total) {
+    // progress counters: one per workgroup (at most one per 4 rows per layer, plus role padding and PROJ roles) + error word
+    if (n_layers <= 0 || n_segs <= 0 || rows_total <= 0) return 0;
+    const size_t blocks = (size_t)n_layers * ((size_t)(rows_total + 3) / 4 + (size_t)(rows_total + 15) / 16 + 16 * (size_t)n_segs);
+    return (blocks + 1 + 16) * sizeof(unsigned);
+}
+
+template <int KS, int OUT>
+static int launch_stack(const StackParams& p, int blocks, int lds, hipStream_t st) {
+    auto kern = gsn_stack_kernel<KS, OUT>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return SFSN_EHIP;  // (per device, cheap: set on every launch -- a process may drive several GPUs)
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, p);
+    return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;
+}
+
+extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, int n_layers, int n_segs, int T, int H,
+                                   const int* rows_per_wg, int lag, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!segs || !fin || n_layers <= 0 || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0 || !scratch) return SFSN_EINVAL;
+    if (H % 16 != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
+    const int KS = (H + 63) / 64, NT = H / 16, HP = KS * 64;
+    const bool fused = H <= 256;  // both matrices of a layer >= 1 fit one CU
+    const int roles_per_layer = fused ? 1 : 2;
+    if (n_segs * (1 + (n_layers - 1) * roles_per_layer) > STACK_MAX_ROLES) return SFSN_EUNSUPPORTED;
+    if (lag < 0) return SFSN_EINVAL;
+    StackParams p;
+    const int out = 2 | (segs[0].spikes_f32 ? 1 : 0);
+    int blocks = 0, nroles = 0, lds = 0, rows_total = 0;
+    int prev_role[SFSN_MAX_SEGMENTS];
+    for (int l = 0; l < n_layers; ++l) {
+        int rpw = rows_per_wg ? rows_per_wg[l] : 8;
+        if (rpw != 4 && rpw != 8 && rpw != 16) return SFSN_EINVAL;
+        for (int i = 0; i < n_segs; ++i) {
+            const sfsn_scan_segment& s = segs[l * n_segs + i];
+            const sfsn_fused_input& f = fin[l * n_segs + i];
+            if (!s.spikes_i8 || (s.spikes_f32 != nullptr) != ((out & 1) != 0) || s.membrane) return SFSN_EINVAL;
+            if (s.R <= 0 || !s.w_hh || !s.w_dq || !s.bias || !s.bn_alpha || !s.bn_beta || !s.h_state || !s.c_state) return SFSN_EINVAL;
+            if (s.R != segs[i].R) return SFSN_EINVAL;  // a segment has the same rows in every layer
+            if (!aligned16(s.w_hh) || !aligned16(s.h_state) || !aligned16(s.c_state) || !aligned16(s.spikes_f32) || !aligned16(s.spikes_i8) ||
+                !aligned16(s.zin))
+                return SFSN_EINVAL;
+            if (l == 0) rows_total += s.R;
+            const bool last = l == n_layers - 1;
+            if (l > 0) {
+                if (!f.w_ih || !f.w_ih_dq || !aligned16(f.w_ih)) return SFSN_EINVAL;
+                if (f.spikes_in != segs[(l - 1) * n_segs + i].spikes_i8) return SFSN_EINVAL;  // the layer below, same segment
+            }
+            if (l == 0 || !fused) {
+                if (!s.zin) return SFSN_EINVAL;  // layer 0: the precomputed input term; H > 256: the PROJ role's output buffer
+            }
+            if (l > 0 && !fused) {  // PROJ role first (lower block indices than the scan it feeds)
+                StackRoleDev& r = p.role[nroles];
+                r = StackRoleDev{};
+                r.bias = s.bias; r.zin = const_cast<float*>(s.zin); r.spikes_in = f.spikes_in; r.w_ih = f.w_ih; r.w_ih_dq = f.w_ih_dq;
+                r.R = s.R; r.kind = STACK_PROJ; r.rpw = 16; r.block0 = blocks; r.nblocks = (s.R + 15) / 16;
+                r.src = prev_role[i]; r.src_rpw = p.role[prev_role[i]].rpw; r.pub = 1;
+                blocks = (blocks + r.nblocks + 7) & ~7;
+                prev_role[i] = nroles++;
+                const int need = ProjLayout<5>::bytes(NT);
+                if (need > lds) lds = need;
+            }
+            StackRoleDev& r = p.role[nroles];
+            r = StackRoleDev{};
+            r.w_hh = s.w_hh; r.w_dq = s.w_dq; r.bias = s.bias; r.bn_alpha = s.bn_alpha; r.bn_beta = s.bn_beta;
+            r.h_state = s.h_state; r.c_state = s.c_state; r.spikes_f32 = s.spikes_f32; r.spikes_i8 = s.spikes_i8;
+            r.zin = const_cast<float*>(s.zin);
+            r.R = s.R; r.rpw = rpw; r.block0 = blocks; r.nblocks = (s.R + rpw - 1) / rpw;
+            r.pub = last ? 0 : 1;
+            if (l == 0) {
+                r.kind = STACK_ZIN; r.src = -1; r.src_rpw = rpw;
+            } else if (fused) {
+                r.kind = STACK_FUSED; r.spikes_in = f.spikes_in; r.w_ih = f.w_ih; r.w_ih_dq = f.w_ih_dq;
+                r.src = prev_role[i]; r.src_rpw = p.role[prev_role[i]].rpw;
+            } else {
+                r.kind = STACK_ZIN; r.src = prev_role[i]; r.src_rpw = 16;
+            }
+            blocks = (blocks + r.nblocks + 7) & ~7;
+            prev_role[i] = nroles++;
+            int need = 0;
+            if (r.kind == STACK_FUSED) {
+                switch (KS) {
+                    case 1: need = FusedLayout<1>::bytes(rpw, NT); break;
+                    case 2: need = FusedLayout<2>::bytes(rpw, NT); break;
+                    case 3: need = FusedLayout<3>::bytes(rpw, NT); break;
+                    default: need = FusedLayout<4>::bytes(rpw, NT); break;
+                }
+            } else {
+                switch (KS) {  // (the repacked-epilogue variant has the same layout)
+                    case 1: need = ScanCfg<1, 1, 8, 1, 3, 0>::LDS_BYTES; break;
+                    case 2: need = ScanCfg<1, 2, 8, 1, 3, 0>::LDS_BYTES; break;
+                    case 3: need = ScanCfg<1, 3, 8, 2, 3, 0>::LDS_BYTES; break;
+                    case 4: need = ScanCfg<1, 4, 8, 2, 3, 0>::LDS_BYTES; break;
+                    default: need = ScanCfg<1, 5, 8, 3, 3, 1>::LDS_BYTES; break;
+                }
+            }
+            if (need > lds) lds = need;
+        }
+    }
+    if (lds > 160 * 1024 - 64) return SFSN_EUNSUPPORTED;
+    if ((size_t)(blocks + 1) * sizeof(unsigned) > scratch_bytes) return SFSN_EINVAL;
+    p.prog = static_cast<unsigned*>(scratch);
+    p.nroles = nroles; p.T = T; p.H = H; p.NT = NT; p.lag = lag;
+    lds = (lds + 15) & ~15;
+    p.gate_off = lds;
+    lds += 16;
+    (void)HP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(scratch, 0, (size_t)(blocks + 1) * sizeof(unsigned), st) != hipSuccess) return SFSN_EHIP;
+#define STACK_CASE(KS_, OUT_) \
+    if (KS == KS_ && out == OUT_) return launch_stack<KS_, OUT_>(p, blocks, lds, st);
+    STACK_CASE(1, 2) STACK_CASE(1, 3) STACK_CASE(2, 2) STACK_CASE(2, 3) STACK_CASE(3, 2) STACK_CASE(3, 3) STACK_CASE(4, 2) STACK_CASE(4, 3)
+    STACK_CASE(5, 2) STACK_CASE(5, 3)
+#undef STACK_CASE
+    return SFSN_EUNSUPPORTED;
+}

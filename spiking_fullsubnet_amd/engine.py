@@ -219,6 +219,12 @@ class Engine:
         self.pipeline_chunk = 128  # frames per chunk of the time-pipelined schedule
         self.pipeline_default = False  # opt-in until the stages own disjoint CU sets
         self.pipeline_two_phase = bool(int(os.environ.get('SFSN_TWO_PHASE', '1')))
+        # layer-pipelined stack scan (sfsn_gsn_stack_scan): all layers of a stack in one launch, layer l+1 trailing layer l
+        # by a few frames.  Shared gate weights only; membrane outputs (a test tap of the per-layer kernel) use the per-layer path.
+        self.stack_scan = bool(int(os.environ.get('SFSN_STACK_SCAN', '1')))
+        self.stack_rows_per_wg = {"fb": 4, "sb": 8}  # rows per workgroup of every layer of a stack: sum of workgroups <= CUs
+        self.stack_lag = 16
+        self._stack_scratch: List[torch.Tensor] = []
 
     # ---------------------------------------------------------------------------------------------
     def _stream(self):
@@ -364,6 +370,52 @@ class Engine:
         self.launches["fused"] = self.launches.get("fused", 0) + 1
         with self.timed("scan:" + tag, st):
             check(L.sfsn_gsn_layer_scan_fused(segs, fin, len(seqs), nt, H, st), "sfsn_gsn_layer_scan_fused")
+
+    def _stackable(self, seqs, want_membrane) -> bool:
+        return bool(self.stack_scan and self.spec.shared and not want_membrane and len(seqs[0].cells) >= 2
+                    and len(seqs) * (1 + (len(seqs[0].cells) - 1) * (1 if seqs[0].H <= 256 else 2)) <= 24)
+
+    def _stage_stack(self, seqs, d, t0, nt, st, tag):
+        """Every layer of the given sequence models in one launch (layer 0's input term is already in d["zin"][0])."""
+        L = self.lib
+        H, nl, ns = seqs[0].H, len(seqs[0].cells), len(seqs)
+        HP = (H + 63) // 64 * 64
+        segs = (ScanSegment * (nl * ns))()
+        fin = (FusedInput * (nl * ns))()
+        rows = 0
+        for l in range(nl):
+            for i, seq in enumerate(seqs):
+                cell, sg, R = seq.cells[l], segs[l * ns + i], d["s8"][l][i].shape[1]
+                rows += R if l == 0 else 0
+                sg.zin = _ptr(d["zin"][l][i]) if (l == 0 or H > 256) else None
+                sg.w_hh, sg.w_dq, sg.bias = _ptr(cell.w_hh_q), _ptr(cell.w_hh_dq), _ptr(cell.bias)
+                sg.bn_alpha, sg.bn_beta = _ptr(cell.alpha), _ptr(cell.beta)
+                sg.h_state, sg.c_state = _ptr(d["states"][l][i][0]), _ptr(d["states"][l][i][1])
+                spk = d["spk"][l][i]
+                sg.spikes_f32 = None if spk is None else ctypes.c_void_p(spk.data_ptr() + t0 * R * H * 4)
+                sg.membrane = None
+                sg.spikes_i8 = ctypes.c_void_p(d["s8"][l][i].data_ptr() + t0 * R * HP)
+                sg.R = R
+                if l > 0:
+                    pk, dq = cell.w_ih_q[0]
+                    fin[l * ns + i].spikes_in = d["s8"][l - 1][i].data_ptr() + t0 * R * HP
+                    fin[l * ns + i].w_ih, fin[l * ns + i].w_ih_dq = pk.data_ptr(), dq.data_ptr()
+        nbytes = L.sfsn_stack_scratch_bytes(nl, ns, rows)
+        scratch = self._workspace(("stack_scratch", tag, nl, ns, rows, torch.cuda.current_stream(self.device).cuda_stream),
+                                  lambda: dict(t=torch.zeros((nbytes // 4,), dtype=torch.int32, device=self.device)))["t"]
+        if not any(scratch is t for t in self._stack_scratch):
+            self._stack_scratch.append(scratch)
+        rpw = (ctypes.c_int * nl)(*([self.stack_rows_per_wg[tag]] * nl))
+        self.launches["stack"] = self.launches.get("stack", 0) + 1
+        with self.timed("scan:" + tag, st):
+            check(L.sfsn_gsn_stack_scan(segs, fin, nl, ns, nt, H, rpw, self.stack_lag, _ptr(scratch), nbytes, st), "sfsn_gsn_stack_scan")
+
+    def check_stack_errors(self) -> None:
+        """Raise if a hand-off wait of a stack launch expired (synchronises; tests and bench call it after a forward)."""
+        torch.cuda.synchronize(self.device)
+        for t in self._stack_scratch:
+            if int(t[0].item()) != 0:
+                raise RuntimeError("sfsn_gsn_stack_scan: a layer-to-layer hand-off wait expired (results invalid)")
 
     def _stage_proj(self, seqs, s8s, projs, t0, nt, st, tag):
         L = self.lib
@@ -598,6 +650,16 @@ class Engine:
             fused = self._fusable(seqs, rpw, want_membrane)
             done = []
             pick = lambda lst, idx: [lst[i] for i in idx]
+            if not pipeline and self._stackable(seqs, want_membrane):
+                # all layers in one launch: features, layer 0's input term, the stack scan, the projection
+                for (t0, nt) in bounds:
+                    feat_fn(t0, nt, hG[first])
+                    self._stage_input(seqs, 0, xs_, d["zin"][0], t0, nt, hG[first], tag)
+                    self._stage_stack(seqs, d, t0, nt, hS[first], tag)
+                    self._stage_proj(seqs, d["s8"][nl - 1], d["proj"], t0, nt, hG[first], tag)
+                    if post_fn is not None:
+                        post_fn(t0, nt, hG[first])
+                return done
             # layer 0: groups whose real-valued input product can run inside the scan / the rest (input product first)
             fx = [i for i in range(len(seqs)) if self._fusable_x(seqs[i], xs_[i], rpw, want_membrane)]
             rest = [i for i in range(len(seqs)) if i not in fx]
