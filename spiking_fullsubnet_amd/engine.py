@@ -221,7 +221,8 @@ class Engine:
         self.pipeline_two_phase = bool(int(os.environ.get('SFSN_TWO_PHASE', '1')))
         # layer-pipelined stack scan (sfsn_gsn_stack_scan): all layers of a stack in one launch, layer l+1 trailing layer l
         # by a few frames.  Shared gate weights only; membrane outputs (a test tap of the per-layer kernel) use the per-layer path.
-        self.stack_scan = bool(int(os.environ.get('SFSN_STACK_SCAN', '1')))
+        _ss = os.environ.get('SFSN_STACK_SCAN', 'auto')
+        self.stack_scan = "auto" if _ss == "auto" else bool(int(_ss))
         self.stack_rows_per_wg = {"fb": 4, "sb": 8}  # rows per workgroup of every layer of a stack: sum of workgroups <= CUs
         self.stack_lag = 16
         self._stack_scratch: List[torch.Tensor] = []
@@ -371,9 +372,19 @@ class Engine:
         with self.timed("scan:" + tag, st):
             check(L.sfsn_gsn_layer_scan_fused(segs, fin, len(seqs), nt, H, st), "sfsn_gsn_layer_scan_fused")
 
-    def _stackable(self, seqs, want_membrane) -> bool:
-        return bool(self.stack_scan and self.spec.shared and not want_membrane and len(seqs[0].cells) >= 2
-                    and len(seqs) * (1 + (len(seqs[0].cells) - 1) * (1 if seqs[0].H <= 256 else 2)) <= 24)
+    def _stackable(self, seqs, Rs, want_membrane) -> bool:
+        """All layers of a stack in one launch (sfsn_gsn_stack_scan)?  The layer-pipelined launch wins where one layer's
+        workgroups leave most of the chip idle (the full-band model: B/4 workgroups -- 2 x 1.13 -> 1.25 ms at B=64, T=1000);
+        where a single layer already fills the chip at 4 rows per workgroup (the sub-band models at B=64: 208 workgroups)
+        the two layers side by side each get half the CUs and twice the rows per CU, and two full-chip launches in a row are
+        faster (measured: 2 x 0.74 + 0.16 ms against 1.83 ms).  `stack_scan`: True / False / "auto" (by that occupancy rule)."""
+        if not (self.stack_scan and self.spec.shared and not want_membrane and len(seqs[0].cells) >= 2
+                and len(seqs) * (1 + (len(seqs[0].cells) - 1) * (1 if seqs[0].H <= 256 else 2)) <= 24):
+            return False
+        if self.stack_scan == "auto":
+            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            return sum((R + 3) // 4 for R in Rs) * len(seqs[0].cells) <= n_cu
+        return True
 
     def _stage_stack(self, seqs, d, t0, nt, st, tag):
         """Every layer of the given sequence models in one launch (layer 0's input term is already in d["zin"][0])."""
@@ -405,7 +416,8 @@ class Engine:
                                   lambda: dict(t=torch.zeros((nbytes // 4,), dtype=torch.int32, device=self.device)))["t"]
         if not any(scratch is t for t in self._stack_scratch):
             self._stack_scratch.append(scratch)
-        rpw = (ctypes.c_int * nl)(*([self.stack_rows_per_wg[tag]] * nl))
+        rp = 4 if self.stack_scan == "auto" else self.stack_rows_per_wg[tag]  # auto only stacks what fits the chip at 4 rows
+        rpw = (ctypes.c_int * nl)(*([rp] * nl))
         self.launches["stack"] = self.launches.get("stack", 0) + 1
         with self.timed("scan:" + tag, st):
             check(L.sfsn_gsn_stack_scan(segs, fin, nl, ns, nt, H, rpw, self.stack_lag, _ptr(scratch), nbytes, st), "sfsn_gsn_stack_scan")
@@ -650,7 +662,7 @@ class Engine:
             fused = self._fusable(seqs, rpw, want_membrane)
             done = []
             pick = lambda lst, idx: [lst[i] for i in idx]
-            if not pipeline and self._stackable(seqs, want_membrane):
+            if not pipeline and self._stackable(seqs, [x.shape[1] for x in xs_], want_membrane):
                 # all layers in one launch: features, layer 0's input term, the stack scan, the projection
                 for (t0, nt) in bounds:
                     feat_fn(t0, nt, hG[first])
