@@ -599,6 +599,7 @@ def test_fused_input_scan_is_bit_identical(front, kw, seed):
     wave = torch.from_numpy(rw.synth_wave(4, 70, seed)).to(DEV)  # even batch: group 0's rows are a multiple of 16 (layer-0 fusion)
     stft = model._stft(wave)
     eng = model.engine()
+    eng.stack_scan = False  # this test is about the per-layer entry points (tests/test_stack_scan.py covers the stack launch)
     eng.rows_per_wg = (16, 16)
     outs = []
     for fuse, chunk in ((False, 0), (True, 0), (True, 32)):
@@ -634,6 +635,7 @@ def test_full_size_fused_forwards_in_flight_equal_the_plain_forward():
     kw, seed = rw.LIVE_M, 21
     model = build_module("live", kw, rw.live_state_dict(kw, seed))
     eng = model.engine()
+    eng.stack_scan = False  # this test is about the per-layer entry points (tests/test_stack_scan.py covers the stack launch)
     stft = model._stft(torch.from_numpy(rw.synth_wave(64, 1000, 3)).to(DEV))
     eng.fuse_input, eng.rows_per_wg = False, (0, 0)
     ref = eng.forward_stft(stft)
@@ -662,6 +664,7 @@ def test_fused_scans_on_very_short_sequences(T):
     kw, seed = rw.LIVE_M, 31
     model = build_module("live", kw, rw.live_state_dict(kw, seed))
     eng = model.engine()
+    eng.stack_scan = False  # this test is about the per-layer entry points (tests/test_stack_scan.py covers the stack launch)
     rng = np.random.default_rng(T)
     stft = _t((0.3 * (rng.standard_normal((2, 257, T)) + 1j * rng.standard_normal((2, 257, T)))).astype(np.complex64))
     eng.rows_per_wg = (16, 16)
