@@ -47,7 +47,7 @@ extern "C" {
 #define SFSN_MAX_GROUPS 8      /* sub-band groups per model                                                     */
 
 int sfsn_abi_version(void);
-/* First 16 hex digits of the sha256 of the sources this library was built from (include/sfsn.h, csrc/*): lets a binding
+/* First 16 hex digits of the sha256 of the sources this library was built from (include/sfsn.h and the files under csrc/): lets a binding
  * refuse a stale build whose struct layouts or entry points no longer match the header it was written against. */
 const char* sfsn_source_hash(void);
 const char* sfsn_strerror(int code);

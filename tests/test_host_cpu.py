@@ -24,7 +24,10 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sfsn_abi_version() == 1
+    header_ver = int(re.search(r"#define SFSN_ABI_VERSION (\d+)", header).group(1))
+    assert L.sfsn_abi_version() == header_ver == _lib.ABI_VERSION
+    L.sfsn_source_hash.restype = __import__('ctypes').c_char_p
+    assert L.sfsn_source_hash().decode() == _lib.source_hash()  # the staleness check of _lib.lib()
     assert L.sfsn_strerror(-4).decode().startswith("Number of frequency bins")
 
 
