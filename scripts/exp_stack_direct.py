@@ -21,7 +21,7 @@ def run(H, nl, rpw, lag, T=1000, Rs=None, reps=5):
             w = (rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float32)
             pk, dq = pack_w3(w); pk, dq = dv(pk), dv(dq)
             sg = segs[l * ns + i]
-            zin = dv((rng.standard_normal((T, R, H)) * 0.5).astype(np.float32)) if (l == 0 or H > 256) else None
+            zin = dv((rng.standard_normal((T, R, H)) * 0.5).astype(np.float32)) if (l == 0 or H > 256 or not os.environ.get('NOZIN')) else None
             sg.zin = None if zin is None else zin.data_ptr()
             sg.w_hh, sg.w_dq = pk.data_ptr(), dq.data_ptr()
             sg.bias = dv((rng.standard_normal(2 * H) * 0.1).astype(np.float32)).data_ptr()

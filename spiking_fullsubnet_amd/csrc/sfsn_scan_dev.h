@@ -152,7 +152,11 @@ __device__ __forceinline__ void store16_sc1(void* base_uniform, unsigned byte_of
     const unsigned long long a = reinterpret_cast<unsigned long long>(base_uniform);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
     const unsigned long long base = ((unsigned long long)hi << 32) | lo;
-    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(byte_off), "v"(data), "s"(base) : "memory");
+    // The trailing s_nop is NOT optional: a VMEM store of more than 8 bytes reads its data VGPRs after issue, and a VALU write
+    // of one of them in the next slot needs a wait state.  hipcc's hazard recogniser inserts it for stores it emits itself but
+    // cannot see through inline asm -- without it element 0 of the stored vector was replaced by whatever the next instruction
+    // computed (seen as LDS addresses in the input-term buffer for H = 160, and as a faulting address in a non-inlined build).
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(byte_off), "v"(data), "s"(base) : "memory");
 }
 
 template <int G, int KS, int NW, int TPW, int OUT, int LP>
@@ -300,6 +304,18 @@ __device__ __forceinline__ void scan_prologue(const ScanSegDev& sg, char* smem, 
 
 }
 
+__device__ __forceinline__ void wait_vmcnt_n(int n) {  // s_waitcnt vmcnt(n) for any wave-uniform runtime n (the field is an immediate)
+    switch (n) {
+#define W_(K) case K: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
+        W_(0) W_(1) W_(2) W_(3) W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15)
+        W_(16) W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25) W_(26) W_(27) W_(28) W_(29) W_(30) W_(31)
+        W_(32) W_(33) W_(34) W_(35) W_(36) W_(37) W_(38) W_(39) W_(40) W_(41) W_(42) W_(43) W_(44) W_(45) W_(46) W_(47)
+        W_(48) W_(49) W_(50) W_(51) W_(52) W_(53) W_(54) W_(55) W_(56) W_(57) W_(58) W_(59) W_(60) W_(61) W_(62)
+#undef W_
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+}
+
 // ---- the scan body for a wave that owns NTL (compile-time) output tiles -------------------------------------
 // Straight-line code per step: no per-tile or per-row branch.  Rows past R are CLAMPED duplicates of row R-1: they
 // run the same instruction sequence on the same data, produce bit-identical values and store them to the same
@@ -333,6 +349,13 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
                 if (avail < 0) break;  // a bounded spin expired: give up (uniform), the error word is set
             }
             if (t > 0) fl.template run<OUT, PUB>(hbuf + (t & 1) * 16 * LDH, spikes_f32, spikes_i8, t - 1, R, H);
+            if constexpr (PUB) {
+                // wave 0 publishes at the top of step t+1 that the flush stores of steps <= t-D are complete -- for EVERY wave:
+                // a wave without tiles has no DMA to wait for, so it bounds its own stores in flight to the last D steps
+                // (with 16 rows per workgroup the waves without tiles do flush)
+                const int inflight = C::RING_D * fl.template stores_per_frame<OUT, true>();
+                if (inflight < 63) wait_vmcnt_n(inflight); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();
         }

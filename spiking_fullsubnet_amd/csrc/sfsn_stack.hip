@@ -19,6 +19,7 @@
 // sfsn_spike_proj + sfsn_gsn_layer_scan (tested).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sfsn.h"
 #include "sfsn_scan_dev.h"
@@ -70,7 +71,12 @@ struct StackGeom {
 // ---------------------------------------------------------------------------------------------------------------------
 template <int KS>
 struct FusedLayout {
-    static constexpr int HP = KS * 64, LDH = HP + 32, D = 3, NCH = KS * 4;
+    #ifndef SFSN_FUSED_RING
+#define SFSN_FUSED_RING 3
+#endif
+    // input-spike ring depth: the slot of step t+1 is waited for at the end of step t and was requested D-2 steps before
+    // that -- a hand-off through L2 / Infinity Cache (write-through producer) needs more lead than a read of settled data
+    static constexpr int HP = KS * 64, LDH = HP + 32, D = SFSN_FUSED_RING, NCH = KS * 4;
     __device__ __host__ static constexpr int slot_bytes(int rpw) { return ((rpw * HP + 1023) / 1024) * 1024; }
     __device__ __host__ static constexpr int hbuf_off(int rpw) { return D * slot_bytes(rpw); }
     __device__ __host__ static constexpr int cst_off(int rpw) { return hbuf_off(rpw) + 2 * 16 * LDH; }
@@ -222,8 +228,8 @@ __device__ __forceinline__ void stack_fused_body(const StackRoleDev& rl, const S
         }
         if constexpr (PUB) {
             // After the barrier that ended step t-1 every wave has passed the wait of step t-1, which covers the flush
-            // stores issued at steps <= t-3, i.e. frames <= t-4: t-3 frames are complete in memory.
-            if (wave == 0 && lane == 0 && t - 3 > 0) stack_publish(lk, t - 3);
+            // stores issued at steps <= t-D, i.e. frames <= t-D-1: t-D frames are complete in memory.
+            if (wave == 0 && lane == 0 && t - D > 0) stack_publish(lk, t - D);
         }
         step(t, std::false_type{});
     }
@@ -470,6 +476,196 @@ __device__ __forceinline__ void stack_zin_role(const StackRoleDev& rl, const Sta
                                                          H, NT, R, row0, rowc, n, q, tid, wave, rpw, &lk, gate_word);
 }
 
+// =====================================================================================================================
+// The WIDE flavour (H <= 256, 16 waves per workgroup): every recurrent layer runs the 16-wave scan body of the per-layer
+// kernel (one output tile per wave, four waves per SIMD hide each other's LDS / MFMA latency: 0.75 / 0.93 us per step at 4 /
+// 8 rows per workgroup, against 1.6-1.8 us for any body that computes the input product inside the recurrent workgroup),
+// and the input term of a layer >= 1 is produced, frame by frame, by PROJ16 workgroups of the same launch: 32 rows each,
+// W_ih register resident (one tile per wave), both column tiles of a frame back to back -- a full-efficiency product whose
+// fp32 result goes to the consumer through L2 / Infinity Cache (write-through stores, sc1 loads).
+// =====================================================================================================================
+template <int KS>
+struct Proj16Layout {
+    static constexpr int HP = KS * 64, D = 8, NCH = KS * 4, ROWS = 32;  // D: write-through stores retire slowly -- seven steps of them may be in flight
+    static constexpr int SLOT = ROWS * HP;
+    static constexpr int CST_OFF = D * SLOT;
+    static constexpr int BYTES = CST_OFF + 2 * HP * 4;
+};
+
+template <int KS>
+__device__ __forceinline__ void stack_proj16_role(const StackRoleDev& rl, const StackLink& lk, char* smem, int* gate_word, int T, int H,
+                                                  int NT, int blk) {
+    using L = Proj16Layout<KS>;
+    constexpr int HP = L::HP, D = L::D, NCH = L::NCH, SLOT = L::SLOT, NW = 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int R = rl.R;
+    const int row0 = blk * L::ROWS;
+    float(*cst)[HP] = reinterpret_cast<float(*)[HP]>(smem + L::CST_OFF);  // bias_f, dq_ih
+    for (int j = tid; j < HP; j += NW * 64) {
+        const bool in = j < H;
+        cst[0][j] = in ? rl.bias[j] : 0.0f;
+        cst[1][j] = in ? rl.w_ih_dq[j] : 0.0f;
+    }
+    const bool have = wave < NT;
+    const int ct = have ? wave : 0;
+    const int cc = ct * 16 + q * 4;
+    v4i W[KS][3];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const size_t tile = (size_t)d * NT + ct;
+            W[ks][d] = *reinterpret_cast<const v4i*>(rl.w_ih + ((tile * KS + ks) * 64 + lane) * 16);
+        }
+    // input ring: a slot = the 32 rows of a frame as 32 * NCH 16-byte chunks, chunk (row r, position p) holds global chunk
+    // (p - r) mod NCH of that row; piece k = chunks [64 k, 64 k + 64), wave w fetches piece min(w, last)
+    constexpr int npiece = (L::ROWS * NCH) >> 6;
+    const int piece = wave < npiece ? wave : npiece - 1;
+    const int e = piece * 64 + lane;
+    const int er = e / NCH, esl = e - er * NCH;
+    const int erow = (row0 + er < R) ? row0 + er : R - 1;
+    const unsigned src_off = (unsigned)(erow * HP + ((esl - er % NCH + NCH) % NCH) * 16);
+    const size_t frame = (size_t)R * HP;
+    auto issue = [&](int slot, int td) __attribute__((always_inline)) {
+        dma16_to_lds<true>(__builtin_amdgcn_readfirstlane((unsigned)(slot * SLOT + piece * 1024)),
+                           reinterpret_cast<const float*>(rl.spikes_in + (size_t)td * frame), src_off);
+    };
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int avail = 0;
+    {
+        const int need = D < T ? D : T;
+        avail = stack_refresh(lk, need, T, gate_word, wave, lane);
+    }
+    for (int s0 = 0; s0 < D - 1; ++s0) issue(s0, s0 < T ? s0 : (T > 0 ? T - 1 : 0));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+
+    const v4f bf = *reinterpret_cast<const v4f*>(&cst[0][cc]), dqi = *reinterpret_cast<const v4f*>(&cst[1][cc]);
+    unsigned zoff[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int r = row0 + c * 16 + n;
+        zoff[c] = (unsigned)(((r < R) ? r : R - 1) * H + cc) * 4u;  // rows past R are clamped duplicates (same value, same address)
+    }
+    // operations this wave issues per step: one DMA and (with a tile) two 16-byte stores
+    const int ns = have ? 2 : 0;
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        if (t > 0) {
+            const int need = (t + D < T) ? t + D : T;
+            if (avail >= 0 && need > avail) avail = stack_refresh(lk, need, T, gate_word, wave, lane);
+            // stores issued at steps <= t-D are complete for every wave (the wait that ended step t-1): frames [0, t-D+1)
+            if (wave == 0 && lane == 0 && t - D + 1 > 0) stack_publish(lk, t - D + 1);
+        }
+        if (avail < 0) break;
+        {
+            const int td = (t + D - 1 < T) ? t + D - 1 : T - 1;
+            issue((t + D - 1) % D, td);
+        }
+        float* zt = rl.zin + (size_t)t * R * H;
+        const char* sl = smem + (t % D) * SLOT;
+        if (have) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int r = c * 16 + n;
+                v4i e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0}, e2 = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const v4i bs = *reinterpret_cast<const v4i*>(sl + r * HP + ((ks * 4 + q + r) % NCH) * 16);
+                    e0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[ks][0], bs, e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[ks][1], bs, e1, 0, 0, 0);
+                    e2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[ks][2], bs, e2, 0, 0, 0);
+                }
+                v4f z;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) z[r4] = __builtin_fmaf(recombine3(e0[r4], e1[r4], e2[r4]), dqi[r4], bf[r4]);  // = sfsn_spike_proj
+                v4i zi;
+                __builtin_memcpy(&zi, &z, 16);
+                store16_sc1(zt, zoff[c], zi);
+            }
+        }
+        // my piece of step t+1's slot was issued at the top of step t-D+2; since then D-2 more DMAs and D-1 steps' stores
+        if (t < D) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            wait_vmcnt_n((D - 1) * ns + (D - 2));
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave == 0 && lane == 0) stack_publish(lk, T);
+}
+
+template <int KS, int OUT, int FLG>
+__device__ __forceinline__ void stack_zin16_role(const StackRoleDev& rl, const StackLink& lk, char* smem, int* gate_word, int T, int H, int NT,
+                                                 int blk) {
+    constexpr int NW = 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int rpw = rl.rpw, R = rl.R;
+    const int row0 = blk * rpw;
+    const int rowc = (row0 + (n & (rpw - 1)) < R) ? row0 + (n & (rpw - 1)) : R - 1;
+    ScanSegDev sg;
+    sg.zin = rl.zin; sg.w_hh = rl.w_hh; sg.w_dq = rl.w_dq; sg.bias = rl.bias; sg.bn_alpha = rl.bn_alpha; sg.bn_beta = rl.bn_beta;
+    sg.h_state = rl.h_state; sg.c_state = rl.c_state; sg.spikes_f32 = rl.spikes_f32; sg.spikes_i8 = rl.spikes_i8; sg.membrane = nullptr;
+    sg.R = R;
+    scan_prologue<1, KS, NW, 1, OUT, 0>(sg, smem, tid, H, NT, R, row0, rpw);
+    if (wave < NT)
+        scan_body<1, KS, NW, 1, OUT, 0, 1, FLG>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, nullptr, sg.h_state, sg.c_state, smem, T, H, NT, R, row0,
+                                                rowc, n, q, tid, wave, rpw, &lk, gate_word);
+    else
+        scan_body<1, KS, NW, 1, OUT, 0, 0, FLG>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, nullptr, sg.h_state, sg.c_state, smem, T, H, NT, R, row0,
+                                                rowc, n, q, tid, wave, rpw, &lk, gate_word);
+}
+
+template <int KS, int OUT>
+__global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams p) {
+    extern __shared__ __attribute__((aligned(16))) char scan_smem[];
+    int* gate_word_p = reinterpret_cast<int*>(scan_smem + p.gate_off);
+    int ri = -1;
+    for (int i = 0; i < p.nroles; ++i)
+        if ((int)blockIdx.x >= p.role[i].block0 && (int)blockIdx.x < p.role[i].block0 + p.role[i].nblocks) ri = i;
+    if (ri < 0) return;
+    const StackRoleDev& rl = p.role[ri];
+    const int blk = (int)blockIdx.x - rl.block0;
+    StackLink lk;
+    lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = p.prog; lk.lag = p.lag;
+    if (rl.pub) lk.out = p.prog + 1 + blockIdx.x;
+    const int my_rpw = rl.kind == STACK_PROJ ? Proj16Layout<KS>::ROWS : rl.rpw;
+    if (rl.src >= 0) {
+        const StackRoleDev& sr = p.role[rl.src];
+        const int r0 = blk * my_rpw;
+        int r1 = r0 + my_rpw - 1;
+        if (r1 > rl.R - 1) r1 = rl.R - 1;
+        const int b0 = r0 / rl.src_rpw, b1 = r1 / rl.src_rpw;
+        lk.in = p.prog + 1 + sr.block0 + b0;
+        lk.n_in = b1 - b0 + 1;
+    }
+    const int T = p.T, H = p.H, NT = p.NT;
+    if (rl.kind == STACK_PROJ) {
+        stack_proj16_role<KS>(rl, lk, scan_smem, gate_word_p, T, H, NT, blk);
+    } else {
+        const bool rp4 = rl.rpw == 4;
+        const int flg = (rl.src >= 0 ? 1 : 0) | (rl.pub ? 2 : 0);
+#define ZIN16_CASE(F)                                                                                     \
+    if (flg == F) {                                                                                       \
+        if (rp4)                                                                                          \
+            stack_zin16_role<KS, OUT | 512, F>(rl, lk, scan_smem, gate_word_p, T, H, NT, blk);            \
+        else                                                                                              \
+            stack_zin16_role<KS, OUT, F>(rl, lk, scan_smem, gate_word_p, T, H, NT, blk);                  \
+    }
+        ZIN16_CASE(0) ZIN16_CASE(1) ZIN16_CASE(2) ZIN16_CASE(3)
+#undef ZIN16_CASE
+    }
+}
+
 // OUT: bit 0 fp32 spikes, bit 1 int8 spikes (always).  The 4-row repacked epilogue (bit 9) is selected per role from rpw.
 template <int KS, int OUT>
 __global__ __launch_bounds__(512) void gsn_stack_kernel(const StackParams p) {
@@ -551,7 +747,16 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
     if (!segs || !fin || n_layers <= 0 || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0 || !scratch) return SFSN_EINVAL;
     if (H % 16 != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     const int KS = (H + 63) / 64, NT = H / 16, HP = KS * 64;
-    const bool fused = H <= 256;  // both matrices of a layer >= 1 fit one CU
+    bool fused = H <= 256;  // both matrices of a layer >= 1 fit one CU
+    // H <= 256 with input-term buffers for the layers >= 1: the WIDE flavour (16-wave scans + PROJ16 roles); without them
+    // the 8-wave fused-input roles
+    bool wide = fused;
+    for (int l = 1; l < n_layers && wide; ++l)
+        for (int i = 0; i < n_segs; ++i)
+            if (!segs[l * n_segs + i].zin) wide = false;
+    if (n_layers == 1 && fused) wide = true;
+    if (getenv("SFSN_STACK_NARROW")) wide = false;
+    if (wide) fused = false;
     const int roles_per_layer = fused ? 1 : 2;
     if (n_segs * (1 + (n_layers - 1) * roles_per_layer) > STACK_MAX_ROLES) return SFSN_EUNSUPPORTED;
     if (lag < 0) return SFSN_EINVAL;
@@ -584,11 +789,13 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
                 StackRoleDev& r = p.role[nroles];
                 r = StackRoleDev{};
                 r.bias = s.bias; r.zin = const_cast<float*>(s.zin); r.spikes_in = f.spikes_in; r.w_ih = f.w_ih; r.w_ih_dq = f.w_ih_dq;
-                r.R = s.R; r.kind = STACK_PROJ; r.rpw = 16; r.block0 = blocks; r.nblocks = (s.R + 15) / 16;
+                const int prows = wide ? 32 : 16;
+                r.R = s.R; r.kind = STACK_PROJ; r.rpw = prows; r.block0 = blocks; r.nblocks = (s.R + prows - 1) / prows;
                 r.src = prev_role[i]; r.src_rpw = p.role[prev_role[i]].rpw; r.pub = 1;
                 blocks = (blocks + r.nblocks + 7) & ~7;
                 prev_role[i] = nroles++;
-                const int need = ProjLayout<5>::bytes(NT);
+                int need = ProjLayout<5>::bytes(NT);
+                if (wide) need = KS == 1 ? Proj16Layout<1>::BYTES : KS == 2 ? Proj16Layout<2>::BYTES : KS == 3 ? Proj16Layout<3>::BYTES : Proj16Layout<4>::BYTES;
                 if (need > lds) lds = need;
             }
             StackRoleDev& r = p.role[nroles];
@@ -604,12 +811,19 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
                 r.kind = STACK_FUSED; r.spikes_in = f.spikes_in; r.w_ih = f.w_ih; r.w_ih_dq = f.w_ih_dq;
                 r.src = prev_role[i]; r.src_rpw = p.role[prev_role[i]].rpw;
             } else {
-                r.kind = STACK_ZIN; r.src = prev_role[i]; r.src_rpw = 16;
+                r.kind = STACK_ZIN; r.src = prev_role[i]; r.src_rpw = wide ? 32 : 16;
             }
             blocks = (blocks + r.nblocks + 7) & ~7;
             prev_role[i] = nroles++;
             int need = 0;
-            if (r.kind == STACK_FUSED) {
+            if (wide) {
+                switch (KS) {  // (the repacked-epilogue variant has the same layout)
+                    case 1: need = ScanCfg<1, 1, 16, 1, 3, 0>::LDS_BYTES; break;
+                    case 2: need = ScanCfg<1, 2, 16, 1, 3, 0>::LDS_BYTES; break;
+                    case 3: need = ScanCfg<1, 3, 16, 1, 3, 0>::LDS_BYTES; break;
+                    default: need = ScanCfg<1, 4, 16, 1, 3, 0>::LDS_BYTES; break;
+                }
+            } else if (r.kind == STACK_FUSED) {
                 switch (KS) {
                     case 1: need = FusedLayout<1>::bytes(rpw, NT); break;
                     case 2: need = FusedLayout<2>::bytes(rpw, NT); break;
@@ -638,6 +852,17 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
     (void)HP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(scratch, 0, (size_t)(blocks + 1) * sizeof(unsigned), st) != hipSuccess) return SFSN_EHIP;
+#define WIDE_CASE(KS_, OUT_)                                                                                                  \
+    if (wide && KS == KS_ && out == OUT_) {                                                                                   \
+        auto kern = gsn_stack_wide_kernel<KS_, OUT_>;                                                                         \
+        if (lds > 64 * 1024 &&                                                                                                \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
+            return SFSN_EHIP;                                                                                                 \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, st, p);                                                       \
+        return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;                                                         \
+    }
+    WIDE_CASE(1, 2) WIDE_CASE(1, 3) WIDE_CASE(2, 2) WIDE_CASE(2, 3) WIDE_CASE(3, 2) WIDE_CASE(3, 3) WIDE_CASE(4, 2) WIDE_CASE(4, 3)
+#undef WIDE_CASE
 #define STACK_CASE(KS_, OUT_) \
     if (KS == KS_ && out == OUT_) return launch_stack<KS_, OUT_>(p, blocks, lds, st);
     STACK_CASE(1, 2) STACK_CASE(1, 3) STACK_CASE(2, 2) STACK_CASE(2, 3) STACK_CASE(3, 2) STACK_CASE(3, 3) STACK_CASE(4, 2) STACK_CASE(4, 3)

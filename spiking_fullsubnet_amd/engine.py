@@ -225,6 +225,7 @@ class Engine:
         self.stack_scan = "auto" if _ss == "auto" else bool(int(_ss))
         self.stack_rows_per_wg = {"fb": 4, "sb": 8}  # rows per workgroup of every layer of a stack: sum of workgroups <= CUs
         self.stack_lag = 16
+        self.stack_wide = True
         self._stack_scratch: List[torch.Tensor] = []
 
     # ---------------------------------------------------------------------------------------------
@@ -398,7 +399,9 @@ class Engine:
             for i, seq in enumerate(seqs):
                 cell, sg, R = seq.cells[l], segs[l * ns + i], d["s8"][l][i].shape[1]
                 rows += R if l == 0 else 0
-                sg.zin = _ptr(d["zin"][l][i]) if (l == 0 or H > 256) else None
+                # layers >= 1: an input-term buffer selects the wide flavour for H <= 256 (16-wave scans fed by PROJ workgroups
+                # of the same launch); without it the 8-wave fused-input roles run
+                sg.zin = _ptr(d["zin"][l][i]) if (l == 0 or H > 256 or self.stack_wide) else None
                 sg.w_hh, sg.w_dq, sg.bias = _ptr(cell.w_hh_q), _ptr(cell.w_hh_dq), _ptr(cell.bias)
                 sg.bn_alpha, sg.bn_beta = _ptr(cell.alpha), _ptr(cell.beta)
                 sg.h_state, sg.c_state = _ptr(d["states"][l][i][0]), _ptr(d["states"][l][i][1])

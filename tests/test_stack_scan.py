@@ -46,9 +46,10 @@ def _cells(rng, I, H, nl):
     return out
 
 
-def run_stack(hip, zin0s, cells, T, H, rpw, lag=4, want_f32=True, h0=None, c0=None):
+def run_stack(hip, zin0s, cells, T, H, rpw, lag=4, want_f32=True, h0=None, c0=None, wide=True):
     """zin0s: per segment [T, R, H] = x . W_ih^T of layer 0 (bias added here).  Returns per layer / segment fp32 spikes,
-    int8 spikes and the final states."""
+    int8 spikes and the final states.  wide: give the layers >= 1 an input-term buffer (H <= 256: selects the 16-wave flavour
+    with PROJ workgroups; without it the 8-wave fused-input roles run; H > 256 always needs the buffer)."""
     from spiking_fullsubnet_amd._lib import FusedInput, ScanSegment, check
     from spiking_fullsubnet_amd.engine import pack_w3
     nl, ns = len(cells), len(zin0s)
@@ -66,7 +67,7 @@ def run_stack(hip, zin0s, cells, T, H, rpw, lag=4, want_f32=True, h0=None, c0=No
         for i, z0 in enumerate(zin0s):
             R = z0.shape[1]
             s = segs[l * ns + i]
-            z = _t((z0 + sd["bias_ih"][:H]).astype(np.float32)) if l == 0 else (torch.empty((T, R, H), device=DEV) if H > 256 else None)
+            z = _t((z0 + sd["bias_ih"][:H]).astype(np.float32)) if l == 0 else (torch.empty((T, R, H), device=DEV) if (H > 256 or wide) else None)
             h = _t(np.zeros((R, H), np.float32) if h0 is None else h0[l][i])
             c = _t(np.zeros((R, H), np.float32) if c0 is None else c0[l][i])
             spk = torch.empty((T, R, H), device=DEV) if want_f32 else None
@@ -94,8 +95,9 @@ STACKS = [  # I, H, layers, rows per segment, T, rows per workgroup
 ]
 
 
+@pytest.mark.parametrize("wide", [True, False], ids=["wide", "narrow"])
 @pytest.mark.parametrize("I,H,nl,Rs,T,rpw", STACKS)
-def test_stack_scan_vs_oracle_and_per_layer_calls(hip, I, H, nl, Rs, T, rpw):
+def test_stack_scan_vs_oracle_and_per_layer_calls(hip, I, H, nl, Rs, T, rpw, wide):
     """Every layer's spikes against the oracle's StackedGSU restatement (causal rule: exact until a first flip inside the
     don't-care band) and, bit for bit, against sfsn_spike_proj + sfsn_gsn_layer_scan run layer by layer."""
     from test_hip_parity import run_scan
@@ -104,7 +106,7 @@ def test_stack_scan_vs_oracle_and_per_layer_calls(hip, I, H, nl, Rs, T, rpw):
     o = Oracle("f32")
     xs = [rng.standard_normal((T, R, I)).astype(np.float32) for R in Rs]
     zin0 = [o.linear(x, cells[0][0]["weight_ih"]) for x in xs]
-    got = run_stack(hip, zin0, cells, T, H, rpw)
+    got = run_stack(hip, zin0, cells, T, H, rpw, wide=wide)
     for i, x in enumerate(xs):
         # oracle, layer by layer on ITS OWN spikes (NEURON:56-61)
         inp, valid = x, np.full(x.shape[1], T)
