@@ -41,7 +41,9 @@ for front, kw, seed in cases:
         print(front, kw.get("fb_hidden_size"), "rpw", rp, "bit-identical" if ok else f"MISMATCH {bad[:6]}", "launches", eng.launches, flush=True)
     eng.stack_rows_per_wg = {"fb": 4, "sb": 8}
     rps = [tuple(int(v) for v in a.split(",")) for a in os.environ.get("RPS", "4,8").split(";")]
-    for mode in (False, True):
+    for mode in (False, True, "narrow"):
+        eng.stack_wide = mode != "narrow"
+        mode = bool(mode)
         for rp in (rps if mode else [(0, 0)]):
             eng.stack_scan = mode
             if mode: eng.stack_rows_per_wg = {"fb": rp[0], "sb": rp[1]}
@@ -52,5 +54,5 @@ for front, kw, seed in cases:
             eng.timers, eng.timer_tags = {}, {"scan:sb", "scan:fb"}
             for _ in range(3): eng.forward_stft(stft)
             tm = eng.timer_summary(); eng.timers = None
-            print(f"   stack={mode} rpw={rp}: {dt*1e3:.3f} ms per forward (B={B}, T={T}); scans: " +
+            print(f"   stack={mode} wide={eng.stack_wide} rpw={rp}: {dt*1e3:.3f} ms per forward (B={B}, T={T}); scans: " +
                   ", ".join(f"{k} {v['min_ms']:.3f} ms x{v['n']//3}" for k, v in tm.items()), flush=True)

@@ -46,6 +46,14 @@ def run(H, nl, rpw, lag, T=1000, Rs=None, reps=5):
     torch.cuda.synchronize()
     ms = min(a.elapsed_time(b) for a, b in ev)
     rate = [float((s8[l][0] != 0).float().mean().item()) for l in range(nl)]
+    if os.environ.get("SFSN_STACK_DEBUG"):
+        w = scratch.cpu().numpy().astype(np.int64)
+        # block layout: per layer [PROJ roles (if any)] then scan roles, each role padded to a multiple of 8 blocks
+        nb_ = int(os.environ.get('BLOCKS', '240'))
+        dbg = w[nb_ + 1: nb_ + 1 + 4 * nb_].reshape(-1, 4); t0 = dbg[:104, 2].min()
+        for (name, b0, b1) in (("L0 scan", 0, 104), ("PROJ seg0", 104, 120), ("L1 scan seg0", 120, 184), ("PROJ seg1", 184, 190), ("L1 scan seg1", 192, 216), ("PROJ seg2", 216, 220), ("L1 scan seg2", 224, 240)):
+            d = dbg[b0:b1]
+            print(f"   {name:14s} waits/WG {d[:,0].mean():7.1f}  polls/WG {d[:,1].mean():8.1f}  start us [{(d[:,2].min()-t0)/100:8.1f}, {(d[:,2].max()-t0)/100:8.1f}]  end us [{(d[:,3].min()-t0)/100:8.1f}, {(d[:,3].max()-t0)/100:8.1f}]")
     print(f"H={H} layers={nl} rpw={rpw} lag={lag} T={T} rows={Rs}: {ms:.3f} ms = {1e3*ms/T:.3f} us/step; spike rates {['%.2f' % r for r in rate]}", flush=True)
 
 if __name__ == "__main__":

@@ -112,6 +112,7 @@ struct StackLink {
     unsigned* out;       // this workgroup's counter; nullptr = nothing to publish
     unsigned* err;       // launch-wide error word (non-zero = a bounded spin expired)
     int lag;             // frames a consumer lets its producer run ahead before it starts / resumes (amortises the polls)
+    unsigned* dbg;       // optional: [0] += hand-off waits entered, [1] += poll iterations spent in them (who waits for whom)
 };
 
 #define SFSN_STACK_SPIN_LIMIT 400000  // x (s_sleep 32 + one L2 round trip) ~ 1 s
@@ -135,7 +136,9 @@ __device__ __forceinline__ int stack_refresh(const StackLink& lk, int need, int 
                 break;
             }
             __builtin_amdgcn_s_sleep(32);
+            if (lk.dbg) lk.dbg[1] += 1;
         }
+        if (lk.dbg) lk.dbg[0] += 1;
         *reinterpret_cast<volatile int*>(word) = v;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -156,7 +159,11 @@ __device__ __forceinline__ void store16_sc1(void* base_uniform, unsigned byte_of
     // of one of them in the next slot needs a wait state.  hipcc's hazard recogniser inserts it for stores it emits itself but
     // cannot see through inline asm -- without it element 0 of the stored vector was replaced by whatever the next instruction
     // computed (seen as LDS addresses in the input-term buffer for H = 160, and as a faulting address in a non-inlined build).
+#ifdef SFSN_EXP_PLAIN_I8  // timing experiment only (the hand-off is NOT safe with plain stores)
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(byte_off), "v"(data), "s"(base) : "memory");
+#else
     asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(byte_off), "v"(data), "s"(base) : "memory");
+#endif
 }
 
 template <int G, int KS, int NW, int TPW, int OUT, int LP>

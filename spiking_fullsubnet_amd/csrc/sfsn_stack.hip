@@ -52,6 +52,7 @@ struct StackRoleDev {
 struct StackParams {
     StackRoleDev role[STACK_MAX_ROLES];
     unsigned* prog;  // [0] error word, [1 + block] frames published by that workgroup
+    unsigned* dbg;   // optional [2 * block]: hand-off waits / poll iterations per workgroup (SFSN_STACK_DEBUG=1)
     int nroles, T, H, NT, lag;
     int gate_off;    // byte offset of the gate word in the dynamic LDS allocation (behind every role's layout)
 };
@@ -637,6 +638,8 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
     const int blk = (int)blockIdx.x - rl.block0;
     StackLink lk;
     lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = p.prog; lk.lag = p.lag;
+    lk.dbg = p.dbg ? p.dbg + 4 * blockIdx.x : nullptr;
+    if (lk.dbg && threadIdx.x == 0) lk.dbg[2] = (unsigned)wall_clock64();
     if (rl.pub) lk.out = p.prog + 1 + blockIdx.x;
     const int my_rpw = rl.kind == STACK_PROJ ? Proj16Layout<KS>::ROWS : rl.rpw;
     if (rl.src >= 0) {
@@ -664,6 +667,7 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         ZIN16_CASE(0) ZIN16_CASE(1) ZIN16_CASE(2) ZIN16_CASE(3)
 #undef ZIN16_CASE
     }
+    if (lk.dbg && threadIdx.x == 0) lk.dbg[3] = (unsigned)wall_clock64();
 }
 
 // OUT: bit 0 fp32 spikes, bit 1 int8 spikes (always).  The 4-row repacked epilogue (bit 9) is selected per role from rpw.
@@ -680,6 +684,8 @@ __global__ __launch_bounds__(512) void gsn_stack_kernel(const StackParams p) {
     const int blk = (int)blockIdx.x - rl.block0;
     StackLink lk;
     lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = p.prog; lk.lag = p.lag;
+    lk.dbg = p.dbg ? p.dbg + 4 * blockIdx.x : nullptr;
+    if (lk.dbg && threadIdx.x == 0) lk.dbg[2] = (unsigned)wall_clock64();
     if (rl.pub) lk.out = p.prog + 1 + blockIdx.x;
     const int my_rpw = rl.kind == STACK_PROJ ? 16 : rl.rpw;
     if (rl.src >= 0) {  // the producer workgroups that own my rows
@@ -729,7 +735,7 @@ extern "C" size_t sfsn_stack_scratch_bytes(int n_layers, int n_segs, int rows_to
     // progress counters: one per workgroup (at most one per 4 rows per layer, plus role padding and PROJ roles) + error word
     if (n_layers <= 0 || n_segs <= 0 || rows_total <= 0) return 0;
     const size_t blocks = (size_t)n_layers * ((size_t)(rows_total + 3) / 4 + (size_t)(rows_total + 15) / 16 + 16 * (size_t)n_segs);
-    return (blocks + 1 + 16) * sizeof(unsigned);
+    return (blocks + 1 + 16) * sizeof(unsigned) * 5;  // counters + (optional) two debug words per workgroup
 }
 
 template <int KS, int OUT>
@@ -845,13 +851,15 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
     if (lds > 160 * 1024 - 64) return SFSN_EUNSUPPORTED;
     if ((size_t)(blocks + 1) * sizeof(unsigned) > scratch_bytes) return SFSN_EINVAL;
     p.prog = static_cast<unsigned*>(scratch);
+    p.dbg = nullptr;
+    if (getenv("SFSN_STACK_DEBUG") && (size_t)(blocks + 1) * 5 * sizeof(unsigned) <= scratch_bytes) p.dbg = p.prog + blocks + 1;
     p.nroles = nroles; p.T = T; p.H = H; p.NT = NT; p.lag = lag;
     lds = (lds + 15) & ~15;
     p.gate_off = lds;
     lds += 16;
     (void)HP;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(scratch, 0, (size_t)(blocks + 1) * sizeof(unsigned), st) != hipSuccess) return SFSN_EHIP;
+    if (hipMemsetAsync(scratch, 0, (size_t)(blocks + 1) * sizeof(unsigned) * (p.dbg ? 5 : 1), st) != hipSuccess) return SFSN_EHIP;
 #define WIDE_CASE(KS_, OUT_)                                                                                                  \
     if (wide && KS == KS_ && out == OUT_) {                                                                                   \
         auto kern = gsn_stack_wide_kernel<KS_, OUT_>;                                                                         \

@@ -373,21 +373,35 @@ class Engine:
         with self.timed("scan:" + tag, st):
             check(L.sfsn_gsn_layer_scan_fused(segs, fin, len(seqs), nt, H, st), "sfsn_gsn_layer_scan_fused")
 
-    def _stackable(self, seqs, Rs, want_membrane) -> bool:
-        """All layers of a stack in one launch (sfsn_gsn_stack_scan)?  The layer-pipelined launch wins where one layer's
-        workgroups leave most of the chip idle (the full-band model: B/4 workgroups -- 2 x 1.13 -> 1.25 ms at B=64, T=1000);
-        where a single layer already fills the chip at 4 rows per workgroup (the sub-band models at B=64: 208 workgroups)
-        the two layers side by side each get half the CUs and twice the rows per CU, and two full-chip launches in a row are
-        faster (measured: 2 x 0.74 + 0.16 ms against 1.83 ms).  `stack_scan`: True / False / "auto" (by that occupancy rule)."""
-        if not (self.stack_scan and self.spec.shared and not want_membrane and len(seqs[0].cells) >= 2
-                and len(seqs) * (1 + (len(seqs[0].cells) - 1) * (1 if seqs[0].H <= 256 else 2)) <= 24):
-            return False
-        if self.stack_scan == "auto":
-            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
-            return sum((R + 3) // 4 for R in Rs) * len(seqs[0].cells) <= n_cu
-        return True
+    def _stack_choice(self, seqs, Rs, want_membrane):
+        """(use the stack launch?, wide flavour?, rows per workgroup) for one stack of sequence models.
 
-    def _stage_stack(self, seqs, d, t0, nt, st, tag):
+        sfsn_gsn_stack_scan runs all layers of a stack in one launch, layer l+1 trailing layer l.  It wins where one layer's
+        workgroups leave most of the chip idle; where a single layer already fills the chip at 4 rows per workgroup the layers
+        side by side get half the CUs each and the input terms' traffic through L2 / HBM doubles up, and full-chip launches
+        in a row are faster.  Measured on MI355X, T=1000, baseline_m sizes (scripts/exp_stack.py), sub-band stack
+        (per-layer scans + input products / narrow stack / wide stack, ms): B=4 1.9 / 1.7 / 1.2, B=16 1.9 / 1.7 / 1.2,
+        B=32 2.0 / 1.7 / 1.95, B=64 1.66 / 1.83 / 2.33; full-band stack (H=320, B rows) 2.26 -> 1.25 at every B.
+        `stack_scan`: "auto" (the rule below), True (always, `stack_rows_per_wg` / `stack_wide` as set), False (never)."""
+        nl, H = len(seqs[0].cells), seqs[0].H
+        ok = bool(self.stack_scan and self.spec.shared and not want_membrane and nl >= 2
+                  and len(seqs) * (1 + (nl - 1) * 2) <= 24)
+        if not ok:
+            return False, False, 0
+        tag_rpw = self.stack_rows_per_wg
+        if self.stack_scan != "auto":
+            return True, self.stack_wide, None
+        rows = sum(Rs)
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if H > 256:  # the full-band model: few rows, PROJ + gated scan roles
+            return (rows + 3) // 4 * nl + (rows + 15) // 16 <= n_cu, False, 4
+        if rows <= n_cu:       # every layer's workgroups at 8 rows + the PROJ workgroups fit several times over
+            return True, True, 8
+        if rows <= 2 * n_cu:   # 8 rows per workgroup: both layers side by side still fit
+            return True, False, 8
+        return False, False, 0
+
+    def _stage_stack(self, seqs, d, t0, nt, st, tag, wide, rpw_stack):
         """Every layer of the given sequence models in one launch (layer 0's input term is already in d["zin"][0])."""
         L = self.lib
         H, nl, ns = seqs[0].H, len(seqs[0].cells), len(seqs)
@@ -401,7 +415,7 @@ class Engine:
                 rows += R if l == 0 else 0
                 # layers >= 1: an input-term buffer selects the wide flavour for H <= 256 (16-wave scans fed by PROJ workgroups
                 # of the same launch); without it the 8-wave fused-input roles run
-                sg.zin = _ptr(d["zin"][l][i]) if (l == 0 or H > 256 or self.stack_wide) else None
+                sg.zin = _ptr(d["zin"][l][i]) if (l == 0 or H > 256 or wide) else None
                 sg.w_hh, sg.w_dq, sg.bias = _ptr(cell.w_hh_q), _ptr(cell.w_hh_dq), _ptr(cell.bias)
                 sg.bn_alpha, sg.bn_beta = _ptr(cell.alpha), _ptr(cell.beta)
                 sg.h_state, sg.c_state = _ptr(d["states"][l][i][0]), _ptr(d["states"][l][i][1])
@@ -419,7 +433,7 @@ class Engine:
                                   lambda: dict(t=torch.zeros((nbytes // 4,), dtype=torch.int32, device=self.device)))["t"]
         if not any(scratch is t for t in self._stack_scratch):
             self._stack_scratch.append(scratch)
-        rp = 4 if self.stack_scan == "auto" else self.stack_rows_per_wg[tag]  # auto only stacks what fits the chip at 4 rows
+        rp = rpw_stack if rpw_stack else self.stack_rows_per_wg[tag]
         rpw = (ctypes.c_int * nl)(*([rp] * nl))
         self.launches["stack"] = self.launches.get("stack", 0) + 1
         with self.timed("scan:" + tag, st):
@@ -665,12 +679,13 @@ class Engine:
             fused = self._fusable(seqs, rpw, want_membrane)
             done = []
             pick = lambda lst, idx: [lst[i] for i in idx]
-            if not pipeline and self._stackable(seqs, [x.shape[1] for x in xs_], want_membrane):
+            use_stack, wide, rpw_stack = self._stack_choice(seqs, [x.shape[1] for x in xs_], want_membrane)
+            if not pipeline and use_stack:
                 # all layers in one launch: features, layer 0's input term, the stack scan, the projection
                 for (t0, nt) in bounds:
                     feat_fn(t0, nt, hG[first])
                     self._stage_input(seqs, 0, xs_, d["zin"][0], t0, nt, hG[first], tag)
-                    self._stage_stack(seqs, d, t0, nt, hS[first], tag)
+                    self._stage_stack(seqs, d, t0, nt, hS[first], tag, wide, rpw_stack)
                     self._stage_proj(seqs, d["s8"][nl - 1], d["proj"], t0, nt, hG[first], tag)
                     if post_fn is not None:
                         post_fn(t0, nt, hG[first])
