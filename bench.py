@@ -39,10 +39,43 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+INT8_PEAK_TOPS = 5000.0  # dense int8 MFMA peak = the dense fp8 figure of that guide (2x bf16; micro-benchmark ceiling 3944 TOPS)
 # API-faithful algorithmic bytes per clip-frame of the sub-band scan, baseline_m sizes:
 #   read 256 (noisy_mag) + 64 (fb_out) floats, write 1,152 coefficients and both layers' fp32 spikes
 #   (13 rows x 2 x 224) = 29,184 B.  The scan kernel is launched once per layer, so one launch is charged half.
 SB_SCAN_BYTES_PER_FRAME_PER_LAUNCH = 29184 / 2
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU (the driver's
+    own invocation does exactly this; with SFSN_BENCH_BACKEND=gloo the ranks may share GPUs -- a plumbing check)."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+
+
+def _pmc_profile():
+    """PMC-derived figures (HBM bytes per launch, MFMA busy cycles) from the committed rocprofv3 passes -- used only when they
+    were taken with THIS library build (source hash) and workload; otherwise the fields stay null (bench.py cannot read
+    hardware counters itself)."""
+    try:
+        from spiking_fullsubnet_amd import _lib
+        pj = json.load(open(PROFILE_JSON))
+        if pj.get("source_hash") != _lib.source_hash():
+            return None
+        return pj
+    except Exception:
+        return None
 
 
 def main():
@@ -54,15 +87,13 @@ def main():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layer-outputs", action="store_true", help="skip the fp32 spike tensors of the module API (reported in config)")
-    ap.add_argument("--sequential", action="store_true", help="force the sequential single-stream schedule")
-    ap.add_argument("--pipeline", action="store_true", help="force the time-pipelined multi-stream schedule")
-    ap.add_argument("--time-all", action="store_true", help="HIP-event time every launch group, not only the dominant kernel")
-    ap.add_argument("--seq-chunk", type=int, default=0, help="frames per chunk of the single-stream schedule")
-    ap.add_argument("--rpw", type=str, default="", help="rows per scan workgroup 'fb,sb' (0 = auto)")
+    ap.add_argument("--sequential", action="store_true", help="the timed region runs one forward at a time (= --inflight 1)")
+    ap.add_argument("--time-all", action="store_true", help="HIP-event time every launch group, not only the scans")
+    ap.add_argument("--rpw", type=str, default="", help="rows per scan workgroup 'fb,sb' of the per-layer launches (0 = auto)")
     ap.add_argument("--inflight", type=int, default=12, help="forwards in flight on separate HIP streams (batch-level pipelining)")
-    ap.add_argument("--chunk", type=int, default=0, help="frames per pipeline chunk (default: engine default)")
-    ap.add_argument("--no-phase-a", action="store_true", help="skip the single-stream phase (no roofline object): profiling runs of the timed region alone")
-    ap.add_argument("--no-saturated", action="store_true", help="skip the 4x-rows launch of the dominant kernel (roofline.saturated)")
+    ap.add_argument("--no-phase-a", action="store_true", help="skip the untimed single-forward phases (no roofline object): profiling runs of the timed region alone")
+    ap.add_argument("--no-saturated", action="store_true", help="(kept for old command lines; the saturated-launch leg is gone)")
+    ap.add_argument("--stack", type=str, default="auto", help="stack scan policy: auto | 0 | 1")
     ap.add_argument("--streaming", action="store_true", help="BASELINE configs[4]: frame-by-frame session, per-call latency (own JSON line)")
     ap.add_argument("--hop", type=int, default=1, help="frames per streaming call")
     ap.add_argument("--no-graph", action="store_true", help="streaming: launch the kernels one by one instead of replaying the HIP graph")
@@ -71,10 +102,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _self_launch(args)
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     # one rank per GPU.  (SFSN_BENCH_BACKEND=gloo lets several ranks share one GPU: a plumbing check of the multi-rank
     # code path on a single-GPU box, not a measurement.)
@@ -93,6 +123,7 @@ def main():
 
     import refweights as rw
     import spiking_fullsubnet_amd as pkg
+    from spiking_fullsubnet_amd import _lib
 
     kw = rw.LIVE_M
     B, T = args.batch, args.frames
@@ -101,24 +132,20 @@ def main():
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     model = model.eval().to(dev)
     wave = torch.from_numpy(rw.synth_wave(B, T, seed=rank)).to(dev)
-    stft = model.stft(wave).contiguous()  # untimed: the STFT is the edge of the path
+    stft = model._stft(wave).contiguous()  # untimed: the STFT is the edge of the path
     assert stft.shape == (B, 257, T)
     eng = model.engine()
+    eng.stack_scan = "auto" if args.stack == "auto" else bool(int(args.stack))
     if args.streaming:
         return streaming_bench(args, model, dev, world, rank)
-    if args.chunk:
-        eng.pipeline_chunk = args.chunk
-    if args.seq_chunk:
-        eng.seq_chunk = args.seq_chunk
     want_layers = not args.no_layer_outputs
     gathered = {}  # per HIP stream (lane): the all-gathered magnitudes of that lane's batch
 
-    info = {}
-
     def forward():
-        res = eng.forward_stft(stft, want_layers=want_layers, pipeline=False if args.sequential else (True if args.pipeline else None))
-        info.update(pipelined=res["pipelined"], n_chunks=res["n_chunks"])
+        res = eng.forward_stft(stft, want_layers=want_layers, pipeline=False)
         if world > 1:
+            # the one exchange of the path (the analogue of accelerator.gather_for_metrics, audiozen/trainer.py:511,555): enqueued on
+            # the forward's own stream, so with several forwards in flight it overlaps the scans of the other lanes
             key = torch.cuda.current_stream(dev).cuda_stream
             if key not in gathered:
                 gathered[key] = torch.empty((world * B, 1, 257, T), dtype=torch.float32, device=dev)
@@ -157,55 +184,46 @@ def main():
     copy_gbps = 10 * 2 * src_.numel() * 4 / (time.perf_counter() - t_c) / 1e9
     del src_, dst_
 
-    # ---- phase A (untimed for `value`): one forward at a time on one stream, the latency-optimal launch geometry.  The
-    #      dominant kernel runs alone here, so its HIP-event duration is the kernel's own (roofline), not a time share.
-    eng.rows_per_wg = (0, 0)
-    eng.timers, eng.timer_tags = {}, (None if args.time_all else {"scan:sb", "scan:fb"})
-    ka = max(2, min(args.steps, 8))
-    if args.no_phase_a:
-        scan_ms, single = {}, None
-        args.no_saturated = True
-    else:
-        dt_a = timed_region(forward, ka, min(args.warmup, 2) + 1)
-        scan_ms = eng.timer_summary()
-        single = dict(ms_per_step=round(1e3 * dt_a / ka, 4), value=round(world * B * T * ka / dt_a, 1), steps=ka)
-    eng.timers = None
+    scan_tags = None if args.time_all else {"scan:sb", "scan:fb", "stack:sb", "stack:fb", "scanx:sb", "scanf:sb"}
+    geom_b = tuple(int(v) for v in args.rpw.split(",")) if args.rpw else (4, 16)
+    n_lanes = 1 if args.sequential else max(1, min(args.inflight, args.steps // 2))  # a short run cannot amortise many lanes
 
-    # ---- the same kernel with the chip full (untimed for `value`): at B=64 a sub-band scan launch is 208 workgroups of 4 rows,
-    #      a latency-bound chain per workgroup; four times the rows (16 per workgroup, same 208 workgroups) shows what the
-    #      kernel moves per second when every CU has a full tile -- which is also how it runs in the timed region below,
-    #      where the scans of several forwards share the chip
-    saturated = None
-    if world == 1 and not args.no_saturated and B * 4 * T <= 256 * 1000:
-        stft4 = stft.repeat(4, 1, 1)
-        eng.timers, eng.timer_tags = {}, {"scan:sb"}
-        for _ in range(3):
-            eng.forward_stft(stft4, want_layers=want_layers, pipeline=False)
-        sat = eng.timer_summary().get("scan:sb")
+    # ---- phase S (untimed for `value`): THE STRICT NUMBER -- one forward at a time on one stream, B clips x T frames per step,
+    #      nothing else in flight.  Launch geometry = the engine's default for a forward alone (full-band stack in one
+    #      layer-pipelined launch, sub-band layers as full-chip launches at 4 rows per workgroup).
+    single, t_s, t_k = None, {}, {}
+    if not args.no_phase_a:
+        eng.rows_per_wg = (0, 0)
+        eng.timers, eng.timer_tags = {}, scan_tags
+        ka = max(2, min(args.steps, 8))
+        dt_a = timed_region(forward, ka, min(args.warmup, 2) + 1)
+        t_s = eng.timer_summary()
         eng.timers = None
-        eng._ws.clear()
-        del stft4
-        torch.cuda.empty_cache()
-        if sat:
-            ach = SB_SCAN_BYTES_PER_FRAME_PER_LAUNCH * 4 * B * T / (sat["min_ms"] * 1e-3) / 1e9
-            saturated = dict(clips=4 * B, launch_ms=round(sat["min_ms"], 4), achieved=round(ach, 1), unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4),
-                             note="same kernel, 4x the rows in one launch (16 rows per workgroup): not the bench workload, shown to separate "
-                                  "the kernel's efficiency from the occupancy of a B=64 launch")
+        eng.check_stack_errors()
+        single = dict(ms_per_step=round(1e3 * dt_a / ka, 4), value=round(world * B * T * ka / dt_a, 1), steps=ka, in_flight=1)
+        # ---- phase K (untimed): the scan kernels of the timed region's geometry, each alone on the chip (one forward at a time)
+        if n_lanes > 1:
+            eng.rows_per_wg = geom_b
+            eng.timers, eng.timer_tags = {}, scan_tags
+            for _ in range(4):
+                forward()
+            t_k = eng.timer_summary()
+            eng.timers = None
 
     # ---- phase B (THE timed region): `--inflight` forwards in flight on as many HIP streams -- batch-level pipelining of
     #      independent batches, as a serving loop runs them.  The recurrent scans are latency-bound chains that occupy a
-    #      fraction of the CUs (16 rows per workgroup here, so that several scans fit side by side); the next batches'
+    #      fraction of the CUs (16 rows per sub-band workgroup here, so that several scans fit side by side); the next batches'
     #      scans and time-parallel kernels fill the rest of the chip.  Every step is one complete pass over one batch.
-    n_lanes = 1
-    if args.inflight > 1:
-        eng.rows_per_wg = tuple(int(v) for v in args.rpw.split(",")) if args.rpw else (4, 16)
-        n_lanes = max(1, min(args.inflight, args.steps // 2))  # a short run cannot amortise the fill / drain of many lanes
+    t_b = {}
+    if n_lanes > 1:
+        eng.rows_per_wg = geom_b
         lanes = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
         counter = [0]
         for s_ in lanes:  # untimed: first use of a lane allocates its scratch buffers and warms its memory pool
             with torch.cuda.stream(s_):
                 forward()
         torch.cuda.synchronize()
+        eng.timers, eng.timer_tags = {}, {"scanf:sb"}  # the dominant kernel's launches in the timed region itself (1 group / forward)
 
         def step():
             s_ = lanes[counter[0] % len(lanes)]
@@ -213,51 +231,78 @@ def main():
             with torch.cuda.stream(s_):
                 return forward()
     else:
-        if args.rpw:
-            eng.rows_per_wg = tuple(int(v) for v in args.rpw.split(","))
+        eng.rows_per_wg = tuple(int(v) for v in args.rpw.split(",")) if args.rpw else (0, 0)
         step = forward
     dt = timed_region(step, args.steps, args.warmup)
+    if eng.timers is not None:
+        t_b = eng.timer_summary()
+        eng.timers = None
+    eng.check_stack_errors()
 
     if rank == 0:
         frames = world * B * T * args.steps
         ms_per_step = 1e3 * dt / args.steps
-        sb_ms = scan_ms.get("scan:sb")
+        alg = SB_SCAN_BYTES_PER_FRAME_PER_LAUNCH * B * T  # algorithmic bytes of one sub-band layer launch
+        pj = _pmc_profile()
+
+        def hbm(ms, nbytes=alg):
+            a = nbytes / (ms * 1e-3) / 1e9
+            return dict(launch_ms=round(ms, 4), achieved=round(a, 1), unit="GB/s", frac=round(a / HBM_PEAK_GBPS, 4))
+
         roofline = None
-        if sb_ms:
-            # one launch of the scan kernel covers T / n_chunks frames of every clip (time-pipelined schedule)
-            frames_per_launch = B * T / info["n_chunks"]
-            bytes_per_launch = SB_SCAN_BYTES_PER_FRAME_PER_LAUNCH * frames_per_launch
-            achieved = bytes_per_launch / (sb_ms["mean_ms"] * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if tj.get("B") == B and tj.get("T") == T:  # measured on one whole-sequence launch; scale to this launch's frames
-                    traffic = int(tj.get("sb_scan_hbm_bytes_per_launch") / info["n_chunks"])
-            roofline = dict(bound="hbm", kernel="gsn_scan_kernel<G=1,KS=4,NW=16,TPW=1,OUT=fp32+int8 spikes,4-row repacked epilogue> (3 sub-band groups in one launch, one launch per layer)",
-                            achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                            traffic=traffic, launch_ms=round(sb_ms["mean_ms"], 4), launches=sb_ms["n"],
-                            algorithmic_bytes_per_launch=int(bytes_per_launch), measured_copy_GBps=round(copy_gbps, 1),
-                            per_step_us=round(1e3 * sb_ms["mean_ms"] / (T / info["n_chunks"]), 3),
-                            frames_per_launch=int(frames_per_launch), schedule=("time-pipelined x%d chunks on %d streams" % (info["n_chunks"], 4)) if info["pipelined"] else "sequential",
-                            measured_in="phase A: single stream, one forward at a time (the kernel runs alone; in the timed region "
-                                        "several forwards share the chip and a launch's wall time is a time share, not the kernel's own)",
-                            other_kernels_ms={k: round(v["mean_ms"], 4) for k, v in scan_ms.items() if k not in ("scan:sb", "scan:fb")})
-            fb_ms = scan_ms.get("scan:fb")
-            if fb_ms:
-                # the other recurrent kernel: one launch per full-band layer, B rows x H=320 on B/4 CUs -- a pure dependency
-                # chain (its algorithmic traffic is ~1 % of the sub-band scan's): reported as time per step
-                roofline["full_band_scan"] = dict(kernel="gsn_scan_kernel<G=1,KS=5,NW=8,TPW=3,LP=1> (W_hh: two digit planes in registers, one in LDS)",
-                                                  launch_ms=round(fb_ms["mean_ms"], 4), per_step_us=round(1e3 * fb_ms["mean_ms"] / (T / info["n_chunks"]), 3),
-                                                  workgroups=(B + 3) // 4)
-            if traffic is not None and tj.get("forward_hbm_bytes") and want_layers:
-                # the whole job against the same roof: PMC-measured HBM bytes of one forward (all kernels) / time per step of
-                # the timed region (several forwards in flight)
-                jb = float(tj["forward_hbm_bytes"])
-                if saturated:
-                    roofline["saturated"] = saturated
-                roofline["job"] = dict(hbm_bytes_per_step=int(jb), achieved=round(jb / (ms_per_step * 1e-3) / 1e9, 1), unit="GB/s",
-                                       frac=round(jb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
+        if single is not None:
+            # --- the sub-band scan of a forward ALONE (phase S): gsn_scan_kernel, 4 rows per workgroup, one launch per layer
+            ss = t_s.get("scan:sb")
+            strict = None
+            if ss:
+                strict = dict(kernel="gsn_scan_kernel<G=1,KS=4,NW=16,TPW=1,OUT=fp32+int8 spikes,4-row repacked epilogue> (3 sub-band groups, "
+                                     "one launch per layer, 208 workgroups)", **hbm(ss["mean_ms"]), per_step_us=round(1e3 * ss["mean_ms"] / T, 3),
+                              launches=ss["n"], algorithmic_bytes_per_launch=int(alg),
+                              traffic=(pj or {}).get("sb_scan_rpw4_hbm_bytes_per_launch"))
+            # --- the full-band stack (phase S): both layers + the layer-2 input product in ONE layer-pipelined launch
+            fb = t_s.get("stack:fb")
+            full_band = None
+            if fb:
+                Hf, nl = kw["fb_hidden_size"], kw["fb_num_layers"]
+                steps_ms = fb["mean_ms"]
+                useful = 2.0 * B * Hf * Hf * (2 * nl - 1) * T  # int8 MACs x 2 of the recurrent + layer>=1 input products, one digit plane
+                # executed by the matrix cores: x3 digit planes, 16-column MFMA tiles for 4 (scan) / 16 (input product) rows
+                executed = 2.0 * Hf * Hf * 3 * T * (nl * (B / 4) * 16 + (nl - 1) * B)
+                full_band = dict(kernel="gsn_stack_kernel<KS=5> (scan roles: W_hh two digit planes in registers + one in LDS; PROJ role feeds layer 2)",
+                                 launch_ms=round(steps_ms, 4), per_step_us=round(1e3 * steps_ms / T, 3),
+                                 workgroups=nl * ((B + 3) // 4) + (nl - 1) * ((B + 15) // 16), launches_per_forward=1,
+                                 mfma=dict(useful_TOPS=round(useful / (steps_ms * 1e-3) / 1e12, 2), executed_TOPS=round(executed / (steps_ms * 1e-3) / 1e12, 2),
+                                           peak_TOPS=INT8_PEAK_TOPS, useful_frac_of_peak=round(useful / (steps_ms * 1e-3) / 1e12 / INT8_PEAK_TOPS, 5),
+                                           pmc=(pj or {}).get("full_band_stack_mfma"),
+                                           note="useful = 2*B*H*H ops per recurrent / input product per frame; executed counts the three int8 digit "
+                                                "planes and the 16-column MFMA tiles; pmc = SQ_VALU_MFMA_BUSY_CYCLES based utilisation from "
+                                                "profiles/ (null unless taken with this build)"))
+            if n_lanes > 1 and t_k.get("scanf:sb"):
+                # --- the kernel that dominates the TIMED region (by CU-time): the fused-input sub-band layer-2 scan at 16 rows per
+                #     workgroup; alone on the chip (phase K) and as it ran inside the timed region (HIP events on the lane streams:
+                #     a time share, other forwards' kernels run beside it)
+                kf, kx, kp = t_k["scanf:sb"], t_k.get("scanx:sb"), t_k.get("scan:sb")
+                roofline = dict(bound="hbm",
+                                kernel="gsn_scan_fused_kernel<KS=4,OUT=fp32+int8 spikes> (sub-band layer 2, input product inside, 16 rows per workgroup, "
+                                       "52 workgroups, 3 groups in one launch)",
+                                **hbm((t_b.get("scanf:sb") or kf)["mean_ms"]), peak=HBM_PEAK_GBPS,
+                                traffic=(pj or {}).get("sb_fused_hbm_bytes_per_launch"),
+                                measured_in="the timed region (HIP events on the launch streams; 12 forwards share the chip, so a launch's wall time is a time share)",
+                                alone_on_chip=hbm(kf["mean_ms"]), launches=(t_b.get("scanf:sb") or kf)["n"],
+                                algorithmic_bytes_per_launch=int(alg), frames_per_launch=B * T, per_step_us=round(1e3 * kf["mean_ms"] / T, 3),
+                                other_scan_kernels_alone_ms={k: round(v["mean_ms"], 4) for k, v in dict(layer1_fused_x=kx, layer1_plain=kp).items() if v})
+            elif strict is not None:
+                roofline = dict(bound="hbm", peak=HBM_PEAK_GBPS, measured_in="single stream: the kernel runs alone", **strict)
+            if roofline is not None:
+                roofline["measured_copy_GBps"] = round(copy_gbps, 1)
+                roofline["sub_band_scan_single_forward"] = strict
+                roofline["full_band_stack"] = full_band
+                if pj and pj.get("forward_hbm_bytes") and want_layers and n_lanes > 1:
+                    jb = float(pj["forward_hbm_bytes"])
+                    roofline["job"] = dict(hbm_bytes_per_step=int(jb), achieved=round(jb / (ms_per_step * 1e-3) / 1e9, 1), unit="GB/s",
+                                           frac=round(jb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                           note="PMC-measured HBM bytes of one forward in the timed region's geometry (all kernels) / time per step")
+                roofline["profiles"] = PROFILE_JSON.replace(ROOT + os.sep, "") if pj else None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(kw, sd, stft)
@@ -270,9 +315,11 @@ def main():
                                          ", full model (full-band + 3 sub-band groups / 13 units), live baseline_m sizes, fp32 parity mode",
                                 clips_per_gpu=B, frames=T, bins=257,
                                 layer_outputs="api-faithful (fp32 spikes returned)" if want_layers else "skipped",
-                                in_flight=(n_lanes if args.inflight > 1 else 1), scan_rows_per_workgroup=list(eng.rows_per_wg),
+                                in_flight=n_lanes, scan_rows_per_workgroup=list(eng.rows_per_wg),
                                 single_stream=single,
-                                parallelism=f"clip-sharded x{world}" + (" + RCCL all_gather(enh_mag)" if world > 1 else "")),
+                                world_size=(dist.get_world_size() if world > 1 else 1), backend=(backend if world > 1 else None),
+                                library=dict(abi=_lib.ABI_VERSION, source_hash=_lib.source_hash(), stack_scan=str(eng.stack_scan)),
+                                parallelism=f"clip-sharded x{world}" + (" + RCCL all_gather(enh_mag) per step, on the forward's stream" if world > 1 else "")),
                     roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -349,6 +396,8 @@ def cpu_baseline(kw, sd, stft):
     except Exception:  # the baseline is reported, never required
         pass
     return dict(value=round(frames / el, 1), unit="frames/s", cores=os.cpu_count(), kind="port", single_core_value=single, cpu_model=cpu_model,
+                scaling_note="the row-parallel oracle forks and joins its OpenMP team per time step: all cores give only a few x one core "
+                             "(a stated baseline, not a tuned CPU implementation)",
                 sample=f"{n} x (B={sample.shape[0]}, T={Ts} prefix of the same synthetic batch), {el:.1f} s of wall time, fp32 oracle "
                        f"(oracle/sfsn_oracle.c via oracle.model), OpenMP threads = all {os.cpu_count()} host cores",
                 reference_pytorch_cpu="3,265 frames/s for the reference's own PyTorch forward at B=64,T=1000 on 8 vCPU (BASELINE.md section 2, survey container)")

@@ -14,7 +14,7 @@ model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rw.live_st
 model = model.eval().to(dev)
 eng = model.engine()
 wave = torch.from_numpy(rw.synth_wave(64, 1000, 0)).to(dev)
-stft = model.stft(wave).contiguous()
+stft = model._stft(wave).contiguous()
 a = torch.empty(256 * 1024 * 1024 // 4, device=dev); b = torch.empty_like(a)
 n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
 print("CUs", n_cu)

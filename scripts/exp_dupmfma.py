@@ -11,7 +11,7 @@ sd = rw.live_state_dict(kw, 21)
 m = pkg.SpikingFullSubNet(**kw); m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}); m = m.eval().to(dev)
 eng = m.engine()
 for B in (64, 256):
-    stft = m.stft(torch.from_numpy(rw.synth_wave(B, 1000, 0)).to(dev))
+    stft = m._stft(torch.from_numpy(rw.synth_wave(B, 1000, 0)).to(dev))
     eng.rows_per_wg = (16, 16)
     eng.timers, eng.timer_tags = {}, {"scan:sb", "scan:fb"}
     for _ in range(3): eng.forward_stft(stft)

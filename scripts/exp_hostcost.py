@@ -9,7 +9,7 @@ dev = torch.device("cuda")
 kw = rw.LIVE_M
 m = pkg.SpikingFullSubNet(**kw); m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rw.live_state_dict(kw, 21).items()}); m = m.eval().to(dev)
 eng = m.engine(); eng.rows_per_wg = (4, 16)
-stft = m.stft(torch.from_numpy(rw.synth_wave(64, 1000, 0)).to(dev))
+stft = m._stft(torch.from_numpy(rw.synth_wave(64, 1000, 0)).to(dev))
 lanes = [torch.cuda.Stream(device=dev) for _ in range(12)]
 for s_ in lanes:
     with torch.cuda.stream(s_): eng.forward_stft(stft)

@@ -11,7 +11,7 @@ model = pkg.SpikingFullSubNet(**kw)
 model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rw.live_state_dict(kw, 21).items()})
 model = model.eval().to(dev)
 eng = model.engine()
-stft = model.stft(torch.from_numpy(rw.synth_wave(64, 1000, 0)).to(dev)).contiguous()
+stft = model._stft(torch.from_numpy(rw.synth_wave(64, 1000, 0)).to(dev)).contiguous()
 def run(pipe, chunk, n=4):
     eng.pipeline_chunk = chunk
     eng.forward_stft(stft, pipeline=pipe); torch.cuda.synchronize()

@@ -51,7 +51,7 @@ for front, kw, seed in cases:
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(5): eng.forward_stft(stft)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
-            eng.timers, eng.timer_tags = {}, {"scan:sb", "scan:fb"}
+            eng.timers, eng.timer_tags = {}, {"scan:sb", "scan:fb", "stack:sb", "stack:fb", "scanx:sb", "scanf:sb"}
             for _ in range(3): eng.forward_stft(stft)
             tm = eng.timer_summary(); eng.timers = None
             print(f"   stack={mode} wide={eng.stack_wide} rpw={rp}: {dt*1e3:.3f} ms per forward (B={B}, T={T}); scans: " +

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(512) void spike_proj_kernel(const int8_t* __restric
     }
 
     const int MT = (M + 15) >> 4;
-    const bool vec = (ldy & 3) == 0;
+    const bool vec = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0;
     for (int mt = (int)blockIdx.x * MW + mw; mt < MT; mt += (int)gridDim.x * MW) {
         const int row = mt * 16 + n;
         const int rowc = row < M ? row : M - 1;
@@ -1613,16 +1613,31 @@ __global__ __launch_bounds__(DFP_THREADS) void deepfilter_pass_kernel(const floa
 // host side: argument checks, dispatch on compile-time shapes, launches
 // =====================================================================================================
 static inline int hip_ok(hipError_t e) { return e == hipSuccess ? SFSN_OK : SFSN_EHIP; }
+// Per-DEVICE caches: one process may drive several GPUs (the function attribute below and the CU count are per device).
+#define SFSN_MAX_DEVICES 64
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SFSN_MAX_DEVICES) dev = 0;
+    return dev;
+}
 static int cu_count() {  // compute units of the current device (256 on MI355X); 256 if the query fails
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n = v;
-        else
-            n = 256;
+    static int n[SFSN_MAX_DEVICES] = {0};
+    const int dev = current_device();
+    if (n[dev] == 0) {
+        int v = 0;
+        n[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
     }
-    return n;
+    return n[dev];
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize raised to `bytes` on the current device (idempotent; a benign race between host
+// threads sets it twice at worst).  `seen` is the caller's per-kernel table of the largest size set per device.
+static int raise_lds(const void* kern, int bytes, int* seen) {
+    const int dev = current_device();
+    if (bytes > seen[dev]) {
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return SFSN_EHIP;
+        seen[dev] = bytes;
+    }
+    return SFSN_OK;
 }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -1653,13 +1668,8 @@ static int launch_scan_variant(const ScanParams& p, int tiles, hipStream_t st) {
     using C = ScanCfg<G, KS, NW, TPW, OUT, LP>;
     auto kern = gsn_scan_kernel<G, KS, NW, TPW, OUT, LP>;
     if (C::LDS_BYTES > 64 * 1024) {
-        static bool raised = false;  // idempotent attribute; a benign race between threads sets it twice at worst
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) !=
-                hipSuccess)
-                return SFSN_EHIP;
-            raised = true;
-        }
+        static int seen[SFSN_MAX_DEVICES] = {0};
+        if (raise_lds(reinterpret_cast<const void*>(kern), C::LDS_BYTES, seen) != SFSN_OK) return SFSN_EHIP;
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(NW * 64), C::LDS_BYTES, st, p);
     return hip_ok(hipGetLastError());
@@ -1795,12 +1805,8 @@ extern "C" int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs, const sf
 #define FUSED_CASE(KS_, OUT_)                                                                                              \
     if (KS == KS_ && out == OUT_) {                                                                                        \
         auto kern = gsn_scan_fused_kernel<KS_, OUT_>;                                                                      \
-        static int raised = 0; /* idempotent attribute, raised to the largest size seen (not a stream operation) */        \
-        if (lds > raised) {                                                                                                \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
-                return SFSN_EHIP;                                                                                          \
-            raised = lds;                                                                                                  \
-        }                                                                                                                  \
+        static int seen[SFSN_MAX_DEVICES] = {0}; /* per device, raised to the largest size seen (not a stream operation) */ \
+        if (raise_lds(reinterpret_cast<const void*>(kern), lds, seen) != SFSN_OK) return SFSN_EHIP;                        \
         hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, st, p);                                                      \
         return hip_ok(hipGetLastError());                                                                                  \
     }
@@ -1845,12 +1851,8 @@ extern "C" int sfsn_gsn_layer_scan_fused_x(const sfsn_scan_segment* segs, const 
 #define FUSEDX_CASE(KS_, OUT_)                                                                                             \
     if (KS == KS_ && out == OUT_) {                                                                                        \
         auto kern = gsn_scan_fusedx_kernel<KS_, OUT_>;                                                                     \
-        static int raised = 0;                                                                                             \
-        if (lds > raised) {                                                                                                \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
-                return SFSN_EHIP;                                                                                          \
-            raised = lds;                                                                                                  \
-        }                                                                                                                  \
+        static int seen[SFSN_MAX_DEVICES] = {0}; /* per device, raised to the largest size seen (not a stream operation) */ \
+        if (raise_lds(reinterpret_cast<const void*>(kern), lds, seen) != SFSN_OK) return SFSN_EHIP;                        \
         hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, st, p);                                                      \
         return hip_ok(hipGetLastError());                                                                                  \
     }
@@ -1867,7 +1869,7 @@ static inline void pick_tiling(int NT, int& TPW, int& NWN) {
 extern "C" int sfsn_spike_proj(const int8_t* s, const int8_t* w_packed, const float* w_dq, const float* bias, float* y, int M,
                                int K, int N, int ldy, void* stream) {
     if (!s || !w_packed || !w_dq || !y || M <= 0 || K <= 0 || N <= 0 || ldy < N) return SFSN_EINVAL;
-    if (!aligned16(s) || !aligned16(w_packed) || !aligned16(w_dq) || !aligned16(y)) return SFSN_EINVAL;
+    if (!aligned16(s) || !aligned16(w_packed) || !aligned16(w_dq) || (reinterpret_cast<uintptr_t>(y) & 3u)) return SFSN_EINVAL;
     const int NT = (N + 15) / 16, KS = (K + 63) / 64;
     int TPW, NWN;
     pick_tiling(NT, TPW, NWN);
@@ -1877,7 +1879,8 @@ extern "C" int sfsn_spike_proj(const int8_t* s, const int8_t* w_packed, const fl
     if (grid > 2048) grid = 2048;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = (size_t)2 * 64 * (KS * 64 + 16) + (size_t)64 * (N + 4) * sizeof(float);
-    const bool fast = (N % 4 == 0) && (ldy % 4 == 0) && M >= 64 && lds <= 150 * 1024;
+    // (a y that is only 4-byte aligned -- a chunk offset t0*R*P*4 with odd t0*R*P -- takes the generic kernel's scalar stores)
+    const bool fast = (N % 4 == 0) && (ldy % 4 == 0) && M >= 64 && lds <= 150 * 1024 && aligned16(y);
     if (fast) {
         int fgrid = (M + 63) / 64;
         { const int cap = cu_count() * (TPW == 1 ? 2 : 1); if (fgrid > cap) fgrid = cap; }  // resident workgroups only: the W tiles are loaded once per workgroup

@@ -208,6 +208,7 @@ class Engine:
         self.sb = [_pack_seq(sd, f"sb_model.sb_models.{g}.", spec, spec.sb_input_size(g), spec.sb_hidden, spec.sb_layers,
                              spec.sb_proj_size(g), spec.ln_sb, self.device) for g in range(spec.n_groups)]
         self._ws: Dict[tuple, dict] = {}
+        self.ws_budget_bytes = int(float(os.environ.get("SFSN_WS_BUDGET_GB", "96")) * 2**30)  # scratch cache budget (of 288 GB HBM)
         self.timers: Optional[dict] = None  # set to {} to record HIP events around each launch group (bench.py)
         self.seq_chunk = 0  # frames per chunk of the single-stream schedule (0 = whole sequence per launch)
         self.rows_per_wg = (0, 0)  # (full-band, sub-band) rows per scan workgroup; 0 = let the library spread over all CUs
@@ -272,12 +273,30 @@ class Engine:
             out[tag] = dict(mean_ms=float(np.mean(ms)), min_ms=float(np.min(ms)), n=len(ms))
         return out
 
+    @staticmethod
+    def _nbytes(obj) -> int:
+        if torch.is_tensor(obj):
+            return obj.numel() * obj.element_size()
+        if isinstance(obj, dict):
+            return sum(Engine._nbytes(v) for v in obj.values())
+        if isinstance(obj, (list, tuple)):
+            return sum(Engine._nbytes(v) for v in obj)
+        return 0
+
     def _workspace(self, key, make):
+        """Scratch cache: least-recently-used entries are dropped once the total exceeds `ws_budget_bytes` (the entry being
+        asked for is never dropped).  Entries are keyed on (tag, rows, stream) and sized by CAPACITY (see _alloc_stack): a
+        stream that sees clips of many lengths keeps one buffer set, grown to the longest."""
         ws = self._ws.get(key)
         if ws is None:
-            if len(self._ws) > 64:  # (tag, geometry, stream): a dozen forwards in flight hold two entries each
-                self._ws.clear()
             ws = self._ws[key] = make()
+            total = sum(self._nbytes(v) for v in self._ws.values())
+            for k in list(self._ws.keys()):
+                if total <= self.ws_budget_bytes or k == key:
+                    continue
+                total -= self._nbytes(self._ws.pop(k))
+        else:
+            self._ws[key] = self._ws.pop(key)  # most recently used last (dicts keep insertion order)
         return ws
 
     # ---- per-stage launch helpers: every one works on the frame range [t0, t0+nt) and on an explicit stream, so
@@ -349,7 +368,7 @@ class Engine:
             fin[i].x = x.data_ptr() + t0 * R * seq.I * 4
             fin[i].w_ih, fin[i].I = cell.w_ih_f32.data_ptr(), seq.I
         self.launches["fused_x"] = self.launches.get("fused_x", 0) + 1
-        with self.timed("scan:" + tag, st):
+        with self.timed("scanx:" + tag, st):
             check(L.sfsn_gsn_layer_scan_fused_x(segs, fin, len(seqs), nt, H, st), "sfsn_gsn_layer_scan_fused_x")
 
     def _stage_scan_fused(self, seqs, l, states, spks, s8s, t0, nt, st, tag):
@@ -370,7 +389,7 @@ class Engine:
             fin[i].spikes_in = s8s[l - 1][i].data_ptr() + t0 * R * HP
             fin[i].w_ih, fin[i].w_ih_dq = pk.data_ptr(), dq.data_ptr()
         self.launches["fused"] = self.launches.get("fused", 0) + 1
-        with self.timed("scan:" + tag, st):
+        with self.timed("scanf:" + tag, st):
             check(L.sfsn_gsn_layer_scan_fused(segs, fin, len(seqs), nt, H, st), "sfsn_gsn_layer_scan_fused")
 
     def _stack_choice(self, seqs, Rs, want_membrane):
@@ -436,7 +455,7 @@ class Engine:
         rp = rpw_stack if rpw_stack else self.stack_rows_per_wg[tag]
         rpw = (ctypes.c_int * nl)(*([rp] * nl))
         self.launches["stack"] = self.launches.get("stack", 0) + 1
-        with self.timed("scan:" + tag, st):
+        with self.timed("stack:" + tag, st):
             check(L.sfsn_gsn_stack_scan(segs, fin, nl, ns, nt, H, rpw, self.stack_lag, _ptr(scratch), nbytes, st), "sfsn_gsn_stack_scan")
 
     def check_stack_errors(self) -> None:
@@ -472,12 +491,20 @@ class Engine:
         """Per-forward tensors of a stack of sequence models sharing (H, L): API outputs are fresh, scratch is cached."""
         dev, H, G, nl = self.device, seqs[0].H, seqs[0].cells[0].G, len(seqs[0].cells)
         HP = (H + 63) // 64 * 64
-        ws = self._workspace((tag, T, nt_max, tuple(Rs), torch.cuda.current_stream(dev).cuda_stream), lambda: dict(
-            zin=[[torch.empty((nt_max, R, G * H), dtype=torch.float32, device=dev) for R in Rs] for _ in range(nl)],
-            s8=[[torch.zeros((T, R, HP), dtype=torch.int8, device=dev) for R in Rs] for _ in range(nl)]))
+        key = (tag, tuple(Rs), torch.cuda.current_stream(dev).cuda_stream)
+        old = self._ws.get(key)
+        if old is not None and (old["T"] < T or old["nt"] < nt_max):  # grow: one buffer set per (tag, rows, stream), sized for the
+            T_cap, nt_cap = max(T, old["T"]), max(nt_max, old["nt"])  # longest clip seen -- not one set per clip length
+            del self._ws[key], old
+        else:
+            T_cap, nt_cap = T, nt_max
+        ws = self._workspace(key, lambda: dict(
+            T=T_cap, nt=nt_cap,
+            zin=[[torch.empty((nt_cap, R, G * H), dtype=torch.float32, device=dev) for R in Rs] for _ in range(nl)],
+            s8=[[torch.zeros((T_cap, R, HP), dtype=torch.int8, device=dev) for R in Rs] for _ in range(nl)]))  # (pad columns stay 0)
         f32 = dict(dtype=torch.float32, device=dev)
         return dict(
-            zin=ws["zin"], s8=ws["s8"],
+            zin=[[z[:nt_max] for z in zl] for zl in ws["zin"]], s8=[[b[:T] for b in bl] for bl in ws["s8"]],
             states=self._zero_states(Rs, H, nl),  # zero init, modeling:100-106 (one fill kernel for all of them)
             spk=[[torch.empty((T, R, H), **f32) if want_layers else None for R in Rs] for _ in range(nl)],
             mem=[[torch.empty((T, R, H), **f32) if want_membrane else None for R in Rs] for _ in range(nl)],

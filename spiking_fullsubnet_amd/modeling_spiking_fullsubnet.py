@@ -132,6 +132,46 @@ class _EngineMixin:
         window = torch.hann_window(self.n_fft, device=spec.device)
         return torch.istft(spec, self.n_fft, self.hop_length, self.win_length, window=window, length=length)
 
+    # ---- the public attributes the reference modules carry: `self.stft = partial(audio_feature.stft, n_fft, hop, win)` and
+    #      `self.istft = partial(audio_feature.istft, ...)` (MODEL:404-405, FROZEN:547-558) -- same call signatures and return
+    #      values (audio_feature.py:236-347), computed by the device kernels; forward() uses the complex fast path directly
+    def stft(self, y, output_type=None, **kwargs):
+        """(mag, phase, real, imag) [B, F, T] -- or, by output_type, (mag, phase) / (real, imag) / the complex tensor."""
+        if kwargs:
+            raise NotImplementedError(f"extra torch.stft arguments are not supported here: {sorted(kwargs)}")
+        if y.ndim not in (2, 3):
+            raise ValueError(f"Only support single-/multi-channel signals. Received {y.ndim=}.")  # audio_feature.py:259-260
+        shape = y.shape
+        c = self._stft(y.reshape(-1, shape[-1]) if y.ndim == 3 else y)
+        if y.ndim == 3:
+            c = c.reshape(shape[0], -1, *c.shape[-2:])
+        if output_type == "complex":
+            return c
+        if output_type == "real_imag":
+            return c.real, c.imag
+        mag, phase = torch.abs(c), torch.angle(c)
+        if output_type == "mag_phase":
+            return mag, phase
+        return mag, phase, c.real, c.imag
+
+    def istft(self, feature, length=None, input_type="complex"):
+        """[B, F, T] spectrogram(s) -> [B, length] (audio_feature.py:297-347: "complex" tensor, ("real", "imag") or (mag, phase))."""
+        if input_type == "real_imag":
+            if not (isinstance(feature, (tuple, list)) and len(feature) == 2):
+                raise ValueError(f"Only support tuple or list. Received {type(feature)}.")
+            c = torch.complex(real=feature[0], imag=feature[1])
+        elif input_type == "complex":
+            if not (torch.is_tensor(feature) and torch.is_complex(feature)):
+                raise ValueError(f"Only support complex-valued tensor. Received {type(feature)}")
+            c = feature
+        elif input_type == "mag_phase":
+            if not (isinstance(feature, (tuple, list)) and len(feature) == 2):
+                raise ValueError(f"Only support tuple or list. Received {type(feature)}.")
+            c = torch.polar(feature[0], feature[1])
+        else:
+            raise ValueError(f"Only support 'real_imag', 'complex', and 'mag_phase'. Received {input_type=}")
+        return self._istft(c, length)
+
     def _layer_kwargs(self) -> dict:
         if self.layer_outputs not in ("tensors", "counts", "none"):
             raise ValueError(f"layer_outputs must be 'tensors', 'counts' or 'none', got {self.layer_outputs!r}")
@@ -157,7 +197,7 @@ class _EngineMixin:
         the device between calls; one HIP-graph replay per hop.  Live front-end only."""
         from .streaming import StreamingSession
         self._check_mode()
-        return StreamingSession(self.engine(), batch=batch, hop=hop, graph=graph, rows_per_wg=rows_per_wg)
+        return StreamingSession(self.engine(), batch=batch, hop=hop, graph=graph, rows_per_wg=rows_per_wg, owner=self)
 
     def _check_mode(self):
         if self.training:
@@ -196,13 +236,6 @@ class SpikingFullSubNet(_EngineMixin, nn.Module):
     def _spec(self) -> PathSpec:
         return self._path_spec
 
-    # ---- the two edges of the path (audio_feature.py:236-347): see _EngineMixin.spectral_backend -------------
-    def stft(self, y):
-        return self._stft(y)
-
-    def istft(self, spec, length=None):
-        return self._istft(spec, length)
-
     @torch.no_grad()
     def forward_stft(self, noisy_cmp, want_layers=True, want_membrane=False, want_counts=False):
         """The hot path alone: complex64 [B, 257, T] -> Engine.forward_stft result dict."""
@@ -214,10 +247,10 @@ class SpikingFullSubNet(_EngineMixin, nn.Module):
         assert input.ndim == 2, f"Input tensor must be 2D, but got {input.ndim}D."
         self._check_mode()
         batch_size, sequence_length = input.shape
-        res = self.engine().forward_stft(self.stft(input), **self._layer_kwargs())
+        res = self.engine().forward_stft(self._stft(input), **self._layer_kwargs())
         enh_stft = res["enh_stft"]  # [B, S, F, T]
         if self.num_spks > 1:
-            enh_y = self.istft(enh_stft.reshape(batch_size * self.num_spks, *enh_stft.shape[2:]), length=sequence_length)
+            enh_y = self._istft(enh_stft.reshape(batch_size * self.num_spks, *enh_stft.shape[2:]), length=sequence_length)
             return enh_y.reshape(batch_size, self.num_spks, -1), res["fb_all"], res["sb_all"]
-        enh_y = self.istft(enh_stft[:, 0], length=sequence_length)
+        enh_y = self._istft(enh_stft[:, 0], length=sequence_length)
         return enh_y, res["enh_mag"][:, 0], res["fb_all"], res["sb_all"]

@@ -40,8 +40,9 @@ def stft(y: torch.Tensor, n_fft: int, hop_length: int, win_length: Optional[int]
     w = hann(n_fft, y.device) if window is None else window.to(device=y.device, dtype=torch.float32).contiguous()
     out = torch.empty((B, n_fft // 2 + 1, T), dtype=torch.complex64, device=y.device)
     y = y.contiguous()
-    check(_lib.lib().sfsn_stft(y.data_ptr(), B, L, n_fft, hop_length, w.data_ptr(), torch.view_as_real(out).data_ptr(), T, _stream(y.device)),
-          "sfsn_stft")
+    with torch.cuda.device(y.device):  # the C ABI launches on the calling thread's current device
+        check(_lib.lib().sfsn_stft(y.data_ptr(), B, L, n_fft, hop_length, w.data_ptr(), torch.view_as_real(out).data_ptr(), T, _stream(y.device)),
+              "sfsn_stft")
     return out
 
 
@@ -60,6 +61,7 @@ def istft(spec: torch.Tensor, n_fft: int, hop_length: int, win_length: Optional[
     w = hann(n_fft, spec.device) if window is None else window.to(device=spec.device, dtype=torch.float32).contiguous()
     spec = spec.contiguous()
     out = torch.empty((B, length), dtype=torch.float32, device=spec.device)
-    check(_lib.lib().sfsn_istft(torch.view_as_real(spec).data_ptr(), B, T, n_fft, hop_length, w.data_ptr(), out.data_ptr(), length,
-                                _stream(spec.device)), "sfsn_istft")
+    with torch.cuda.device(spec.device):
+        check(_lib.lib().sfsn_istft(torch.view_as_real(spec).data_ptr(), B, T, n_fft, hop_length, w.data_ptr(), out.data_ptr(), length,
+                                    _stream(spec.device)), "sfsn_istft")
     return out

@@ -28,8 +28,12 @@ from .engine import Engine, _ptr
 class StreamingSession:
     """``step(frames [B, F, hop] complex64) -> (enh_stft [B, S, F, hop], enh_mag [B, S, F, hop])`` with state carried."""
 
-    def __init__(self, engine: Engine, batch: int = 1, hop: int = 1, graph: bool = True, rows_per_wg=None):
+    def __init__(self, engine: Engine, batch: int = 1, hop: int = 1, graph: bool = True, rows_per_wg=None, owner=None):
         spec = engine.spec
+        # the module the engine was packed from: reset() checks that its parameters have not changed since (the session's
+        # captured graph holds pointers to THIS engine's packed weights)
+        import weakref
+        self._owner = weakref.ref(owner) if owner is not None else None
         if spec.laplace:
             raise NotImplementedError("the frozen front-end's offline Laplace normalisation (model_low_freq.py:147-169) needs the whole "
                                       "utterance; streaming is defined for the live (LayerNorm) front-end only")
@@ -74,6 +78,10 @@ class StreamingSession:
     # -----------------------------------------------------------------------------------------------------------------
     def reset(self) -> None:
         """Back to the start of an utterance: zero (h, c) (modeling_spiking_fullsubnet.py:100-106) and zero history."""
+        owner = self._owner() if self._owner is not None else None
+        if owner is not None and owner.engine() is not self.eng:
+            raise RuntimeError("the module's parameters (or device) changed after this streaming session was created: its packed "
+                               "weights are stale -- create a new session with module.streaming(...)")
         for d in (self.fb, self.sb):
             for layer in d["states"]:
                 for h, c in layer:
@@ -84,6 +92,10 @@ class StreamingSession:
 
     def _enqueue(self) -> None:
         """One hop on torch's current stream: history shift, then the offline forward's kernels on frames [D, D+hop)."""
+        with torch.cuda.device(self.dev):  # the C ABI launches on the calling thread's current device
+            self._enqueue_on_device()
+
+    def _enqueue_on_device(self) -> None:
         eng, spec, L = self.eng, self.eng.spec, self.eng.lib
         B, F, D, hop, Th, S, ng = self.B, self.F, self.D, self.hop, self.Th, spec.num_spks, spec.n_groups
         st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)

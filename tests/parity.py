@@ -81,9 +81,30 @@ def check_chain(spk, spk_ref, near_ref, t_up, name="", mem=None, mem_ref=None):
         err = np.where(scale > RUNAWAY, 0.0, np.abs(mine64 - ref64) - MEM_RTOL * scale)[tt]
         if err.size:
             assert err.max() <= MEM_ATOL, f"{name}: membrane error exceeds {MEM_ATOL:g}+{MEM_RTOL:g}*|c| by {err.max() - MEM_ATOL:.3g} before any divergence"
-    stats = dict(name=name, rows=R, diverged=int((first < T).sum()), own_explained=explained,
+    div_rows = np.nonzero(first < T)[0]
+    stats = dict(name=name, rows=R, frames=T, diverged=int((first < T).sum()), own_explained=explained, own_unexplained=unexplained,
+                 first_flips=[[int(r), int(first[r])] for r in div_rows[:16]],  # (row, frame) of the first differing spike
                  spike_agreement=float(1.0 - diff.mean()), valid_frac=float(t_valid.sum() / max(1, T * R)))
     return t_valid, stats
+
+
+def report(case: str, stats, extra=None) -> None:
+    """Append a per-fixture, per-layer divergence record (rows diverged, first-flip frames, explained / unexplained) to the
+    JSON-lines report the GPU run leaves behind (gpurun_out/parity_report.jsonl, or $SFSN_PARITY_REPORT), so that a green
+    suite also says HOW clean every fixture was."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.environ.get("SFSN_PARITY_REPORT", os.path.join(root, "gpurun_out", "parity_report.jsonl"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as fh:
+            fh.write(json.dumps(dict(case=case, rows_diverged=sum(s["diverged"] for s in stats),
+                                     unexplained=sum(s.get("own_unexplained", 0) for s in stats),
+                                     min_spike_agreement=min((s["spike_agreement"] for s in stats), default=1.0),
+                                     layers=stats, **(extra or {}))) + "\n")
+    except OSError:
+        pass  # a read-only checkout must not fail the test
 
 
 def check_continuous(y, y_ref, t_valid_rows, name="", rel=REL, atol=ATOL):

@@ -105,6 +105,88 @@ def test_scan_free_running_vs_oracle(hip, I, H, R, T, shared, bn):
     np.testing.assert_allclose(cT[ok], ref_c[ok], atol=parity.MEM_ATOL, rtol=parity.MEM_RTOL)
 
 
+def test_checkpoint_directory_loaded_on_the_device_passes_parity(tmp_path):
+    """SURVEY 8f rank 3 on the GPU: an accelerate-style checkpoint directory (pytorch_model.bin of the generator next to a
+    discriminator file, audiozen/trainer.py:225,238-242) with the trained model_zoo baseline_m weights, loaded into a module
+    that is ALREADY on the device through checkpoint.load_checkpoint(prepack=True) -- the kernel-side weight images are built
+    at load time -- then the golden fixture's parity check, spike for spike."""
+    import spiking_fullsubnet_amd as pkg
+    from safetensors.torch import save_file
+    from spiking_fullsubnet_amd import checkpoint
+    gold = load("frozen_m_zoo.npz")
+    zoo = {k[3:]: torch.from_numpy(gold[k]) for k in gold if k.startswith("sd/")}
+    d_bin, d_st = tmp_path / "best", tmp_path / "epoch_0001"
+    d_bin.mkdir(), d_st.mkdir()
+    torch.save(zoo, d_bin / "pytorch_model.bin")
+    torch.save({"junk": torch.zeros(1)}, d_bin / "pytorch_model_1.bin")
+    save_file({("module." + k): v.contiguous() for k, v in zoo.items()}, str(d_st / "model.safetensors"))
+    spec = omodel.spec_from_frozen_kwargs(rw.FROZEN_M)
+    for d in (d_bin, d_st):
+        model = pkg.Separator(**rw.FROZEN_M).eval().to(DEV)
+        e0 = model._engine if hasattr(model, "_engine") else None
+        missing, unexpected = checkpoint.load_checkpoint(model, str(d), prepack=True)
+        assert missing == [] and unexpected == []
+        eng = model._engine
+        assert eng is not None and eng is not e0 and eng.fb.cells[0].w_hh_q.device.type == "cuda"  # packed at load time
+        out = hip_result(model, gold["stft"])
+        assert model._engine is eng  # the forward reused the pre-packed weights
+        stats = parity.check_model(out, gold, spec, tag=f"checkpoint {d.name}:")
+        parity.report(f"checkpoint-bridge:{d.name}:frozen_m_zoo", stats)
+        for st in stats:
+            assert st["diverged"] == 0 and st["spike_agreement"] == 1.0, st
+
+
+def test_scratch_cache_is_keyed_on_capacity_and_bounded():
+    """evaluation over clips of many lengths must not pin one scratch set per length.  One buffer set per (stack,
+    rows, stream), grown to the longest clip; a byte budget evicts least-recently-used sets; results do not depend on what the
+    cache held before (bit identity with a fresh engine)."""
+    kw, seed = rw.LIVE_M, 5
+    sd = rw.live_state_dict(kw, seed)
+    model = build_module("live", kw, sd)
+    eng = model.engine()
+    waves = {T: torch.from_numpy(rw.synth_wave(2, T, T)).to(DEV) for T in (40, 90, 33, 64, 90, 17)}
+    outs = {}
+    for T, w in waves.items():
+        outs[T] = eng.forward_stft(model._stft(w))
+    torch.cuda.synchronize()
+    stacks = [k for k in eng._ws if k[0] in ("fb", "sb")]
+    assert len(stacks) == 2, list(eng._ws)  # one full-band and one sub-band set, not one per length
+    assert all(eng._ws[k]["T"] == 90 for k in stacks)
+    fresh = build_module("live", kw, sd).engine()
+    for T in (33, 17):
+        ref = fresh.forward_stft(model._stft(waves[T]))
+        assert torch.equal(torch.view_as_real(ref["enh_stft"]), torch.view_as_real(outs[T]["enh_stft"]))
+        for x, y in zip(ref["fb_all"] + sum(ref["sb_all"], []), outs[T]["fb_all"] + sum(outs[T]["sb_all"], [])):
+            assert torch.equal(x, y)
+    # other batch sizes add sets; a tiny budget keeps only the most recent ones
+    eng.ws_budget_bytes = 1
+    for B in (1, 3, 4):
+        eng.forward_stft(model._stft(torch.from_numpy(rw.synth_wave(B, 20, B)).to(DEV)))
+    torch.cuda.synchronize()
+    assert len(eng._ws) <= 3, list(eng._ws)
+
+
+def test_stft_and_istft_attributes_keep_the_reference_signatures():
+    """`model.stft(y)` is `partial(audio_feature.stft, ...)` in the reference (MODEL:404-405): (mag, phase, real, imag), or by
+    output_type; `model.istft(feature, length=, input_type=)` accepts the three feature forms (audio_feature.py:236-347)."""
+    model = build_module("live", rw.LIVE_TINY, rw.live_state_dict(rw.LIVE_TINY, 11))
+    y = torch.from_numpy(rw.synth_wave(2, 30, 1)).to(DEV)
+    mag, phase, real, imag = model.stft(y)
+    c = torch.stft(y, 512, 128, 512, window=torch.hann_window(512, device=DEV), return_complex=True, pad_mode="constant")
+    assert mag.shape == c.shape and torch.allclose(real, c.real, atol=2e-5) and torch.allclose(imag, c.imag, atol=2e-5)
+    assert torch.allclose(mag, c.abs(), atol=2e-5) and torch.allclose(torch.polar(mag, phase), c, atol=3e-5)
+    assert torch.is_complex(model.stft(y, output_type="complex")) and len(model.stft(y, output_type="real_imag")) == 2
+    assert len(model.stft(y, output_type="mag_phase")) == 2
+    assert model.stft(y.reshape(1, 2, -1))[0].shape == (1, 2, 257, c.shape[-1])  # multi-channel input, audio_feature.py:265-284
+    ref = torch.istft(c, 512, 128, 512, window=torch.hann_window(512, device=DEV), length=y.shape[-1])
+    for feat, kind in ((c, "complex"), ((c.real, c.imag), "real_imag"), ((c.abs(), c.angle()), "mag_phase")):
+        assert torch.allclose(model.istft(feat, length=y.shape[-1], input_type=kind), ref, atol=2e-5)
+    with pytest.raises(ValueError):
+        model.istft(c.real, input_type="complex")
+    with pytest.raises(ValueError):
+        model.stft(y.reshape(1, 1, 2, -1))
+
+
 def test_scan_teacher_forced_single_steps(hip):
     """Each step started from the ORACLE's state (T=1 launches): membranes within 1e-5 + 2e-6*|c| per step and spikes
     equal wherever the oracle membrane is outside the +-TAU band -- no error can accumulate along the chain."""
@@ -183,6 +265,30 @@ def test_spike_proj_matches_exact_product(hip, M, K, N):
     np.testing.assert_allclose(y.cpu().numpy(), exact, atol=2e-6, rtol=1e-6)
 
 
+def test_spike_proj_accepts_a_4_byte_aligned_output(hip):
+    """A projection whose row pitch is not a multiple of 4 floats (P = 2*ctr*df*S with ctr = 1, df = 3) written at an odd
+    chunk offset: the output pointer is only 4-byte aligned.  The fast (vector-store) kernels need 16 bytes; the entry point
+    must fall back to scalar stores instead of refusing (the chunked / streaming schedules hit this)."""
+    from spiking_fullsubnet_amd._lib import check
+    from spiking_fullsubnet_amd.engine import pack_w3
+    rng = np.random.default_rng(4)
+    M, K, N = 150, 96, 6
+    KP = (K + 63) // 64 * 64
+    s8 = np.zeros((M, KP), np.int8)
+    s8[:, :K] = rng.random((M, K)) > 0.6
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    pk, dq = pack_w3(w)
+    ts, tp, td, tb = _t(s8), _t(pk), _t(dq), _t(b)
+    ya = torch.zeros((M * N + 8,), device=DEV)
+    yb = torch.zeros((M * N + 8,), device=DEV)
+    check(hip.sfsn_spike_proj(_p(ts), _p(tp), _p(td), _p(tb), _p(ya), M, K, N, N, None), "aligned")
+    check(hip.sfsn_spike_proj(_p(ts), _p(tp), _p(td), _p(tb), ctypes.c_void_p(yb.data_ptr() + 4), M, K, N, N, None), "offset by one float")
+    torch.cuda.synchronize()
+    assert torch.equal(ya[:M * N], yb[1:M * N + 1]) and float(yb[0]) == 0.0 and float(yb[M * N + 1]) == 0.0
+    assert hip.sfsn_spike_proj(_p(ts), _p(tp), _p(td), _p(tb), ctypes.c_void_p(yb.data_ptr() + 2), M, K, N, N, None) < 0  # not even 4-byte aligned
+
+
 @pytest.mark.parametrize("M,K,N", [(100, 38, 224), (77, 94, 160), (64, 158, 224), (130, 64, 320), (33, 12, 32), (40, 64, 240)])
 def test_input_proj_f32(hip, M, K, N):
     from spiking_fullsubnet_amd._lib import check
@@ -245,19 +351,20 @@ def test_module_vs_reference_golden(fname, front, kw, seed):
     model = build_module(front, kw, sd)
     out = hip_result(model, gold["stft"])
     stats = parity.check_model(out, gold, spec, tag=fname + ":")
+    parity.report("golden:" + fname, stats)
+    # every committed fixture is short (T <= 126 frames): on those NOT A SINGLE spike of any layer may differ from the reference's
+    # recording -- so none of the output checks below can ever be skipped because "a row diverged"
     for st in stats:
-        assert st["spike_agreement"] > 0.995, st
-    clean = all(st["diverged"] == 0 for st in stats)
+        assert st["diverged"] == 0 and st["spike_agreement"] == 1.0, st
     outs = model(_t(gold["wave"]))
     torch.cuda.synchronize()
     assert outs[0].shape == gold["enh_y"].shape
-    if clean:
-        B, S, F, T = out["enh_mag"].shape
-        if "enh_mag" in gold:
-            np.testing.assert_allclose(out["enh_mag"].reshape(B * S, F, T), gold["enh_mag"], rtol=parity.REL, atol=parity.ATOL)
-            np.testing.assert_allclose(outs[1].cpu().numpy(), gold["enh_mag"], rtol=2e-4, atol=1e-4)  # includes the device STFT
-        np.testing.assert_allclose(outs[0].cpu().numpy(), gold["enh_y"], rtol=1e-3, atol=2e-5)          # device STFT + iSTFT
-    if "synops" in gold and clean:
+    B, S, F, T = out["enh_mag"].shape
+    if "enh_mag" in gold:
+        np.testing.assert_allclose(out["enh_mag"].reshape(B * S, F, T), gold["enh_mag"], rtol=parity.REL, atol=parity.ATOL)
+        np.testing.assert_allclose(outs[1].cpu().numpy(), gold["enh_mag"], rtol=2e-4, atol=1e-4)  # includes the device STFT
+    np.testing.assert_allclose(outs[0].cpu().numpy(), gold["enh_y"], rtol=1e-3, atol=2e-5)          # device STFT + iSTFT
+    if "synops" in gold:
         assert omodel.compute_synops(out["fb_all"], out["sb_all"], spec["shared"]) == pytest.approx(float(gold["synops"]), rel=1e-6)
 
 
@@ -272,8 +379,9 @@ def test_module_vs_oracle_seeded(front, kw, seed, B, T):
     ora = omodel.forward_from_stft(spec, sd, stft, "f32", want_membrane=True)
     out = hip_result(build_module(front, kw, sd), stft)
     stats = parity.check_model(out, parity.gold_from_oracle(ora), spec, tag="oracle:")
-    for st in stats:
-        assert st["spike_agreement"] > 0.99, st
+    parity.report(f"oracle-seeded:{front}:sbH{spec['sb_hidden']}:B{B}xT{T}", stats)
+    for st in stats:  # (a first flip outside the don't-care band already failed inside check_model)
+        assert st["spike_agreement"] > 0.999, st
     if front == "frozen":  # Laplace means themselves
         assert np.isfinite(out["enh_mag"]).all()
 
@@ -370,7 +478,7 @@ def test_full_size_properties():
     sd = rw.live_state_dict(kw, seed)
     model = build_module("live", kw, sd)
     wave = torch.from_numpy(rw.synth_wave(B, T, 0)).to(DEV)
-    stft = model.stft(wave)
+    stft = model._stft(wave)
     assert stft.shape == (B, 257, T)
     r1 = model.forward_stft(stft)
     r2 = model.forward_stft(stft)
@@ -382,17 +490,34 @@ def test_full_size_properties():
     torch.cuda.synchronize()
     assert torch.equal(torch.view_as_real(sub["enh_stft"]), torch.view_as_real(r1["enh_stft"][5:13]))
     assert torch.equal(sub["fb_all"][2], r1["fb_all"][2][:, 5:13])
-    # oracle on clips 0,1 x 120 frames: causal model => the prefix of the long run must match the short oracle run
-    Tc = 120
+    # oracle on 8 clips spread over the batch (first, middle, last) x 300 frames: clips are independent and the model is causal
+    # in T, so the long run restricted to those clips / frames must match the short oracle run -- for the default schedule
+    # (full-band stack launch + per-layer sub-band scans at 4 rows per workgroup) AND for the geometry the bench's timed
+    # region uses (sub-band scans at 16 rows per workgroup with both fused-input variants)
+    Tc, clips = 300, [0, 1, 30, 31, 32, 33, 62, 63]
     spec = omodel.spec_from_live_kwargs(kw)
-    ora = omodel.forward_from_stft(spec, sd, stft[:2, :, :Tc].cpu().numpy(), "f32", want_membrane=True)
-    out = dict(enh_stft=r1["enh_stft"][:2, :, :, :Tc].cpu().numpy(), fb_all=[a[:Tc, :2].cpu().numpy() for a in r1["fb_all"]], sb_all=[])
-    for g, lst in enumerate(r1["sb_all"]):
-        N = spec_units(spec, g)
-        out["sb_all"].append([a[:Tc, :2 * N].cpu().numpy() for a in lst])
-    stats = parity.check_model(out, parity.gold_from_oracle(ora), spec, tag="full-size prefix:")
-    for st in stats:
-        assert st["spike_agreement"] > 0.99, st
+    ora = omodel.forward_from_stft(spec, sd, stft[clips, :, :Tc].cpu().numpy(), "f32", want_membrane=True)
+    gold_sub = parity.gold_from_oracle(ora)
+    eng = model.engine()
+    for label, rpw in (("default", (0, 0)), ("timed-region geometry", (4, 16))):
+        eng.rows_per_wg = rpw
+        n0 = dict(eng.launches)
+        rr = r1 if rpw == (0, 0) else model.forward_stft(stft)
+        torch.cuda.synchronize()
+        if rpw != (0, 0):
+            assert eng.launches.get("fused", 0) > n0.get("fused", 0) and eng.launches.get("fused_x", 0) > n0.get("fused_x", 0)
+        ci = torch.tensor(clips, device=DEV)
+        out = dict(enh_stft=rr["enh_stft"][ci][:, :, :, :Tc].cpu().numpy(), fb_all=[a[:Tc, ci].cpu().numpy() for a in rr["fb_all"]], sb_all=[])
+        for g, lst in enumerate(rr["sb_all"]):
+            N = spec_units(spec, g)
+            rows = torch.cat([torch.arange(c * N, (c + 1) * N, device=DEV) for c in clips])
+            out["sb_all"].append([a[:Tc, rows].cpu().numpy() for a in lst])
+        stats = parity.check_model(out, gold_sub, spec, tag=f"full-size ({label}):")
+        parity.report(f"full-size:B64xT1000:{label}:clips{clips}:T{Tc}", stats)
+        for st in stats:
+            assert st["spike_agreement"] > 0.999, st
+        assert sum(st["diverged"] for st in stats) <= 4, stats  # 8 clips x 14 rows x 4 layers x 300 frames: (nearly) no flips at all
+    eng.rows_per_wg = (0, 0)
     rates = [float(a.mean()) for a in r1["fb_all"][1:3]]
     assert all(0.02 < r < 0.98 for r in rates), rates  # the synthetic model is alive, not saturated
 

@@ -249,3 +249,45 @@ def test_gather_clips_world2_gloo(n_clips):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference checkout only exists in the build container")
+def test_reference_plugin_loader_instantiates_the_dropins_with_bit_identical_init():
+    """The drop-in seam: the reference's own loader, `audiozen.utils.instantiate(path, args)` (audiozen/utils.py:113-128,
+    called at recipes/intel_ndns/spiking_fullsubnet/run.py:25), builds this package's modules from the recipe's TOML -- only the
+    dotted path changes -- and under the same torch.manual_seed the parameters come out BIT-IDENTICAL to the reference module's
+    (same names, order, shapes: the checkpoint contract of audiozen/trainer.py:225)."""
+    import importlib
+    import sys
+    import types
+    import tomli
+    for name in ("librosa", "soundfile", "onnxruntime", "pesq", "pystoi"):  # data / metric deps of audiozen that the path never touches
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+            sys.modules[name] = m
+    sys.modules["pesq"].pesq = lambda *a, **k: 0.0
+    sys.modules["pystoi"].stoi = lambda *a, **k: 0.0
+    sys.path.insert(0, REFERENCE)
+    try:
+        from audiozen.utils import instantiate
+        cfg = tomli.load(open(os.path.join(REFERENCE, "recipes/intel_ndns/spiking_fullsubnet/baseline_m.toml"), "rb"))
+        args = cfg["model"]["args"]
+        assert cfg["model"]["path"] == "audiozen.models.spiking_fullsubnet.modeling_spiking_fullsubnet.SpikingFullSubNet"
+        torch.manual_seed(1234)
+        ref = instantiate(cfg["model"]["path"], args=args)
+        torch.manual_seed(1234)
+        mine = instantiate("spiking_fullsubnet_amd.modeling_spiking_fullsubnet.SpikingFullSubNet", args=args)
+        import spiking_fullsubnet_amd as pkg
+        assert isinstance(mine, pkg.SpikingFullSubNet)
+        a, b = ref.state_dict(), mine.state_dict()
+        assert list(a.keys()) == list(b.keys())
+        for k in a:
+            assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+        assert [n for n, _ in ref.named_parameters()] == [n for n, _ in mine.named_parameters()]
+        mine.load_state_dict(a, strict=True)  # and a reference checkpoint loads strictly
+    finally:
+        sys.path.remove(REFERENCE)
