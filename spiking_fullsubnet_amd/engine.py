@@ -226,6 +226,15 @@ class Engine:
         self.stack_scan = "auto" if _ss == "auto" else bool(int(_ss))
         self.stack_rows_per_wg = {"fb": 4, "sb": 8}  # rows per workgroup of every layer of a stack: sum of workgroups <= CUs
         self.stack_lag = 16
+        # full-band / sub-band overlap of ONE forward: the sequence is cut into this many chunks, the full-band model runs them
+        # on one stream, the sub-band models follow one chunk behind on a second stream (they need the full-band output of the
+        # SAME frames only, MODEL:441-447; states are carried by the ABI's h_state / c_state).  The full-band chain (few
+        # workgroups, long) then hides behind the sub-band work of the previous chunk.  0 / 1 = off.
+        # Measured (B=64, T=1000, scripts/exp_overlap.py): 3.93 ms without, 3.67 / 3.60 / 3.62 / 3.87 / 4.38 ms with 2 / 3 / 4 / 5 / 8
+        # chunks -- every chunk costs ~0.15 ms of launch boundaries, scan prologues and hand-off lag.  Off when several forwards
+        # are in flight anyway (bench.py's timed region sets 0).
+        self.overlap_chunks = int(os.environ.get("SFSN_OVERLAP_CHUNKS", "3"))
+        self._ov_streams = None
         self.stack_wide = True
         self._stack_scratch: List[torch.Tensor] = []
 
@@ -651,7 +660,12 @@ class Engine:
         # sequential schedule: optionally still cut the sequence into chunks (single stream): the chunk-sized input-term
         # buffer is then produced and consumed while it is still in the 256 MB Infinity Cache instead of making a round
         # trip through HBM (745 MB per sub-band layer at B=64, T=1000)
-        nt_max = chunk if pipeline else (self.seq_chunk if 0 < self.seq_chunk < T else T)
+        overlap = bool(not pipeline and self.overlap_chunks > 1 and not spec.laplace and not (0 < self.seq_chunk < T)
+                       and T >= 96 * self.overlap_chunks)
+        if overlap:
+            nt_max = -(-T // self.overlap_chunks)
+        else:
+            nt_max = chunk if pipeline else (self.seq_chunk if 0 < self.seq_chunk < T else T)
         bounds = [(t0, min(nt_max, T - t0)) for t0 in range(0, T, nt_max)]
         S, ng = spec.num_spks, spec.n_groups
         nl_fb, nl_sb = spec.fb_layers, spec.sb_layers
@@ -687,15 +701,28 @@ class Engine:
             fork.record(main)
             for s_ in sstreams + gstreams:
                 s_.wait_event(fork)
+        elif overlap:
+            if self._ov_streams is None:
+                self._ov_streams = {}
+            if main.cuda_stream not in self._ov_streams:  # a pair per calling stream: forwards in flight stay independent
+                self._ov_streams[main.cuda_stream] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            sa, sb_ = self._ov_streams[main.cuda_stream]
+            sstreams = gstreams = [sa] * nl_fb + [sb_] * nl_sb
+            rpw_fb, rpw_sb = self.rows_per_wg
+            fork = torch.cuda.Event()
+            fork.record(main)
+            sa.wait_event(fork)
+            sb_.wait_event(fork)
         else:
             sstreams = gstreams = [main] * n_stage
             rpw_fb, rpw_sb = self.rows_per_wg
+        staged = pipeline or overlap  # several streams chained by events
         hS = [self._handle(s_) for s_ in sstreams]
         hG = [self._handle(s_) for s_ in gstreams]
 
         def link(src, dst):
             """dst waits for everything enqueued on src so far (no-op on the sequential path)."""
-            if pipeline and src is not dst:
+            if staged and src is not dst:
                 ev = torch.cuda.Event()
                 ev.record(src)
                 dst.wait_event(ev)
@@ -709,13 +736,19 @@ class Engine:
             use_stack, wide, rpw_stack = self._stack_choice(seqs, [x.shape[1] for x in xs_], want_membrane)
             if not pipeline and use_stack:
                 # all layers in one launch: features, layer 0's input term, the stack scan, the projection
-                for (t0, nt) in bounds:
+                for c, (t0, nt) in enumerate(bounds):
+                    if staged and gate_events is not None:
+                        gstreams[first].wait_event(gate_events[c])
                     feat_fn(t0, nt, hG[first])
                     self._stage_input(seqs, 0, xs_, d["zin"][0], t0, nt, hG[first], tag)
                     self._stage_stack(seqs, d, t0, nt, hS[first], tag, wide, rpw_stack)
                     self._stage_proj(seqs, d["s8"][nl - 1], d["proj"], t0, nt, hG[first], tag)
                     if post_fn is not None:
                         post_fn(t0, nt, hG[first])
+                    if staged:
+                        ev = torch.cuda.Event()
+                        ev.record(gstreams[first])
+                        done.append(ev)
                 return done
             # layer 0: groups whose real-valued input product can run inside the scan / the rest (input product first)
             fx = [i for i in range(len(seqs)) if self._fusable_x(seqs[i], xs_[i], rpw, want_membrane)]
@@ -726,7 +759,7 @@ class Engine:
                     g, sc = gstreams[si], sstreams[si]
                     # ---- what the scan of this layer consumes
                     if l == 0:
-                        if pipeline and gate_events is not None:
+                        if staged and gate_events is not None:
                             g.wait_event(gate_events[c])
                         feat_fn(t0, nt, hG[si])
                         if rest:
@@ -748,14 +781,14 @@ class Engine:
                         self._stage_scan_fused(seqs, l, d["states"][l], d["spk"][l], d["s8"], t0, nt, hS[si], tag)
                     else:
                         self._stage_scan(seqs, l, d["zin"][l], d["states"][l], d["spk"][l], d["s8"][l], d["mem"][l], t0, nt, hS[si], tag, rpw)
-                    if pipeline:
+                    if staged:
                         link(sc, g)  # the chunk-local zin buffer is reused by the next chunk's input product
                     # ---- after the last layer: projection and whatever follows the model
                     if l == nl - 1:
                         self._stage_proj(seqs, d["s8"][l], d["proj"], t0, nt, hG[si], tag)
                         if post_fn is not None:
                             post_fn(t0, nt, hG[si])
-                        if pipeline:
+                        if staged:
                             ev = torch.cuda.Event()
                             ev.record(g)
                             done.append(ev)
@@ -788,9 +821,9 @@ class Engine:
             gstreams[nl_fb].wait_event(fb_done[-1])
             sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, None)
         else:
-            sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, fb_done if pipeline else None)
-        if pipeline:
-            for s_ in sstreams + gstreams:
+            sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, fb_done if staged else None)
+        if staged:
+            for s_ in {id(x): x for x in sstreams + gstreams}.values():
                 link(s_, main)
 
         if want_counts and not want_layers:
@@ -808,4 +841,4 @@ class Engine:
             return [x] + [d["spk"][l][i] for l in range(len(d["spk"]))] + [d["proj"][i]]
         return dict(enh_stft=enh, enh_mag=enh_mag, fb_all=outs(x_fb, fb, 0), sb_all=[outs(xs[g], sb, g) for g in range(ng)],
                     fb_mem=[fb["mem"][l][0] for l in range(nl_fb)], sb_mem=[[sb["mem"][l][g] for l in range(nl_sb)] for g in range(ng)],
-                    mu_fb=mu_fb, mu_sb=mu_sb, pipelined=bool(pipeline), n_chunks=len(bounds))
+                    mu_fb=mu_fb, mu_sb=mu_sb, pipelined=bool(pipeline), overlapped=overlap, n_chunks=len(bounds))

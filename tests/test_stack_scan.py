@@ -265,3 +265,26 @@ def test_full_size_stack_scan_equals_the_per_layer_forward():
         for x, y in zip(ref["fb_all"] + sum(ref["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])):
             assert torch.equal(x, y)
     eng.stack_scan = "auto"
+
+
+@pytest.mark.parametrize("front,kw,seed", [("live", rw.LIVE_M, 5), ("live", rw.LIVE_TINY_2SPK, 8), ("frozen", rw.FROZEN_S, 6)])
+def test_full_band_sub_band_chunk_overlap_is_bit_identical(front, kw, seed):
+    """`overlap_chunks`: the sequence in chunks, the full-band model on one stream and the sub-band models one chunk behind on a
+    second one (states carried through the ABI): every returned tensor equals the one-stream forward, bit for bit.  The frozen
+    front-end's utterance-level Laplace means need the whole full-band output: it silently stays on one stream."""
+    sd = rw.live_state_dict(kw, seed) if front == "live" else rw.frozen_state_dict(kw, seed)
+    model = _build(front, kw, sd)
+    stft = model._stft(torch.from_numpy(rw.synth_wave(3, 400, seed)).to(DEV))
+    eng = model.engine()
+    eng.overlap_chunks = 0
+    ref = eng.forward_stft(stft)
+    torch.cuda.synchronize()
+    for n in (2, 4):
+        eng.overlap_chunks = n
+        b = eng.forward_stft(stft)
+        eng.check_stack_errors()
+        assert b["overlapped"] == (front == "live") and b["n_chunks"] == (n if front == "live" else 1)
+        assert torch.equal(torch.view_as_real(ref["enh_stft"]), torch.view_as_real(b["enh_stft"]))
+        assert torch.equal(ref["enh_mag"], b["enh_mag"])
+        for x, y in zip(ref["fb_all"] + sum(ref["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])):
+            assert torch.equal(x, y)
