@@ -237,6 +237,7 @@ class Engine:
         self._ov_streams = None
         self.stack_wide = True
         self._stack_scratch: List[torch.Tensor] = []
+        self._stack_err_pending: List[tuple] = []  # (event, pinned copy of a launch's error word): polled at the next forward
 
     # ---------------------------------------------------------------------------------------------
     def _stream(self):
@@ -466,10 +467,35 @@ class Engine:
         self.launches["stack"] = self.launches.get("stack", 0) + 1
         with self.timed("stack:" + tag, st):
             check(L.sfsn_gsn_stack_scan(segs, fin, nl, ns, nt, H, rpw, self.stack_lag, _ptr(scratch), nbytes, st), "sfsn_gsn_stack_scan")
+        # the launch's error word (a bounded hand-off wait expired) travels to pinned host memory behind the launch; it is looked
+        # at without blocking at the next forward (and by check_stack_errors): a failed launch cannot go unnoticed for long
+        if not torch.cuda.is_current_stream_capturing():
+            stream = self._tstream(st)
+            with torch.cuda.stream(stream):
+                pin = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+                pin.copy_(scratch[:1], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            self._stack_err_pending.append((ev, pin))
+
+    def _poll_stack_errors(self, block: bool = False) -> None:
+        keep = []
+        for ev, pin in self._stack_err_pending:
+            if block:
+                ev.synchronize()
+            if ev.query():
+                if int(pin[0]) != 0:
+                    self._stack_err_pending = []
+                    raise RuntimeError("sfsn_gsn_stack_scan: a layer-to-layer hand-off wait expired in an earlier launch "
+                                       "(that forward's results are invalid)")
+            else:
+                keep.append((ev, pin))
+        self._stack_err_pending = keep
 
     def check_stack_errors(self) -> None:
         """Raise if a hand-off wait of a stack launch expired (synchronises; tests and bench call it after a forward)."""
         torch.cuda.synchronize(self.device)
+        self._poll_stack_errors(block=True)
         for t in self._stack_scratch:
             if int(t[0].item()) != 0:
                 raise RuntimeError("sfsn_gsn_stack_scan: a layer-to-layer hand-off wait expired (results invalid)")
@@ -622,6 +648,8 @@ class Engine:
                      want_counts: bool = False) -> dict:
         """See ``_forward_stft``; runs with this engine's device current (the C ABI launches on the calling thread's device)."""
         with torch.cuda.device(self.device):
+            if self._stack_err_pending:
+                self._poll_stack_errors()
             return self._forward_stft(stft, want_layers, want_membrane, pipeline, want_counts)
 
     def _forward_stft(self, stft: torch.Tensor, want_layers: bool = True, want_membrane: bool = False, pipeline: Optional[bool] = None,
