@@ -72,6 +72,11 @@ size_t sfsn_w3_packed_bytes(int n_out, int k_in);               /* 3 * NT * KS *
 int sfsn_w3_padded_rows(int n_out);                            /* NT * 16 (length of dq) */
 int sfsn_w3_pack(const float* w /* [n_out][k_in] host */, int n_out, int k_in, int8_t* packed /* host */,
                  float* dq /* [NT*16] host */);
+/* The 16-bit-weight fast mode (BASELINE configs[2] "bf16" wording; SURVEY 0: the parity gate is the exact mode, this one reports
+ * its spike agreement and output error separately): bits = 16 rounds every weight to 16 significant bits of the same per-row
+ * grid and leaves the least-significant digit plane all zero; bits = 24 is sfsn_w3_pack.  Same layout, same kernels. */
+int sfsn_w3_pack_bits(const float* w /* host */, int n_out, int k_in, int bits /* 24 | 16 */, int8_t* packed /* host */,
+                      float* dq /* host */);
 /* Inverse (tests): reconstruct W~ [n_out][k_in] from the packed digits. */
 int sfsn_w3_unpack(const int8_t* packed, const float* dq, int n_out, int k_in, float* w);
 

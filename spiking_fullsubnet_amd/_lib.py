@@ -109,6 +109,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_w3_padded_rows.argtypes = [_I]
     L.sfsn_w3_pack.restype = _I
     L.sfsn_w3_pack.argtypes = [_P, _I, _I, _P, _P]
+    L.sfsn_w3_pack_bits.restype = _I
+    L.sfsn_w3_pack_bits.argtypes = [_P, _I, _I, _I, _P, _P]
     L.sfsn_w3_unpack.restype = _I
     L.sfsn_w3_unpack.argtypes = [_P, _P, _I, _I, _P]
     L.sfsn_gsn_layer_scan.restype = _I
@@ -145,7 +147,7 @@ def lib() -> ctypes.CDLL:
 
 
 EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
-           "sfsn_w3_pack", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_stack_scratch_bytes", "sfsn_gsn_stack_scan",
+           "sfsn_w3_pack", "sfsn_w3_pack_bits", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_stack_scratch_bytes", "sfsn_gsn_stack_scan",
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
            "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
 

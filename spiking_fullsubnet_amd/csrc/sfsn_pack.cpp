@@ -25,8 +25,11 @@ extern "C" int sfsn_w3_padded_rows(int n_out) { return n_out <= 0 ? 0 : tiles16(
 // Largest |q| three balanced base-256 digits in [-128,127] can hold with every digit still in range.
 static const double QMAX = 127.0 * 65536.0 + 127.0 * 256.0 + 127.0;  // 8355711
 
-extern "C" int sfsn_w3_pack(const float* w, int n_out, int k_in, int8_t* packed, float* dq) {
-    if (!w || !packed || !dq || n_out <= 0 || k_in <= 0) return SFSN_EINVAL;
+// bits = 24: the exact mode (three digits).  bits = 16: the 16-bit-weight fast mode -- every weight is rounded to 16 significant
+// bits of its row's fixed-point grid (|W - W~| <= 128 dq[n]), stored in the two upper digits; the least-significant digit plane
+// is all zero, so kernels that know it may skip a third of their matrix instructions (the others just add zeros).
+extern "C" int sfsn_w3_pack_bits(const float* w, int n_out, int k_in, int bits, int8_t* packed, float* dq) {
+    if (!w || !packed || !dq || n_out <= 0 || k_in <= 0 || (bits != 24 && bits != 16)) return SFSN_EINVAL;
     const int NT = tiles16(n_out), KS = steps64(k_in);
     memset(packed, 0, sfsn_w3_packed_bytes(n_out, k_in));
     for (int n = 0; n < NT * 16; ++n) dq[n] = 0.0f;
@@ -49,7 +52,13 @@ extern "C" int sfsn_w3_pack(const float* w, int n_out, int k_in, int8_t* packed,
         dq[n] = (float)ldexp(1.0, e - 23);
         const int nt = n >> 4, nn = n & 15;
         for (int k = 0; k < k_in; ++k) {
-            const long q = lrint(ldexp((double)row[k], 23 - e));      // exact scaling, round to nearest even
+            long q = lrint(ldexp((double)row[k], 23 - e));            // exact scaling, round to nearest even
+            if (bits == 16) {
+                long q16 = lrint(ldexp((double)row[k], 15 - e));      // round to the 16-bit grid (nearest even)
+                if (q16 > 32639) q16 = 32639;                         // (the row maximum may round up past the digit range)
+                if (q16 < -32639) q16 = -32639;
+                q = q16 * 256;
+            }
             const int d0 = (int)(((q + 128) & 255) - 128);
             const long q1 = (q - d0) >> 8;  // exact: q - d0 is a multiple of 256
             const int d1 = (int)(((q1 + 128) & 255) - 128);
@@ -64,6 +73,10 @@ extern "C" int sfsn_w3_pack(const float* w, int n_out, int k_in, int8_t* packed,
         }
     }
     return SFSN_OK;
+}
+
+extern "C" int sfsn_w3_pack(const float* w, int n_out, int k_in, int8_t* packed, float* dq) {
+    return sfsn_w3_pack_bits(w, n_out, k_in, 24, packed, dq);
 }
 
 extern "C" int sfsn_w3_unpack(const int8_t* packed, const float* dq, int n_out, int k_in, float* w) {

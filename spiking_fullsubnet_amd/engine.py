@@ -70,14 +70,15 @@ def _dev(a: np.ndarray, device) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
-def pack_w3(w: np.ndarray):
-    """fp32 [N, K] -> (int8 digits in MFMA fragment order, dq [pad16(N)]) as numpy arrays (host packing)."""
+def pack_w3(w: np.ndarray, bits: int = 24):
+    """fp32 [N, K] -> (int8 digits in MFMA fragment order, dq [pad16(N)]) as numpy arrays (host packing).  bits = 16: the
+    16-bit-weight mode (weights rounded to 16 significant bits of the row grid, least-significant digit plane zero)."""
     L = _lib.lib()
     w = np.ascontiguousarray(w, dtype=np.float32)
     n, k = w.shape
     packed = np.empty(L.sfsn_w3_packed_bytes(n, k), np.int8)
     dq = np.empty(L.sfsn_w3_padded_rows(n), np.float32)
-    check(L.sfsn_w3_pack(w.ctypes.data, n, k, packed.ctypes.data, dq.ctypes.data), "sfsn_w3_pack")
+    check(L.sfsn_w3_pack_bits(w.ctypes.data, n, k, bits, packed.ctypes.data, dq.ctypes.data), "sfsn_w3_pack_bits")
     return packed, dq
 
 
@@ -124,7 +125,7 @@ class _Seq:
     ln_b: Optional[torch.Tensor] = None
 
 
-def _pack_seq(sd: Dict[str, np.ndarray], prefix: str, spec: PathSpec, I: int, H: int, L: int, P: int, use_ln: bool, device) -> _Seq:
+def _pack_seq(sd: Dict[str, np.ndarray], prefix: str, spec: PathSpec, I: int, H: int, L: int, P: int, use_ln: bool, device, bits: int = 24) -> _Seq:
     G = 1 if spec.shared else 2
     cells = []
     for l in range(L):
@@ -137,9 +138,9 @@ def _pack_seq(sd: Dict[str, np.ndarray], prefix: str, spec: PathSpec, I: int, H:
             cell.w_ih_f32 = _dev(w_ih.astype(np.float32), device)
         else:
             for g in range(G):
-                pk, dq = pack_w3(w_ih[g * H:(g + 1) * H])
+                pk, dq = pack_w3(w_ih[g * H:(g + 1) * H], bits)
                 cell.w_ih_q.append((_dev(pk, device), _dev(dq, device)))
-        pk, dq = pack_w3(w_hh)
+        pk, dq = pack_w3(w_hh, bits)
         cell.w_hh_q, cell.w_hh_dq = _dev(pk, device), _dev(dq, device)
         cell.bias = _dev(b.astype(np.float32), device)
         if spec.bn:
@@ -152,7 +153,7 @@ def _pack_seq(sd: Dict[str, np.ndarray], prefix: str, spec: PathSpec, I: int, H:
     pn = prefix + spec.proj_name
     pw, pb = sd[pn + ".weight"], sd[pn + ".bias"]
     assert pw.shape == (P, H), (pn, pw.shape, (P, H))
-    pk, dq = pack_w3(pw)
+    pk, dq = pack_w3(pw, bits)
     seq = _Seq(I=I, H=H, P=P, cells=cells, proj_q=_dev(pk, device), proj_dq=_dev(dq, device), proj_b=_dev(pb.astype(np.float32), device))
     if use_ln:
         seq.ln_w = _dev(sd[prefix + "pre_layer_norm.weight"].astype(np.float32), device)
@@ -190,7 +191,13 @@ def _ptr(t: Optional[torch.Tensor]):
 class Engine:
     """Packed weights + launch sequence for one model on one device."""
 
-    def __init__(self, spec: PathSpec, state_dict: Dict[str, np.ndarray], device):
+    def __init__(self, spec: PathSpec, state_dict: Dict[str, np.ndarray], device, weight_bits: int = 24):
+        """weight_bits = 24: the exact fp32-parity mode.  16: the 16-bit-weight fast mode -- the recurrent, spike-input and
+        projection weights rounded to 16 significant bits of their row grid (the real-valued layer-0 input product stays
+        exact); reported against the fp32 oracle by tests/test_hip_parity.py::test_sixteen_bit_weight_mode_report."""
+        if weight_bits not in (24, 16):
+            raise ValueError("weight_bits must be 24 (exact) or 16")
+        self.weight_bits = weight_bits
         self.spec = spec
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -204,9 +211,9 @@ class Engine:
         if len(spec.cutoffs) == 2:
             raise NotImplementedError("single-group models hit a latent reflect-pad quirk of the reference (SubbandModel._freq_unfold)")
         sd = {k: np.asarray(v) for k, v in state_dict.items()}
-        self.fb = _pack_seq(sd, "fb_model.", spec, spec.fb_in, spec.fb_hidden, spec.fb_layers, spec.fb_proj, spec.ln_fb, self.device)
+        self.fb = _pack_seq(sd, "fb_model.", spec, spec.fb_in, spec.fb_hidden, spec.fb_layers, spec.fb_proj, spec.ln_fb, self.device, weight_bits)
         self.sb = [_pack_seq(sd, f"sb_model.sb_models.{g}.", spec, spec.sb_input_size(g), spec.sb_hidden, spec.sb_layers,
-                             spec.sb_proj_size(g), spec.ln_sb, self.device) for g in range(spec.n_groups)]
+                             spec.sb_proj_size(g), spec.ln_sb, self.device, weight_bits) for g in range(spec.n_groups)]
         self._ws: Dict[tuple, dict] = {}
         self.ws_budget_bytes = int(float(os.environ.get("SFSN_WS_BUDGET_GB", "96")) * 2**30)  # scratch cache budget (of 288 GB HBM)
         self.timers: Optional[dict] = None  # set to {} to record HIP events around each launch group (bench.py)

@@ -102,6 +102,9 @@ class _EngineMixin:
 
     _engine = None
     _engine_key = None
+    # 24 = the exact fp32-parity mode; 16 = the 16-bit-weight fast mode (recurrent / spike-input / projection weights rounded to 16
+    # significant bits of their row grid): set `module.weight_bits = 16` before the first forward (or any time: the weights are re-packed)
+    weight_bits = 24
     # What forward() returns in place of the reference's fp32 spike tensors (entries 1..L of every all_layer_outputs list):
     #   "tensors" (default, the reference's API), "counts" (SpikeSummary: exact spike counts + shape -- all that
     #   metric.compute_synops / compute_neuronops read), "none" (None entries).
@@ -183,12 +186,12 @@ class _EngineMixin:
     def engine(self) -> Engine:
         tensors = list(self.state_dict(keep_vars=True).items())
         dev = tensors[0][1].device
-        key = (str(dev),) + tuple((k, t.data_ptr(), t._version) for k, t in tensors)
+        key = (str(dev), self.weight_bits) + tuple((k, t.data_ptr(), t._version) for k, t in tensors)
         if self._engine is None or self._engine_key != key:
             if dev.type != "cuda":
                 raise RuntimeError("spiking_fullsubnet_amd has no CPU path: move the module to a HIP device (`.to('cuda')`) first")
             sd = {k: t.detach().cpu().numpy() for k, t in tensors}
-            self._engine = Engine(self._spec(), sd, dev)
+            self._engine = Engine(self._spec(), sd, dev, weight_bits=self.weight_bits)
             self._engine_key = key
         return self._engine
 

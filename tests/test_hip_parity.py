@@ -187,6 +187,57 @@ def test_stft_and_istft_attributes_keep_the_reference_signatures():
         model.stft(y.reshape(1, 1, 2, -1))
 
 
+def test_sixteen_bit_weight_mode_report():
+    """BASELINE configs[2] asks for a 16-bit mode; SURVEY 0: 16-bit weights cannot meet 1e-4 against the fp32 oracle, so the parity
+    gate stays the exact mode and THIS mode reports, per layer, its spike agreement and, at the output, its error -- beside the
+    floor any fp32 evaluation has (fp32 oracle vs fp64 oracle on the same input).  Trained zoo weights (baseline_m), 400 frames.
+    What it shows (numbers in the parity report): a 2^-16 weight perturbation flips the first spikes within a few frames and the
+    chains then decorrelate like any perturbed spiking recurrence -- ~90 % per-layer spike agreement and ~0.4 relative L2 at the
+    output after 400 frames, against 0.995+ / 0.11 for fp32-vs-fp64 and 0.996+ / 0.03 for the exact mode.  That is why the exact
+    mode is the parity gate and the headline.  Asserted here: the mode runs every kernel path (same layout, zero least-
+    significant digit plane), its output is finite and correlated with the reference, and the exact mode sits on the fp32 floor."""
+    T = 400
+    gold = load("frozen_m_zoo.npz")
+    kw = rw.FROZEN_M
+    sd = {k[3:]: v for k, v in gold.items() if k.startswith("sd/")}
+    spec = omodel.spec_from_frozen_kwargs(kw)
+    wave = torch.from_numpy(rw.synth_wave(2, T, 17, modulated=True))
+    stft = torch.stft(wave, 512, 128, 512, window=torch.hann_window(512), return_complex=True, pad_mode="constant").numpy()
+    o32 = omodel.forward_from_stft(spec, sd, stft, "f32")
+    o64 = omodel.forward_from_stft(spec, sd, stft, "f64")
+    model = build_module("frozen", kw, sd)
+    exact = hip_result(model, stft, want_membrane=False)
+    model.weight_bits = 16
+    fast = hip_result(model, stft, want_membrane=False)
+    assert model.engine().weight_bits == 16
+    model.weight_bits = 24
+
+    def layers(res):
+        return [np.asarray(a) > 0.5 for a in res["fb_all"][1:-1]] + [np.asarray(a) > 0.5 for l in res["sb_all"] for a in l[1:-1]]
+
+    def rel(a, b):
+        return float(np.linalg.norm((np.asarray(a) - np.asarray(b)).ravel()) / np.linalg.norm(np.asarray(b).ravel()))
+
+    agree16 = [float((a == b).mean()) for a, b in zip(layers(fast), layers(o32))]
+    agree24 = [float((a == b).mean()) for a, b in zip(layers(exact), layers(o32))]
+    floor = [float((a == b).mean()) for a, b in zip(layers(o32), layers(o64))]
+    def first_flip(a, b):
+        d = (a != b).reshape(a.shape[0], -1).any(1)
+        return int(np.argmax(d)) if d.any() else T
+
+    rep = dict(frames=T, clips=2, weights="model_zoo baseline_m (trained)",
+               first_differing_frame_vs_fp32_oracle=dict(weight_bits_16=[first_flip(a, b) for a, b in zip(layers(fast), layers(o32))],
+                                                         exact_mode=[first_flip(a, b) for a, b in zip(layers(exact), layers(o32))],
+                                                         fp32_oracle_vs_fp64_oracle=[first_flip(a, b) for a, b in zip(layers(o32), layers(o64))]),
+               spike_agreement_vs_fp32_oracle=dict(weight_bits_16=agree16, exact_mode=agree24, fp32_oracle_vs_fp64_oracle=floor),
+               enh_stft_rel_l2_vs_fp32_oracle=dict(weight_bits_16=rel(fast["enh_stft"], o32["enh_stft"]), exact_mode=rel(exact["enh_stft"], o32["enh_stft"]),
+                                                   fp32_oracle_vs_fp64_oracle=rel(o32["enh_stft"], o64["enh_stft"])))
+    parity.report("sixteen-bit-weight-mode:frozen_m_zoo", [], extra=rep)
+    assert np.isfinite(fast["enh_stft"]).all() and min(agree16) > 0.8 and rep["enh_stft_rel_l2_vs_fp32_oracle"]["weight_bits_16"] < 0.7, rep
+    assert min(agree24) >= min(floor) - 2e-3, rep
+    assert rep["enh_stft_rel_l2_vs_fp32_oracle"]["exact_mode"] <= 1.15 * rep["enh_stft_rel_l2_vs_fp32_oracle"]["fp32_oracle_vs_fp64_oracle"] + 1e-4, rep
+
+
 def test_scan_teacher_forced_single_steps(hip):
     """Each step started from the ORACLE's state (T=1 launches): membranes within 1e-5 + 2e-6*|c| per step and spikes
     equal wherever the oracle membrane is outside the +-TAU band -- no error can accumulate along the chain."""
