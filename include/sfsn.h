@@ -162,8 +162,10 @@ int sfsn_gsn_layer_scan_fused_x(const sfsn_scan_segment* segs /* host */, const 
  *   rows_per_wg[l]: 4, 8 or 16 (NULL: 8 everywhere).  One workgroup occupies a CU: keep the sum over all layers of
  *       ceil(R / rows_per_wg) within the device's CU count, or layers queue behind each other (correct, not pipelined).
  *   lag: frames a consumer lets its producers run ahead before it (re)starts -- amortises its polls; 16-32 is a good value.
- *   scratch: device memory, sfsn_stack_scratch_bytes(...) bytes, private to this launch until it completes.  Word 0 is an
- *       error flag the caller may read back after the launch: non-zero = a bounded hand-off wait expired (results invalid).
+ *   scratch: device memory, sfsn_stack_scratch_bytes(...) bytes, ZEROED by the caller once (before its first use) and private to
+ *       the launches that use it, one at a time: every launch leaves its counters zeroed again (its last workgroup does it -- no
+ *       memset per launch).  Word 0 is an error flag the caller may read back after a launch: non-zero = a bounded hand-off
+ *       wait expired (results invalid); the library never clears it.
  * Shared gate weights only (SFSN_EUNSUPPORTED otherwise: use the per-layer calls). */
 size_t sfsn_stack_scratch_bytes(int n_layers, int n_segs, int rows_total);
 int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs /* host [n_layers][n_segs] */, const sfsn_fused_input* fin /* host, same shape;
@@ -241,6 +243,13 @@ typedef struct sfsn_df_group {
 int sfsn_deepfilter(const float* stft_ri /* [B][F][T][2] */, int B, int F, int T, int S,
                     const sfsn_df_group* groups /* host */, int n_groups, float* enh_ri /* [B][S][F][T][2] */,
                     float* enh_mag /* [B][S][F][T], nullable */, int t0, int nt /* frames [t0, t0+nt) */, void* stream);
+
+/* ----------------------------------------------------------------------------------------------------
+ * Streaming sessions (BASELINE configs[4]): the input history the deep filter reaches back into (MODEL:331-333: df - 1 frames
+ * of the noisy spectrum).  hist [rows][D + hop] complex64, rows = B * F: frames [hop, hop + D) move to [0, D) and the `hop`
+ * new frames of inp [rows][hop] are appended, in place, in one launch.  D + hop <= 16 (SFSN_EUNSUPPORTED beyond).
+ * ---------------------------------------------------------------------------------------------------- */
+int sfsn_hist_shift(float* hist_ri, const float* inp_ri, int rows, int D, int hop, void* stream);
 
 /* ----------------------------------------------------------------------------------------------------
  * Spike counts -- the only thing the reference's energy proxy reads from the spike tensors:

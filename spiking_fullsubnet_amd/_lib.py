@@ -134,6 +134,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_laplace_means.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _P, _P, _P]
     L.sfsn_deepfilter.restype = _I
     L.sfsn_deepfilter.argtypes = [_P, _I, _I, _I, _I, ctypes.POINTER(DfGroup), _I, _P, _P, _I, _I, _P]
+    L.sfsn_hist_shift.restype = _I
+    L.sfsn_hist_shift.argtypes = [_P, _P, _I, _I, _I, _P]
     L.sfsn_spike_count.restype = _I
     L.sfsn_spike_count.argtypes = [ctypes.POINTER(CountTensor), _I, _P]
     L.sfsn_stft.restype = _I
@@ -149,7 +151,7 @@ def lib() -> ctypes.CDLL:
 EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
            "sfsn_w3_pack", "sfsn_w3_pack_bits", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_stack_scratch_bytes", "sfsn_gsn_stack_scan",
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
-           "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
+           "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
 
 
 def check(rc: int, what: str = "") -> None:

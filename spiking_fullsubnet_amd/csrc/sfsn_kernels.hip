@@ -2062,6 +2062,33 @@ extern "C" int sfsn_spike_count(const sfsn_count_tensor* tensors, int n_tensors,
     return hip_ok(hipGetLastError());
 }
 
+// ---- streaming: input history of a session ---------------------------------------------------------------
+// hist [rows][D + hop] complex64 (rows = B * F): drop the oldest `hop` frames, append the new ones -- one launch instead of three
+// elementwise copies per hop.  A thread owns one row: it reads the D frames it keeps and its `hop` new frames into registers
+// before it writes anything, so the shift is safe in place.
+#define SFSN_HIST_MAX 16
+__global__ __launch_bounds__(256) void hist_shift_kernel(float2* __restrict__ hist, const float2* __restrict__ inp, int rows, int D, int hop) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float2* h = hist + (size_t)r * (D + hop);
+    const float2* x = inp + (size_t)r * hop;
+    float2 keep[SFSN_HIST_MAX];
+#pragma unroll
+    for (int i = 0; i < SFSN_HIST_MAX; ++i)
+        if (i < D + hop) keep[i] = i < D ? h[hop + i] : x[i - D];
+#pragma unroll
+    for (int i = 0; i < SFSN_HIST_MAX; ++i)
+        if (i < D + hop) h[i] = keep[i];
+}
+
+extern "C" int sfsn_hist_shift(float* hist_ri, const float* inp_ri, int rows, int D, int hop, void* stream) {
+    if (!hist_ri || !inp_ri || rows <= 0 || D < 0 || hop <= 0) return SFSN_EINVAL;
+    if (D + hop > SFSN_HIST_MAX) return SFSN_EUNSUPPORTED;
+    hipLaunchKernelGGL(hist_shift_kernel, dim3((rows + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<float2*>(hist_ri), reinterpret_cast<const float2*>(inp_ri), rows, D, hop);
+    return hip_ok(hipGetLastError());
+}
+
 extern "C" int sfsn_deepfilter(const float* stft_ri, int B, int F, int T, int S, const sfsn_df_group* groups, int n_groups,
                                float* enh_ri, float* enh_mag, int t0, int nt, void* stream) {
     if (!stft_ri || !enh_ri || !groups || n_groups <= 0 || n_groups > SFSN_MAX_GROUPS || B <= 0 || F < 2 || T <= 0 || S <= 0)

@@ -51,11 +51,32 @@ struct StackRoleDev {
 
 struct StackParams {
     StackRoleDev role[STACK_MAX_ROLES];
-    unsigned* prog;  // [0] error word, [1 + block] frames published by that workgroup
+    unsigned* prog;  // [0] error word, [1] workgroups that have exited, [2 + block] frames published by that workgroup
+    int nblocks;     // grid size (padding blocks included): the LAST workgroup to exit zeroes the counters for the next launch
     unsigned* dbg;   // optional [2 * block]: hand-off waits / poll iterations per workgroup (SFSN_STACK_DEBUG=1)
     int nroles, T, H, NT, lag;
     int gate_off;    // byte offset of the gate word in the dynamic LDS allocation (behind every role's layout)
 };
+
+
+// Every workgroup (padding blocks too) calls this as its last action: the last one to arrive -- nobody polls any more -- zeroes the
+// progress counters and the exit counter, so that the next launch on this scratch buffer starts clean without a memset in front
+// of it (two fill launches of ~5 us each per stack launch: a third of a streaming hop's stack time).  `word`: the gate word of
+// the dynamic LDS allocation (NO static __shared__ in these kernels: the LDS-DMA destinations are absolute addresses from 0).
+__device__ __forceinline__ void stack_exit(const StackParams& p, int* word) {
+    // my own counter stores (write-through, issued by this workgroup's publishing wave) must have reached memory before I count
+    // myself out -- otherwise one of them could land after the last workgroup's zeroing.  No cache fence is needed for that:
+    // draining the waves' own store queues is enough (a __threadfence() here cost ~6 us per launch).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *reinterpret_cast<volatile int*>(word) = atomicAdd(p.prog + 1, 1u) == (unsigned)(p.nblocks - 1) ? 1 : 0;
+    __syncthreads();
+    if (*reinterpret_cast<volatile int*>(word)) {
+        for (int i = threadIdx.x; i < p.nblocks; i += blockDim.x) __hip_atomic_store(p.prog + 2 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(p.prog + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 template <int KS>
 struct StackGeom {
@@ -633,14 +654,17 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
     int ri = -1;
     for (int i = 0; i < p.nroles; ++i)
         if ((int)blockIdx.x >= p.role[i].block0 && (int)blockIdx.x < p.role[i].block0 + p.role[i].nblocks) ri = i;
-    if (ri < 0) return;
+    if (ri < 0) {
+        stack_exit(p, gate_word_p);
+        return;
+    }
     const StackRoleDev& rl = p.role[ri];
     const int blk = (int)blockIdx.x - rl.block0;
     StackLink lk;
     lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = p.prog; lk.lag = p.lag;
     lk.dbg = p.dbg ? p.dbg + 4 * blockIdx.x : nullptr;
     if (lk.dbg && threadIdx.x == 0) lk.dbg[2] = (unsigned)wall_clock64();
-    if (rl.pub) lk.out = p.prog + 1 + blockIdx.x;
+    if (rl.pub) lk.out = p.prog + 2 + blockIdx.x;
     const int my_rpw = rl.kind == STACK_PROJ ? Proj16Layout<KS>::ROWS : rl.rpw;
     if (rl.src >= 0) {
         const StackRoleDev& sr = p.role[rl.src];
@@ -648,7 +672,7 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         int r1 = r0 + my_rpw - 1;
         if (r1 > rl.R - 1) r1 = rl.R - 1;
         const int b0 = r0 / rl.src_rpw, b1 = r1 / rl.src_rpw;
-        lk.in = p.prog + 1 + sr.block0 + b0;
+        lk.in = p.prog + 2 + sr.block0 + b0;
         lk.n_in = b1 - b0 + 1;
     }
     const int T = p.T, H = p.H, NT = p.NT;
@@ -668,6 +692,7 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
 #undef ZIN16_CASE
     }
     if (lk.dbg && threadIdx.x == 0) lk.dbg[3] = (unsigned)wall_clock64();
+    stack_exit(p, gate_word_p);
 }
 
 // OUT: bit 0 fp32 spikes, bit 1 int8 spikes (always).  The 4-row repacked epilogue (bit 9) is selected per role from rpw.
@@ -679,14 +704,17 @@ __global__ __launch_bounds__(512) void gsn_stack_kernel(const StackParams p) {
     int ri = -1;
     for (int i = 0; i < p.nroles; ++i)
         if ((int)blockIdx.x >= p.role[i].block0 && (int)blockIdx.x < p.role[i].block0 + p.role[i].nblocks) ri = i;
-    if (ri < 0) return;  // padding block (role ranges start at multiples of 8: producer and consumer share an XCD)
+    if (ri < 0) {  // padding block (role ranges start at multiples of 8: producer and consumer share an XCD)
+        stack_exit(p, gate_word_p);
+        return;
+    }
     const StackRoleDev& rl = p.role[ri];
     const int blk = (int)blockIdx.x - rl.block0;
     StackLink lk;
     lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = p.prog; lk.lag = p.lag;
     lk.dbg = p.dbg ? p.dbg + 4 * blockIdx.x : nullptr;
     if (lk.dbg && threadIdx.x == 0) lk.dbg[2] = (unsigned)wall_clock64();
-    if (rl.pub) lk.out = p.prog + 1 + blockIdx.x;
+    if (rl.pub) lk.out = p.prog + 2 + blockIdx.x;
     const int my_rpw = rl.kind == STACK_PROJ ? 16 : rl.rpw;
     if (rl.src >= 0) {  // the producer workgroups that own my rows
         const StackRoleDev& sr = p.role[rl.src];
@@ -694,7 +722,7 @@ __global__ __launch_bounds__(512) void gsn_stack_kernel(const StackParams p) {
         int r1 = r0 + my_rpw - 1;
         if (r1 > rl.R - 1) r1 = rl.R - 1;
         const int b0 = r0 / rl.src_rpw, b1 = r1 / rl.src_rpw;
-        lk.in = p.prog + 1 + sr.block0 + b0;
+        lk.in = p.prog + 2 + sr.block0 + b0;
         lk.n_in = b1 - b0 + 1;
     }
     const int T = p.T, H = p.H, NT = p.NT;
@@ -724,6 +752,7 @@ __global__ __launch_bounds__(512) void gsn_stack_kernel(const StackParams p) {
         }
 #undef ZIN_CASE
     }
+    stack_exit(p, gate_word_p);
 }
 
 // =====================================================================================================
@@ -849,17 +878,19 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
         }
     }
     if (lds > 160 * 1024 - 64) return SFSN_EUNSUPPORTED;
-    if ((size_t)(blocks + 1) * sizeof(unsigned) > scratch_bytes) return SFSN_EINVAL;
+    if ((size_t)(blocks + 2) * sizeof(unsigned) > scratch_bytes) return SFSN_EINVAL;
     p.prog = static_cast<unsigned*>(scratch);
     p.dbg = nullptr;
-    if (getenv("SFSN_STACK_DEBUG") && (size_t)(blocks + 1) * 5 * sizeof(unsigned) <= scratch_bytes) p.dbg = p.prog + blocks + 1;
-    p.nroles = nroles; p.T = T; p.H = H; p.NT = NT; p.lag = lag;
+    if (getenv("SFSN_STACK_DEBUG") && (size_t)(blocks + 2) * 5 * sizeof(unsigned) <= scratch_bytes) p.dbg = p.prog + blocks + 2;
+    p.nroles = nroles; p.T = T; p.H = H; p.NT = NT; p.lag = lag; p.nblocks = blocks;
     lds = (lds + 15) & ~15;
     p.gate_off = lds;
     lds += 16;
     (void)HP;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(scratch, 0, (size_t)(blocks + 1) * sizeof(unsigned) * (p.dbg ? 5 : 1), st) != hipSuccess) return SFSN_EHIP;
+    // (no memset here: the counters are zero on entry -- the caller zeroes the scratch buffer ONCE, and every launch's last
+    //  workgroup leaves them zeroed again)
+    if (p.dbg && hipMemsetAsync(p.dbg, 0, (size_t)(blocks + 1) * 4 * sizeof(unsigned), st) != hipSuccess) return SFSN_EHIP;
 #define WIDE_CASE(KS_, OUT_)                                                                                                  \
     if (wide && KS == KS_ && out == OUT_) {                                                                                   \
         auto kern = gsn_stack_wide_kernel<KS_, OUT_>;                                                                         \

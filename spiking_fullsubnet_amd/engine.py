@@ -437,7 +437,7 @@ class Engine:
             return True, False, 8
         return False, False, 0
 
-    def _stage_stack(self, seqs, d, t0, nt, st, tag, wide, rpw_stack):
+    def _stage_stack(self, seqs, d, t0, nt, st, tag, wide, rpw_stack, lag=None, scratch=None):
         """Every layer of the given sequence models in one launch (layer 0's input term is already in d["zin"][0])."""
         L = self.lib
         H, nl, ns = seqs[0].H, len(seqs[0].cells), len(seqs)
@@ -465,15 +465,18 @@ class Engine:
                     fin[l * ns + i].spikes_in = d["s8"][l - 1][i].data_ptr() + t0 * R * HP
                     fin[l * ns + i].w_ih, fin[l * ns + i].w_ih_dq = pk.data_ptr(), dq.data_ptr()
         nbytes = L.sfsn_stack_scratch_bytes(nl, ns, rows)
-        scratch = self._workspace(("stack_scratch", tag, nl, ns, rows, torch.cuda.current_stream(self.device).cuda_stream),
-                                  lambda: dict(t=torch.zeros((nbytes // 4,), dtype=torch.int32, device=self.device)))["t"]
+        if scratch is None:  # (a streaming session owns its own: its captured graph must not outlive a cache entry)
+            scratch = self._workspace(("stack_scratch", tag, nl, ns, rows, torch.cuda.current_stream(self.device).cuda_stream),
+                                      lambda: dict(t=torch.zeros((nbytes // 4,), dtype=torch.int32, device=self.device)))["t"]
+        assert scratch.numel() * 4 >= nbytes
         if not any(scratch is t for t in self._stack_scratch):
             self._stack_scratch.append(scratch)
         rp = rpw_stack if rpw_stack else self.stack_rows_per_wg[tag]
         rpw = (ctypes.c_int * nl)(*([rp] * nl))
         self.launches["stack"] = self.launches.get("stack", 0) + 1
         with self.timed("stack:" + tag, st):
-            check(L.sfsn_gsn_stack_scan(segs, fin, nl, ns, nt, H, rpw, self.stack_lag, _ptr(scratch), nbytes, st), "sfsn_gsn_stack_scan")
+            check(L.sfsn_gsn_stack_scan(segs, fin, nl, ns, nt, H, rpw, self.stack_lag if lag is None else lag, _ptr(scratch), nbytes, st),
+                  "sfsn_gsn_stack_scan")
         # the launch's error word (a bounded hand-off wait expired) travels to pinned host memory behind the launch; it is looked
         # at without blocking at the next forward (and by check_stack_errors): a failed launch cannot go unnoticed for long
         if not torch.cuda.is_current_stream_capturing():

@@ -41,6 +41,7 @@ class StreamingSession:
             raise ValueError("batch and hop must be positive")
         self.eng, self.B, self.hop = engine, batch, hop
         self.rows_per_wg = rows_per_wg  # (full-band, sub-band) rows per scan workgroup; None = the engine's setting
+        self.use_stack = True           # layer-pipelined stack launches where the engine's rule picks them (few rows: always)
         dev = self.dev = engine.device
         self.F = spec.n_fft // 2 + 1
         self.D = D = max(spec.df) - 1  # frames of input history the deep filter reaches back
@@ -58,7 +59,9 @@ class StreamingSession:
         def stack(seqs, Rs):
             H, G, nl = seqs[0].H, seqs[0].cells[0].G, len(seqs[0].cells)
             HP = (H + 63) // 64 * 64
-            return dict(zin=[[torch.empty((hop, R, G * H), **f32) for R in Rs] for _ in range(nl)],
+            nb = engine.lib.sfsn_stack_scratch_bytes(nl, len(Rs), sum(Rs))
+            return dict(spk=[[None] * len(Rs) for _ in range(nl)], scratch=torch.zeros((nb // 4 + 1,), dtype=torch.int32, device=dev),
+                        zin=[[torch.empty((hop, R, G * H), **f32) for R in Rs] for _ in range(nl)],
                         s8=[[torch.zeros((Th, R, HP), dtype=torch.int8, device=dev) for R in Rs] for _ in range(nl)],
                         states=engine._zero_states(Rs, H, nl),
                         proj=[torch.empty((Th, R, seq.P), **f32) for seq, R in zip(seqs, Rs)], nl=nl)
@@ -99,16 +102,27 @@ class StreamingSession:
         eng, spec, L = self.eng, self.eng.spec, self.eng.lib
         B, F, D, hop, Th, S, ng = self.B, self.F, self.D, self.hop, self.Th, spec.num_spks, spec.n_groups
         st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        if D > 0:
-            self._tmp[:, :, :D].copy_(self.hist[:, :, hop:hop + D])
-            self.hist[:, :, :D].copy_(self._tmp[:, :, :D])
-        self.hist[:, :, D:].copy_(self.inp)
         ri = torch.view_as_real(self.hist)
+        if D + hop <= 16:  # history shift + append in one launch
+            check(L.sfsn_hist_shift(_ptr(ri), _ptr(torch.view_as_real(self.inp)), B * F, D, hop, st), "sfsn_hist_shift")
+        else:
+            if D > 0:
+                self._tmp[:, :, :D].copy_(self.hist[:, :, hop:hop + D])
+                self.hist[:, :, :D].copy_(self._tmp[:, :, :D])
+            self.hist[:, :, D:].copy_(self.inp)
         # default: the engine's full-band setting, 16 rows per workgroup for the sub-band stack -- few rows per hop anyway, and
         # that geometry lets layers >= 1 take their input product inside the scan (three launches less per hop)
         rpw_fb, rpw_sb = (eng.rows_per_wg[0], 16) if self.rows_per_wg is None else self.rows_per_wg
 
         def model(seqs, d, xs, tag, rpw):
+            use_stack, wide, rpw_stack = eng._stack_choice(seqs, [x.shape[1] for x in xs], False)
+            if use_stack and self.use_stack:
+                # every layer of the stack in one launch (their prologues -- weights into registers / LDS -- run side by side
+                # instead of one launch after the other; the layers hand each frame over inside the launch)
+                eng._stage_input(seqs, 0, xs, d["zin"][0], D, hop, st, tag)
+                eng._stage_stack(seqs, d, D, hop, st, tag, wide, rpw_stack, lag=0, scratch=d["scratch"])
+                eng._stage_proj(seqs, d["s8"][-1], d["proj"], D, hop, st, tag)
+                return
             fused = eng._fusable(seqs, rpw, False)  # layers >= 1: input product inside the scan (three launches less per hop)
             for l in range(d["nl"]):
                 if l > 0 and fused:
