@@ -8,6 +8,7 @@ from spiking_fullsubnet_amd._lib import ScanSegment, FusedInput, check
 from spiking_fullsubnet_amd.engine import pack_w3
 
 def run(H, nl, rpw, lag, T=1000, Rs=None, reps=5):
+    if os.environ.get("ROWS"): Rs = [int(v) for v in os.environ["ROWS"].split(",")]
     L = _lib.lib(); dev = "cuda:0"
     Rs = Rs or ([512, 192, 128] if H <= 256 else [64])
     ns = len(Rs); HP = (H + 63) // 64 * 64
@@ -49,9 +50,14 @@ def run(H, nl, rpw, lag, T=1000, Rs=None, reps=5):
     if os.environ.get("SFSN_STACK_DEBUG"):
         w = scratch.cpu().numpy().astype(np.int64)
         # block layout: per layer [PROJ roles (if any)] then scan roles, each role padded to a multiple of 8 blocks
-        nb_ = int(os.environ.get('BLOCKS', '240'))
-        dbg = w[nb_ + 1: nb_ + 1 + 4 * nb_].reshape(-1, 4); t0 = dbg[:104, 2].min()
-        for (name, b0, b1) in (("L0 scan", 0, 104), ("PROJ seg0", 104, 120), ("L1 scan seg0", 120, 184), ("PROJ seg1", 184, 190), ("L1 scan seg1", 192, 216), ("PROJ seg2", 216, 220), ("L1 scan seg2", 224, 240)):
+        blk, roles = 0, []
+        for l in range(nl):
+            for i, R in enumerate(Rs):
+                if l > 0:
+                    n = (R + 31) // 32; roles.append((f"PROJ l{l} seg{i}", blk, blk + n)); blk = (blk + n + 7) & ~7
+                n = (R + rpw - 1) // rpw; roles.append((f"scan l{l} seg{i}", blk, blk + n)); blk = (blk + n + 7) & ~7
+        dbg = w[blk + 2: blk + 2 + 4 * blk].reshape(-1, 4); t0 = min(dbg[b0:b1, 2].min() for _, b0, b1 in roles)
+        for (name, b0, b1) in roles:
             d = dbg[b0:b1]
             print(f"   {name:14s} waits/WG {d[:,0].mean():7.1f}  polls/WG {d[:,1].mean():8.1f}  start us [{(d[:,2].min()-t0)/100:8.1f}, {(d[:,2].max()-t0)/100:8.1f}]  end us [{(d[:,3].min()-t0)/100:8.1f}, {(d[:,3].max()-t0)/100:8.1f}]")
     print(f"H={H} layers={nl} rpw={rpw} lag={lag} T={T} rows={Rs}: {ms:.3f} ms = {1e3*ms/T:.3f} us/step; spike rates {['%.2f' % r for r in rate]}", flush=True)
