@@ -13,9 +13,19 @@ For N > 1 every rank owns 64 clips (weak scaling: the path shards over independe
 collective) and each step ends with the RCCL all-gather of the enhanced magnitudes -- the analogue of the
 reference's `accelerator.gather_for_metrics` (audiozen/trainer.py:511,555).
 
+`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (one rank per GPU).
+
+Phases: S -- one forward at a time (the strict figure, `config.single_stream`), then the same forward as whole-sequence
+launches with per-kernel HIP-event timers (the roofline figures of the strict schedule); K -- the scan kernels of the timed
+region's geometry, each alone on the chip; B -- the timed region: `--inflight` independent batches in flight, EXACTLY K steps
+between barrier + synchronize on both sides, max over ranks -> `value`.
+
 Prints ONE JSON line on rank 0 (see the task contract), carrying
-  roofline      -- the dominant kernel (the fused sub-band GSN scan): algorithmic bytes per launch / HIP-event
-                   measured launch duration, against the 8 TB/s HBM3E peak;
+  roofline      -- the kernel that dominates the timed region (the fused sub-band GSN scan): algorithmic bytes per launch /
+                   HIP-event measured launch duration on the launching stream, against the 8 TB/s HBM3E peak; beside it the
+                   sub-band scan of the strict schedule, the full-band stack launch (MFMA utilisation) and the whole job's
+                   PMC traffic / step time.  PMC-derived fields come from profiles/r02_pmc.json and are attached only when
+                   that file was taken with the library build that is running (source hash);
   cpu_baseline  -- the CPU oracle (oracle/, a C restatement of the reference, OpenMP over rows) timed on this
                    host on a bounded sample of the same workload (rank 0, N=1 only).
 """

@@ -97,7 +97,7 @@ class Separator(_EngineMixin, nn.Module):
 
     @torch.no_grad()
     def forward_stft(self, complex_stft, want_layers=True, want_membrane=False, want_counts=False):
-        self._check_mode()
+        self._check_mode(complex_stft)
         return self.engine().forward_stft(complex_stft, want_layers=want_layers, want_membrane=want_membrane, want_counts=want_counts)
 
     @torch.no_grad()
@@ -107,7 +107,7 @@ class Separator(_EngineMixin, nn.Module):
         if ndim == 3:
             assert noisy_y.size(1) == 1, "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
             noisy_y = noisy_y.squeeze(1)
-        self._check_mode()
+        self._check_mode(noisy_y)
         res = self.engine().forward_stft(self._stft(noisy_y), **self._layer_kwargs())
         enhanced_y = self._istft(res["enh_stft"][:, 0], length=noisy_y.size(-1))
         return enhanced_y, res["enh_mag"][:, 0], res["fb_all"], res["sb_all"]

@@ -202,7 +202,11 @@ class _EngineMixin:
         self._check_mode()
         return StreamingSession(self.engine(), batch=batch, hop=hop, graph=graph, rows_per_wg=rows_per_wg, owner=self)
 
-    def _check_mode(self):
+    def _check_mode(self, x=None):
+        if x is not None and x.requires_grad:
+            raise RuntimeError(
+                "the input requires grad, but this package has no backward pass (SURVEY 8f rank 4) and no torch fallback: "
+                "detach the input, or keep the reference module for `-M train`")
         if self.training:
             raise RuntimeError(
                 "training-mode forward (per-time-step batch-statistics BatchNorm and BPTT through the spike surrogate, "
@@ -242,13 +246,13 @@ class SpikingFullSubNet(_EngineMixin, nn.Module):
     @torch.no_grad()
     def forward_stft(self, noisy_cmp, want_layers=True, want_membrane=False, want_counts=False):
         """The hot path alone: complex64 [B, 257, T] -> Engine.forward_stft result dict."""
-        self._check_mode()
+        self._check_mode(noisy_cmp)
         return self.engine().forward_stft(noisy_cmp, want_layers=want_layers, want_membrane=want_membrane, want_counts=want_counts)
 
     @torch.no_grad()
     def forward(self, input):
         assert input.ndim == 2, f"Input tensor must be 2D, but got {input.ndim}D."
-        self._check_mode()
+        self._check_mode(input)
         batch_size, sequence_length = input.shape
         res = self.engine().forward_stft(self._stft(input), **self._layer_kwargs())
         enh_stft = res["enh_stft"]  # [B, S, F, T]

@@ -118,6 +118,20 @@ def test_constructor_rejections_match_reference():
         pkg.Separator(**dict(rw.FROZEN_TINY, norm_type="forgetting_norm"))      # model_low_freq:227-231
 
 
+def test_training_mode_and_grad_inputs_raise_instead_of_falling_back():
+    """The narrowing INTEGRATION.md states: no backward pass and no torch fallback -- a forward that the reference would
+    record for autograd (efficient_spiking_neuron.py:94-101,149-150) is refused before anything is launched."""
+    import spiking_fullsubnet_amd as pkg
+    for m in (pkg.SpikingFullSubNet(**rw.LIVE_TINY), pkg.Separator(**rw.FROZEN_TINY)):
+        y = torch.zeros(1, 2048)
+        with pytest.raises(RuntimeError, match="training-mode"):
+            m.train()(y)
+        with pytest.raises(RuntimeError, match="requires grad"):
+            m.eval()(y.clone().requires_grad_())
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            m.eval()(y)
+
+
 def test_reference_init_is_reproduced():
     """Same RNG consumption order as the reference constructors: torch.manual_seed(s); Model(**kw) gives the same
     initial weights (checked against values recorded from the reference: U(-1/sqrt(H), 1/sqrt(H)) cells first)."""
