@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 2 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 3 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -250,6 +250,70 @@ int sfsn_deepfilter(const float* stft_ri /* [B][F][T][2] */, int B, int F, int T
  * new frames of inp [rows][hop] are appended, in place, in one launch.  D + hop <= 16 (SFSN_EUNSUPPORTED beyond).
  * ---------------------------------------------------------------------------------------------------- */
 int sfsn_hist_shift(float* hist_ri, const float* inp_ri, int rows, int D, int hop, void* stream);
+
+/* ----------------------------------------------------------------------------------------------------
+ * Streaming hop -- BASELINE configs[4]: `hop` new frames of B clips through the WHOLE live model (features, every GSN layer
+ * of the full-band model and of the sub-band groups, projections, deep filter: MODEL:429-473 restricted to the new frames)
+ * in ONE launch, with the (h, c) state of every layer (NEURON:50-62) and the deep filter's input history carried in device
+ * memory between launches.  Replaces the ~15 launches the offline kernels need per hop (each costs ~4.5 us of launch
+ * boundary on this hardware, which is all a one-frame hop consists of).
+ *
+ * One wave owns one 16-neuron tile of one layer for 16 rows and keeps that tile's weights in registers; the waves of
+ * consecutive stages (layer 0 -> layer 1 -> projection -> sub-band layer 0 -> ... -> projection + deep filter) hand each
+ * frame over through L2 with write-through stores and per-wave progress counters, as the stack scan above does per layer.
+ * The recurrent product of a layer is issued before its input has arrived (it needs the previous frame only).
+ * Arithmetic is that of sfsn_features / sfsn_input_proj_f32 (fp32-MFMA form) / sfsn_spike_proj / sfsn_gsn_layer_scan /
+ * sfsn_deepfilter expression by expression.
+ *
+ * Shared gate weights, LayerNorm or no normalisation, H % 16 == 0, H <= 320, I <= 192, P <= 256, at most
+ * SFSN_HOP_MAX_LAYERS layers and SFSN_HOP_MAX_GROUPS groups, D + hop <= 32, and few enough rows that every wave tile gets
+ * its own compute unit (SFSN_EUNSUPPORTED otherwise: the caller then runs the per-kernel sequence).
+ * ---------------------------------------------------------------------------------------------------- */
+#define SFSN_HOP_MAX_LAYERS 3
+#define SFSN_HOP_MAX_GROUPS 4
+typedef struct sfsn_hop_layer {
+    const float* w_ih_f32;  /* layer 0: [H][I] fp32 row-major (NULL for layers >= 1)                               */
+    const int8_t* w_ih;     /* layers >= 1: sfsn_w3_pack(W_ih [H][H]) (NULL for layer 0)                            */
+    const float* w_ih_dq;
+    const int8_t* w_hh;     /* sfsn_w3_pack(W_hh [H][H])                                                            */
+    const float* w_hh_dq;
+    const float* bias;      /* [2H] bias_ih                                                                         */
+    const float* bn_alpha;  /* [H]                                                                                  */
+    const float* bn_beta;   /* [H]                                                                                  */
+    int8_t* h[2];           /* [R][pad64(H)] x 2: spikes of the last frame, in/out; launch k reads h[k & 1] and writes
+                               h[(k + 1) & 1] (k = the launch counter kept in `scratch`); zero both to reset          */
+    float* c;               /* [R][H] membrane, in/out                                                              */
+    int8_t* spikes;         /* [hop][R][pad64(H)] scratch (pad columns zeroed by the caller once)                   */
+} sfsn_hop_layer;
+typedef struct sfsn_hop_seq {      /* one sequence model: the full-band model or one sub-band group                  */
+    sfsn_hop_layer layer[SFSN_HOP_MAX_LAYERS];
+    int n_layers, H, P;
+    sfsn_feature_group feat;       /* geometry + normalisation of this model's input rows (`x` and `mu` unused);
+                                      rows R = B * feat.n_units, row b * n_units + k                                 */
+    const int8_t* w_p;             /* sfsn_w3_pack(proj.weight [P][H])                                               */
+    const float* w_p_dq;
+    const float* b_p;              /* [P]                                                                            */
+    int df;                        /* deep-filter order of a sub-band group; 0 for the full-band model               */
+    int fc;                        /* sub-band group: centre bins per unit (P == 2 * fc * df * S)                    */
+} sfsn_hop_seq;
+typedef struct sfsn_hop_desc {
+    sfsn_hop_seq fb;
+    sfsn_hop_seq sb[SFSN_HOP_MAX_GROUPS];
+    int n_groups;
+    int B, F, S, hop, D;           /* D = max(df) - 1 frames of history                                              */
+    float fdrc;
+    const float* inp_ri;           /* [B][F][hop][2] the new noisy frames                                            */
+    float* hist_ri;                /* [B][F][D][2]   the last D noisy frames, in/out (zero to reset); NULL if D == 0 */
+    float* fb_out;                 /* [hop][B][fb.P] scratch                                                         */
+    float* enh_ri;                 /* [B][S][F][hop][2] out                                                          */
+    float* enh_mag;                /* [B][S][F][hop] out, nullable                                                   */
+    void* scratch;                 /* sfsn_hop_scratch_bytes(desc) bytes, ZEROED by the caller once; word 0 = error flag
+                                      (non-zero after a launch: a bounded hand-off wait expired, results invalid)     */
+    size_t scratch_bytes;
+} sfsn_hop_desc;
+
+size_t sfsn_hop_scratch_bytes(const sfsn_hop_desc* desc /* host */);
+int sfsn_stream_hop(const sfsn_hop_desc* desc /* host */, void* stream);
 
 /* ----------------------------------------------------------------------------------------------------
  * Spike counts -- the only thing the reference's energy proxy reads from the spike tensors:

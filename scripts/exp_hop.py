@@ -1,0 +1,46 @@
+"""One-launch streaming hop (sfsn_stream_hop) against the graph-replay session and the offline forward: equality + latency.
+Run on the MI355X box: python scripts/exp_hop.py [tiny|m] [B] [hop]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np, torch
+import refweights as rw
+from test_hip_parity import build_module
+
+DEV = torch.device("cuda:0")
+name = sys.argv[1] if len(sys.argv) > 1 else "m"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+hop = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+kw = {"m": rw.LIVE_M, "tiny": rw.LIVE_TINY, "2spk": rw.LIVE_TINY_2SPK}[name]
+model = build_module("live", kw, rw.live_state_dict(kw, 5))
+T = 48 * hop
+wave = torch.from_numpy(rw.synth_wave(B, T, 5)).to(DEV)
+stft = torch.stft(wave, kw["n_fft"], kw["hop_length"], kw["win_length"], window=torch.hann_window(kw["win_length"], device=DEV),
+                  return_complex=True, pad_mode="constant")[..., :T].contiguous()
+off = model.engine().forward_stft(stft, want_layers=False)
+for mode in (True, False):
+    sess = model.streaming(batch=B, hop=hop, one_launch=mode)
+    outs, mags = [], []
+    for t0 in range(0, T, hop):
+        e, m = sess.step(stft[..., t0:t0 + hop].contiguous())
+        outs.append(e); mags.append(m)
+    if mode: sess.check_errors()
+    e, m = torch.cat(outs, -1), torch.cat(mags, -1)
+    eq = torch.equal(torch.view_as_real(e), torch.view_as_real(off["enh_stft"])) and torch.equal(m, off["enh_mag"])
+    print("one_launch" if mode else "graph     ", "equal to offline:", eq)
+    if not eq:
+        d = (torch.view_as_real(e) - torch.view_as_real(off["enh_stft"])).abs().amax(dim=(0, 1, 4))  # [F, T]
+        bad_t = (d.amax(0) > 0).nonzero().flatten()
+        bad_f = (d.amax(1) > 0).nonzero().flatten()
+        print("  first bad frame", bad_t[:5].tolist(), "bad bins", bad_f[:8].tolist(), "...", len(bad_f), "max", float(d.max()))
+    frames = [stft[..., (i * hop) % T:(i * hop) % T + hop].contiguous() for i in range(T // hop)]
+    lat = []
+    for i in range(1200):
+        x = frames[i % len(frames)]
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        sess.step(x, copy=False)
+        torch.cuda.synchronize()
+        if i >= 200: lat.append(time.perf_counter() - t0)
+    lat = np.sort(np.array(lat)) * 1e6
+    print("  latency p50 %.1f us  min %.1f  p99 %.1f" % (lat[len(lat) // 2], lat[0], lat[int(len(lat) * .99)]))
+    if mode: sess.check_errors()

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
 NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE = 0, 1, 2
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
-ABI_VERSION = 2  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
+ABI_VERSION = 3  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -50,12 +50,31 @@ class CountTensor(ctypes.Structure):
 
 
 MAX_COUNT_TENSORS = 16
+HOP_MAX_LAYERS = 3
+HOP_MAX_GROUPS = 4
+
+
+class HopLayer(ctypes.Structure):
+    _fields_ = [("w_ih_f32", _P), ("w_ih", _P), ("w_ih_dq", _P), ("w_hh", _P), ("w_hh_dq", _P), ("bias", _P), ("bn_alpha", _P),
+                ("bn_beta", _P), ("h", _P * 2), ("c", _P), ("spikes", _P)]
+
+
+class HopSeq(ctypes.Structure):
+    _fields_ = [("layer", HopLayer * HOP_MAX_LAYERS), ("n_layers", _I), ("H", _I), ("P", _I), ("feat", FeatureGroup), ("w_p", _P),
+                ("w_p_dq", _P), ("b_p", _P), ("df", _I), ("fc", _I)]
+
+
+class HopDesc(ctypes.Structure):
+    _fields_ = [("fb", HopSeq), ("sb", HopSeq * HOP_MAX_GROUPS), ("n_groups", _I), ("B", _I), ("F", _I), ("S", _I), ("hop", _I),
+                ("D", _I), ("fdrc", _F), ("inp_ri", _P), ("hist_ri", _P), ("fb_out", _P), ("enh_ri", _P), ("enh_mag", _P),
+                ("scratch", _P), ("scratch_bytes", ctypes.c_size_t)]
 
 
 def _sources():
     """The files the library is made of, in the order the Makefile hashes them (SRCS)."""
     return [os.path.join(_HERE, "..", "include", "sfsn.h")] + [
-        os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_fft.hip", "sfsn_pack.cpp")]
+        os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_feat_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_hop.hip", "sfsn_fft.hip",
+                                  "sfsn_pack.cpp")]
 
 
 def source_hash() -> str:
@@ -136,6 +155,10 @@ def lib() -> ctypes.CDLL:
     L.sfsn_deepfilter.argtypes = [_P, _I, _I, _I, _I, ctypes.POINTER(DfGroup), _I, _P, _P, _I, _I, _P]
     L.sfsn_hist_shift.restype = _I
     L.sfsn_hist_shift.argtypes = [_P, _P, _I, _I, _I, _P]
+    L.sfsn_hop_scratch_bytes.restype = ctypes.c_size_t
+    L.sfsn_hop_scratch_bytes.argtypes = [ctypes.POINTER(HopDesc)]
+    L.sfsn_stream_hop.restype = _I
+    L.sfsn_stream_hop.argtypes = [ctypes.POINTER(HopDesc), _P]
     L.sfsn_spike_count.restype = _I
     L.sfsn_spike_count.argtypes = [ctypes.POINTER(CountTensor), _I, _P]
     L.sfsn_stft.restype = _I
@@ -151,7 +174,7 @@ def lib() -> ctypes.CDLL:
 EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
            "sfsn_w3_pack", "sfsn_w3_pack_bits", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_stack_scratch_bytes", "sfsn_gsn_stack_scan",
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
-           "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
+           "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
 
 
 def check(rc: int, what: str = "") -> None:

@@ -8,8 +8,11 @@ session therefore keeps, on the device: the (h, c) state of every layer and ``ma
 each ``step`` runs exactly the kernels of the offline forward on ``hop`` new frames.  Outputs are bit-identical to the
 offline forward on the concatenated input (tested).
 
-The ~25 launches of a step are captured once into a HIP graph and replayed per hop: at hop = 1 the step is launch-bound,
-not compute-bound, so the graph is what sets the per-frame latency.
+Two ways to run a hop.  ``one_launch`` (default where the library covers the model: shared gate weights, at most
+3 layers / 4 groups): ``sfsn_stream_hop`` -- the whole frame in ONE launch of a few dozen small workgroups whose waves hand
+the frame from stage to stage through L2 (csrc/sfsn_hop.hip); its state is its own (double-buffered int8 spikes, membranes,
+history).  Otherwise the ~15 launches of the offline kernels, captured once into a HIP graph and replayed per hop: at
+hop = 1 that step is launch-bound, not compute-bound.  Both are bit-identical to the offline forward (tested).
 
 The frozen front-end (``model_low_freq.Separator``) normalises with utterance-level Laplace means
 (model_low_freq.py:147-169), which are not causal: a session on it raises ``NotImplementedError``.
@@ -21,14 +24,15 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import DfGroup, check
+from ._lib import DfGroup, HopDesc, HOP_MAX_GROUPS, HOP_MAX_LAYERS, check
 from .engine import Engine, _ptr
 
 
 class StreamingSession:
     """``step(frames [B, F, hop] complex64) -> (enh_stft [B, S, F, hop], enh_mag [B, S, F, hop])`` with state carried."""
 
-    def __init__(self, engine: Engine, batch: int = 1, hop: int = 1, graph: bool = True, rows_per_wg=None, owner=None):
+    def __init__(self, engine: Engine, batch: int = 1, hop: int = 1, graph: bool = True, rows_per_wg=None, owner=None,
+                 one_launch="auto"):
         spec = engine.spec
         # the module the engine was packed from: reset() checks that its parameters have not changed since (the session's
         # captured graph holds pointers to THIS engine's packed weights)
@@ -75,8 +79,62 @@ class StreamingSession:
         self.fg_sb = engine._feature_groups("sb", self.xs, None)
         self.frames_done = 0
         self._graph: Optional[torch.cuda.CUDAGraph] = None
-        if graph:
+        self._hop = None
+        if one_launch not in ("auto", True, False):
+            raise ValueError("one_launch must be 'auto', True or False")
+        if one_launch:
+            self._hop = self._build_hop()
+            if self._hop is None and one_launch is True:
+                raise NotImplementedError("sfsn_stream_hop does not cover this model / batch (see include/sfsn.h)")
+        if self._hop is None and graph:
             self._capture()
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def _build_hop(self):
+        """Descriptor + state of the one-launch hop (sfsn_stream_hop); None when the library does not cover this session."""
+        eng, spec, L = self.eng, self.eng.spec, self.eng.lib
+        B, F, S, hop, D, ng, dev = self.B, self.F, spec.num_spks, self.hop, self.D, spec.n_groups, self.dev
+        if not spec.shared or ng > HOP_MAX_GROUPS or max(spec.fb_layers, spec.sb_layers) > HOP_MAX_LAYERS or D + hop > 32:
+            return None
+        desc = HopDesc()
+        keep = []  # tensors the descriptor points into
+
+        def zeros(shape, dtype):
+            t = torch.zeros(shape, dtype=dtype, device=dev)
+            keep.append(t)
+            return t
+
+        def fill(dst, seq, fg, R, df, fc):
+            HP = (seq.H + 63) // 64 * 64
+            dst.n_layers, dst.H, dst.P, dst.feat, dst.df, dst.fc = len(seq.cells), seq.H, seq.P, fg, df, fc
+            dst.w_p, dst.w_p_dq, dst.b_p = _ptr(seq.proj_q), _ptr(seq.proj_dq), _ptr(seq.proj_b)
+            for l, cell in enumerate(seq.cells):
+                o = dst.layer[l]
+                if l == 0:
+                    o.w_ih_f32 = _ptr(cell.w_ih_f32)
+                else:
+                    o.w_ih, o.w_ih_dq = _ptr(cell.w_ih_q[0][0]), _ptr(cell.w_ih_q[0][1])
+                o.w_hh, o.w_hh_dq, o.bias, o.bn_alpha, o.bn_beta = (_ptr(cell.w_hh_q), _ptr(cell.w_hh_dq), _ptr(cell.bias), _ptr(cell.alpha),
+                                                                     _ptr(cell.beta))
+                o.h[0], o.h[1] = zeros((R, HP), torch.int8).data_ptr(), zeros((R, HP), torch.int8).data_ptr()
+                o.c, o.spikes = _ptr(zeros((R, seq.H), torch.float32)), _ptr(zeros((hop, R, HP), torch.int8))
+
+        fill(desc.fb, eng.fb, self.fg_fb[0], B, 0, 0)
+        for g in range(ng):
+            fill(desc.sb[g], eng.sb[g], self.fg_sb[g], B * spec.units(g), spec.df[g], spec.ctr[g])
+        desc.n_groups, desc.B, desc.F, desc.S, desc.hop, desc.D, desc.fdrc = ng, B, F, S, hop, D, spec.fdrc
+        hist = zeros((B, F, max(D, 1)), torch.complex64)
+        enh, mag = zeros((B, S, F, hop), torch.complex64), zeros((B, S, F, hop), torch.float32)
+        desc.inp_ri, desc.hist_ri, desc.fb_out = _ptr(self.inp), _ptr(hist), _ptr(zeros((hop, B, spec.fb_proj), torch.float32))
+        desc.enh_ri, desc.enh_mag = _ptr(enh), _ptr(mag)
+        nb = L.sfsn_hop_scratch_bytes(ctypes.byref(desc))
+        if nb == 0:
+            return None
+        scratch = zeros((nb // 4 + 1,), torch.int32)
+        desc.scratch, desc.scratch_bytes = _ptr(scratch), nb
+        # the error word of a launch is looked at, without blocking, at the next step (pinned copy behind the launch)
+        err = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        return dict(desc=desc, keep=keep, hist=hist, enh=enh, mag=mag, scratch=scratch, err=err, err_pending=False)
 
     # -----------------------------------------------------------------------------------------------------------------
     def reset(self) -> None:
@@ -91,7 +149,21 @@ class StreamingSession:
                     h.zero_()
                     c.zero_()
         self.hist.zero_()
+        if self._hop is not None:
+            self.check_errors()
+            scratch = self._hop["scratch"]
+            for t in self._hop["keep"]:
+                if t is not scratch:  # the launch counter (parity of the double-buffered spikes) lives on
+                    t.zero_()
         self.frames_done = 0
+
+    def check_errors(self) -> None:
+        """Raise if a hand-off wait of an earlier one-launch hop expired (blocks until the hops enqueued so far have finished)."""
+        if self._hop is None:
+            return
+        torch.cuda.current_stream(self.dev).synchronize()
+        if int(self._hop["scratch"][0].item()) != 0:
+            raise RuntimeError("sfsn_stream_hop: a bounded hand-off wait expired inside a launch (results invalid)")
 
     def _enqueue(self) -> None:
         """One hop on torch's current stream: history shift, then the offline forward's kernels on frames [D, D+hop)."""
@@ -161,6 +233,23 @@ class StreamingSession:
         if frames.device != self.dev or frames.dtype != torch.complex64 or tuple(frames.shape) != (self.B, self.F, self.hop):
             raise RuntimeError(f"expected complex64 {(self.B, self.F, self.hop)} on {self.dev}, got {frames.dtype} {tuple(frames.shape)} "
                                f"on {frames.device}")
+        if self._hop is not None:
+            h = self._hop
+            if h["err_pending"] and int(h["err"][0]) != 0:  # written behind an earlier launch; no blocking here
+                raise RuntimeError("sfsn_stream_hop: a bounded hand-off wait expired inside a launch (results invalid)")
+            if frames.is_contiguous() and frames.data_ptr() % 8 == 0:
+                h["desc"].inp_ri = frames.data_ptr()  # read in place: no staging copy in front of the launch
+            else:
+                self.inp.copy_(frames)
+                h["desc"].inp_ri = self.inp.data_ptr()
+            with torch.cuda.device(self.dev):
+                check(self.eng.lib.sfsn_stream_hop(ctypes.byref(h["desc"]), ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)),
+                      "sfsn_stream_hop")
+            self.frames_done += self.hop
+            if self.frames_done % 256 < self.hop:  # every ~256 frames: the error word follows the launch into pinned memory
+                h["err"].copy_(h["scratch"][:1], non_blocking=True)
+                h["err_pending"] = True
+            return (h["enh"].clone(), h["mag"].clone()) if copy else (h["enh"], h["mag"])
         self.inp.copy_(frames)
         if self._graph is not None:
             self._graph.replay()

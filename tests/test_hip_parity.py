@@ -621,12 +621,14 @@ def test_forwards_in_flight_on_separate_streams_are_independent():
             assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("one_launch", ["auto", False])
 @pytest.mark.parametrize("kw,seed,B,hop,graph", [(rw.LIVE_TINY, 11, 2, 1, True), (rw.LIVE_M, 5, 1, 1, True), (rw.LIVE_M, 5, 3, 4, True),
                                                   (rw.LIVE_TINY_2SPK, 12, 2, 3, False), (rw.LIVE_TINY_UNSHARED, 7, 1, 1, True)])
-def test_streaming_session_equals_offline_forward(kw, seed, B, hop, graph):
+def test_streaming_session_equals_offline_forward(kw, seed, B, hop, graph, one_launch):
     """BASELINE configs[4] (streaming, state carried, hop frames per call): the frame-by-frame session reproduces the offline
-    forward on the same clip bit for bit (the model is causal after the STFT), and a reset starts a new utterance.  (Offline forward vs
-    oracle / golden vectors: the tests above.)"""
+    forward on the same clip bit for bit (the model is causal after the STFT), and a reset starts a new utterance -- both as ONE
+    launch per hop (sfsn_stream_hop, the default wherever the library covers the model) and as the offline kernels replayed
+    from a HIP graph.  (Offline forward vs oracle / golden vectors: the tests above.)"""
     model = build_module("live", kw, rw.live_state_dict(kw, seed))
     T = 24 * hop if hop > 1 else 40
     wave = torch.from_numpy(rw.synth_wave(B, T, seed)).to(DEV)
@@ -634,18 +636,57 @@ def test_streaming_session_equals_offline_forward(kw, seed, B, hop, graph):
                       return_complex=True, pad_mode="constant")[..., :T].contiguous()
     assert stft.shape[-1] == T
     off = model.engine().forward_stft(stft, want_layers=False)
-    sess = model.streaming(batch=B, hop=hop, graph=graph, rows_per_wg=None if seed != 12 else (0, 0))  # default / unfused geometry
+    sess = model.streaming(batch=B, hop=hop, graph=graph, rows_per_wg=None if seed != 12 else (0, 0),  # default / unfused geometry
+                           one_launch=one_launch)
+    if one_launch == "auto":
+        assert (sess._hop is not None) == bool(kw["shared_weights"])  # every shared-weight recipe takes the one-launch path
+    else:
+        assert sess._hop is None
     for rep in range(2):
         outs, mags = [], []
         for t0 in range(0, T, hop):
-            e, m = sess.step(stft[..., t0:t0 + hop].contiguous())
+            x = stft[..., t0:t0 + hop]
+            e, m = sess.step(x.contiguous() if (t0 // hop) % 2 == 0 else x.clone(memory_format=torch.contiguous_format))
             outs.append(e)
             mags.append(m)
         assert sess.frames_done == T
+        sess.check_errors()
         e, m = torch.cat(outs, -1), torch.cat(mags, -1)
         assert torch.equal(torch.view_as_real(e), torch.view_as_real(off["enh_stft"])), rep
         assert torch.equal(m, off["enh_mag"])
         sess.reset()
+
+
+def test_stream_hop_argument_checks_and_fallback():
+    """sfsn_stream_hop through the C ABI: malformed descriptors are refused, what the launch does not cover reports
+    SFSN_EUNSUPPORTED (the session then replays the offline kernels), one_launch=True insists."""
+    import ctypes
+    from spiking_fullsubnet_amd import _lib
+    L = _lib.lib()
+    model = build_module("live", rw.LIVE_TINY, rw.live_state_dict(rw.LIVE_TINY, 11))
+    sess = model.streaming(batch=1, hop=1)
+    desc = sess._hop["desc"]
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    good = (desc.scratch, desc.scratch_bytes, desc.hop, desc.inp_ri)
+    desc.scratch_bytes = 8
+    assert L.sfsn_stream_hop(ctypes.byref(desc), st) == _lib.SFSN_EINVAL
+    desc.scratch_bytes = good[1]
+    desc.inp_ri = None
+    assert L.sfsn_stream_hop(ctypes.byref(desc), st) == _lib.SFSN_EINVAL
+    desc.inp_ri = good[3]
+    desc.hop = 40
+    assert L.sfsn_stream_hop(ctypes.byref(desc), st) == _lib.SFSN_EUNSUPPORTED
+    assert L.sfsn_hop_scratch_bytes(ctypes.byref(desc)) == 0
+    desc.hop = good[2]
+    assert L.sfsn_hop_scratch_bytes(ctypes.byref(desc)) == good[1]
+    unshared = build_module("live", rw.LIVE_TINY_UNSHARED, rw.live_state_dict(rw.LIVE_TINY_UNSHARED, 7))
+    with pytest.raises(NotImplementedError):
+        unshared.streaming(batch=1, hop=1, one_launch=True)
+    mid = build_module("live", rw.LIVE_M, rw.live_state_dict(rw.LIVE_M, 5))
+    big = mid.streaming(batch=48, hop=1)  # more wave tiles than compute units: the session falls back by itself
+    assert big._hop is None and mid.streaming(batch=16, hop=1)._hop is not None
+    big.step(torch.zeros((48, 257, 1), dtype=torch.complex64, device=DEV))
+    torch.cuda.synchronize()
 
 
 def test_streaming_rejects_the_non_causal_front_end_and_bad_frames():
