@@ -258,21 +258,24 @@ int sfsn_hist_shift(float* hist_ri, const float* inp_ri, int rows, int D, int ho
  * memory between launches.  Replaces the ~15 launches the offline kernels need per hop (each costs ~4.5 us of launch
  * boundary on this hardware, which is all a one-frame hop consists of).
  *
- * One wave owns one 16-neuron tile of one layer for 16 rows and keeps that tile's weights in registers; the waves of
- * consecutive stages (layer 0 -> layer 1 -> projection -> sub-band layer 0 -> ... -> projection + deep filter) hand each
- * frame over through L2 with write-through stores and per-wave progress counters, as the stack scan above does per layer.
+ * One wave owns one 16-neuron tile of one layer for 16 rows and keeps that tile's weights in registers; the workgroups of
+ * consecutive stages (full-band layer 0 -> ... -> sub-band layer 0, which also computes the full-band projection it needs
+ * -> ... -> sub-band projection + deep filter) hand each frame over through L2 as data-tagged granules (a write-through
+ * store carries the spikes AND the launch's tag; consumers poll the payload itself).
  * The recurrent product of a layer is issued before its input has arrived (it needs the previous frame only).
- * Arithmetic is that of sfsn_features / sfsn_input_proj_f32 (fp32-MFMA form) / sfsn_spike_proj / sfsn_gsn_layer_scan /
- * sfsn_deepfilter expression by expression.
+ * Arithmetic is that of sfsn_features / sfsn_spike_proj / sfsn_gsn_layer_scan / sfsn_deepfilter expression by expression;
+ * the real-valued input product is sfsn_input_proj_f32's fp32-MFMA form with four accumulators.
  *
- * Shared gate weights, LayerNorm or no normalisation, H % 16 == 0, H <= 320, I <= 192, P <= 256, at most
+ * Shared gate weights, LayerNorm or no normalisation, H % 16 == 0, H <= 320, I <= 192, P <= 256 (full-band P <= 128), at most
  * SFSN_HOP_MAX_LAYERS layers and SFSN_HOP_MAX_GROUPS groups, D + hop <= 32, and few enough rows that every wave tile gets
  * its own compute unit (SFSN_EUNSUPPORTED otherwise: the caller then runs the per-kernel sequence).
  * ---------------------------------------------------------------------------------------------------- */
 #define SFSN_HOP_MAX_LAYERS 3
 #define SFSN_HOP_MAX_GROUPS 4
 typedef struct sfsn_hop_layer {
-    const float* w_ih_f32;  /* layer 0: [H][I] fp32 row-major (NULL for layers >= 1)                               */
+    const float* w_ih_frag; /* layer 0: fp32 W_ih [H][I] in MFMA fragment order [H/16][KC][64][4], KC = ceil(I/16):
+                               element ((tile*KC + c)*64 + 16*q + n)*4 + e = W_ih[16*tile + n][16*c + 4*q + e], zero where
+                               the column index is >= I (NULL for layers >= 1)                                      */
     const int8_t* w_ih;     /* layers >= 1: sfsn_w3_pack(W_ih [H][H]) (NULL for layer 0)                            */
     const float* w_ih_dq;
     const int8_t* w_hh;     /* sfsn_w3_pack(W_hh [H][H])                                                            */
@@ -280,10 +283,11 @@ typedef struct sfsn_hop_layer {
     const float* bias;      /* [2H] bias_ih                                                                         */
     const float* bn_alpha;  /* [H]                                                                                  */
     const float* bn_beta;   /* [H]                                                                                  */
-    int8_t* h[2];           /* [R][pad64(H)] x 2: spikes of the last frame, in/out; launch k reads h[k & 1] and writes
-                               h[(k + 1) & 1] (k = the launch counter kept in `scratch`); zero both to reset          */
+    int8_t* h[2];           /* [R][pad64(H)] x 2: spikes of the last frame, in/out; launch k (= launch_index) reads
+                               h[k & 1] and writes h[(k + 1) & 1]; zero both to reset                                 */
     float* c;               /* [R][H] membrane, in/out                                                              */
-    int8_t* spikes;         /* [hop][R][pad64(H)] scratch (pad columns zeroed by the caller once)                   */
+    int8_t* spikes;         /* [hop][R][pad64(H)] scratch, zeroed by the caller once (bit 0 of a byte = the spike,
+                               bits 1..7 = the tag of the launch that wrote it)                                      */
 } sfsn_hop_layer;
 typedef struct sfsn_hop_seq {      /* one sequence model: the full-band model or one sub-band group                  */
     sfsn_hop_layer layer[SFSN_HOP_MAX_LAYERS];
@@ -304,16 +308,24 @@ typedef struct sfsn_hop_desc {
     float fdrc;
     const float* inp_ri;           /* [B][F][hop][2] the new noisy frames                                            */
     float* hist_ri;                /* [B][F][D][2]   the last D noisy frames, in/out (zero to reset); NULL if D == 0 */
-    float* fb_out;                 /* [hop][B][fb.P] scratch                                                         */
     float* enh_ri;                 /* [B][S][F][hop][2] out                                                          */
     float* enh_mag;                /* [B][S][F][hop] out, nullable                                                   */
     void* scratch;                 /* sfsn_hop_scratch_bytes(desc) bytes, ZEROED by the caller once; word 0 = error flag
                                       (non-zero after a launch: a bounded hand-off wait expired, results invalid)     */
     size_t scratch_bytes;
+    unsigned launch_index;         /* launches made on this state so far: the caller adds 1 after every launch (it picks
+                                      the hand-off tag and the parity of the double-buffered state; a launch must not
+                                      be replayed with the index of its predecessor, so no graph capture)            */
 } sfsn_hop_desc;
 
 size_t sfsn_hop_scratch_bytes(const sfsn_hop_desc* desc /* host */);
 int sfsn_stream_hop(const sfsn_hop_desc* desc /* host */, void* stream);
+/* Diagnostic: the launch's stages in block order, out[4 * i] = {sequence (0 = full-band, 1 + g = group g), layer (-1 = projection
+ * [+ deep filter]), first workgroup, workgroups}; returns the number of stages (or a negative status).  With SFSN_HOP_DEBUG set
+ * in the environment a launch leaves eight 100 MHz time stamps per wave (4 waves per workgroup) in `scratch`, behind the
+ * 64 bytes of control words: entry, set-up done, recurrent half issued, full-band projection arrived (sub-band layer 0),
+ * input arrived, frame computed, deep filter done, exit (scripts/exp_hop.py prints them per stage). */
+int sfsn_hop_stages(const sfsn_hop_desc* desc /* host */, int* out /* host [cap][4] */, int cap);
 
 /* ----------------------------------------------------------------------------------------------------
  * Spike counts -- the only thing the reference's energy proxy reads from the spike tensors:

@@ -44,3 +44,27 @@ for mode in (True, False):
     lat = np.sort(np.array(lat)) * 1e6
     print("  latency p50 %.1f us  min %.1f  p99 %.1f" % (lat[len(lat) // 2], lat[0], lat[int(len(lat) * .99)]))
     if mode: sess.check_errors()
+
+if os.environ.get("SFSN_HOP_DEBUG"):
+    import ctypes
+    sess = model.streaming(batch=B, hop=hop, one_launch=True)
+    L, desc = sess.eng.lib, sess._hop["desc"]
+    out = (ctypes.c_int * 80)()
+    ns = L.sfsn_hop_stages(ctypes.byref(desc), out, 20)
+    for i in range(6):
+        sess.step(frames[i], copy=False)
+    torch.cuda.synchronize()
+    raw = sess._hop["scratch"].cpu().numpy().view(np.uint8)
+    nwg = out[4 * (ns - 1) + 2] + out[4 * (ns - 1) + 3]
+    nb = 64
+    st = raw[nb:nb + nwg * 8 * 64].view(np.uint64).reshape(nwg, 8, 8).astype(np.int64)
+    t0 = st[:, :, 0].min()
+    us = (st - t0) / 100.0
+    names = ["entry", "setup", "rec", "fb_proj", "input", "computed", "df", "exit"]
+    print("stage            wgs  " + "  ".join("%9s" % n for n in names) + "   (us since the first wave's entry: min..max over the stage's waves)")
+    for i in range(ns):
+        seq, layer, wg0, n = out[4 * i:4 * i + 4]
+        u = us[wg0:wg0 + n].reshape(-1, 8)
+        u = u[st[wg0:wg0 + n].reshape(-1, 8)[:, 7] > 0]  # waves that ran
+        lab = ("fb" if seq == 0 else "sb%d" % (seq - 1)) + (" L%d" % layer if layer >= 0 else " proj")
+        print("%-16s %3d  " % (lab, n) + "  ".join(("%4.1f-%4.1f" % (u[:, j].min(), u[:, j].max()) if u[:, j].min() > -1 else "    -    ") for j in range(8)))

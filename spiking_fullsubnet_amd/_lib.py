@@ -55,7 +55,7 @@ HOP_MAX_GROUPS = 4
 
 
 class HopLayer(ctypes.Structure):
-    _fields_ = [("w_ih_f32", _P), ("w_ih", _P), ("w_ih_dq", _P), ("w_hh", _P), ("w_hh_dq", _P), ("bias", _P), ("bn_alpha", _P),
+    _fields_ = [("w_ih_frag", _P), ("w_ih", _P), ("w_ih_dq", _P), ("w_hh", _P), ("w_hh_dq", _P), ("bias", _P), ("bn_alpha", _P),
                 ("bn_beta", _P), ("h", _P * 2), ("c", _P), ("spikes", _P)]
 
 
@@ -66,8 +66,8 @@ class HopSeq(ctypes.Structure):
 
 class HopDesc(ctypes.Structure):
     _fields_ = [("fb", HopSeq), ("sb", HopSeq * HOP_MAX_GROUPS), ("n_groups", _I), ("B", _I), ("F", _I), ("S", _I), ("hop", _I),
-                ("D", _I), ("fdrc", _F), ("inp_ri", _P), ("hist_ri", _P), ("fb_out", _P), ("enh_ri", _P), ("enh_mag", _P),
-                ("scratch", _P), ("scratch_bytes", ctypes.c_size_t)]
+                ("D", _I), ("fdrc", _F), ("inp_ri", _P), ("hist_ri", _P), ("enh_ri", _P), ("enh_mag", _P),
+                ("scratch", _P), ("scratch_bytes", ctypes.c_size_t), ("launch_index", ctypes.c_uint)]
 
 
 def _sources():
@@ -157,6 +157,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_hist_shift.argtypes = [_P, _P, _I, _I, _I, _P]
     L.sfsn_hop_scratch_bytes.restype = ctypes.c_size_t
     L.sfsn_hop_scratch_bytes.argtypes = [ctypes.POINTER(HopDesc)]
+    L.sfsn_hop_stages.restype = _I
+    L.sfsn_hop_stages.argtypes = [ctypes.POINTER(HopDesc), ctypes.POINTER(_I), _I]
     L.sfsn_stream_hop.restype = _I
     L.sfsn_stream_hop.argtypes = [ctypes.POINTER(HopDesc), _P]
     L.sfsn_spike_count.restype = _I
@@ -174,7 +176,7 @@ def lib() -> ctypes.CDLL:
 EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
            "sfsn_w3_pack", "sfsn_w3_pack_bits", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_stack_scratch_bytes", "sfsn_gsn_stack_scan",
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
-           "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
+           "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
 
 
 def check(rc: int, what: str = "") -> None:

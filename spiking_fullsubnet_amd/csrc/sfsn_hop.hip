@@ -1,25 +1,30 @@
 // sfsn_hop.hip -- the streaming hop: `hop` new frames of B clips through the whole live model in ONE launch (gfx950 only).
 //
 // BASELINE configs[4] (B = 1 per GPU, hop = 1 frame, state resident between frames).  A one-frame hop through the offline
-// kernels is ~15 launches of 4.5-25 us each, every one of them a launch boundary and nothing else: the work of a frame is a
-// few hundred MFMAs.  Here the whole frame is one launch of a few dozen small workgroups:
+// kernels is ~15 launches of 4.5-25 us each, every one of them a launch boundary and little else: the work of a frame is a
+// few hundred MFMAs.  Here the whole frame is one launch of a few dozen workgroups:
 //
 //   * an AGENT is one wave: it owns one 16-neuron output tile of one layer for one 16-row tile, keeps that tile's weight
 //     fragments (W_hh, and W_ih of its layer) in registers, and its slice of the membrane in registers for the launch;
-//   * the stages full-band layer 0 -> ... -> full-band projection -> sub-band layer 0 (all groups side by side) -> ... ->
-//     sub-band projection + deep filter hand each frame over through L2: int8 spike bytes (or fp32 projections) leave with
-//     write-through (sc1) stores, the wave drains its store queue and publishes its own 32-bit frame counter; consumers poll
-//     the counters of the waves they depend on with one lane each (wave-wide ballot) and read the payload with sc1 loads.
-//     No workgroup barrier sits on a hand-off: waves are the unit of synchronisation;
-//   * the recurrent product h(t-1).W_hh of every layer is issued BEFORE the wave starts to wait for its input: only the
-//     input-dependent half of a layer is on the frame's critical path;
+//     eight agents share a workgroup;
+//   * the stages  full-band layer 0 -> ... -> last full-band layer -> sub-band layer 0 (all groups side by side; these
+//     workgroups compute the full-band projection they need themselves: 4 tiles, cheaper than one more hop through L2)
+//     -> ... -> sub-band projection + deep filter  hand each frame over through L2 as DATA-TAGGED GRANULES: a spike word is
+//     four bytes 0/1 whose upper seven bits carry the launch's tag, written by one write-through (sc1) store -- data and
+//     "ready" are the same word, so the producer neither drains its store queue nor publishes a flag, and the consumer
+//     polls the payload itself.  In a consumer workgroup every word is polled by exactly one lane (wave k takes the k-th
+//     64-neuron slice), the masked fragments are parked in LDS, one barrier, and all eight waves read their B operand from
+//     LDS: polling traffic does not grow with the number of waves that need the data;
+//   * the recurrent product h(t-1).W_hh of every layer is issued BEFORE the workgroup starts to wait for its input: only
+//     the input-dependent half of a layer is on the frame's critical path;
 //   * every weight fragment a wave needs is requested at launch, i.e. while the stages upstream are still computing.
 //
 // State between launches lives in device memory (membranes per agent, last spikes double-buffered by launch parity so that a
 // fast wave cannot overwrite what a late peer still has to read, deep-filter history shifted by the thread that owns the bin).
+// The caller numbers the launches (tag and parity come from that number): no counter has to be read, reset or waited for.
 //
-// Arithmetic: the expressions of features_kernel / input_proj_kernel (fp32 MFMA chain, same k order) / spike_proj_kernel /
-// scan_body / deepfilter_kernel, so a session built on this launch is bit-identical to one built on those kernels.
+// Arithmetic: the expressions of features_kernel / spike_proj_kernel / scan_body / deepfilter_kernel; the real-valued input
+// product uses input_proj_kernel's fp32 MFMA operand layout with four accumulators (a quarter of the dependent chain).
 // Deadlock freedom: producers have lower block indices than their consumers, workgroups are dispatched in index order and the
 // launch is refused unless every workgroup can be resident at once; every spin is bounded all the same (error word).
 #include <hip/hip_runtime.h>
@@ -32,18 +37,20 @@
 #include "sfsn_scan_dev.h"
 #include "sfsn_feat_dev.h"
 
-#define HOP_THREADS 256
-#define HOP_WAVES 4
+#define HOP_THREADS 512
+#define HOP_WAVES 8
 #define HOP_MAX_SEQS (1 + SFSN_HOP_MAX_GROUPS)
 #define HOP_MAX_STAGES (HOP_MAX_SEQS * (SFSN_HOP_MAX_LAYERS + 1))
 #define HOP_KS_MAX 5     // 64-wide k steps of the int8 products: H <= 320
 #define HOP_KC_MAX 12    // 16-wide k chunks of the fp32 input product: I <= 192
 #define HOP_NU_MAX 3     // feature slots per lane: I <= 192
+#define HOP_ROWS_PER_WAVE (16 / HOP_WAVES)
+#define HOP_PT_PER_WAVE 2  // P <= 256
 #define HOP_SPIN_LIMIT 2000000u
-#define HOP_CNT0 4       // counters: [0] error word, [1] exit counter, [2] launch counter, [3] reserved, [4 + agent] frames done
+#define HOP_MAX_BLOCKS 256  // workgroups per launch (one per compute unit at most)
 
 struct HopLayerDev {
-    const float* w_ih_f32;
+    const float* w_ih_f32;  // (fragment order)
     const int8_t* w_ih;
     const float* w_ih_dq;
     const int8_t* w_hh;
@@ -67,25 +74,35 @@ struct HopSeqDev {
     float eps;
 };
 struct HopStageDev {
-    int seq, layer;  // layer = -1: the projection (+ deep filter for a sub-band group)
+    int seq, layer;  // layer = -1: the projection + deep filter of a sub-band group
     int wg0, nwg;    // workgroups [wg0, wg0 + nwg)
-    int agent0;      // first counter of the stage; agent (rt, tile) = agent0 + rt * ntpad + tile
     int ntile, ntpad, nrt;
-    int prod;        // stage whose agents feed this one (-1: the input frames)
 };
 struct HopParams {
     HopSeqDev seq[HOP_MAX_SEQS];
     HopStageDev st[HOP_MAX_STAGES];
-    int nseq, nstage, nblocks, nagents;
+    unsigned stage_of_block[HOP_MAX_BLOCKS / 4];  // one byte per workgroup: a single scalar load finds the role
+    int nseq, nstage, nblocks;
     int B, F, S, hop, D, FB, fcov;
     float fdrc;
+    unsigned launch;  // launches made on this state since it was zeroed: tag and state parity
     const float* inp;
     float* hist;
-    float* fb_out;
     float* enh;
     float* mag;
-    unsigned* cnt;
+    unsigned* cnt;    // [0] error word
+    unsigned long long* dbg;  // -DSFSN_HOP_STAMPS builds + SFSN_HOP_DEBUG: 8 time stamps (100 MHz) per wave
 };
+
+#ifdef SFSN_HOP_STAMPS
+// (every lane stores the same value to the same word: no branch, so the compiler's wait-count bookkeeping is not disturbed;
+// a stamps build always has a valid dbg pointer)
+#define HOP_STAMP(i) p.dbg[((size_t)blockIdx.x * HOP_WAVES + wave) * 8 + (i)] = wall_clock64()
+#else
+#define HOP_STAMP(i) \
+    do {             \
+    } while (0)
+#endif
 
 // ---- coherent accesses (agent scope: global_load / global_store ... sc1) ------------------------------------------------
 __device__ __forceinline__ unsigned ld_agent(const void* p) {
@@ -94,62 +111,59 @@ __device__ __forceinline__ unsigned ld_agent(const void* p) {
 __device__ __forceinline__ void st_agent(void* p, unsigned v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ v4i ld16_agent(const void* p) {
-    const unsigned* u = reinterpret_cast<const unsigned*>(p);
-    v4i r;
-    r[0] = (int)ld_agent(u);
-    r[1] = (int)ld_agent(u + 1);
-    r[2] = (int)ld_agent(u + 2);
-    r[3] = (int)ld_agent(u + 3);
-    return r;
-}
 
-// Wave-level wait: every lane watches one counter of [cnt + a0, cnt + a0 + n), the wave leaves when all are >= need.
-// Returns false when the bounded spin expired (error word set); the caller then stops waiting for anything (garbage out,
-// the host raises) but keeps executing its barriers.
-__device__ __forceinline__ bool hop_wait(const unsigned* cnt, int a0, int n, unsigned need, int lane, bool ok) {
-    if (!ok) return false;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        for (unsigned spins = 0;; ++spins) {
-            const unsigned v = i < n ? ld_agent(cnt + HOP_CNT0 + a0 + i) : 0xffffffffu;
-            if (__ballot(v < need) == 0) break;
-            if (spins > HOP_SPIN_LIMIT) {
-                if (lane == 0) st_agent(const_cast<unsigned*>(cnt), 1u);
-                return false;
+// ---- hand-off: data-tagged granules (MI355X_MICROARCH.md, price list row handoff-1to1) ------------------------------------
+__device__ __forceinline__ unsigned hop_tag(unsigned launch) { return launch % 127u + 1u; }
+
+// All waves of the workgroup call this (one barrier inside).  `blk` = the [R][HP] spike block of one frame, written by other
+// workgroups of this launch.  Wave k < KS polls the k-th 64-column slice of row tile `rt16` until every word carries `tagw`
+// (= tag * 0x02020202; columns >= H are padding, never written, read as zero), parks the masked fragment in LDS (`hb`,
+// KS KB); after the barrier every wave reads all KS fragments.  Returns false when the bounded spin expired (error word
+// set) -- the wave then stops polling for good (garbage out, the host raises) but keeps executing its barriers.
+__device__ __forceinline__ bool hop_gather(const int8_t* blk, int rt16, int R, int KS, int H, unsigned tagw, char* hb, v4i (&b)[HOP_KS_MAX],
+                                           bool ok, unsigned* err, int wave, int lane) {
+    const int n = lane & 15, q = lane >> 4;
+    if (wave < KS) {
+        const int row = 16 * rt16 + n, rowc = row < R ? row : R - 1;
+        v4i v = {0, 0, 0, 0};
+        if (wave * 64 + q * 16 < H) {
+            const unsigned* u = reinterpret_cast<const unsigned*>(blk + ((size_t)rowc * KS + wave) * 64 + q * 16);
+            for (unsigned spins = 0;; ++spins) {
+                bool bad = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned w = ld_agent(u + i);
+                    bad |= (w & 0xfefefefeu) != tagw;
+                    v[i] = (int)(w & 0x01010101u);
+                }
+                if (!ok || __ballot(bad) == 0) break;
+                if (spins > HOP_SPIN_LIMIT) {
+                    st_agent(err, 1u);
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_s_sleep(1);
         }
+        *reinterpret_cast<v4i*>(hb + (wave * 64 + lane) * 16) = v;
     }
-    return true;
-}
-
-__device__ __forceinline__ void hop_publish(unsigned* cnt, int agent, unsigned frames, int lane) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's payload stores have been written through
-    if (lane == 0) st_agent(cnt + HOP_CNT0 + agent, frames);
-}
-
-// The last workgroup to leave zeroes the progress counters and the exit counter and advances the launch counter: the next
-// launch starts clean without a memset in front of it.
-__device__ __forceinline__ void hop_exit(const HopParams& p, int* word) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) *reinterpret_cast<volatile int*>(word) = atomicAdd(p.cnt + 1, 1u) == (unsigned)(p.nblocks - 1) ? 1 : 0;
-    __syncthreads();
-    if (*reinterpret_cast<volatile int*>(word)) {
-        for (int i = threadIdx.x; i < p.nagents; i += blockDim.x) st_agent(p.cnt + HOP_CNT0 + i, 0u);
-        if (threadIdx.x == 0) {
-            st_agent(p.cnt + 2, ld_agent(p.cnt + 2) + 1u);
-            st_agent(p.cnt + 1, 0u);
-        }
+#pragma unroll
+    for (int ks = 0; ks < HOP_KS_MAX; ++ks) {
+        b[ks] = v4i{0, 0, 0, 0};
+        if (ks < KS) b[ks] = *reinterpret_cast<const v4i*>(hb + (ks * 64 + lane) * 16);
     }
+    return ok;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// layer role: 4 agents per workgroup (tiles 4w .. 4w+3 of one row tile).  LDS (layer 0 only): the feature rows of the tile.
+// layer role: 8 agents per workgroup (tiles 8w .. 8w+7 of one row tile).
+// LDS: [64 B][hbA: KS_MAX KB (own layer, frame t-1)][hbB: KS_MAX KB (input spikes, frame t)][fbl: 16 x FB floats][xrow: 16 x KPX]
+//      [fbw: the full-band projection's weight fragments, 3 x PT x KS KB (gated layer 0 only)].
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool L0>
-__device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStageDev& sd, const HopSeqDev& sq, char* smem, unsigned epoch) {
+// ONE: hop == 1 (the configuration that matters): no frame loop, so nothing stays live across it.
+template <bool L0, bool ONE>
+__device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStageDev& sd, const HopSeqDev& sq, char* smem) {
     const int l = sd.layer;
     const HopLayerDev& L = sq.layer[l];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -159,47 +173,92 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
     const int rt = wgl / wpr, tile_raw = (wgl - rt * wpr) * HOP_WAVES + wave;
     const bool active = tile_raw < sd.ntile;
     const int tile = active ? tile_raw : 0;
-    const int agent = sd.agent0 + rt * sd.ntpad + tile_raw;
     const int H = sq.H, KS = sq.KS, NT = sq.NT, R = sq.R, HP = KS * 64, I = sq.I, KC = sq.KC;
     const int row = 16 * rt + n, rowc = row < R ? row : R - 1;
     const int cc = 16 * tile + 4 * q;
-    const int hop = p.hop;
-    float* xrow = reinterpret_cast<float*>(smem + 64);
+    const int hop = ONE ? 1 : p.hop;
+    const unsigned tagw = hop_tag(p.launch) * 0x02020202u;
+    char* hbA = smem + 64;
+    char* hbB = hbA + HOP_KS_MAX * 1024;
+    float* fbl = reinterpret_cast<float*>(hbB + HOP_KS_MAX * 1024);
+    float* xrow = fbl + 16 * p.FB;
     const int KPX = KC * 16 + 4;
+    char* fbw = reinterpret_cast<char*>(xrow + 16 * KPX);
+    const bool gated = L0 && sd.seq > 0;  // layer 0 of a sub-band group: its rows need the full-band projection
+    const HopSeqDev& fbq = p.seq[0];
 
-    // ---- weights of my tile into registers (requested now: the stages upstream are still at work)
+    if (gated) {  // 16 bytes per thread per request, four requests in flight (visible after the first gather's barrier)
+        const int n16 = 3 * fbq.PT * fbq.KS * 64;
+        const v4i* src = reinterpret_cast<const v4i*>(fbq.w_p);
+        v4i* dst = reinterpret_cast<v4i*>(fbw);
+        for (int i0 = tid; i0 < n16; i0 += HOP_THREADS * 4) {
+            v4i v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int idx = i0 + HOP_THREADS * i;
+                if (idx > n16 - 1) idx = n16 - 1;
+                v[i] = src[idx];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = i0 + HOP_THREADS * i;
+                if (idx < n16) dst[idx] = v[i];
+            }
+        }
+    }
+    // ---- everything this wave will need is requested now (the stages upstream are still at work); the recurrent half's
+    // operands first
+    const int8_t* hprev = L.h[p.launch & 1u];
+    int8_t* hnext = L.h[(p.launch + 1u) & 1u];
+    v4i h0[HOP_KS_MAX];  // h of the last frame of the previous launch (plain bytes 0/1)
     v4i Whh[3][HOP_KS_MAX], Wih[3][HOP_KS_MAX];
-    float W0[HOP_KC_MAX][4];
+#pragma unroll
+    for (int ks = 0; ks < HOP_KS_MAX; ++ks) {
+        h0[ks] = v4i{0, 0, 0, 0};
+        if (ks < KS) h0[ks] = *reinterpret_cast<const v4i*>(hprev + (size_t)rowc * HP + ks * 64 + q * 16);
+    }
 #pragma unroll
     for (int d = 0; d < 3; ++d)
 #pragma unroll
         for (int ks = 0; ks < HOP_KS_MAX; ++ks) {
             Whh[d][ks] = v4i{0, 0, 0, 0};
-            Wih[d][ks] = v4i{0, 0, 0, 0};
-            if (ks < KS) {
-                const size_t off = ((((size_t)d * NT + tile) * KS + ks) * 64 + lane) * 16;
-                Whh[d][ks] = *reinterpret_cast<const v4i*>(L.w_hh + off);
-                if (!L0) Wih[d][ks] = *reinterpret_cast<const v4i*>(L.w_ih + off);
-            }
+            if (ks < KS) Whh[d][ks] = *reinterpret_cast<const v4i*>(L.w_hh + ((((size_t)d * NT + tile) * KS + ks) * 64 + lane) * 16);
         }
-#pragma unroll
-    for (int c = 0; c < HOP_KC_MAX; ++c)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = c * 16 + q * 4 + e;
-            W0[c][e] = (L0 && c < KC && k < I) ? L.w_ih_f32[(size_t)(16 * tile + n) * I + k] : 0.0f;
-        }
+    v4f c = *reinterpret_cast<const v4f*>(L.c + (size_t)rowc * H + cc);
     const v4f dq = *reinterpret_cast<const v4f*>(L.w_hh_dq + cc);
-    v4f dqi = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (!L0) dqi = *reinterpret_cast<const v4f*>(L.w_ih_dq + cc);
     const v4f bf = *reinterpret_cast<const v4f*>(L.bias + cc);
     const v4f bg = *reinterpret_cast<const v4f*>(L.bias + H + cc);
     const v4f alpha = *reinterpret_cast<const v4f*>(L.alpha + cc);
     const v4f beta = *reinterpret_cast<const v4f*>(L.beta + cc);
+    v4f dqi = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (!L0) dqi = *reinterpret_cast<const v4f*>(L.w_ih_dq + cc);
+    // layer >= 1: W_ih of my tile.  Gated layer 0: the full-band projection's fragments go to LDS (waves < PT use one tile each).
+    const bool fbp = gated && wave < fbq.PT;
+    const int fcol = (fbp ? wave : 0) * 16 + q * 4;
+    v4f fdq = {0.0f, 0.0f, 0.0f, 0.0f}, fbias = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int ks = 0; ks < HOP_KS_MAX; ++ks) {
+            Wih[d][ks] = v4i{0, 0, 0, 0};
+            if (!L0 && ks < KS) Wih[d][ks] = *reinterpret_cast<const v4i*>(L.w_ih + ((((size_t)d * NT + tile) * KS + ks) * 64 + lane) * 16);
+        }
+    if (L0 && fbp) {
+        fdq = *reinterpret_cast<const v4f*>(fbq.w_p_dq + fcol);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fbias[r] = fcol + r < fbq.P ? fbq.b_p[fcol + r] : 0.0f;
+    }
+    // layer 0: W_ih of my tile in MFMA fragment order [tile][chunk][lane][4] (k = 16 chunk + 4 q + e of row 16 tile + n):
+    // one coalesced 16-byte request per chunk
+    v4f W0[HOP_KC_MAX];
+#pragma unroll
+    for (int ch = 0; ch < HOP_KC_MAX; ++ch) {
+        W0[ch] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        if (L0 && ch < KC) W0[ch] = *reinterpret_cast<const v4f*>(L.w_ih_f32 + ((((size_t)tile * KC + ch) * 64 + lane) * 4));
+    }
     v4f db;
 #pragma unroll
     for (int r = 0; r < 4; ++r) db[r] = bg[r] - bf[r];
-    v4f c = *reinterpret_cast<const v4f*>(L.c + (size_t)rowc * H + cc);
     float lw[HOP_NU_MAX], lb[HOP_NU_MAX];
 #pragma unroll
     for (int u = 0; u < HOP_NU_MAX; ++u) {
@@ -208,31 +267,23 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
         lw[u] = in ? sq.ln_w[j] : 0.0f;
         lb[u] = in ? sq.ln_b[j] : 0.0f;
     }
-    if (L0) {  // zero the feature rows once: the k padding of the input product must read zeros
-        for (int i = tid; i < 16 * KPX; i += HOP_THREADS) xrow[i] = 0.0f;
-        __syncthreads();
-    }
+    HOP_STAMP(1);
 
-    const HopStageDev* ps = sd.prod >= 0 ? &p.st[sd.prod] : nullptr;
-    const int8_t* hprev = L.h[epoch & 1u];
-    int8_t* hnext = L.h[(epoch + 1u) & 1u];
+    const int nf = p.F - 1;
     bool ok = true;
     unsigned pk = 0;
 
     for (int t = 0; t < hop; ++t) {
         // ---- recurrent half: needs frame t-1 of my own layer only
-        const int8_t* hsrc = hprev;
-        if (t > 0) {
-            ok = hop_wait(p.cnt, sd.agent0 + rt * sd.ntpad, sd.ntile, (unsigned)t, lane, ok);
-            hsrc = L.spikes + (size_t)(t - 1) * R * HP;
-        }
         v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
         {
             v4i b[HOP_KS_MAX];
+            if (t == 0) {
 #pragma unroll
-            for (int ks = 0; ks < HOP_KS_MAX; ++ks)
-                if (ks < KS) b[ks] = t > 0 ? ld16_agent(hsrc + (size_t)rowc * HP + ks * 64 + q * 16)
-                                           : *reinterpret_cast<const v4i*>(hsrc + (size_t)rowc * HP + ks * 64 + q * 16);
+                for (int ks = 0; ks < HOP_KS_MAX; ++ks) b[ks] = h0[ks];
+            } else {
+                ok = hop_gather(L.spikes + (size_t)(t - 1) * R * HP, rt, R, KS, H, tagw, hbA, b, ok, p.cnt, wave, lane);
+            }
 #pragma unroll
             for (int ks = 0; ks < HOP_KS_MAX; ++ks)
                 if (ks < KS) {
@@ -241,36 +292,83 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
                     a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[2][ks], b[ks], a2, 0, 0, 0);
                 }
         }
+        if (t == 0) HOP_STAMP(2);
         // ---- input half
         v4f z;
         if constexpr (L0) {
-            if (ps) ok = hop_wait(p.cnt, ps->agent0, ps->nrt * ps->ntpad, (unsigned)(t + 1), lane, ok);
-            if (t > 0) __syncthreads();  // everyone has read the previous frame's rows
-            const int nf = p.F - 1;
-            for (int rl = wave; rl < 16; rl += HOP_WAVES) {
-                const int frow = 16 * rt + rl;
-                if (frow >= R) break;
-                const int b = frow / sq.N, k = frow - b * sq.N;
-                float v[HOP_NU_MAX];
-                bool have[HOP_NU_MAX];
-                float sum = 0.0f;
+            // features of my rows (wave w: rows w and w + 8): the magnitude part needs the new frame only -- requested before
+            // the wait for the full-band model
+            float v[HOP_ROWS_PER_WAVE][HOP_NU_MAX];
+#pragma unroll
+            for (int ri = 0; ri < HOP_ROWS_PER_WAVE; ++ri) {
+                const int frow = 16 * rt + wave + HOP_WAVES * ri;
+                const int frc = frow < R ? frow : R - 1;
+                const int b_ = frc / sq.N, k = frc - b_ * sq.N;
 #pragma unroll
                 for (int u = 0; u < HOP_NU_MAX; ++u) {
                     const int j = lane + 64 * u;
-                    have[u] = j < I;
-                    v[u] = 0.0f;
-                    if (have[u]) {
-                        if (j < sq.I1) {
-                            const int bin = reflect_bin(sq.lo + k * sq.ctr - sq.nbr + j, nf);
-                            const float2 xc = *reinterpret_cast<const float2*>(p.inp + (((size_t)b * p.F + bin) * hop + t) * 2);
-                            v[u] = compress_mag(xc.x, xc.y, p.fdrc);
-                        } else {
-                            const int col = reflect_bin(sq.lo + k * sq.ctr_fb - sq.nbr_fb + (j - sq.I1), nf) % p.FB;
-                            v[u] = __uint_as_float(ld_agent(p.fb_out + ((size_t)t * p.B + b) * p.FB + col));
+                    v[ri][u] = 0.0f;
+                    if (j < sq.I1) {
+                        const int bin = reflect_bin(sq.lo + k * sq.ctr - sq.nbr + j, nf);
+                        const float2 xc = *reinterpret_cast<const float2*>(p.inp + (((size_t)b_ * p.F + bin) * hop + t) * 2);
+                        v[ri][u] = compress_mag(xc.x, xc.y, p.fdrc);
+                    }
+                }
+            }
+            const int b0 = (16 * rt) / sq.N;  // first clip of this row tile
+            if (gated) {
+                // the full-band projection of my clips, computed here from the last full-band layer's spikes (MODEL:118 for
+                // the clips this row tile covers): gather, 4 waves x one 16-column tile, park in LDS
+                int b1 = (16 * rt + 15) / sq.N;
+                if (b1 > p.B - 1) b1 = p.B - 1;
+                const HopLayerDev& fl = fbq.layer[fbq.nl - 1];
+                for (int f = b0 / 16; f <= b1 / 16; ++f) {
+                    v4i b[HOP_KS_MAX];
+                    ok = hop_gather(fl.spikes + (size_t)t * fbq.R * fbq.KS * 64, f, fbq.R, fbq.KS, fbq.H, tagw, hbB, b, ok, p.cnt, wave, lane);
+                    if (fbp) {
+                        v4i i0 = {0, 0, 0, 0}, i1 = {0, 0, 0, 0}, i2 = {0, 0, 0, 0};
+#pragma unroll
+                        for (int ks = 0; ks < HOP_KS_MAX; ++ks)
+                            if (ks < fbq.KS) {
+                                const v4i w0 = *reinterpret_cast<const v4i*>(fbw + ((((size_t)0 * fbq.PT + wave) * fbq.KS + ks) * 64 + lane) * 16);
+                                const v4i w1 = *reinterpret_cast<const v4i*>(fbw + ((((size_t)1 * fbq.PT + wave) * fbq.KS + ks) * 64 + lane) * 16);
+                                const v4i w2 = *reinterpret_cast<const v4i*>(fbw + ((((size_t)2 * fbq.PT + wave) * fbq.KS + ks) * 64 + lane) * 16);
+                                i0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, b[ks], i0, 0, 0, 0);
+                                i1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, b[ks], i1, 0, 0, 0);
+                                i2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, b[ks], i2, 0, 0, 0);
+                            }
+                        const int clip = 16 * f + n;  // full-band row = clip
+                        if (clip >= b0 && clip <= b1) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (fcol + r < fbq.P) fbl[(clip - b0) * p.FB + fcol + r] = recombine3(i0[r], i1[r], i2[r]) * fdq[r] + fbias[r];
                         }
                     }
-                    sum += v[u];
+                    __syncthreads();  // fbl rows of this full-band tile are in place / hbB may be reused
                 }
+#pragma unroll
+                for (int ri = 0; ri < HOP_ROWS_PER_WAVE; ++ri) {
+                    const int frow = 16 * rt + wave + HOP_WAVES * ri;
+                    const int frc = frow < R ? frow : R - 1;
+                    const int b_ = frc / sq.N, k = frc - b_ * sq.N;
+#pragma unroll
+                    for (int u = 0; u < HOP_NU_MAX; ++u) {
+                        const int j = lane + 64 * u;
+                        if (j >= sq.I1 && j < I) {
+                            const int col = reflect_bin(sq.lo + k * sq.ctr_fb - sq.nbr_fb + (j - sq.I1), nf) % p.FB;
+                            v[ri][u] = fbl[(b_ - b0) * p.FB + col];
+                        }
+                    }
+                }
+            }
+            if (t == 0) HOP_STAMP(3);
+#pragma unroll
+            for (int ri = 0; ri < HOP_ROWS_PER_WAVE; ++ri) {
+                const int rl = wave + HOP_WAVES * ri;
+                if (16 * rt + rl >= R) break;
+                float sum = 0.0f;
+#pragma unroll
+                for (int u = 0; u < HOP_NU_MAX; ++u) sum += v[ri][u];
                 float y[HOP_NU_MAX];
                 if (sq.norm == SFSN_NORM_LAYERNORM) {
                     const float inv_I = 1.0f / (float)I;
@@ -278,40 +376,43 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
                     float ss = 0.0f;
 #pragma unroll
                     for (int u = 0; u < HOP_NU_MAX; ++u) {
-                        const float d = v[u] - mean;
-                        if (have[u]) ss += d * d;
+                        const float d = v[ri][u] - mean;
+                        if (lane + 64 * u < I) ss += d * d;
                     }
                     const float rstd = __builtin_amdgcn_rsqf(wave_sum(ss) * inv_I + sq.eps);
 #pragma unroll
-                    for (int u = 0; u < HOP_NU_MAX; ++u) y[u] = ((v[u] - mean) * rstd) * lw[u] + lb[u];
+                    for (int u = 0; u < HOP_NU_MAX; ++u) y[u] = ((v[ri][u] - mean) * rstd) * lw[u] + lb[u];
                 } else {
 #pragma unroll
-                    for (int u = 0; u < HOP_NU_MAX; ++u) y[u] = v[u];
+                    for (int u = 0; u < HOP_NU_MAX; ++u) y[u] = v[ri][u];
                 }
 #pragma unroll
-                for (int u = 0; u < HOP_NU_MAX; ++u)
-                    if (have[u]) xrow[rl * KPX + lane + 64 * u] = y[u];
+                for (int u = 0; u < HOP_NU_MAX; ++u) {  // the k padding of the input product must read zeros
+                    const int j = lane + 64 * u;
+                    if (j < KC * 16) xrow[rl * KPX + j] = j < I ? y[u] : 0.0f;
+                }
             }
             __syncthreads();
-            // fp32 MFMA chain in input_proj_kernel's k order: lane (n, q) holds k = 16c + 4q + e of row n
-            v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (t == 0) HOP_STAMP(4);
+            // fp32 MFMA products in input_proj_kernel's operand layout (lane (n, q) holds k = 16c + 4q + e of row n); four
+            // accumulators by chunk so that the dependent chain is a quarter as long
+            v4f acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
             const int xr = (16 * rt + n < R) ? n : (R - 1 - 16 * rt);
 #pragma unroll
             for (int cch = 0; cch < HOP_KC_MAX; ++cch)
                 if (cch < KC) {
                     const v4f bx = *reinterpret_cast<const v4f*>(xrow + xr * KPX + cch * 16 + q * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W0[cch][e], bx[e], acc, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) acc[cch & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(W0[cch][e], bx[e], acc[cch & 3], 0, 0, 0);
                 }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z[r] = acc[r] + bf[r];
+            for (int r = 0; r < 4; ++r) z[r] = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + bf[r];
         } else {
-            ok = hop_wait(p.cnt, ps->agent0 + rt * ps->ntpad, ps->ntile, (unsigned)(t + 1), lane, ok);
-            const int8_t* ssrc = sq.layer[l - 1].spikes + (size_t)t * R * HP;
             v4i b[HOP_KS_MAX];
-#pragma unroll
-            for (int ks = 0; ks < HOP_KS_MAX; ++ks)
-                if (ks < KS) b[ks] = ld16_agent(ssrc + (size_t)rowc * HP + ks * 64 + q * 16);
+            ok = hop_gather(sq.layer[l - 1].spikes + (size_t)t * R * HP, rt, R, KS, H, tagw, hbB, b, ok, p.cnt, wave, lane);
+            if (t == 0) HOP_STAMP(4);
             v4i i0 = {0, 0, 0, 0}, i1 = {0, 0, 0, 0}, i2 = {0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < HOP_KS_MAX; ++ks)
@@ -335,8 +436,8 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
             c[r] = y;
             pk |= (y >= 0.0f) ? (1u << (8 * r)) : 0u;
         }
-        if (active && row < R) st_agent(L.spikes + ((size_t)t * R + row) * HP + cc, pk);
-        if (active) hop_publish(p.cnt, agent, (unsigned)(t + 1), lane);
+        if (active && row < R) st_agent(L.spikes + ((size_t)t * R + row) * HP + cc, pk | tagw);  // data + tag: published
+        if (t == 0) HOP_STAMP(5);
     }
     if (active && row < R) {
         *reinterpret_cast<v4f*>(L.c + (size_t)row * H + cc) = c;
@@ -345,98 +446,78 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// projection role: one workgroup per row tile, its 4 waves loop over the 16-column tiles of P with the weight fragments in
-// LDS.  Full-band: fp32 rows to fb_out (read by the sub-band layer-0 agents).  Sub-band group: rows to LDS, then the deep
-// filter of the group's bins for this frame, then (after the last frame) the history shift of those bins.
-// LDS: [64 B control][W_p: 3 x PT x KS KB][16 x (P + 4) floats].
+// projection + deep filter of a sub-band group: one workgroup per row tile; wave w owns the 16-column tiles w and w + 8 of
+// P (weight fragments in registers).  Rows to LDS, then the deep filter of the tile's bins for this frame, then (after the
+// last frame) the history shift of those bins.  LDS: [64 B][hb: KS_MAX KB][16 x (P + 4) floats].
 // ---------------------------------------------------------------------------------------------------------------------
+template <bool ONE>
 __device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStageDev& sd, const HopSeqDev& sq, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     const int rt = (int)blockIdx.x - sd.wg0;
-    const int agent = sd.agent0 + rt * sd.ntpad + wave;
     const int H = sq.H, KS = sq.KS, R = sq.R, HP = KS * 64, P = sq.P, PT = sq.PT;
-    const int row = 16 * rt + n, rowc = row < R ? row : R - 1;
-    const int hop = p.hop, D = p.D, S = p.S, F = p.F;
-    const bool is_fb = sq.df == 0;
-    char* wp = smem + 64;
+    const int hop = ONE ? 1 : p.hop, D = p.D, S = p.S, F = p.F;
+    const unsigned tagw = hop_tag(p.launch) * 0x02020202u;
     const int LDP = P + 4;
-    float* pbuf = reinterpret_cast<float*>(wp + (size_t)3 * PT * KS * 1024);
+    char* hb = smem + 64;
+    float* pbuf = reinterpret_cast<float*>(hb + HOP_KS_MAX * 1024);
 
-    {  // W_p -> LDS, 16 bytes per thread per request, eight requests in flight
-        const int n16 = 3 * PT * KS * 64;
-        const v4i* src = reinterpret_cast<const v4i*>(sq.w_p);
-        v4i* dst = reinterpret_cast<v4i*>(wp);
-        for (int i0 = tid; i0 < n16; i0 += HOP_THREADS * 8) {
-            v4i v[8];
+    v4i Wp[HOP_PT_PER_WAVE][3][HOP_KS_MAX];
+    v4f dqv[HOP_PT_PER_WAVE], bv[HOP_PT_PER_WAVE];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int idx = i0 + HOP_THREADS * i;
-                if (idx > n16 - 1) idx = n16 - 1;
-                v[i] = src[idx];
-            }
+    for (int i = 0; i < HOP_PT_PER_WAVE; ++i) {
+        const int pt = wave + HOP_WAVES * i;
+        const bool have = pt < PT;
+        const int col = (have ? pt : 0) * 16 + q * 4;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int idx = i0 + HOP_THREADS * i;
-                if (idx < n16) dst[idx] = v[i];
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int ks = 0; ks < HOP_KS_MAX; ++ks) {
+                Wp[i][d][ks] = v4i{0, 0, 0, 0};
+                if (have && ks < KS) Wp[i][d][ks] = *reinterpret_cast<const v4i*>(sq.w_p + ((((size_t)d * PT + pt) * KS + ks) * 64 + lane) * 16);
             }
-        }
-        __syncthreads();
+        dqv[i] = *reinterpret_cast<const v4f*>(sq.w_p_dq + col);  // padded to PT * 16
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[i][r] = col + r < P ? sq.b_p[col + r] : 0.0f;
     }
-    const HopStageDev& ps = p.st[sd.prod];
+    HOP_STAMP(1);
     const HopLayerDev& last = sq.layer[sq.nl - 1];
     bool ok = true;
 
     for (int t = 0; t < hop; ++t) {
-        ok = hop_wait(p.cnt, ps.agent0 + rt * ps.ntpad, ps.ntile, (unsigned)(t + 1), lane, ok);
-        const int8_t* ssrc = last.spikes + (size_t)t * R * HP;
         v4i b[HOP_KS_MAX];
+        // (for t > 0 the barrier inside also orders the previous frame's deep-filter reads of pbuf before the writes below)
+        ok = hop_gather(last.spikes + (size_t)t * R * HP, rt, R, KS, H, tagw, hb, b, ok, p.cnt, wave, lane);
+        if (t == 0) HOP_STAMP(4);
 #pragma unroll
-        for (int ks = 0; ks < HOP_KS_MAX; ++ks)
-            if (ks < KS) b[ks] = ld16_agent(ssrc + (size_t)rowc * HP + ks * 64 + q * 16);
-        if (!is_fb && t > 0) __syncthreads();  // the previous frame's deep filter has read pbuf
-        for (int pt = wave; pt < PT; pt += HOP_WAVES) {
+        for (int i = 0; i < HOP_PT_PER_WAVE; ++i) {
+            const int pt = wave + HOP_WAVES * i;
+            if (pt >= PT) break;
             v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < HOP_KS_MAX; ++ks)
                 if (ks < KS) {
-                    const v4i w0 = *reinterpret_cast<const v4i*>(wp + ((((size_t)0 * PT + pt) * KS + ks) * 64 + lane) * 16);
-                    const v4i w1 = *reinterpret_cast<const v4i*>(wp + ((((size_t)1 * PT + pt) * KS + ks) * 64 + lane) * 16);
-                    const v4i w2 = *reinterpret_cast<const v4i*>(wp + ((((size_t)2 * PT + pt) * KS + ks) * 64 + lane) * 16);
-                    a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, b[ks], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, b[ks], a1, 0, 0, 0);
-                    a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, b[ks], a2, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wp[i][0][ks], b[ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wp[i][1][ks], b[ks], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wp[i][2][ks], b[ks], a2, 0, 0, 0);
                 }
             const int col = pt * 16 + q * 4;
-            const v4f dq = *reinterpret_cast<const v4f*>(sq.w_p_dq + col);  // padded to PT * 16
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float bias = col + r < P ? sq.b_p[col + r] : 0.0f;
-                const float o = recombine3(a0[r], a1[r], a2[r]) * dq[r] + bias;
-                if (col + r < P) {
-                    if (is_fb) {
-                        if (row < R) st_agent(p.fb_out + ((size_t)t * p.B + row) * p.FB + col + r, __float_as_uint(o));
-                    } else {
-                        pbuf[n * LDP + col + r] = o;
-                    }
-                }
-            }
+            for (int r = 0; r < 4; ++r)
+                if (col + r < P) pbuf[n * LDP + col + r] = recombine3(a0[r], a1[r], a2[r]) * dqv[i][r] + bv[i][r];
         }
-        if (is_fb) {
-            hop_publish(p.cnt, agent, (unsigned)(t + 1), lane);
-            continue;
-        }
+        if (t == 0) HOP_STAMP(5);
         __syncthreads();
         // ---- deep filter of this row tile's bins for frame t (deepfilter_kernel's expressions and tap order)
         const int fc = sq.fc, df = sq.df, nrow = (R - 16 * rt) < 16 ? (R - 16 * rt) : 16;
         for (int idx = tid; idx < nrow * fc; idx += HOP_THREADS) {
             const int rl = idx / fc, fci = idx - rl * fc;
-            const int frow = 16 * rt + rl, b = frow / sq.N, k = frow - b * sq.N;
+            const int frow = 16 * rt + rl, b_ = frow / sq.N, k = frow - b_ * sq.N;
             const int f = sq.lo + k * fc + fci;
             const float* pr = pbuf + rl * LDP;
-            const float* hrow = p.hist + ((size_t)b * F + f) * D * 2;
-            const float* irow = p.inp + ((size_t)b * F + f) * hop * 2;
+            const float* hrow = p.hist + ((size_t)b_ * F + f) * D * 2;
+            const float* irow = p.inp + ((size_t)b_ * F + f) * hop * 2;
             for (int s = 0; s < S; ++s) {
                 float yr = 0.0f, yi = 0.0f;
                 for (int d = 0; d < df; ++d) {
@@ -448,7 +529,7 @@ __device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStage
                     yr += xv.x * cr - xv.y * ci;
                     yi += xv.x * ci + xv.y * cr;
                 }
-                const size_t o = (((size_t)b * S + s) * F + f) * hop + t;
+                const size_t o = (((size_t)b_ * S + s) * F + f) * hop + t;
                 *reinterpret_cast<float2*>(p.enh + 2 * o) = make_float2(yr, yi);
                 if (p.mag) p.mag[o] = fast_abs2(yr, yi);
             }
@@ -456,25 +537,26 @@ __device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStage
         // bins no group covers (at least the Nyquist bin) pass through (MODEL:461-470): the first group's first workgroup
         if (sd.seq == 1 && rt == 0)
             for (int idx = tid; idx < p.B * (F - p.fcov); idx += HOP_THREADS) {
-                const int b = idx / (F - p.fcov), f = p.fcov + idx - b * (F - p.fcov);
-                const float2 xv = *reinterpret_cast<const float2*>(p.inp + (((size_t)b * F + f) * hop + t) * 2);
+                const int b_ = idx / (F - p.fcov), f = p.fcov + idx - b_ * (F - p.fcov);
+                const float2 xv = *reinterpret_cast<const float2*>(p.inp + (((size_t)b_ * F + f) * hop + t) * 2);
                 for (int s = 0; s < S; ++s) {
-                    const size_t o = (((size_t)b * S + s) * F + f) * hop + t;
+                    const size_t o = (((size_t)b_ * S + s) * F + f) * hop + t;
                     *reinterpret_cast<float2*>(p.enh + 2 * o) = xv;
                     if (p.mag) p.mag[o] = fast_abs2(xv.x, xv.y);
                 }
             }
+        if (t == 0) HOP_STAMP(6);
     }
-    if (is_fb || D == 0) return;
+    if (D == 0) return;
     // ---- history of my bins: the last D of [old history | new frames]; one thread owns a bin, ascending order reads ahead
     __syncthreads();
     const int fc = sq.fc, nrow = (R - 16 * rt) < 16 ? (R - 16 * rt) : 16;
     for (int idx = tid; idx < nrow * fc; idx += HOP_THREADS) {
         const int rl = idx / fc, fci = idx - rl * fc;
-        const int frow = 16 * rt + rl, b = frow / sq.N, k = frow - b * sq.N;
+        const int frow = 16 * rt + rl, b_ = frow / sq.N, k = frow - b_ * sq.N;
         const int f = sq.lo + k * fc + fci;
-        float* hrow = p.hist + ((size_t)b * F + f) * D * 2;
-        const float* irow = p.inp + ((size_t)b * F + f) * hop * 2;
+        float* hrow = p.hist + ((size_t)b_ * F + f) * D * 2;
+        const float* irow = p.inp + ((size_t)b_ * F + f) * hop * 2;
         for (int i = 0; i < D; ++i) {
             const int src = i + hop;
             const float2 v = src < D ? *reinterpret_cast<const float2*>(hrow + 2 * src) : *reinterpret_cast<const float2*>(irow + 2 * (src - D));
@@ -483,23 +565,23 @@ __device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStage
     }
 }
 
+template <bool ONE>
 __global__ __launch_bounds__(HOP_THREADS) void stream_hop_kernel(const HopParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int si = 0;
-    for (int i = 0; i < p.nstage; ++i)
-        if ((int)blockIdx.x >= p.st[i].wg0) si = i;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    HOP_STAMP(0);
+    const int si = (int)((p.stage_of_block[blockIdx.x >> 2] >> (8 * (blockIdx.x & 3))) & 0xffu);
     const HopStageDev& sd = p.st[si];
     const HopSeqDev& sq = p.seq[sd.seq];
-    const unsigned epoch = ld_agent(p.cnt + 2);
     if (sd.layer >= 0) {
         if (sd.layer == 0)
-            hop_layer_role<true>(p, sd, sq, smem, epoch);
+            hop_layer_role<true, ONE>(p, sd, sq, smem);
         else
-            hop_layer_role<false>(p, sd, sq, smem, epoch);
+            hop_layer_role<false, ONE>(p, sd, sq, smem);
     } else {
-        hop_proj_role(p, sd, sq, smem);
+        hop_proj_role<ONE>(p, sd, sq, smem);
     }
-    hop_exit(p, reinterpret_cast<int*>(smem));
+    HOP_STAMP(7);
 }
 
 // =====================================================================================================================
@@ -531,9 +613,9 @@ static int hop_fill_seq(HopSeqDev& d, const sfsn_hop_seq& s, int B, int F, int S
     for (int l = 0; l < s.n_layers; ++l) {
         const sfsn_hop_layer& L = s.layer[l];
         if (!L.w_hh || !L.w_hh_dq || !L.bias || !L.bn_alpha || !L.bn_beta || !L.h[0] || !L.h[1] || !L.c || !L.spikes) return SFSN_EINVAL;
-        if (l == 0 ? !L.w_ih_f32 : (!L.w_ih || !L.w_ih_dq)) return SFSN_EINVAL;
+        if (l == 0 ? !L.w_ih_frag : (!L.w_ih || !L.w_ih_dq)) return SFSN_EINVAL;
         HopLayerDev& o = d.layer[l];
-        o.w_ih_f32 = L.w_ih_f32; o.w_ih = L.w_ih; o.w_ih_dq = L.w_ih_dq; o.w_hh = L.w_hh; o.w_hh_dq = L.w_hh_dq; o.bias = L.bias;
+        o.w_ih_f32 = L.w_ih_frag; o.w_ih = L.w_ih; o.w_ih_dq = L.w_ih_dq; o.w_hh = L.w_hh; o.w_hh_dq = L.w_hh_dq; o.bias = L.bias;
         o.alpha = L.bn_alpha; o.beta = L.bn_beta; o.h[0] = L.h[0]; o.h[1] = L.h[1]; o.c = L.c; o.spikes = L.spikes;
     }
     return SFSN_OK;
@@ -542,10 +624,10 @@ static int hop_fill_seq(HopSeqDev& d, const sfsn_hop_seq& s, int B, int F, int S
 static int hop_plan(HopParams& p, size_t& lds, const sfsn_hop_desc* d) {
     if (!d || d->n_groups < 1 || d->n_groups > SFSN_HOP_MAX_GROUPS) return d ? SFSN_EUNSUPPORTED : SFSN_EINVAL;
     if (d->B <= 0 || d->F < 2 || d->S < 1 || d->hop < 1 || d->D < 0 || d->D + d->hop > 32) return SFSN_EUNSUPPORTED;
-    if (!d->inp_ri || !d->fb_out || !d->enh_ri || (d->D > 0 && !d->hist_ri)) return SFSN_EINVAL;
+    if (!d->inp_ri || !d->enh_ri || (d->D > 0 && !d->hist_ri)) return SFSN_EINVAL;
     memset(&p, 0, sizeof(p));
     p.B = d->B; p.F = d->F; p.S = d->S; p.hop = d->hop; p.D = d->D; p.FB = d->fb.P; p.fdrc = d->fdrc;
-    p.inp = d->inp_ri; p.hist = d->hist_ri; p.fb_out = d->fb_out; p.enh = d->enh_ri; p.mag = d->enh_mag;
+    p.inp = d->inp_ri; p.hist = d->hist_ri; p.enh = d->enh_ri; p.mag = d->enh_mag;
     p.nseq = 1 + d->n_groups;
     int rc = hop_fill_seq(p.seq[0], d->fb, d->B, d->F, d->S, true, 0);
     if (rc != SFSN_OK) return rc;
@@ -560,66 +642,42 @@ static int hop_plan(HopParams& p, size_t& lds, const sfsn_hop_desc* d) {
     }
     if (dmax - 1 > d->D || fcov > d->F) return SFSN_EINVAL;
     p.fcov = fcov;
-    // stages in dependency order: producers get the lower block indices
-    int ns = 0, wg = 0, ag = 0;
-    lds = 64;
-    auto add_layers = [&](int si_seq, int prod0) {
+    if (p.seq[0].PT > HOP_WAVES) return SFSN_EUNSUPPORTED;  // the sub-band layer-0 workgroups compute it with one tile per wave
+    // stages in dependency order: producers get the lower block indices.  Sub-band stages go layer by layer over all groups
+    // (the groups' layer-0 workgroups all wait for the same full-band layer).
+    int ns = 0, wg = 0;
+    auto add = [&](int si_seq, int layer) {
         const HopSeqDev& q = p.seq[si_seq];
-        const int nrt = (q.R + 15) / 16;
-        int prev = prod0;
-        for (int l = 0; l < q.nl; ++l) {
-            HopStageDev& s = p.st[ns];
-            s.seq = si_seq; s.layer = l; s.ntile = q.NT; s.ntpad = (q.NT + HOP_WAVES - 1) / HOP_WAVES * HOP_WAVES; s.nrt = nrt;
-            s.wg0 = wg; s.nwg = nrt * s.ntpad / HOP_WAVES; s.agent0 = ag; s.prod = prev;
-            wg += s.nwg; ag += nrt * s.ntpad;
-            prev = ns++;
-            if (l == 0) {
-                const size_t need = 64 + (size_t)16 * (q.KC * 16 + 4) * sizeof(float);
-                if (need > lds) lds = need;
-            }
-        }
-        return prev;
+        HopStageDev& s = p.st[ns++];
+        s.seq = si_seq; s.layer = layer; s.nrt = (q.R + 15) / 16;
+        s.ntile = layer >= 0 ? q.NT : HOP_WAVES;
+        s.ntpad = (s.ntile + HOP_WAVES - 1) / HOP_WAVES * HOP_WAVES;
+        s.wg0 = wg; s.nwg = s.nrt * s.ntpad / HOP_WAVES;
+        wg += s.nwg;
     };
-    auto add_proj = [&](int si_seq, int prod) {
-        const HopSeqDev& q = p.seq[si_seq];
-        const int nrt = (q.R + 15) / 16;
-        HopStageDev& s = p.st[ns];
-        s.seq = si_seq; s.layer = -1; s.ntile = HOP_WAVES; s.ntpad = HOP_WAVES; s.nrt = nrt;
-        s.wg0 = wg; s.nwg = nrt; s.agent0 = ag; s.prod = prod;
-        wg += s.nwg; ag += nrt * HOP_WAVES;
-        const size_t need = 64 + (size_t)3 * q.PT * q.KS * 1024 + (size_t)16 * (q.P + 4) * sizeof(float);
-        if (need > lds) lds = need;
-        return ns++;
-    };
-    const int fb_last = add_layers(0, -1);
-    const int fb_proj = add_proj(0, fb_last);
-    // sub-band stages layer by layer over all groups (the groups' layer-0 agents all wait for the same full-band projection)
-    int prev[SFSN_HOP_MAX_GROUPS];
-    int maxl = 0;
-    for (int g = 0; g < d->n_groups; ++g) {
-        prev[g] = fb_proj;
-        if (p.seq[1 + g].nl > maxl) maxl = p.seq[1 + g].nl;
+    int maxl = 0, kcmax = 0, pmax = 0;
+    for (int i = 0; i < p.nseq; ++i) {
+        if (i > 0 && p.seq[i].nl > maxl) maxl = p.seq[i].nl;
+        if (p.seq[i].KC > kcmax) kcmax = p.seq[i].KC;
+        if (i > 0 && p.seq[i].P > pmax) pmax = p.seq[i].P;
     }
+    for (int l = 0; l < p.seq[0].nl; ++l) add(0, l);
     for (int l = 0; l < maxl; ++l)
-        for (int g = 0; g < d->n_groups; ++g) {
-            const HopSeqDev& q = p.seq[1 + g];
-            if (l >= q.nl) continue;
-            const int nrt = (q.R + 15) / 16;
-            HopStageDev& s = p.st[ns];
-            s.seq = 1 + g; s.layer = l; s.ntile = q.NT; s.ntpad = (q.NT + HOP_WAVES - 1) / HOP_WAVES * HOP_WAVES; s.nrt = nrt;
-            s.wg0 = wg; s.nwg = nrt * s.ntpad / HOP_WAVES; s.agent0 = ag; s.prod = prev[g];
-            wg += s.nwg; ag += nrt * s.ntpad;
-            prev[g] = ns++;
-            if (l == 0) {
-                const size_t need = 64 + (size_t)16 * (q.KC * 16 + 4) * sizeof(float);
-                if (need > lds) lds = need;
-            }
-        }
-    for (int g = 0; g < d->n_groups; ++g) add_proj(1 + g, prev[g]);
-    p.nstage = ns; p.nblocks = wg; p.nagents = ag;
-    if (lds > 160 * 1024) return SFSN_EUNSUPPORTED;  // all of a CU's LDS
+        for (int g = 0; g < d->n_groups; ++g)
+            if (l < p.seq[1 + g].nl) add(1 + g, l);
+    for (int g = 0; g < d->n_groups; ++g) add(1 + g, -1);
+    p.nstage = ns; p.nblocks = wg;
+    if (wg > HOP_MAX_BLOCKS) return SFSN_EUNSUPPORTED;
+    for (int i = 0; i < ns; ++i)
+        for (int b = p.st[i].wg0; b < p.st[i].wg0 + p.st[i].nwg; ++b) p.stage_of_block[b >> 2] |= (unsigned)i << (8 * (b & 3));
+    const size_t lds_layer = 64 + (size_t)2 * HOP_KS_MAX * 1024 + ((size_t)16 * p.FB + (size_t)16 * (kcmax * 16 + 4)) * sizeof(float) +
+                             (size_t)3 * p.seq[0].PT * p.seq[0].KS * 1024;
+    const size_t lds_proj = 64 + (size_t)HOP_KS_MAX * 1024 + (size_t)16 * (pmax + 4) * sizeof(float);
+    lds = lds_layer > lds_proj ? lds_layer : lds_proj;
     return SFSN_OK;
 }
+
+static size_t hop_counter_bytes(const HopParams&) { return 64; }
 
 // every workgroup must be resident at once (peers of a stage wait for each other): one per compute unit at most
 static int hop_fits_device(int nblocks) {
@@ -634,7 +692,18 @@ extern "C" size_t sfsn_hop_scratch_bytes(const sfsn_hop_desc* desc) {
     size_t lds;
     if (hop_plan(p, lds, desc) != SFSN_OK) return 0;
     if (hop_fits_device(p.nblocks) == SFSN_EUNSUPPORTED) return 0;  // (no device at all: the launch reports it)
-    return (size_t)(HOP_CNT0 + p.nagents + 16) * sizeof(unsigned);
+    return hop_counter_bytes(p) + (size_t)p.nblocks * HOP_WAVES * 8 * sizeof(unsigned long long);
+}
+
+extern "C" int sfsn_hop_stages(const sfsn_hop_desc* desc, int* out, int cap) {
+    HopParams p;
+    size_t lds;
+    const int rc = hop_plan(p, lds, desc);
+    if (rc != SFSN_OK) return rc;
+    for (int i = 0; i < p.nstage && i < cap; ++i) {
+        out[4 * i + 0] = p.st[i].seq; out[4 * i + 1] = p.st[i].layer; out[4 * i + 2] = p.st[i].wg0; out[4 * i + 3] = p.st[i].nwg;
+    }
+    return p.nstage;
 }
 
 extern "C" int sfsn_stream_hop(const sfsn_hop_desc* desc, void* stream) {
@@ -642,19 +711,26 @@ extern "C" int sfsn_stream_hop(const sfsn_hop_desc* desc, void* stream) {
     size_t lds;
     const int rc = hop_plan(local, lds, desc);
     if (rc != SFSN_OK) return rc;
-    if (!desc->scratch || desc->scratch_bytes < (size_t)(HOP_CNT0 + local.nagents) * sizeof(unsigned)) return SFSN_EINVAL;
+    if (!desc->scratch || desc->scratch_bytes < hop_counter_bytes(local) + (size_t)local.nblocks * HOP_WAVES * 64) return SFSN_EINVAL;
     local.cnt = static_cast<unsigned*>(desc->scratch);
+    local.launch = desc->launch_index;
+    // per-wave time stamps behind the control words (written by -DSFSN_HOP_STAMPS builds only; scripts/exp_hop.py reads them)
+    local.dbg = reinterpret_cast<unsigned long long*>(static_cast<char*>(desc->scratch) + hop_counter_bytes(local));
     int dev = 0;
     const int fit = hop_fits_device(local.nblocks);
     if (fit != SFSN_OK) return fit;
     if (hipGetDevice(&dev) != hipSuccess) return SFSN_EHIP;
-    static int lds_set[64];
-    if (lds > 64 * 1024 && dev < 64 && lds_set[dev] < (int)lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stream_hop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-            hipSuccess)
-            return SFSN_EHIP;
-        lds_set[dev] = 160 * 1024;
+    static int lds_set[2][64];
+    const int one = local.hop == 1 ? 1 : 0;
+    const void* kern = one ? reinterpret_cast<const void*>(stream_hop_kernel<true>) : reinterpret_cast<const void*>(stream_hop_kernel<false>);
+    if (lds > 64 * 1024 && dev < 64 && !lds_set[one][dev]) {
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SFSN_EHIP;
+        lds_set[one][dev] = 1;
     }
-    hipLaunchKernelGGL(stream_hop_kernel, dim3(local.nblocks), dim3(HOP_THREADS), lds, static_cast<hipStream_t>(stream), local);
+    if (lds > 160 * 1024) return SFSN_EUNSUPPORTED;
+    if (one)
+        hipLaunchKernelGGL(stream_hop_kernel<true>, dim3(local.nblocks), dim3(HOP_THREADS), lds, static_cast<hipStream_t>(stream), local);
+    else
+        hipLaunchKernelGGL(stream_hop_kernel<false>, dim3(local.nblocks), dim3(HOP_THREADS), lds, static_cast<hipStream_t>(stream), local);
     return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;
 }

@@ -97,7 +97,8 @@ class StreamingSession:
         if not spec.shared or ng > HOP_MAX_GROUPS or max(spec.fb_layers, spec.sb_layers) > HOP_MAX_LAYERS or D + hop > 32:
             return None
         desc = HopDesc()
-        keep = []  # tensors the descriptor points into
+        keep = []        # state tensors the descriptor points into (zeroed by reset())
+        keep_const = []  # re-laid-out weights
 
         def zeros(shape, dtype):
             t = torch.zeros(shape, dtype=dtype, device=dev)
@@ -110,8 +111,13 @@ class StreamingSession:
             dst.w_p, dst.w_p_dq, dst.b_p = _ptr(seq.proj_q), _ptr(seq.proj_dq), _ptr(seq.proj_b)
             for l, cell in enumerate(seq.cells):
                 o = dst.layer[l]
-                if l == 0:
-                    o.w_ih_f32 = _ptr(cell.w_ih_f32)
+                if l == 0:  # fp32 input weights in MFMA fragment order (include/sfsn.h): one coalesced request per 16 columns
+                    w = cell.w_ih_f32
+                    kc = (w.shape[1] + 15) // 16
+                    w = torch.nn.functional.pad(w, (0, kc * 16 - w.shape[1]))
+                    frag = w.view(seq.H // 16, 16, kc, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+                    keep_const.append(frag)
+                    o.w_ih_frag = _ptr(frag)
                 else:
                     o.w_ih, o.w_ih_dq = _ptr(cell.w_ih_q[0][0]), _ptr(cell.w_ih_q[0][1])
                 o.w_hh, o.w_hh_dq, o.bias, o.bn_alpha, o.bn_beta = (_ptr(cell.w_hh_q), _ptr(cell.w_hh_dq), _ptr(cell.bias), _ptr(cell.alpha),
@@ -125,7 +131,7 @@ class StreamingSession:
         desc.n_groups, desc.B, desc.F, desc.S, desc.hop, desc.D, desc.fdrc = ng, B, F, S, hop, D, spec.fdrc
         hist = zeros((B, F, max(D, 1)), torch.complex64)
         enh, mag = zeros((B, S, F, hop), torch.complex64), zeros((B, S, F, hop), torch.float32)
-        desc.inp_ri, desc.hist_ri, desc.fb_out = _ptr(self.inp), _ptr(hist), _ptr(zeros((hop, B, spec.fb_proj), torch.float32))
+        desc.inp_ri, desc.hist_ri = _ptr(self.inp), _ptr(hist)
         desc.enh_ri, desc.enh_mag = _ptr(enh), _ptr(mag)
         nb = L.sfsn_hop_scratch_bytes(ctypes.byref(desc))
         if nb == 0:
@@ -134,7 +140,7 @@ class StreamingSession:
         desc.scratch, desc.scratch_bytes = _ptr(scratch), nb
         # the error word of a launch is looked at, without blocking, at the next step (pinned copy behind the launch)
         err = torch.zeros((1,), dtype=torch.int32).pin_memory()
-        return dict(desc=desc, keep=keep, hist=hist, enh=enh, mag=mag, scratch=scratch, err=err, err_pending=False)
+        return dict(desc=desc, keep=keep, keep_const=keep_const, hist=hist, enh=enh, mag=mag, scratch=scratch, err=err, err_pending=False)
 
     # -----------------------------------------------------------------------------------------------------------------
     def reset(self) -> None:
@@ -151,10 +157,8 @@ class StreamingSession:
         self.hist.zero_()
         if self._hop is not None:
             self.check_errors()
-            scratch = self._hop["scratch"]
             for t in self._hop["keep"]:
-                if t is not scratch:  # the launch counter (parity of the double-buffered spikes) lives on
-                    t.zero_()
+                t.zero_()
         self.frames_done = 0
 
     def check_errors(self) -> None:
@@ -245,6 +249,7 @@ class StreamingSession:
             with torch.cuda.device(self.dev):
                 check(self.eng.lib.sfsn_stream_hop(ctypes.byref(h["desc"]), ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)),
                       "sfsn_stream_hop")
+            h["desc"].launch_index += 1
             self.frames_done += self.hop
             if self.frames_done % 256 < self.hop:  # every ~256 frames: the error word follows the launch into pinned memory
                 h["err"].copy_(h["scratch"][:1], non_blocking=True)
