@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--streaming", action="store_true", help="BASELINE configs[4]: frame-by-frame session, per-call latency (own JSON line)")
     ap.add_argument("--hop", type=int, default=1, help="frames per streaming call")
     ap.add_argument("--no-graph", action="store_true", help="streaming: launch the kernels one by one instead of replaying the HIP graph")
+    ap.add_argument("--no-one-launch", action="store_true", help="streaming: the offline kernels per hop (HIP graph) instead of sfsn_stream_hop")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -356,20 +357,25 @@ def streaming_bench(args, model, dev, world, rank):
     B = args.batch if args.batch != 64 else 1
     hop, steps, warmup = args.hop, max(args.steps, 2000), max(args.warmup, 200)
     rpw = tuple(int(v) for v in args.rpw.split(",")) if args.rpw else None
-    sess = model.streaming(batch=B, hop=hop, graph=not args.no_graph, rows_per_wg=rpw)
+    sess = model.streaming(batch=B, hop=hop, graph=not args.no_graph, rows_per_wg=rpw, one_launch=False if args.no_one_launch else "auto")
+    one_launch = sess._hop is not None
     g = torch.Generator(device="cpu").manual_seed(3)
     frames = (0.05 * torch.randn((steps + warmup, B, 257, hop, 2), generator=g)).to(dev)
     frames = torch.view_as_complex(frames)
-    lat = []
+    lat, enq = [], []
     for i in range(steps + warmup):
         x = frames[i]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         sess.step(x, copy=False)
+        t1 = time.perf_counter()
         torch.cuda.synchronize()
         if i >= warmup:
             lat.append(time.perf_counter() - t0)
+            enq.append(t1 - t0)
     lat = np.sort(np.asarray(lat)) * 1e6
+    enq = np.sort(np.asarray(enq)) * 1e6
+    sess.check_errors()
     # throughput of back-to-back calls without a host sync per call (the graph replays queue up)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -384,7 +390,12 @@ def streaming_bench(args, model, dev, world, rank):
             "ms_per_step": round(float(lat.mean()) / 1e3, 4), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (0.05*randn complex frames; seeded random weights, randomised BN stats)",
             "config": {"workload": "configs[4]: streaming, live baseline_m sizes, fp32 parity mode", "clips_per_gpu": B, "hop_frames": hop,
-                       "hip_graph": not args.no_graph, "p99_us": round(float(lat[int(len(lat) * 0.99)]), 1),
+                       "schedule": ("one launch per hop (sfsn_stream_hop: a wave per layer tile, frame handed from stage to stage through L2)"
+                                    if one_launch else "the offline kernels per hop, replayed from a HIP graph" if not args.no_graph
+                                    else "the offline kernels per hop, launched one by one"),
+                       "one_launch": one_launch, "hip_graph": (not args.no_graph) and not one_launch,
+                       "host_enqueue_p50_us": round(float(enq[len(enq) // 2]), 1),
+                       "p99_us": round(float(lat[int(len(lat) * 0.99)]), 1),
                        "min_us": round(float(lat[0]), 1), "unsynchronised_calls_per_s": round(steps / dt, 1),
                        "real_time_factor_at_8ms_hop": round(8e3 * hop / float(lat[len(lat) // 2]), 1)}}))
 

@@ -68,3 +68,29 @@ if os.environ.get("SFSN_HOP_DEBUG"):
         u = u[st[wg0:wg0 + n].reshape(-1, 8)[:, 7] > 0]  # waves that ran
         lab = ("fb" if seq == 0 else "sb%d" % (seq - 1)) + (" L%d" % layer if layer >= 0 else " proj")
         print("%-16s %3d  " % (lab, n) + "  ".join(("%4.1f-%4.1f" % (u[:, j].min(), u[:, j].max()) if u[:, j].min() > -1 else "    -    ") for j in range(8)))
+
+# where the host time goes: enqueue alone, enqueue + blocking sync, enqueue + spinning on an event
+sess = model.streaming(batch=B, hop=hop, one_launch=True)
+ev = torch.cuda.Event()
+def timeit(fn, n=1500, skip=300):
+    ts = []
+    for i in range(n):
+        x = frames[i % len(frames)]
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        fn(x)
+        ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+    ts = np.sort(np.array(ts[skip:])) * 1e6
+    return ts[len(ts) // 2]
+def f_enq(x): sess.step(x, copy=False)
+def f_sync(x): sess.step(x, copy=False); torch.cuda.synchronize()
+def f_ssync(x): sess.step(x, copy=False); torch.cuda.current_stream().synchronize()
+def f_spin(x):
+    sess.step(x, copy=False); ev.record()
+    while not ev.query(): pass
+print("host: enqueue %.1f us | + device sync %.1f | + stream sync %.1f | + event spin %.1f" % (timeit(f_enq), timeit(f_sync), timeit(f_ssync), timeit(f_spin)))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for i in range(2000): sess.step(frames[i % len(frames)], copy=False)
+pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(8)

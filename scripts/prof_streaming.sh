@@ -9,7 +9,7 @@ import csv
 rows=list(csv.DictReader(open('gpurun_out/prof_stream/t/s_kernel_trace.csv')))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # take a window late in the run: find the last hist_shift occurrences
-idx=[i for i,r in enumerate(rows) if 'hist_shift' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'hist_shift' in r['Kernel_Name'] or 'stream_hop' in r['Kernel_Name']]
 a,b=idx[-3],idx[-2]
 t0=int(rows[a]['Start_Timestamp'])
 for r in rows[a:b+1]:

@@ -46,6 +46,7 @@
 #define HOP_NU_MAX 3     // feature slots per lane: I <= 192
 #define HOP_ROWS_PER_WAVE (16 / HOP_WAVES)
 #define HOP_PT_PER_WAVE 2  // P <= 256
+#define HOP_DF_MAX 8      // deep-filter taps held in registers by the one-frame fast path (D + 1 <= 8)
 #define HOP_SPIN_LIMIT 2000000u
 #define HOP_MAX_BLOCKS 256  // workgroups per launch (one per compute unit at most)
 
@@ -484,6 +485,35 @@ __device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStage
     HOP_STAMP(1);
     const HopLayerDev& last = sq.layer[sq.nl - 1];
     bool ok = true;
+    const int fc = sq.fc, df = sq.df, nrow = (R - 16 * rt) < 16 ? (R - 16 * rt) : 16;
+
+    // ---- what does not depend on the network happens before the wait: the pass-through bins, and (hop == 1, the usual shape:
+    // one bin per thread, df <= HOP_DF_MAX) this thread's deep-filter taps into registers
+    if (sd.seq == 1 && rt == 0)  // bins no group covers (at least the Nyquist bin) pass through (MODEL:461-470)
+        for (int idx = tid; idx < p.B * (F - p.fcov) * hop; idx += HOP_THREADS) {
+            const int t = idx % hop, r_ = idx / hop;
+            const int b_ = r_ / (F - p.fcov), f = p.fcov + r_ - b_ * (F - p.fcov);
+            const float2 xv = *reinterpret_cast<const float2*>(p.inp + (((size_t)b_ * F + f) * hop + t) * 2);
+            for (int s = 0; s < S; ++s) {
+                const size_t o = (((size_t)b_ * S + s) * F + f) * hop + t;
+                *reinterpret_cast<float2*>(p.enh + 2 * o) = xv;
+                if (p.mag) p.mag[o] = fast_abs2(xv.x, xv.y);
+            }
+        }
+    const bool fast = ONE && nrow * fc <= HOP_THREADS && D <= HOP_DF_MAX - 1;
+    float2 tap[HOP_DF_MAX];  // [old history (D) | new frame]
+    if (fast && tid < nrow * fc) {
+        const int rl = tid / fc, fci = tid - rl * fc;
+        const int frow = 16 * rt + rl, b_ = frow / sq.N, k = frow - b_ * sq.N;
+        const int f = sq.lo + k * fc + fci;
+        const float* hrow = p.hist + ((size_t)b_ * F + f) * D * 2;
+#pragma unroll
+        for (int i = 0; i < HOP_DF_MAX; ++i) {
+            tap[i] = make_float2(0.0f, 0.0f);
+            if (i < D) tap[i] = *reinterpret_cast<const float2*>(hrow + 2 * i);
+            if (i == D) tap[i] = *reinterpret_cast<const float2*>(p.inp + ((size_t)b_ * F + f) * 2);
+        }
+    }
 
     for (int t = 0; t < hop; ++t) {
         v4i b[HOP_KS_MAX];
@@ -510,7 +540,36 @@ __device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStage
         if (t == 0) HOP_STAMP(5);
         __syncthreads();
         // ---- deep filter of this row tile's bins for frame t (deepfilter_kernel's expressions and tap order)
-        const int fc = sq.fc, df = sq.df, nrow = (R - 16 * rt) < 16 ? (R - 16 * rt) : 16;
+        if (fast) {
+            if (tid < nrow * fc) {
+                const int rl = tid / fc, fci = tid - rl * fc;
+                const int frow = 16 * rt + rl, b_ = frow / sq.N, k = frow - b_ * sq.N;
+                const int f = sq.lo + k * fc + fci;
+                const float* pr = pbuf + rl * LDP;
+                for (int s = 0; s < S; ++s) {
+                    float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < HOP_DF_MAX; ++i) {  // tap i of [history | frame] is filter tap d = i - (D - (df - 1))
+                        const int d = i - (D - (df - 1));
+                        if (d >= 0 && i <= D) {
+                            const float cr = pr[((0 * fc + fci) * df + d) * S + s];
+                            const float ci = pr[((1 * fc + fci) * df + d) * S + s];
+                            yr += tap[i].x * cr - tap[i].y * ci;
+                            yi += tap[i].x * ci + tap[i].y * cr;
+                        }
+                    }
+                    const size_t o = ((size_t)b_ * S + s) * F + f;
+                    *reinterpret_cast<float2*>(p.enh + 2 * o) = make_float2(yr, yi);
+                    if (p.mag) p.mag[o] = fast_abs2(yr, yi);
+                }
+                float* hrow = p.hist + ((size_t)b_ * F + f) * D * 2;  // history: drop the oldest frame, append the new one
+#pragma unroll
+                for (int i = 0; i < HOP_DF_MAX - 1; ++i)
+                    if (i < D) *reinterpret_cast<float2*>(hrow + 2 * i) = tap[i + 1];
+            }
+            if (t == 0) HOP_STAMP(6);
+            continue;
+        }
         for (int idx = tid; idx < nrow * fc; idx += HOP_THREADS) {
             const int rl = idx / fc, fci = idx - rl * fc;
             const int frow = 16 * rt + rl, b_ = frow / sq.N, k = frow - b_ * sq.N;
@@ -534,23 +593,11 @@ __device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStage
                 if (p.mag) p.mag[o] = fast_abs2(yr, yi);
             }
         }
-        // bins no group covers (at least the Nyquist bin) pass through (MODEL:461-470): the first group's first workgroup
-        if (sd.seq == 1 && rt == 0)
-            for (int idx = tid; idx < p.B * (F - p.fcov); idx += HOP_THREADS) {
-                const int b_ = idx / (F - p.fcov), f = p.fcov + idx - b_ * (F - p.fcov);
-                const float2 xv = *reinterpret_cast<const float2*>(p.inp + (((size_t)b_ * F + f) * hop + t) * 2);
-                for (int s = 0; s < S; ++s) {
-                    const size_t o = (((size_t)b_ * S + s) * F + f) * hop + t;
-                    *reinterpret_cast<float2*>(p.enh + 2 * o) = xv;
-                    if (p.mag) p.mag[o] = fast_abs2(xv.x, xv.y);
-                }
-            }
         if (t == 0) HOP_STAMP(6);
     }
-    if (D == 0) return;
+    if (fast || D == 0) return;
     // ---- history of my bins: the last D of [old history | new frames]; one thread owns a bin, ascending order reads ahead
     __syncthreads();
-    const int fc = sq.fc, nrow = (R - 16 * rt) < 16 ? (R - 16 * rt) : 16;
     for (int idx = tid; idx < nrow * fc; idx += HOP_THREADS) {
         const int rl = idx / fc, fci = idx - rl * fc;
         const int frow = 16 * rt + rl, b_ = frow / sq.N, k = frow - b_ * sq.N;
@@ -570,6 +617,13 @@ __global__ __launch_bounds__(HOP_THREADS) void stream_hop_kernel(const HopParams
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     HOP_STAMP(0);
+    if ((int)blockIdx.x < p.st[0].nwg) {
+        // layer 0 of the full-band model is the head of the frame's critical path: its descriptors sit at fixed kernarg
+        // offsets, so every scalar load is issued at once instead of table -> stage -> sequence
+        hop_layer_role<true, ONE>(p, p.st[0], p.seq[0], smem);
+        HOP_STAMP(7);
+        return;
+    }
     const int si = (int)((p.stage_of_block[blockIdx.x >> 2] >> (8 * (blockIdx.x & 3))) & 0xffu);
     const HopStageDev& sd = p.st[si];
     const HopSeqDev& sq = p.seq[sd.seq];

@@ -486,20 +486,20 @@ class Engine:
                 pin.copy_(scratch[:1], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(stream)
-            self._stack_err_pending.append((ev, pin))
+            self._stack_err_pending.append((ev, pin, f"{tag} rows={rows} frames={nt} wide={wide} rows_per_wg={rp} lag={self.stack_lag if lag is None else lag}"))
 
     def _poll_stack_errors(self, block: bool = False) -> None:
         keep = []
-        for ev, pin in self._stack_err_pending:
+        for ev, pin, what in self._stack_err_pending:
             if block:
                 ev.synchronize()
             if ev.query():
                 if int(pin[0]) != 0:
                     self._stack_err_pending = []
                     raise RuntimeError("sfsn_gsn_stack_scan: a layer-to-layer hand-off wait expired in an earlier launch "
-                                       "(that forward's results are invalid)")
+                                       f"(that forward's results are invalid): {what}")
             else:
-                keep.append((ev, pin))
+                keep.append((ev, pin, what))
         self._stack_err_pending = keep
 
     def check_stack_errors(self) -> None:
@@ -700,6 +700,20 @@ class Engine:
         # trip through HBM (745 MB per sub-band layer at B=64, T=1000)
         overlap = bool(not pipeline and self.overlap_chunks > 1 and not spec.laplace and not (0 < self.seq_chunk < T)
                        and T >= 96 * self.overlap_chunks)
+        if overlap and self.stack_scan is True:
+            # forced stack launches for both models: side by side on two streams they must not ask for more workgroups than the
+            # chip has compute units -- in-launch hand-offs rely on producers being resident (the "auto" rule never gets here)
+            def blocks(seqs, Rs, tag):
+                use, wide, rp = self._stack_choice(seqs, Rs, want_membrane)
+                rp = rp or self.stack_rows_per_wg[tag]
+                nl = len(seqs[0].cells)
+                scan = sum(-(-R // rp) for R in Rs)
+                proj = sum(-(-R // 16) for R in Rs) if (wide or seqs[0].H > 256) else 0
+                return (nl * (scan + 7) // 8 * 8 + (nl - 1) * (proj + 7) // 8 * 8) if use else 0
+            n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+            b_fb, b_sb = blocks([self.fb], [B], "fb"), blocks(self.sb, [B * spec.units(g) for g in range(spec.n_groups)], "sb")
+            if b_fb and b_sb and b_fb + b_sb > n_cu:
+                overlap = False
         if overlap:
             nt_max = -(-T // self.overlap_chunks)
         else:

@@ -20,12 +20,22 @@ The frozen front-end (``model_low_freq.Separator``) normalises with utterance-le
 from __future__ import annotations
 
 import ctypes
+import math
+import os
 from typing import Optional, Tuple
 
 import torch
 
 from ._lib import DfGroup, HopDesc, HOP_MAX_GROUPS, HOP_MAX_LAYERS, check
 from .engine import Engine, _ptr
+
+
+def _raw_stream(device_index: int) -> int:
+    """The HIP stream handle of torch's current stream on a device (without building a torch.cuda.Stream object per call)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(device_index)
+    except AttributeError:  # pragma: no cover - older / newer torch without the private accessor
+        return torch.cuda.current_stream(device_index).cuda_stream
 
 
 class StreamingSession:
@@ -79,9 +89,12 @@ class StreamingSession:
         self.fg_sb = engine._feature_groups("sb", self.xs, None)
         self.frames_done = 0
         self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._dev_index = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         self._hop = None
         if one_launch not in ("auto", True, False):
             raise ValueError("one_launch must be 'auto', True or False")
+        if one_launch == "auto" and os.environ.get("SFSN_ONE_LAUNCH", "1") == "0":  # diagnostic: the per-kernel sequence everywhere
+            one_launch = False
         if one_launch:
             self._hop = self._build_hop()
             if self._hop is None and one_launch is True:
@@ -96,51 +109,100 @@ class StreamingSession:
         B, F, S, hop, D, ng, dev = self.B, self.F, spec.num_spks, self.hop, self.D, spec.n_groups, self.dev
         if not spec.shared or ng > HOP_MAX_GROUPS or max(spec.fb_layers, spec.sb_layers) > HOP_MAX_LAYERS or D + hop > 32:
             return None
-        desc = HopDesc()
-        keep = []        # state tensors the descriptor points into (zeroed by reset())
-        keep_const = []  # re-laid-out weights
+        # Two arenas instead of ~80 separately allocated tensors: the weights a launch reads (2.9 MB at baseline_m) and the state
+        # it reads and writes sit in two contiguous ranges -- a launch that starts cold on every compute unit then misses
+        # in the TLBs for a handful of pages, not for one page per tensor.
+        class Pool:
+            def __init__(self):
+                self.size, self.buf = 0, None
 
-        def zeros(shape, dtype):
-            t = torch.zeros(shape, dtype=dtype, device=dev)
-            keep.append(t)
-            return t
+            def take(self, nbytes):
+                off = self.size
+                self.size += (nbytes + 255) // 256 * 256
+                return None if self.buf is None else self.buf[off:off + nbytes]
+
+            def put(self, t):  # a copy of tensor t inside the pool -> its address (0 in the sizing pass)
+                v = self.take(t.numel() * t.element_size())
+                if v is None:
+                    return None
+                v.copy_(t.contiguous().view(-1).view(torch.uint8))
+                return ctypes.c_void_p(v.data_ptr())
+
+            def zeros(self, shape, dtype):
+                n = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+                v = self.take(n)
+                return None if v is None else v.view(dtype).view(shape)
+
+        wpool, spool = Pool(), Pool()
+
+        def ptr(t):
+            return None if t is None else ctypes.c_void_p(t.data_ptr())
 
         def fill(dst, seq, fg, R, df, fc):
             HP = (seq.H + 63) // 64 * 64
-            dst.n_layers, dst.H, dst.P, dst.feat, dst.df, dst.fc = len(seq.cells), seq.H, seq.P, fg, df, fc
-            dst.w_p, dst.w_p_dq, dst.b_p = _ptr(seq.proj_q), _ptr(seq.proj_dq), _ptr(seq.proj_b)
+            dst.n_layers, dst.H, dst.P, dst.df, dst.fc = len(seq.cells), seq.H, seq.P, df, fc
+            dst.feat = fg
+            if seq.ln_w is not None:
+                dst.feat.ln_w, dst.feat.ln_b = wpool.put(seq.ln_w), wpool.put(seq.ln_b)
+            dst.w_p, dst.w_p_dq, dst.b_p = wpool.put(seq.proj_q), wpool.put(seq.proj_dq), wpool.put(seq.proj_b)
             for l, cell in enumerate(seq.cells):
                 o = dst.layer[l]
+                o.w_hh, o.w_hh_dq = wpool.put(cell.w_hh_q), wpool.put(cell.w_hh_dq)
                 if l == 0:  # fp32 input weights in MFMA fragment order (include/sfsn.h): one coalesced request per 16 columns
                     w = cell.w_ih_f32
                     kc = (w.shape[1] + 15) // 16
                     w = torch.nn.functional.pad(w, (0, kc * 16 - w.shape[1]))
-                    frag = w.view(seq.H // 16, 16, kc, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
-                    keep_const.append(frag)
-                    o.w_ih_frag = _ptr(frag)
+                    o.w_ih_frag = wpool.put(w.view(seq.H // 16, 16, kc, 4, 4).permute(0, 2, 3, 1, 4).contiguous())
                 else:
-                    o.w_ih, o.w_ih_dq = _ptr(cell.w_ih_q[0][0]), _ptr(cell.w_ih_q[0][1])
-                o.w_hh, o.w_hh_dq, o.bias, o.bn_alpha, o.bn_beta = (_ptr(cell.w_hh_q), _ptr(cell.w_hh_dq), _ptr(cell.bias), _ptr(cell.alpha),
-                                                                     _ptr(cell.beta))
-                o.h[0], o.h[1] = zeros((R, HP), torch.int8).data_ptr(), zeros((R, HP), torch.int8).data_ptr()
-                o.c, o.spikes = _ptr(zeros((R, seq.H), torch.float32)), _ptr(zeros((hop, R, HP), torch.int8))
+                    o.w_ih, o.w_ih_dq = wpool.put(cell.w_ih_q[0][0]), wpool.put(cell.w_ih_q[0][1])
+                o.bias, o.bn_alpha, o.bn_beta = wpool.put(cell.bias), wpool.put(cell.alpha), wpool.put(cell.beta)
+                h0, h1 = spool.zeros((R, HP), torch.int8), spool.zeros((R, HP), torch.int8)
+                c, spk = spool.zeros((R, seq.H), torch.float32), spool.zeros((hop, R, HP), torch.int8)
+                o.h[0], o.h[1] = (None, None) if h0 is None else (h0.data_ptr(), h1.data_ptr())
+                o.c, o.spikes = ptr(c), ptr(spk)
 
-        fill(desc.fb, eng.fb, self.fg_fb[0], B, 0, 0)
-        for g in range(ng):
-            fill(desc.sb[g], eng.sb[g], self.fg_sb[g], B * spec.units(g), spec.df[g], spec.ctr[g])
-        desc.n_groups, desc.B, desc.F, desc.S, desc.hop, desc.D, desc.fdrc = ng, B, F, S, hop, D, spec.fdrc
-        hist = zeros((B, F, max(D, 1)), torch.complex64)
-        enh, mag = zeros((B, S, F, hop), torch.complex64), zeros((B, S, F, hop), torch.float32)
-        desc.inp_ri, desc.hist_ri = _ptr(self.inp), _ptr(hist)
-        desc.enh_ri, desc.enh_mag = _ptr(enh), _ptr(mag)
-        nb = L.sfsn_hop_scratch_bytes(ctypes.byref(desc))
-        if nb == 0:
-            return None
-        scratch = zeros((nb // 4 + 1,), torch.int32)
-        desc.scratch, desc.scratch_bytes = _ptr(scratch), nb
+        out = {}
+        for sizing in (True, False):
+            if not sizing:
+                wpool.buf = torch.zeros((max(wpool.size, 256),), dtype=torch.uint8, device=dev)
+                spool.buf = torch.zeros((max(spool.size, 256),), dtype=torch.uint8, device=dev)
+                wpool.size = spool.size = 0
+            desc = HopDesc()
+            fill(desc.fb, eng.fb, self.fg_fb[0], B, 0, 0)
+            for g in range(ng):
+                fill(desc.sb[g], eng.sb[g], self.fg_sb[g], B * spec.units(g), spec.df[g], spec.ctr[g])
+            desc.n_groups, desc.B, desc.F, desc.S, desc.hop, desc.D, desc.fdrc = ng, B, F, S, hop, D, spec.fdrc
+            hist = spool.zeros((B, F, max(D, 1), 2), torch.float32)
+            enh, mag = spool.zeros((B, S, F, hop, 2), torch.float32), spool.zeros((B, S, F, hop), torch.float32)
+            if sizing:
+                # the scratch size depends on the launch geometry only: ask with placeholder (non-NULL) addresses
+                probe = torch.zeros((16,), dtype=torch.uint8, device=dev)
+                a = probe.data_ptr()
+                for sq_ in [desc.fb] + [desc.sb[g] for g in range(ng)]:
+                    sq_.w_p, sq_.w_p_dq, sq_.b_p = a, a, a
+                    sq_.feat.ln_w, sq_.feat.ln_b = (a, a) if sq_.feat.norm == 1 else (None, None)
+                    for l in range(sq_.n_layers):
+                        o = sq_.layer[l]
+                        o.w_hh, o.w_hh_dq, o.bias, o.bn_alpha, o.bn_beta, o.c, o.spikes = a, a, a, a, a, a, a
+                        o.h[0], o.h[1] = a, a
+                        if l == 0:
+                            o.w_ih_frag = a
+                        else:
+                            o.w_ih, o.w_ih_dq = a, a
+                desc.inp_ri, desc.hist_ri, desc.enh_ri, desc.enh_mag = a, a, a, a
+                nb = L.sfsn_hop_scratch_bytes(ctypes.byref(desc))
+                if nb == 0:
+                    return None
+                out["nb"] = nb
+                continue
+            desc.inp_ri, desc.hist_ri = _ptr(self.inp), ptr(hist)
+            desc.enh_ri, desc.enh_mag = ptr(enh), ptr(mag)
+            scratch = torch.zeros((out["nb"] // 4 + 1,), dtype=torch.int32, device=dev)  # word 0: the error flag
+            desc.scratch, desc.scratch_bytes = ptr(scratch), out["nb"]
         # the error word of a launch is looked at, without blocking, at the next step (pinned copy behind the launch)
         err = torch.zeros((1,), dtype=torch.int32).pin_memory()
-        return dict(desc=desc, keep=keep, keep_const=keep_const, hist=hist, enh=enh, mag=mag, scratch=scratch, err=err, err_pending=False)
+        return dict(desc=desc, ref=ctypes.byref(desc), wpool=wpool.buf, spool=spool.buf, enh=torch.view_as_complex(enh), mag=mag, scratch=scratch, err=err,
+                    err_pending=False)
 
     # -----------------------------------------------------------------------------------------------------------------
     def reset(self) -> None:
@@ -157,8 +219,7 @@ class StreamingSession:
         self.hist.zero_()
         if self._hop is not None:
             self.check_errors()
-            for t in self._hop["keep"]:
-                t.zero_()
+            self._hop["spool"].zero_()  # (h, c), tagged spike buffers, history, outputs: one fill
         self.frames_done = 0
 
     def check_errors(self) -> None:
@@ -246,9 +307,15 @@ class StreamingSession:
             else:
                 self.inp.copy_(frames)
                 h["desc"].inp_ri = self.inp.data_ptr()
-            with torch.cuda.device(self.dev):
-                check(self.eng.lib.sfsn_stream_hop(ctypes.byref(h["desc"]), ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)),
-                      "sfsn_stream_hop")
+            idx = self._dev_index
+            st = ctypes.c_void_p(_raw_stream(idx))
+            if torch.cuda.current_device() == idx:  # the C ABI launches on the calling thread's current device
+                rc = self.eng.lib.sfsn_stream_hop(h["ref"], st)
+            else:
+                with torch.cuda.device(self.dev):
+                    rc = self.eng.lib.sfsn_stream_hop(h["ref"], st)
+            if rc:
+                check(rc, "sfsn_stream_hop")
             h["desc"].launch_index += 1
             self.frames_done += self.hop
             if self.frames_done % 256 < self.hop:  # every ~256 frames: the error word follows the launch into pinned memory

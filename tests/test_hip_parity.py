@@ -683,9 +683,9 @@ def test_stream_hop_argument_checks_and_fallback():
     with pytest.raises(NotImplementedError):
         unshared.streaming(batch=1, hop=1, one_launch=True)
     mid = build_module("live", rw.LIVE_M, rw.live_state_dict(rw.LIVE_M, 5))
-    big = mid.streaming(batch=48, hop=1)  # more wave tiles than compute units: the session falls back by itself
+    big = mid.streaming(batch=64, hop=1)  # more workgroups than compute units: the session falls back by itself
     assert big._hop is None and mid.streaming(batch=16, hop=1)._hop is not None
-    big.step(torch.zeros((48, 257, 1), dtype=torch.complex64, device=DEV))
+    big.step(torch.zeros((64, 257, 1), dtype=torch.complex64, device=DEV))
     torch.cuda.synchronize()
 
 
