@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 3 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 4 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -316,6 +316,20 @@ typedef struct sfsn_hop_desc {
     unsigned launch_index;         /* launches made on this state so far: the caller adds 1 after every launch (it picks
                                       the hand-off tag and the parity of the double-buffered state; a launch must not
                                       be replayed with the index of its predecessor, so no graph capture)            */
+    /* Waveform mode (hop == 1, n_fft 512 / hop_length 128; wave_in != NULL): the launch also computes the new frame's
+     * spectrum from the samples (torch.stft(center=True) framing: the frame that ends with these 128 samples, i.e. frame
+     * frame_index of the utterance when the caller has fed 128 * (frame_index + 2) samples) and turns the enhanced frame back
+     * into samples (torch.istft's overlap-add and envelope): wave_out receives the 128 padded positions
+     * [128 * frame_index, 128 * frame_index + 128), i.e. output samples [128 * (frame_index - 2), 128 * (frame_index - 1)) --
+     * the first two launches of an utterance write the part torch.istft trims.  inp_ri is ignored. */
+    const float* wave_in;          /* [B][128] the new samples                                                       */
+    float* wave_state;             /* [B][512] the last 512 input samples, in/out (zero = start of an utterance)      */
+    float* ola_state;              /* [B][S][512] overlap-add accumulator of the output, in/out (zero to reset)       */
+    float* wave_out;               /* [B][S][128] out                                                                */
+    const float* window;           /* [512] analysis / synthesis window (the reference: hann)                       */
+    float* spec_g;                 /* [B][F][4] scratch ({re, tag, im, tag} granules of the noisy frame), zeroed once */
+    float* enh_g;                  /* [B][S][F][4] scratch (granules of the enhanced frame), zeroed once              */
+    int frame_index;
 } sfsn_hop_desc;
 
 size_t sfsn_hop_scratch_bytes(const sfsn_hop_desc* desc /* host */);

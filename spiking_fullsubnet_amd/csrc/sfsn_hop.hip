@@ -36,17 +36,19 @@
 
 #include "sfsn_scan_dev.h"
 #include "sfsn_feat_dev.h"
+#include "sfsn_fft_dev.h"
 
 #define HOP_THREADS 512
 #define HOP_WAVES 8
 #define HOP_MAX_SEQS (1 + SFSN_HOP_MAX_GROUPS)
-#define HOP_MAX_STAGES (HOP_MAX_SEQS * (SFSN_HOP_MAX_LAYERS + 1))
+#define HOP_MAX_STAGES (HOP_MAX_SEQS * (SFSN_HOP_MAX_LAYERS + 1) + 2)
 #define HOP_KS_MAX 5     // 64-wide k steps of the int8 products: H <= 320
 #define HOP_KC_MAX 12    // 16-wide k chunks of the fp32 input product: I <= 192
 #define HOP_NU_MAX 3     // feature slots per lane: I <= 192
 #define HOP_ROWS_PER_WAVE (16 / HOP_WAVES)
 #define HOP_PT_PER_WAVE 2  // P <= 256
-#define HOP_DF_MAX 8      // deep-filter taps held in registers by the one-frame fast path (D + 1 <= 8)
+#define HOP_DF_MAX 6      // deep-filter taps held in registers by the one-frame fast path (D + 1 <= 6: df <= 6)
+#define HOP_DF_ITEMS 2    // bins per thread on that path: 16 rows x 64 centre bins = 1024 = 2 x 512 threads
 #define HOP_SPIN_LIMIT 2000000u
 #define HOP_MAX_BLOCKS 256  // workgroups per launch (one per compute unit at most)
 
@@ -75,7 +77,7 @@ struct HopSeqDev {
     float eps;
 };
 struct HopStageDev {
-    int seq, layer;  // layer = -1: the projection + deep filter of a sub-band group
+    int seq, layer;  // layer = -1: the projection + deep filter of a sub-band group; -2 / -3: waveform mode's STFT / inverse STFT
     int wg0, nwg;    // workgroups [wg0, wg0 + nwg)
     int ntile, ntpad, nrt;
 };
@@ -88,6 +90,16 @@ struct HopParams {
     float fdrc;
     unsigned launch;  // launches made on this state since it was zeroed: tag and state parity
     const float* inp;
+    // waveform mode (hop == 1): the new samples, the last 512 input samples, the output's overlap-add accumulator, the output,
+    // the window, the noisy / enhanced frame as {re, tag, im, tag} granules, the index of the frame this launch computes
+    const float* wave_in;
+    float* wave_state;
+    float* ola_state;
+    float* wave_out;
+    const float* window;
+    float* spec_g;
+    float* enh_g;
+    int frame_index;
     float* hist;
     float* enh;
     float* mag;
@@ -111,6 +123,13 @@ __device__ __forceinline__ unsigned ld_agent(const void* p) {
 }
 __device__ __forceinline__ void st_agent(void* p, unsigned v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ unsigned long long ld64_agent(const void* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st64_agent(void* p, unsigned long long v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- hand-off: data-tagged granules (MI355X_MICROARCH.md, price list row handoff-1to1) ------------------------------------
@@ -155,6 +174,30 @@ __device__ __forceinline__ bool hop_gather(const int8_t* blk, int rt16, int R, i
         if (ks < KS) b[ks] = *reinterpret_cast<const v4i*>(hb + (ks * 64 + lane) * 16);
     }
     return ok;
+}
+
+// A complex value as two 8-byte {value, tag} granules (waveform mode: the noisy frame comes from the STFT workgroups of this
+// launch, the enhanced frame goes to the inverse-STFT workgroups).  Every lane polls its own granules.
+__device__ __forceinline__ void hop_put_cplx(float* g, float2 v, unsigned tagw) {
+    st64_agent(g, ((unsigned long long)tagw << 32) | __float_as_uint(v.x));
+    st64_agent(g + 2, ((unsigned long long)tagw << 32) | __float_as_uint(v.y));
+}
+__device__ __forceinline__ float2 hop_take_cplx(const float* g, unsigned tagw, bool& ok, unsigned* err) {
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned long long a = ld64_agent(g), c = ld64_agent(g + 2);
+        if (((unsigned)(a >> 32) == tagw && (unsigned)(c >> 32) == tagw) || !ok)
+            return make_float2(__uint_as_float((unsigned)a), __uint_as_float((unsigned)c));
+        if (spins > HOP_SPIN_LIMIT) {
+            st_agent(err, 1u);
+            ok = false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// bin f of clip b's new frame t: the caller's spectrum, or (waveform mode) the STFT workgroups' granules
+__device__ __forceinline__ float2 hop_in_bin(const HopParams& p, int b, int f, int t, int hop, unsigned tagw, bool& ok) {
+    if (!p.spec_g) return *reinterpret_cast<const float2*>(p.inp + (((size_t)b * p.F + f) * hop + t) * 2);
+    return hop_take_cplx(p.spec_g + (((size_t)b * p.F + f) * hop + t) * 4, tagw, ok, p.cnt);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -311,7 +354,7 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
                     v[ri][u] = 0.0f;
                     if (j < sq.I1) {
                         const int bin = reflect_bin(sq.lo + k * sq.ctr - sq.nbr + j, nf);
-                        const float2 xc = *reinterpret_cast<const float2*>(p.inp + (((size_t)b_ * p.F + bin) * hop + t) * 2);
+                        const float2 xc = hop_in_bin(p, b_, bin, t, hop, tagw, ok);
                         v[ri][u] = compress_mag(xc.x, xc.y, p.fdrc);
                     }
                 }
@@ -493,25 +536,30 @@ __device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStage
         for (int idx = tid; idx < p.B * (F - p.fcov) * hop; idx += HOP_THREADS) {
             const int t = idx % hop, r_ = idx / hop;
             const int b_ = r_ / (F - p.fcov), f = p.fcov + r_ - b_ * (F - p.fcov);
-            const float2 xv = *reinterpret_cast<const float2*>(p.inp + (((size_t)b_ * F + f) * hop + t) * 2);
+            const float2 xv = hop_in_bin(p, b_, f, t, hop, tagw, ok);
             for (int s = 0; s < S; ++s) {
                 const size_t o = (((size_t)b_ * S + s) * F + f) * hop + t;
                 *reinterpret_cast<float2*>(p.enh + 2 * o) = xv;
                 if (p.mag) p.mag[o] = fast_abs2(xv.x, xv.y);
+                if (p.enh_g) hop_put_cplx(p.enh_g + 4 * o, xv, tagw);
             }
         }
-    const bool fast = ONE && nrow * fc <= HOP_THREADS && D <= HOP_DF_MAX - 1;
-    float2 tap[HOP_DF_MAX];  // [old history (D) | new frame]
-    if (fast && tid < nrow * fc) {
-        const int rl = tid / fc, fci = tid - rl * fc;
-        const int frow = 16 * rt + rl, b_ = frow / sq.N, k = frow - b_ * sq.N;
-        const int f = sq.lo + k * fc + fci;
-        const float* hrow = p.hist + ((size_t)b_ * F + f) * D * 2;
+    const bool fast = ONE && nrow * fc <= HOP_THREADS * HOP_DF_ITEMS && D <= HOP_DF_MAX - 1;
+    float2 tap[HOP_DF_ITEMS][HOP_DF_MAX];  // [old history (D) | new frame] of this thread's bins tid, tid + 512
 #pragma unroll
-        for (int i = 0; i < HOP_DF_MAX; ++i) {
-            tap[i] = make_float2(0.0f, 0.0f);
-            if (i < D) tap[i] = *reinterpret_cast<const float2*>(hrow + 2 * i);
-            if (i == D) tap[i] = *reinterpret_cast<const float2*>(p.inp + ((size_t)b_ * F + f) * 2);
+    for (int it = 0; it < HOP_DF_ITEMS; ++it) {
+        const int idx = tid + HOP_THREADS * it;
+        if (fast && idx < nrow * fc) {
+            const int rl = idx / fc, fci = idx - rl * fc;
+            const int frow = 16 * rt + rl, b_ = frow / sq.N, k = frow - b_ * sq.N;
+            const int f = sq.lo + k * fc + fci;
+            const float* hrow = p.hist + ((size_t)b_ * F + f) * D * 2;
+#pragma unroll
+            for (int i = 0; i < HOP_DF_MAX; ++i) {
+                tap[it][i] = make_float2(0.0f, 0.0f);
+                if (i < D) tap[it][i] = *reinterpret_cast<const float2*>(hrow + 2 * i);
+                if (i == D) tap[it][i] = hop_in_bin(p, b_, f, 0, 1, tagw, ok);
+            }
         }
     }
 
@@ -541,8 +589,11 @@ __device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStage
         __syncthreads();
         // ---- deep filter of this row tile's bins for frame t (deepfilter_kernel's expressions and tap order)
         if (fast) {
-            if (tid < nrow * fc) {
-                const int rl = tid / fc, fci = tid - rl * fc;
+#pragma unroll
+            for (int it = 0; it < HOP_DF_ITEMS; ++it) {
+                const int idx = tid + HOP_THREADS * it;
+                if (idx >= nrow * fc) break;
+                const int rl = idx / fc, fci = idx - rl * fc;
                 const int frow = 16 * rt + rl, b_ = frow / sq.N, k = frow - b_ * sq.N;
                 const int f = sq.lo + k * fc + fci;
                 const float* pr = pbuf + rl * LDP;
@@ -554,18 +605,19 @@ __device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStage
                         if (d >= 0 && i <= D) {
                             const float cr = pr[((0 * fc + fci) * df + d) * S + s];
                             const float ci = pr[((1 * fc + fci) * df + d) * S + s];
-                            yr += tap[i].x * cr - tap[i].y * ci;
-                            yi += tap[i].x * ci + tap[i].y * cr;
+                            yr += tap[it][i].x * cr - tap[it][i].y * ci;
+                            yi += tap[it][i].x * ci + tap[it][i].y * cr;
                         }
                     }
                     const size_t o = ((size_t)b_ * S + s) * F + f;
                     *reinterpret_cast<float2*>(p.enh + 2 * o) = make_float2(yr, yi);
                     if (p.mag) p.mag[o] = fast_abs2(yr, yi);
+                    if (p.enh_g) hop_put_cplx(p.enh_g + 4 * o, make_float2(yr, yi), tagw);
                 }
                 float* hrow = p.hist + ((size_t)b_ * F + f) * D * 2;  // history: drop the oldest frame, append the new one
 #pragma unroll
                 for (int i = 0; i < HOP_DF_MAX - 1; ++i)
-                    if (i < D) *reinterpret_cast<float2*>(hrow + 2 * i) = tap[i + 1];
+                    if (i < D) *reinterpret_cast<float2*>(hrow + 2 * i) = tap[it][i + 1];
             }
             if (t == 0) HOP_STAMP(6);
             continue;
@@ -612,6 +664,128 @@ __device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStage
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// waveform mode (hop == 1), first stage: the new frame's spectrum.  One workgroup per 16 clips, a wave per clip: the frame is
+// the last 384 samples of the state followed by the 128 new ones; sfsn_fft.hip's transform (same code, same bits); the bins
+// leave as granules; then the state moves on by one hop.  LDS: [64 B][unit table 4 KB][8 x 2 KB exchange].
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hop_stft_role(const HopParams& p, const HopStageDev& sd, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = (int)blockIdx.x - sd.wg0;
+    const int nclip = (p.B - 16 * rt) < 16 ? (p.B - 16 * rt) : 16;
+    const unsigned tagw = hop_tag(p.launch) * 0x02020202u;
+    float2* unit = reinterpret_cast<float2*>(smem + 64);
+    float2(*fbuf)[FFT_N] = reinterpret_cast<float2(*)[FFT_N]>(smem + 64 + FFT_NFFT * 8);
+    fill_unit_table(unit, tid, HOP_THREADS);
+    __syncthreads();
+    const Twiddles tw = make_twiddles<false>(unit, lane);
+    float2 win[4], wk[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = 2 * (lane + 64 * r);
+        win[r] = make_float2(p.window[n], p.window[n + 1]);
+        wk[r] = unit_at<false>(unit, lane + 64 * r);
+    }
+    for (int ci = wave; ci < nclip; ci += HOP_WAVES) {
+        const int b = 16 * rt + ci;
+        const float* ws = p.wave_state + (size_t)b * FFT_NFFT;
+        const float* wn = p.wave_in + (size_t)b * 128;
+        float2 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 2 * (lane + 64 * r);  // sample j of the frame: state[128 + j] for j < 384, then the new samples
+            const float2 x = j < 384 ? *reinterpret_cast<const float2*>(ws + 128 + j) : *reinterpret_cast<const float2*>(wn + j - 384);
+            v[r] = make_float2(x.x * win[r].x, x.y * win[r].y);
+        }
+        fft256<false>(v, fbuf[wave], lane, tw);
+        float2 X[4], nyq = make_float2(0.0f, 0.0f);
+        rfft512_split(v, fbuf[wave], lane, wk, X, nyq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hop_put_cplx(p.spec_g + ((size_t)b * p.F + lane + 64 * r) * 4, X[r], tagw);
+        if (lane == 0) hop_put_cplx(p.spec_g + ((size_t)b * p.F + FFT_N) * 4, nyq, tagw);
+    }
+    // the state moves on by one hop (every sample is read before any is written)
+    float keep[16];
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci) {
+        keep[ci] = 0.0f;
+        if (ci < nclip) {
+            const int b = 16 * rt + ci;
+            keep[ci] = tid < 384 ? p.wave_state[(size_t)b * FFT_NFFT + 128 + tid] : p.wave_in[(size_t)b * 128 + tid - 384];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci)
+        if (ci < nclip) p.wave_state[(size_t)(16 * rt + ci) * FFT_NFFT + tid] = keep[ci];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// waveform mode, last stage: the enhanced frame back to samples.  A wave per (clip, speaker): polls the 257 bins of the
+// enhanced frame (granules written by the deep-filter workgroups), sfsn_fft.hip's inverse transform and window, overlap-add
+// in registers against the carried accumulator (ascending frame order, as istft_kernel adds them), the hop that is now
+// complete divided by the squared-window envelope of the frames that exist (t - q >= 0), accumulator moved on by one hop.
+// LDS: [64 B][unit table 4 KB][8 x 2 KB exchange][8 x 264 float2 spectrum rows].
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hop_istft_role(const HopParams& p, const HopStageDev& sd, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = ((int)blockIdx.x - sd.wg0) * HOP_WAVES + wave;  // clip * S + speaker
+    const unsigned tagw = hop_tag(p.launch) * 0x02020202u;
+    float2* unit = reinterpret_cast<float2*>(smem + 64);
+    float2(*fbuf)[FFT_N] = reinterpret_cast<float2(*)[FFT_N]>(smem + 64 + FFT_NFFT * 8);
+    float2(*xs)[264] = reinterpret_cast<float2(*)[264]>(smem + 64 + FFT_NFFT * 8 + HOP_WAVES * FFT_N * 8);
+    fill_unit_table(unit, tid, HOP_THREADS);
+    __syncthreads();
+    if (pair >= p.B * p.S) return;
+    const Twiddles tw = make_twiddles<true>(unit, lane);
+    float2 win[4], wk[4], ola[4];
+    float* os = p.ola_state + (size_t)pair * FFT_NFFT;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = 2 * (lane + 64 * r);
+        win[r] = make_float2(p.window[n], p.window[n + 1]);
+        wk[r] = unit_at<true>(unit, lane + 64 * r);
+        ola[r] = *reinterpret_cast<const float2*>(os + n);
+    }
+    bool ok = true;
+    const float* eg = p.enh_g + (size_t)pair * p.F * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xs[wave][lane + 64 * r] = hop_take_cplx(eg + (size_t)(lane + 64 * r) * 4, tagw, ok, p.cnt);
+    if (lane == 0) xs[wave][FFT_N] = hop_take_cplx(eg + (size_t)FFT_N * 4, tagw, ok, p.cnt);
+    __builtin_amdgcn_wave_barrier();
+    float2 v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = lane + 64 * r;
+        v[r] = irfft512_presplit(xs[wave][k], xs[wave][FFT_N - k], k, wk[r]);
+    }
+    fft256<true>(v, fbuf[wave], lane, tw);
+    const float sc = 1.0f / (float)FFT_N;
+    float2 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float2 res = make_float2(v[r].x * sc * win[r].x, v[r].y * sc * win[r].y);
+        acc[r] = make_float2(ola[r].x + res.x, ola[r].y + res.y);
+    }
+    // the hop that is complete now: padded positions n = 128 t + 2 lane + e; envelope over the frames t - q that exist, oldest first
+    float2 env = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int q = 3; q >= 0; --q)
+        if (p.frame_index - q >= 0) {
+            env.x += win[q].x * win[q].x;
+            env.y += win[q].y * win[q].y;
+        }
+    const float2 out = make_float2(env.x > 1e-11f ? acc[0].x / env.x : 0.0f, env.y > 1e-11f ? acc[0].y / env.y : 0.0f);
+    *reinterpret_cast<float2*>(p.wave_out + (size_t)pair * 128 + 2 * lane) = out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = 2 * (lane + 64 * r);
+        *reinterpret_cast<float2*>(os + n) = r < 3 ? acc[r + 1] : make_float2(0.0f, 0.0f);
+    }
+}
+
 template <bool ONE>
 __global__ __launch_bounds__(HOP_THREADS) void stream_hop_kernel(const HopParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -632,8 +806,12 @@ __global__ __launch_bounds__(HOP_THREADS) void stream_hop_kernel(const HopParams
             hop_layer_role<true, ONE>(p, sd, sq, smem);
         else
             hop_layer_role<false, ONE>(p, sd, sq, smem);
-    } else {
+    } else if (sd.layer == -1) {
         hop_proj_role<ONE>(p, sd, sq, smem);
+    } else if (ONE && sd.layer == -2) {
+        hop_stft_role(p, sd, smem);
+    } else if (ONE) {
+        hop_istft_role(p, sd, smem);
     }
     HOP_STAMP(7);
 }
@@ -678,10 +856,19 @@ static int hop_fill_seq(HopSeqDev& d, const sfsn_hop_seq& s, int B, int F, int S
 static int hop_plan(HopParams& p, size_t& lds, const sfsn_hop_desc* d) {
     if (!d || d->n_groups < 1 || d->n_groups > SFSN_HOP_MAX_GROUPS) return d ? SFSN_EUNSUPPORTED : SFSN_EINVAL;
     if (d->B <= 0 || d->F < 2 || d->S < 1 || d->hop < 1 || d->D < 0 || d->D + d->hop > 32) return SFSN_EUNSUPPORTED;
-    if (!d->inp_ri || !d->enh_ri || (d->D > 0 && !d->hist_ri)) return SFSN_EINVAL;
+    const bool wave = d->wave_in != nullptr;
+    if ((!wave && !d->inp_ri) || !d->enh_ri || (d->D > 0 && !d->hist_ri)) return SFSN_EINVAL;
+    if (wave) {
+        if (!d->wave_state || !d->ola_state || !d->wave_out || !d->window || !d->spec_g || !d->enh_g) return SFSN_EINVAL;
+        if (d->hop != 1 || d->F != FFT_F) return SFSN_EUNSUPPORTED;  // one 128-sample hop per launch, 512-point frames
+    }
     memset(&p, 0, sizeof(p));
     p.B = d->B; p.F = d->F; p.S = d->S; p.hop = d->hop; p.D = d->D; p.FB = d->fb.P; p.fdrc = d->fdrc;
     p.inp = d->inp_ri; p.hist = d->hist_ri; p.enh = d->enh_ri; p.mag = d->enh_mag;
+    if (wave) {
+        p.wave_in = d->wave_in; p.wave_state = d->wave_state; p.ola_state = d->ola_state; p.wave_out = d->wave_out;
+        p.window = d->window; p.spec_g = d->spec_g; p.enh_g = d->enh_g; p.frame_index = d->frame_index;
+    }
     p.nseq = 1 + d->n_groups;
     int rc = hop_fill_seq(p.seq[0], d->fb, d->B, d->F, d->S, true, 0);
     if (rc != SFSN_OK) return rc;
@@ -715,11 +902,29 @@ static int hop_plan(HopParams& p, size_t& lds, const sfsn_hop_desc* d) {
         if (p.seq[i].KC > kcmax) kcmax = p.seq[i].KC;
         if (i > 0 && p.seq[i].P > pmax) pmax = p.seq[i].P;
     }
-    for (int l = 0; l < p.seq[0].nl; ++l) add(0, l);
+    auto add_wave = [&](int layer, int n) {
+        HopStageDev& s = p.st[ns++];
+        s.seq = 0; s.layer = layer; s.nrt = n; s.ntile = HOP_WAVES; s.ntpad = HOP_WAVES;
+        s.wg0 = wg; s.nwg = n;
+        wg += n;
+    };
+    for (int l = 0; l < p.seq[0].nl; ++l) {
+        add(0, l);
+        if (l == 0 && wave) add_wave(-2, (d->B + 15) / 16);  // (behind the full-band layer 0, whose descriptors sit at stage 0)
+    }
     for (int l = 0; l < maxl; ++l)
         for (int g = 0; g < d->n_groups; ++g)
             if (l < p.seq[1 + g].nl) add(1 + g, l);
     for (int g = 0; g < d->n_groups; ++g) add(1 + g, -1);
+    if (wave) {
+        add_wave(-3, (d->B * d->S + HOP_WAVES - 1) / HOP_WAVES);
+        // the deep filter's one-bin-per-thread path is the one that writes the enhanced granules
+        for (int g = 0; g < d->n_groups; ++g) {
+            const HopSeqDev& q = p.seq[1 + g];
+            const int rows = q.R < 16 ? q.R : 16;
+            if (rows * q.fc > HOP_THREADS * HOP_DF_ITEMS || d->D > HOP_DF_MAX - 1) return SFSN_EUNSUPPORTED;
+        }
+    }
     p.nstage = ns; p.nblocks = wg;
     if (wg > HOP_MAX_BLOCKS) return SFSN_EUNSUPPORTED;
     for (int i = 0; i < ns; ++i)
@@ -728,6 +933,8 @@ static int hop_plan(HopParams& p, size_t& lds, const sfsn_hop_desc* d) {
                              (size_t)3 * p.seq[0].PT * p.seq[0].KS * 1024;
     const size_t lds_proj = 64 + (size_t)HOP_KS_MAX * 1024 + (size_t)16 * (pmax + 4) * sizeof(float);
     lds = lds_layer > lds_proj ? lds_layer : lds_proj;
+    const size_t lds_wave = 64 + (size_t)FFT_NFFT * 8 + (size_t)HOP_WAVES * FFT_N * 8 + (size_t)HOP_WAVES * 264 * 8;
+    if (wave && lds_wave > lds) lds = lds_wave;
     return SFSN_OK;
 }
 

@@ -195,12 +195,13 @@ class _EngineMixin:
             self._engine_key = key
         return self._engine
 
-    def streaming(self, batch: int = 1, hop: int = 1, graph: bool = True, rows_per_wg=None, one_launch="auto"):
+    def streaming(self, batch: int = 1, hop: int = 1, graph: bool = True, rows_per_wg=None, one_launch="auto", waveform: bool = False):
         """Frame-by-frame session on STFT frames (``streaming.StreamingSession``): state and deep-filter history stay on
         the device between calls; one HIP-graph replay per hop.  Live front-end only."""
         from .streaming import StreamingSession
         self._check_mode()
-        return StreamingSession(self.engine(), batch=batch, hop=hop, graph=graph, rows_per_wg=rows_per_wg, owner=self, one_launch=one_launch)
+        return StreamingSession(self.engine(), batch=batch, hop=hop, graph=graph, rows_per_wg=rows_per_wg, owner=self, one_launch=one_launch,
+                                waveform=waveform)
 
     def _check_mode(self, x=None):
         if x is not None and x.requires_grad:

@@ -42,7 +42,7 @@ class StreamingSession:
     """``step(frames [B, F, hop] complex64) -> (enh_stft [B, S, F, hop], enh_mag [B, S, F, hop])`` with state carried."""
 
     def __init__(self, engine: Engine, batch: int = 1, hop: int = 1, graph: bool = True, rows_per_wg=None, owner=None,
-                 one_launch="auto"):
+                 one_launch="auto", waveform: bool = False):
         spec = engine.spec
         # the module the engine was packed from: reset() checks that its parameters have not changed since (the session's
         # captured graph holds pointers to THIS engine's packed weights)
@@ -91,6 +91,12 @@ class StreamingSession:
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._dev_index = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         self._hop = None
+        self.waveform = bool(waveform)  # step_wave(): samples in, samples out (STFT and inverse STFT inside the launch)
+        self._wave_calls = 0
+        if self.waveform:
+            if hop != 1 or spec.n_fft != 512:
+                raise NotImplementedError("waveform streaming: one 128-sample hop per call, 512-point frames")
+            one_launch = True
         if one_launch not in ("auto", True, False):
             raise ValueError("one_launch must be 'auto', True or False")
         if one_launch == "auto" and os.environ.get("SFSN_ONE_LAUNCH", "1") == "0":  # diagnostic: the per-kernel sequence everywhere
@@ -174,6 +180,12 @@ class StreamingSession:
             desc.n_groups, desc.B, desc.F, desc.S, desc.hop, desc.D, desc.fdrc = ng, B, F, S, hop, D, spec.fdrc
             hist = spool.zeros((B, F, max(D, 1), 2), torch.float32)
             enh, mag = spool.zeros((B, S, F, hop, 2), torch.float32), spool.zeros((B, S, F, hop), torch.float32)
+            wv = None
+            if self.waveform:
+                wv = dict(state=spool.zeros((B, 512), torch.float32), ola=spool.zeros((B, S, 512), torch.float32),
+                          out=spool.zeros((B, S, 128), torch.float32), spec_g=spool.zeros((B, F, 4), torch.float32),
+                          enh_g=spool.zeros((B, S, F, 4), torch.float32))
+                window = wpool.put(torch.hann_window(512, device=dev, dtype=torch.float32))
             if sizing:
                 # the scratch size depends on the launch geometry only: ask with placeholder (non-NULL) addresses
                 probe = torch.zeros((16,), dtype=torch.uint8, device=dev)
@@ -190,6 +202,8 @@ class StreamingSession:
                         else:
                             o.w_ih, o.w_ih_dq = a, a
                 desc.inp_ri, desc.hist_ri, desc.enh_ri, desc.enh_mag = a, a, a, a
+                if self.waveform:
+                    desc.wave_in = desc.wave_state = desc.ola_state = desc.wave_out = desc.window = desc.spec_g = desc.enh_g = a
                 nb = L.sfsn_hop_scratch_bytes(ctypes.byref(desc))
                 if nb == 0:
                     return None
@@ -197,11 +211,14 @@ class StreamingSession:
                 continue
             desc.inp_ri, desc.hist_ri = _ptr(self.inp), ptr(hist)
             desc.enh_ri, desc.enh_mag = ptr(enh), ptr(mag)
+            if self.waveform:
+                desc.wave_state, desc.ola_state, desc.wave_out = ptr(wv["state"]), ptr(wv["ola"]), ptr(wv["out"])
+                desc.window, desc.spec_g, desc.enh_g = window, ptr(wv["spec_g"]), ptr(wv["enh_g"])
             scratch = torch.zeros((out["nb"] // 4 + 1,), dtype=torch.int32, device=dev)  # word 0: the error flag
             desc.scratch, desc.scratch_bytes = ptr(scratch), out["nb"]
         # the error word of a launch is looked at, without blocking, at the next step (pinned copy behind the launch)
         err = torch.zeros((1,), dtype=torch.int32).pin_memory()
-        return dict(desc=desc, ref=ctypes.byref(desc), wpool=wpool.buf, spool=spool.buf, enh=torch.view_as_complex(enh), mag=mag, scratch=scratch, err=err,
+        return dict(desc=desc, ref=ctypes.byref(desc), wave=wv, wpool=wpool.buf, spool=spool.buf, enh=torch.view_as_complex(enh), mag=mag, scratch=scratch, err=err,
                     err_pending=False)
 
     # -----------------------------------------------------------------------------------------------------------------
@@ -219,7 +236,8 @@ class StreamingSession:
         self.hist.zero_()
         if self._hop is not None:
             self.check_errors()
-            self._hop["spool"].zero_()  # (h, c), tagged spike buffers, history, outputs: one fill
+            self._hop["spool"].zero_()  # (h, c), tagged spike buffers, history, outputs, waveform state: one fill
+            self._wave_calls = 0
         self.frames_done = 0
 
     def check_errors(self) -> None:
@@ -298,6 +316,8 @@ class StreamingSession:
         if frames.device != self.dev or frames.dtype != torch.complex64 or tuple(frames.shape) != (self.B, self.F, self.hop):
             raise RuntimeError(f"expected complex64 {(self.B, self.F, self.hop)} on {self.dev}, got {frames.dtype} {tuple(frames.shape)} "
                                f"on {frames.device}")
+        if self.waveform:
+            raise RuntimeError("this session was opened with waveform=True: use step_wave(samples)")
         if self._hop is not None:
             h = self._hop
             if h["err_pending"] and int(h["err"][0]) != 0:  # written behind an earlier launch; no blocking here
@@ -330,3 +350,42 @@ class StreamingSession:
         self.frames_done += self.hop
         e, m = self.enh[..., self.D:], self.enh_mag[..., self.D:]
         return (e.clone(), m.clone()) if copy else (e, m)
+
+    def step_wave(self, samples: torch.Tensor, copy: bool = True) -> torch.Tensor:
+        """Waveform streaming (``waveform=True``): ``samples`` float32 [B, 128] on the device -- the next 8 ms of every clip.
+        Returns enhanced samples [B, S, 128]: call c returns the samples that entered with call c - 3 (the framing of
+        torch.stft(center=True) needs 256 samples of look-ahead, the overlap-add another hop: 24 ms of algorithmic delay, as for
+        any causal use of the reference's 32 ms / 8 ms analysis); the first three calls of an utterance return zeros.
+        One launch per call: the frame's STFT, the whole model, the inverse STFT with its overlap-add state."""
+        if not self.waveform:
+            raise RuntimeError("open the session with waveform=True")
+        if samples.device != self.dev or samples.dtype != torch.float32 or tuple(samples.shape) != (self.B, 128) or not samples.is_contiguous():
+            raise RuntimeError(f"expected contiguous float32 {(self.B, 128)} on {self.dev}, got {samples.dtype} {tuple(samples.shape)}")
+        h = self._hop
+        c = self._wave_calls
+        self._wave_calls += 1
+        if c == 0:  # no frame ends here yet (frame 0 covers samples [-256, 256)): the samples only enter the state
+            h["wave"]["state"][:, 384:].copy_(samples)
+            return torch.zeros_like(h["wave"]["out"])
+        if h["err_pending"] and int(h["err"][0]) != 0:
+            raise RuntimeError("sfsn_stream_hop: a bounded hand-off wait expired inside a launch (results invalid)")
+        d = h["desc"]
+        d.wave_in, d.frame_index = samples.data_ptr(), c - 1
+        idx = self._dev_index
+        st = ctypes.c_void_p(_raw_stream(idx))
+        if torch.cuda.current_device() == idx:
+            rc = self.eng.lib.sfsn_stream_hop(h["ref"], st)
+        else:
+            with torch.cuda.device(self.dev):
+                rc = self.eng.lib.sfsn_stream_hop(h["ref"], st)
+        if rc:
+            check(rc, "sfsn_stream_hop")
+        d.launch_index += 1
+        self.frames_done += 1
+        if self.frames_done % 256 == 0:
+            h["err"].copy_(h["scratch"][:1], non_blocking=True)
+            h["err_pending"] = True
+        out = h["wave"]["out"]
+        if c < 3:  # padded positions torch.istft trims
+            return torch.zeros_like(out)
+        return out.clone() if copy else out

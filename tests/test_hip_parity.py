@@ -657,6 +657,35 @@ def test_streaming_session_equals_offline_forward(kw, seed, B, hop, graph, one_l
         sess.reset()
 
 
+@pytest.mark.parametrize("kw,seed,B", [(rw.LIVE_TINY, 11, 2), (rw.LIVE_M, 5, 1), (rw.LIVE_TINY_2SPK, 12, 3), (rw.LIVE_M, 5, 17)])
+def test_waveform_streaming_equals_offline_forward(kw, seed, B):
+    """Samples in, samples out, 128 at a time (8 ms): the session with waveform=True -- STFT of the new frame, the whole model
+    and the inverse STFT with its overlap-add state in ONE launch per hop -- reproduces the offline forward's waveform bit for
+    bit, three hops late (the look-ahead of torch.stft(center=True) + the overlap-add); a reset starts a new utterance."""
+    model = build_module("live", kw, rw.live_state_dict(kw, seed))
+    n_hops = 44
+    wave = torch.from_numpy(rw.synth_wave(B, n_hops + 1, seed)).to(DEV)  # [B, 128 * n_hops]
+    y = model(wave)[0]
+    y = y.reshape(B, -1, y.shape[-1])  # [B, S, L]
+    sess = model.streaming(batch=B, waveform=True)
+    with pytest.raises(RuntimeError):
+        sess.step(torch.zeros((B, 257, 1), dtype=torch.complex64, device=DEV))
+    for rep in range(2):
+        outs = []
+        for c in range(n_hops):
+            o = sess.step_wave(wave[:, 128 * c:128 * (c + 1)].contiguous())
+            if c < 3:
+                assert not bool(o.any())
+            else:
+                outs.append(o)
+        sess.check_errors()
+        got = torch.cat(outs, -1)  # the samples that entered with calls 0 .. n_hops - 4
+        assert got.shape[-1] == 128 * (n_hops - 3)
+        ref = y[..., :got.shape[-1]]
+        assert torch.equal(got, ref), (rep, float((got - ref).abs().max()))
+        sess.reset()
+
+
 def test_stream_hop_argument_checks_and_fallback():
     """sfsn_stream_hop through the C ABI: malformed descriptors are refused, what the launch does not cover reports
     SFSN_EUNSUPPORTED (the session then replays the offline kernels), one_launch=True insists."""
