@@ -196,8 +196,9 @@ class _EngineMixin:
         return self._engine
 
     def streaming(self, batch: int = 1, hop: int = 1, graph: bool = True, rows_per_wg=None, one_launch="auto", waveform: bool = False):
-        """Frame-by-frame session on STFT frames (``streaming.StreamingSession``): state and deep-filter history stay on
-        the device between calls; one HIP-graph replay per hop.  Live front-end only."""
+        """Frame-by-frame session (``streaming.StreamingSession``): state and deep-filter history stay on the device between
+        calls; one launch per hop (``sfsn_stream_hop``) where the library covers the model, else the offline kernels replayed
+        from a HIP graph.  ``waveform=True``: samples in, samples out (``step_wave``).  Live front-end only."""
         from .streaming import StreamingSession
         self._check_mode()
         return StreamingSession(self.engine(), batch=batch, hop=hop, graph=graph, rows_per_wg=rows_per_wg, owner=self, one_launch=one_launch,

@@ -118,6 +118,67 @@ def test_constructor_rejections_match_reference():
         pkg.Separator(**dict(rw.FROZEN_TINY, norm_type="forgetting_norm"))      # model_low_freq:227-231
 
 
+def test_stream_hop_plan_on_the_host():
+    """sfsn_hop_stages (host-only part of sfsn_stream_hop): the stage table of a launch for the baseline_m geometry -- stages in
+    dependency order, eight wave tiles per workgroup -- and what the launch does not cover."""
+    import ctypes
+    from spiking_fullsubnet_amd import _lib
+    L = _lib.lib()
+    kw = rw.LIVE_M
+    keep = ctypes.create_string_buffer(64)
+    a = ctypes.addressof(keep)  # any non-NULL address: the plan never dereferences device pointers
+
+    def seq(dst, H, P, nl, lo, n_units, ctr, nbr, ctr_fb, nbr_fb, df, fc):
+        dst.n_layers, dst.H, dst.P, dst.df, dst.fc = nl, H, P, df, fc
+        dst.feat.lo, dst.feat.n_units, dst.feat.ctr, dst.feat.nbr, dst.feat.ctr_fb, dst.feat.nbr_fb = lo, n_units, ctr, nbr, ctr_fb, nbr_fb
+        dst.feat.norm, dst.feat.ln_w, dst.feat.ln_b, dst.feat.ln_eps = _lib.NORM_LAYERNORM, a, a, 1e-5
+        dst.w_p, dst.w_p_dq, dst.b_p = a, a, a
+        for l in range(nl):
+            o = dst.layer[l]
+            o.w_hh, o.w_hh_dq, o.bias, o.bn_alpha, o.bn_beta, o.c, o.spikes = a, a, a, a, a, a, a
+            o.h[0], o.h[1] = a, a
+            if l == 0:
+                o.w_ih_frag = a
+            else:
+                o.w_ih, o.w_ih_dq = a, a
+
+    def desc(B=1, hop=1, waveform=False):
+        d = _lib.HopDesc()
+        seq(d.fb, kw["fb_hidden_size"], kw["fb_proj_size"], kw["fb_num_layers"], 0, 1, kw["fb_input_size"], 0, 0, 0, 0, 0)
+        cut, ctr, nbr, df = kw["freq_cutoffs"], kw["center_freq_sizes"], kw["neighbor_freq_sizes"], kw["df_orders"]
+        for g in range(3):
+            seq(d.sb[g], kw["sb_hidden_size"], 2 * ctr[g] * df[g], kw["sb_num_layers"], cut[g], (cut[g + 1] - cut[g]) // ctr[g], ctr[g], nbr[g],
+                ctr[g], 0, df[g], ctr[g])
+        d.n_groups, d.B, d.F, d.S, d.hop, d.D, d.fdrc = 3, B, 257, 1, hop, max(df) - 1, 0.5
+        d.inp_ri = d.hist_ri = d.enh_ri = d.enh_mag = a
+        if waveform:
+            d.wave_in = d.wave_state = d.ola_state = d.wave_out = d.window = d.spec_g = d.enh_g = a
+        return d
+
+    out = (ctypes.c_int * 128)()
+    n = L.sfsn_hop_stages(ctypes.byref(desc()), out, 32)
+    stages = [tuple(out[4 * i:4 * i + 4]) for i in range(n)]
+    # (sequence, layer, first workgroup, workgroups): 20 / 14 tiles per layer -> 3 / 2 workgroups of eight waves
+    assert stages == [(0, 0, 0, 3), (0, 1, 3, 3), (1, 0, 6, 2), (2, 0, 8, 2), (3, 0, 10, 2), (1, 1, 12, 2), (2, 1, 14, 2), (3, 1, 16, 2),
+                      (1, -1, 18, 1), (2, -1, 19, 1), (3, -1, 20, 1)]
+    n = L.sfsn_hop_stages(ctypes.byref(desc(waveform=True)), out, 32)
+    stages = [tuple(out[4 * i:4 * i + 4]) for i in range(n)]
+    assert stages[1] == (0, -2, 3, 1) and stages[-1] == (0, -3, 22, 1) and n == 13  # STFT behind the first stage, inverse STFT last
+    n = L.sfsn_hop_stages(ctypes.byref(desc(B=3, hop=4)), out, 32)
+    assert n == 11 and out[4 * 2 + 3] == 4  # group 0: 24 rows = two row tiles x two workgroups
+    assert L.sfsn_hop_stages(ctypes.byref(desc(hop=30)), out, 32) == _lib.SFSN_EUNSUPPORTED          # D + hop > 32
+    assert L.sfsn_hop_stages(ctypes.byref(desc(hop=2, waveform=True)), out, 32) == _lib.SFSN_EUNSUPPORTED  # one hop per launch
+    bad = desc()
+    bad.sb[1].P += 2
+    assert L.sfsn_hop_stages(ctypes.byref(bad), out, 32) == _lib.SFSN_EINVAL                         # P != 2 * fc * df * S
+    bad = desc()
+    bad.fb.layer[1].w_ih = None
+    assert L.sfsn_hop_stages(ctypes.byref(bad), out, 32) == _lib.SFSN_EINVAL
+    bad = desc()
+    bad.fb.feat.norm = _lib.NORM_LAPLACE
+    assert L.sfsn_hop_stages(ctypes.byref(bad), out, 32) == _lib.SFSN_EUNSUPPORTED                   # utterance statistics: not causal
+
+
 def test_training_mode_and_grad_inputs_raise_instead_of_falling_back():
     """The narrowing INTEGRATION.md states: no backward pass and no torch fallback -- a forward that the reference would
     record for autograd (efficient_spiking_neuron.py:94-101,149-150) is refused before anything is launched."""
