@@ -988,3 +988,24 @@ def test_fused_scan_entry_points_reject_what_they_do_not_cover(hip):
     assert hip.sfsn_gsn_layer_scan_fused(sg, fi, 1, 4, 224, None) == SFSN_EINVAL
     assert hip.sfsn_gsn_layer_scan_fused(sg, fi, 0, 4, 224, None) == SFSN_EINVAL
     torch.cuda.synchronize()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (one rank per GPU; with
+    SFSN_BENCH_BACKEND=gloo the two ranks share this box's GPU -- a plumbing check of the N > 1 path): one JSON line, n_gpus 2,
+    the whole-job value of both ranks' clips."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SFSN_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                          "--no-phase-a", "--inflight", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo"
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 4
