@@ -110,14 +110,19 @@ class StreamingSession:
 
     # -----------------------------------------------------------------------------------------------------------------
     def _build_hop(self):
-        """Descriptor + state of the one-launch hop (sfsn_stream_hop); None when the library does not cover this session."""
+        """Descriptors + state of the one-launch hop (sfsn_stream_hop); None when the library does not cover this session.
+
+        A launch wants every workgroup resident at once (one per compute unit), which bounds the clips per launch (32 at
+        baseline_m on an MI355X); a bigger batch is cut into equal parts, one launch each, back to back on the stream -- every part
+        has its own state, all parts share the weights and write into the same output tensors."""
         eng, spec, L = self.eng, self.eng.spec, self.eng.lib
         B, F, S, hop, D, ng, dev = self.B, self.F, spec.num_spks, self.hop, self.D, spec.n_groups, self.dev
         if not spec.shared or ng > HOP_MAX_GROUPS or max(spec.fb_layers, spec.sb_layers) > HOP_MAX_LAYERS or D + hop > 32:
             return None
-        # Two arenas instead of ~80 separately allocated tensors: the weights a launch reads (2.9 MB at baseline_m) and the state
-        # it reads and writes sit in two contiguous ranges -- a launch that starts cold on every compute unit then misses
-        # in the TLBs for a handful of pages, not for one page per tensor.
+
+        # Arenas instead of ~80 separately allocated tensors: the weights a launch reads (2.9 MB at baseline_m) and the state it
+        # reads and writes sit in contiguous ranges -- a launch that starts cold on every compute unit then misses in the TLBs
+        # for a handful of pages, not for one page per tensor.
         class Pool:
             def __init__(self):
                 self.size, self.buf = 0, None
@@ -127,99 +132,156 @@ class StreamingSession:
                 self.size += (nbytes + 255) // 256 * 256
                 return None if self.buf is None else self.buf[off:off + nbytes]
 
-            def put(self, t):  # a copy of tensor t inside the pool -> its address (0 in the sizing pass)
+            def put(self, t):  # a copy of tensor t inside the pool -> its address (None in the sizing pass)
                 v = self.take(t.numel() * t.element_size())
                 if v is None:
                     return None
                 v.copy_(t.contiguous().view(-1).view(torch.uint8))
-                return ctypes.c_void_p(v.data_ptr())
+                return v.data_ptr()
 
             def zeros(self, shape, dtype):
-                n = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
-                v = self.take(n)
+                v = self.take(math.prod(shape) * torch.empty((), dtype=dtype).element_size())
                 return None if v is None else v.view(dtype).view(shape)
 
-        wpool, spool = Pool(), Pool()
+            def allocate(self):
+                self.buf = torch.zeros((max(self.size, 256),), dtype=torch.uint8, device=dev)
+                self.size = 0
 
         def ptr(t):
-            return None if t is None else ctypes.c_void_p(t.data_ptr())
+            return None if t is None else t.data_ptr()
 
-        def fill(dst, seq, fg, R, df, fc):
-            HP = (seq.H + 63) // 64 * 64
-            dst.n_layers, dst.H, dst.P, dst.df, dst.fc = len(seq.cells), seq.H, seq.P, df, fc
-            dst.feat = fg
-            if seq.ln_w is not None:
-                dst.feat.ln_w, dst.feat.ln_b = wpool.put(seq.ln_w), wpool.put(seq.ln_b)
-            dst.w_p, dst.w_p_dq, dst.b_p = wpool.put(seq.proj_q), wpool.put(seq.proj_dq), wpool.put(seq.proj_b)
-            for l, cell in enumerate(seq.cells):
-                o = dst.layer[l]
-                o.w_hh, o.w_hh_dq = wpool.put(cell.w_hh_q), wpool.put(cell.w_hh_dq)
-                if l == 0:  # fp32 input weights in MFMA fragment order (include/sfsn.h): one coalesced request per 16 columns
-                    w = cell.w_ih_f32
-                    kc = (w.shape[1] + 15) // 16
-                    w = torch.nn.functional.pad(w, (0, kc * 16 - w.shape[1]))
-                    o.w_ih_frag = wpool.put(w.view(seq.H // 16, 16, kc, 4, 4).permute(0, 2, 3, 1, 4).contiguous())
-                else:
-                    o.w_ih, o.w_ih_dq = wpool.put(cell.w_ih_q[0][0]), wpool.put(cell.w_ih_q[0][1])
-                o.bias, o.bn_alpha, o.bn_beta = wpool.put(cell.bias), wpool.put(cell.alpha), wpool.put(cell.beta)
-                h0, h1 = spool.zeros((R, HP), torch.int8), spool.zeros((R, HP), torch.int8)
-                c, spk = spool.zeros((R, seq.H), torch.float32), spool.zeros((hop, R, HP), torch.int8)
-                o.h[0], o.h[1] = (None, None) if h0 is None else (h0.data_ptr(), h1.data_ptr())
-                o.c, o.spikes = ptr(c), ptr(spk)
+        # ---- weights, once (two passes: size, then copy)
+        wpool = Pool()
+        seqs = [eng.fb] + list(eng.sb)
 
-        out = {}
-        for sizing in (True, False):
-            if not sizing:
-                wpool.buf = torch.zeros((max(wpool.size, 256),), dtype=torch.uint8, device=dev)
-                spool.buf = torch.zeros((max(spool.size, 256),), dtype=torch.uint8, device=dev)
-                wpool.size = spool.size = 0
+        def put_weights():
+            w = []
+            for seq in seqs:
+                d = dict(p=(wpool.put(seq.proj_q), wpool.put(seq.proj_dq), wpool.put(seq.proj_b)), layers=[],
+                         ln=(wpool.put(seq.ln_w), wpool.put(seq.ln_b)) if seq.ln_w is not None else None)
+                for l, cell in enumerate(seq.cells):
+                    e = dict(hh=(wpool.put(cell.w_hh_q), wpool.put(cell.w_hh_dq)))
+                    if l == 0:  # fp32 input weights in MFMA fragment order (include/sfsn.h): one coalesced request per 16 columns
+                        w0 = cell.w_ih_f32
+                        kc = (w0.shape[1] + 15) // 16
+                        w0 = torch.nn.functional.pad(w0, (0, kc * 16 - w0.shape[1]))
+                        e["ih"] = (wpool.put(w0.view(seq.H // 16, 16, kc, 4, 4).permute(0, 2, 3, 1, 4).contiguous()),)
+                    else:
+                        e["ih"] = (wpool.put(cell.w_ih_q[0][0]), wpool.put(cell.w_ih_q[0][1]))
+                    e["c"] = (wpool.put(cell.bias), wpool.put(cell.alpha), wpool.put(cell.beta))
+                    d["layers"].append(e)
+                w.append(d)
+            win = wpool.put(torch.hann_window(512, device=dev, dtype=torch.float32)) if self.waveform else None
+            return w, win
+
+        put_weights()
+        wpool.allocate()
+        weights, window = put_weights()
+
+        # ---- one part = the clips [b0, b0 + nb) of the batch: descriptor + state
+        def make_desc(nb, spool, a=None):
+            """a: placeholder address for the sizing call (the plan never dereferences device pointers)."""
             desc = HopDesc()
-            fill(desc.fb, eng.fb, self.fg_fb[0], B, 0, 0)
-            for g in range(ng):
-                fill(desc.sb[g], eng.sb[g], self.fg_sb[g], B * spec.units(g), spec.df[g], spec.ctr[g])
-            desc.n_groups, desc.B, desc.F, desc.S, desc.hop, desc.D, desc.fdrc = ng, B, F, S, hop, D, spec.fdrc
-            hist = spool.zeros((B, F, max(D, 1), 2), torch.float32)
-            enh, mag = spool.zeros((B, S, F, hop, 2), torch.float32), spool.zeros((B, S, F, hop), torch.float32)
-            wv = None
+            fgs = [self.fg_fb[0]] + [self.fg_sb[g] for g in range(ng)]
+            dsts = [desc.fb] + [desc.sb[g] for g in range(ng)]
+            for i, (dst, seq, fg, w) in enumerate(zip(dsts, seqs, fgs, weights)):
+                R = nb * (1 if i == 0 else spec.units(i - 1))
+                HP = (seq.H + 63) // 64 * 64
+                dst.n_layers, dst.H, dst.P = len(seq.cells), seq.H, seq.P
+                dst.df, dst.fc = (0, 0) if i == 0 else (spec.df[i - 1], spec.ctr[i - 1])
+                dst.feat = fg
+                if w["ln"] is not None:
+                    dst.feat.ln_w, dst.feat.ln_b = w["ln"]
+                dst.w_p, dst.w_p_dq, dst.b_p = w["p"]
+                for l, e in enumerate(w["layers"]):
+                    o = dst.layer[l]
+                    o.w_hh, o.w_hh_dq = e["hh"]
+                    if l == 0:
+                        o.w_ih_frag = e["ih"][0]
+                    else:
+                        o.w_ih, o.w_ih_dq = e["ih"]
+                    o.bias, o.bn_alpha, o.bn_beta = e["c"]
+                    h0, h1 = spool.zeros((R, HP), torch.int8), spool.zeros((R, HP), torch.int8)
+                    c, spk = spool.zeros((R, seq.H), torch.float32), spool.zeros((hop, R, HP), torch.int8)
+                    o.h[0], o.h[1], o.c, o.spikes = (a, a, a, a) if a else (ptr(h0), ptr(h1), ptr(c), ptr(spk))
+            desc.n_groups, desc.B, desc.F, desc.S, desc.hop, desc.D, desc.fdrc = ng, nb, F, S, hop, D, spec.fdrc
+            st = dict(hist=spool.zeros((nb, F, max(D, 1), 2), torch.float32))
             if self.waveform:
-                wv = dict(state=spool.zeros((B, 512), torch.float32), ola=spool.zeros((B, S, 512), torch.float32),
-                          out=spool.zeros((B, S, 128), torch.float32), spec_g=spool.zeros((B, F, 4), torch.float32),
-                          enh_g=spool.zeros((B, S, F, 4), torch.float32))
-                window = wpool.put(torch.hann_window(512, device=dev, dtype=torch.float32))
-            if sizing:
-                # the scratch size depends on the launch geometry only: ask with placeholder (non-NULL) addresses
-                probe = torch.zeros((16,), dtype=torch.uint8, device=dev)
-                a = probe.data_ptr()
-                for sq_ in [desc.fb] + [desc.sb[g] for g in range(ng)]:
-                    sq_.w_p, sq_.w_p_dq, sq_.b_p = a, a, a
-                    sq_.feat.ln_w, sq_.feat.ln_b = (a, a) if sq_.feat.norm == 1 else (None, None)
-                    for l in range(sq_.n_layers):
-                        o = sq_.layer[l]
-                        o.w_hh, o.w_hh_dq, o.bias, o.bn_alpha, o.bn_beta, o.c, o.spikes = a, a, a, a, a, a, a
-                        o.h[0], o.h[1] = a, a
-                        if l == 0:
-                            o.w_ih_frag = a
-                        else:
-                            o.w_ih, o.w_ih_dq = a, a
-                desc.inp_ri, desc.hist_ri, desc.enh_ri, desc.enh_mag = a, a, a, a
+                st.update(state=spool.zeros((nb, 512), torch.float32), ola=spool.zeros((nb, S, 512), torch.float32),
+                          spec_g=spool.zeros((nb, F, 4), torch.float32), enh_g=spool.zeros((nb, S, F, 4), torch.float32))
+            if a:
+                desc.inp_ri = desc.hist_ri = desc.enh_ri = desc.enh_mag = a
                 if self.waveform:
                     desc.wave_in = desc.wave_state = desc.ola_state = desc.wave_out = desc.window = desc.spec_g = desc.enh_g = a
-                nb = L.sfsn_hop_scratch_bytes(ctypes.byref(desc))
-                if nb == 0:
-                    return None
-                out["nb"] = nb
-                continue
-            desc.inp_ri, desc.hist_ri = _ptr(self.inp), ptr(hist)
-            desc.enh_ri, desc.enh_mag = ptr(enh), ptr(mag)
+            else:
+                desc.hist_ri = ptr(st["hist"])
+                if self.waveform:
+                    desc.wave_state, desc.ola_state, desc.window = ptr(st["state"]), ptr(st["ola"]), window
+                    desc.spec_g, desc.enh_g = ptr(st["spec_g"]), ptr(st["enh_g"])
+            return desc, st
+
+        probe = torch.zeros((16,), dtype=torch.uint8, device=dev)
+        n_parts, nbytes = 0, 0
+        for n in range(1, 9):  # equal parts: the fewest launches whose workgroups fit the chip
+            if n > B:
+                break
+            nbytes = L.sfsn_hop_scratch_bytes(ctypes.byref(make_desc(-(-B // n), Pool(), probe.data_ptr())[0]))
+            if nbytes:
+                n_parts = n
+                break
+        if not n_parts:
+            return None
+        per = -(-B // n_parts)
+        enh = torch.zeros((B, S, F, hop, 2), dtype=torch.float32, device=dev)
+        mag = torch.zeros((B, S, F, hop), dtype=torch.float32, device=dev)
+        wave_out = torch.zeros((B, S, 128), dtype=torch.float32, device=dev) if self.waveform else None
+        parts = []
+        for b0 in range(0, B, per):
+            nb = min(per, B - b0)
+            spool = Pool()
+            make_desc(nb, spool, probe.data_ptr())
+            spool.allocate()
+            desc, st = make_desc(nb, spool)
+            desc.inp_ri = _ptr(self.inp)
+            desc.enh_ri, desc.enh_mag = ptr(enh[b0:]), ptr(mag[b0:])
             if self.waveform:
-                desc.wave_state, desc.ola_state, desc.wave_out = ptr(wv["state"]), ptr(wv["ola"]), ptr(wv["out"])
-                desc.window, desc.spec_g, desc.enh_g = window, ptr(wv["spec_g"]), ptr(wv["enh_g"])
-            scratch = torch.zeros((out["nb"] // 4 + 1,), dtype=torch.int32, device=dev)  # word 0: the error flag
-            desc.scratch, desc.scratch_bytes = ptr(scratch), out["nb"]
-        # the error word of a launch is looked at, without blocking, at the next step (pinned copy behind the launch)
-        err = torch.zeros((1,), dtype=torch.int32).pin_memory()
-        return dict(desc=desc, ref=ctypes.byref(desc), wave=wv, wpool=wpool.buf, spool=spool.buf, enh=torch.view_as_complex(enh), mag=mag, scratch=scratch, err=err,
-                    err_pending=False)
+                desc.wave_in, desc.wave_out = probe.data_ptr(), ptr(wave_out[b0:])  # (wave_in: set per call)
+            nbytes = L.sfsn_hop_scratch_bytes(ctypes.byref(desc))
+            assert nbytes, "the sizing call accepted this geometry"
+            scratch = torch.zeros((nbytes // 4 + 1,), dtype=torch.int32, device=dev)  # word 0: the error flag
+            desc.scratch, desc.scratch_bytes = ptr(scratch), nbytes
+            # the error word of a launch is looked at, without blocking, at a later step (pinned copy behind the launch)
+            parts.append(dict(desc=desc, ref=ctypes.byref(desc), b0=b0, nb=nb, st=st, spool=spool.buf, scratch=scratch,
+                              err=torch.zeros((1,), dtype=torch.int32).pin_memory(), err_pending=False))
+        return dict(parts=parts, desc=parts[0]["desc"], scratch=parts[0]["scratch"], wpool=wpool.buf, enh=torch.view_as_complex(enh),
+                    mag=mag, wave_out=wave_out)
+
+    def _launch_hops(self, base_ptr: int, stride_bytes: int, field: str, frame_index=None) -> None:
+        """One sfsn_stream_hop launch per part, back to back on torch's current stream; `field` of each descriptor is pointed at
+        the part's slice of the caller's input (clips are the slowest axis: a part is a contiguous range)."""
+        idx = self._dev_index
+        st = ctypes.c_void_p(_raw_stream(idx))
+        same = torch.cuda.current_device() == idx  # the C ABI launches on the calling thread's current device
+        for part in self._hop["parts"]:
+            if part["err_pending"] and int(part["err"][0]) != 0:  # written behind an earlier launch; no blocking here
+                raise RuntimeError("sfsn_stream_hop: a bounded hand-off wait expired inside a launch (results invalid)")
+            d = part["desc"]
+            setattr(d, field, base_ptr + part["b0"] * stride_bytes)
+            if frame_index is not None:
+                d.frame_index = frame_index
+            if same:
+                rc = self.eng.lib.sfsn_stream_hop(part["ref"], st)
+            else:
+                with torch.cuda.device(self.dev):
+                    rc = self.eng.lib.sfsn_stream_hop(part["ref"], st)
+            if rc:
+                check(rc, "sfsn_stream_hop")
+            d.launch_index += 1
+        self.frames_done += self.hop
+        if self.frames_done % 256 < self.hop:  # every ~256 frames the error words follow the launches into pinned memory
+            for part in self._hop["parts"]:
+                part["err"].copy_(part["scratch"][:1], non_blocking=True)
+                part["err_pending"] = True
 
     # -----------------------------------------------------------------------------------------------------------------
     def reset(self) -> None:
@@ -236,7 +298,8 @@ class StreamingSession:
         self.hist.zero_()
         if self._hop is not None:
             self.check_errors()
-            self._hop["spool"].zero_()  # (h, c), tagged spike buffers, history, outputs, waveform state: one fill
+            for part in self._hop["parts"]:
+                part["spool"].zero_()  # (h, c), tagged spike buffers, history, waveform state: one fill per part
             self._wave_calls = 0
         self.frames_done = 0
 
@@ -245,8 +308,9 @@ class StreamingSession:
         if self._hop is None:
             return
         torch.cuda.current_stream(self.dev).synchronize()
-        if int(self._hop["scratch"][0].item()) != 0:
-            raise RuntimeError("sfsn_stream_hop: a bounded hand-off wait expired inside a launch (results invalid)")
+        for part in self._hop["parts"]:
+            if int(part["scratch"][0].item()) != 0:
+                raise RuntimeError("sfsn_stream_hop: a bounded hand-off wait expired inside a launch (results invalid)")
 
     def _enqueue(self) -> None:
         """One hop on torch's current stream: history shift, then the offline forward's kernels on frames [D, D+hop)."""
@@ -320,27 +384,10 @@ class StreamingSession:
             raise RuntimeError("this session was opened with waveform=True: use step_wave(samples)")
         if self._hop is not None:
             h = self._hop
-            if h["err_pending"] and int(h["err"][0]) != 0:  # written behind an earlier launch; no blocking here
-                raise RuntimeError("sfsn_stream_hop: a bounded hand-off wait expired inside a launch (results invalid)")
-            if frames.is_contiguous() and frames.data_ptr() % 8 == 0:
-                h["desc"].inp_ri = frames.data_ptr()  # read in place: no staging copy in front of the launch
-            else:
+            if not (frames.is_contiguous() and frames.data_ptr() % 8 == 0):
                 self.inp.copy_(frames)
-                h["desc"].inp_ri = self.inp.data_ptr()
-            idx = self._dev_index
-            st = ctypes.c_void_p(_raw_stream(idx))
-            if torch.cuda.current_device() == idx:  # the C ABI launches on the calling thread's current device
-                rc = self.eng.lib.sfsn_stream_hop(h["ref"], st)
-            else:
-                with torch.cuda.device(self.dev):
-                    rc = self.eng.lib.sfsn_stream_hop(h["ref"], st)
-            if rc:
-                check(rc, "sfsn_stream_hop")
-            h["desc"].launch_index += 1
-            self.frames_done += self.hop
-            if self.frames_done % 256 < self.hop:  # every ~256 frames: the error word follows the launch into pinned memory
-                h["err"].copy_(h["scratch"][:1], non_blocking=True)
-                h["err_pending"] = True
+                frames = self.inp
+            self._launch_hops(frames.data_ptr(), self.F * self.hop * 8, "inp_ri")  # read in place: no staging copy in front
             return (h["enh"].clone(), h["mag"].clone()) if copy else (h["enh"], h["mag"])
         self.inp.copy_(frames)
         if self._graph is not None:
@@ -364,28 +411,12 @@ class StreamingSession:
         h = self._hop
         c = self._wave_calls
         self._wave_calls += 1
+        out = h["wave_out"]
         if c == 0:  # no frame ends here yet (frame 0 covers samples [-256, 256)): the samples only enter the state
-            h["wave"]["state"][:, 384:].copy_(samples)
-            return torch.zeros_like(h["wave"]["out"])
-        if h["err_pending"] and int(h["err"][0]) != 0:
-            raise RuntimeError("sfsn_stream_hop: a bounded hand-off wait expired inside a launch (results invalid)")
-        d = h["desc"]
-        d.wave_in, d.frame_index = samples.data_ptr(), c - 1
-        idx = self._dev_index
-        st = ctypes.c_void_p(_raw_stream(idx))
-        if torch.cuda.current_device() == idx:
-            rc = self.eng.lib.sfsn_stream_hop(h["ref"], st)
-        else:
-            with torch.cuda.device(self.dev):
-                rc = self.eng.lib.sfsn_stream_hop(h["ref"], st)
-        if rc:
-            check(rc, "sfsn_stream_hop")
-        d.launch_index += 1
-        self.frames_done += 1
-        if self.frames_done % 256 == 0:
-            h["err"].copy_(h["scratch"][:1], non_blocking=True)
-            h["err_pending"] = True
-        out = h["wave"]["out"]
+            for part in h["parts"]:
+                part["st"]["state"][:, 384:].copy_(samples[part["b0"]:part["b0"] + part["nb"]])
+            return torch.zeros_like(out)
+        self._launch_hops(samples.data_ptr(), 128 * 4, "wave_in", frame_index=c - 1)
         if c < 3:  # padded positions torch.istft trims
             return torch.zeros_like(out)
         return out.clone() if copy else out

@@ -623,7 +623,8 @@ def test_forwards_in_flight_on_separate_streams_are_independent():
 
 @pytest.mark.parametrize("one_launch", ["auto", False])
 @pytest.mark.parametrize("kw,seed,B,hop,graph", [(rw.LIVE_TINY, 11, 2, 1, True), (rw.LIVE_M, 5, 1, 1, True), (rw.LIVE_M, 5, 3, 4, True),
-                                                  (rw.LIVE_TINY_2SPK, 12, 2, 3, False), (rw.LIVE_TINY_UNSHARED, 7, 1, 1, True)])
+                                                  (rw.LIVE_TINY_2SPK, 12, 2, 3, False), (rw.LIVE_TINY_UNSHARED, 7, 1, 1, True),
+                                                  (rw.LIVE_M, 5, 37, 1, True)])
 def test_streaming_session_equals_offline_forward(kw, seed, B, hop, graph, one_launch):
     """BASELINE configs[4] (streaming, state carried, hop frames per call): the frame-by-frame session reproduces the offline
     forward on the same clip bit for bit (the model is causal after the STFT), and a reset starts a new utterance -- both as ONE
@@ -657,7 +658,7 @@ def test_streaming_session_equals_offline_forward(kw, seed, B, hop, graph, one_l
         sess.reset()
 
 
-@pytest.mark.parametrize("kw,seed,B", [(rw.LIVE_TINY, 11, 2), (rw.LIVE_M, 5, 1), (rw.LIVE_TINY_2SPK, 12, 3), (rw.LIVE_M, 5, 17)])
+@pytest.mark.parametrize("kw,seed,B", [(rw.LIVE_TINY, 11, 2), (rw.LIVE_M, 5, 1), (rw.LIVE_TINY_2SPK, 12, 3), (rw.LIVE_M, 5, 17), (rw.LIVE_M, 5, 35)])
 def test_waveform_streaming_equals_offline_forward(kw, seed, B):
     """Samples in, samples out, 128 at a time (8 ms): the session with waveform=True -- STFT of the new frame, the whole model
     and the inverse STFT with its overlap-add state in ONE launch per hop -- reproduces the offline forward's waveform bit for
@@ -712,8 +713,9 @@ def test_stream_hop_argument_checks_and_fallback():
     with pytest.raises(NotImplementedError):
         unshared.streaming(batch=1, hop=1, one_launch=True)
     mid = build_module("live", rw.LIVE_M, rw.live_state_dict(rw.LIVE_M, 5))
-    big = mid.streaming(batch=64, hop=1)  # more workgroups than compute units: the session falls back by itself
-    assert big._hop is None and mid.streaming(batch=16, hop=1)._hop is not None
+    # more workgroups than compute units in one launch: the batch is cut into equal parts, one launch each
+    assert len(mid.streaming(batch=16, hop=1)._hop["parts"]) == 1 and len(mid.streaming(batch=64, hop=1)._hop["parts"]) == 2
+    big = mid.streaming(batch=64, hop=1, one_launch=False)  # the per-kernel sequence still serves any batch
     big.step(torch.zeros((64, 257, 1), dtype=torch.complex64, device=DEV))
     torch.cuda.synchronize()
 
