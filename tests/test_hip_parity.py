@@ -624,7 +624,9 @@ def test_forwards_in_flight_on_separate_streams_are_independent():
 @pytest.mark.parametrize("one_launch", ["auto", False])
 @pytest.mark.parametrize("kw,seed,B,hop,graph", [(rw.LIVE_TINY, 11, 2, 1, True), (rw.LIVE_M, 5, 1, 1, True), (rw.LIVE_M, 5, 3, 4, True),
                                                   (rw.LIVE_TINY_2SPK, 12, 2, 3, False), (rw.LIVE_TINY_UNSHARED, 7, 1, 1, True),
-                                                  (rw.LIVE_M, 5, 37, 1, True)])
+                                                  (rw.LIVE_M, 5, 37, 1, True),
+                                                  (dict(rw.LIVE_TINY, use_pre_layer_norm_fb=False, use_pre_layer_norm_sb=False, bn=False), 13, 2, 1, True),
+                                                  (dict(rw.LIVE_TINY, df_orders=[1, 1, 1]), 14, 3, 2, True)])
 def test_streaming_session_equals_offline_forward(kw, seed, B, hop, graph, one_launch):
     """BASELINE configs[4] (streaming, state carried, hop frames per call): the frame-by-frame session reproduces the offline
     forward on the same clip bit for bit (the model is causal after the STFT), and a reset starts a new utterance -- both as ONE
@@ -658,7 +660,8 @@ def test_streaming_session_equals_offline_forward(kw, seed, B, hop, graph, one_l
         sess.reset()
 
 
-@pytest.mark.parametrize("kw,seed,B", [(rw.LIVE_TINY, 11, 2), (rw.LIVE_M, 5, 1), (rw.LIVE_TINY_2SPK, 12, 3), (rw.LIVE_M, 5, 17), (rw.LIVE_M, 5, 35)])
+@pytest.mark.parametrize("kw,seed,B", [(rw.LIVE_TINY, 11, 2), (rw.LIVE_M, 5, 1), (rw.LIVE_TINY_2SPK, 12, 3), (rw.LIVE_M, 5, 17), (rw.LIVE_M, 5, 35),
+                                       (dict(rw.LIVE_TINY, df_orders=[1, 1, 1], use_pre_layer_norm_sb=False), 15, 1)])
 def test_waveform_streaming_equals_offline_forward(kw, seed, B):
     """Samples in, samples out, 128 at a time (8 ms): the session with waveform=True -- STFT of the new frame, the whole model
     and the inverse STFT with its overlap-add state in ONE launch per hop -- reproduces the offline forward's waveform bit for
