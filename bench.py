@@ -197,7 +197,14 @@ def main():
     del src_, dst_
 
     scan_tags = None if args.time_all else {"scan:sb", "scan:fb", "stack:sb", "stack:fb", "scanx:sb", "scanf:sb"}
-    geom_b = tuple(int(v) for v in args.rpw.split(",")) if args.rpw else (4, 16)
+    geom_b = tuple(int(v) for v in args.rpw.split(",")) if args.rpw else (8, 16)
+
+    def set_geometry(g):
+        """(full-band, sub-band) rows per scan workgroup; the full-band entry also sets the rows per workgroup of the full-band
+        stack launch.  (0, 0) = the engine's defaults for a forward alone (4 rows: shortest chain); the timed region runs
+        (8, 16): half / a quarter of the workgroups per forward, so that more forwards' scans fit side by side."""
+        eng.rows_per_wg = g
+        eng.stack_rows_fb_auto = g[0] if g[0] in (4, 8, 16) else 4
     n_lanes = 1 if args.sequential else max(1, min(args.inflight, args.steps // 2))  # a short run cannot amortise many lanes
 
     # ---- phase S (untimed for `value`): THE STRICT NUMBER -- one forward at a time on one stream, B clips x T frames per step,
@@ -205,7 +212,7 @@ def main():
     #      layer-pipelined launch, sub-band layers as full-chip launches at 4 rows per workgroup).
     single, t_s, t_k = None, {}, {}
     if not args.no_phase_a:
-        eng.rows_per_wg = (0, 0)
+        set_geometry((0, 0))
         ka = max(2, min(args.steps, 8))
         dt_a = timed_region(forward, ka, min(args.warmup, 2) + 1)
         eng.check_stack_errors()
@@ -225,7 +232,8 @@ def main():
                       if eng.overlap_chunks > 1 else "full-band stack in one layer-pipelined launch; sub-band layers as full-chip launches")
         # ---- phase K (untimed): the scan kernels of the timed region's geometry, each alone on the chip (one forward at a time)
         if n_lanes > 1:
-            eng.rows_per_wg, ov = geom_b, eng.overlap_chunks
+            set_geometry(geom_b)
+            ov = eng.overlap_chunks
             eng.overlap_chunks = 0
             eng.timers, eng.timer_tags = {}, scan_tags
             for _ in range(4):
@@ -242,7 +250,7 @@ def main():
     ov_default = eng.overlap_chunks
     if n_lanes > 1:
         eng.overlap_chunks = 0  # the full-band / sub-band overlap of ONE forward only pays when nothing else fills the chip
-        eng.rows_per_wg = geom_b
+        set_geometry(geom_b)
         lanes = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
         counter = [0]
         for s_ in lanes:  # untimed: first use of a lane allocates its scratch buffers and warms its memory pool
@@ -257,7 +265,7 @@ def main():
             with torch.cuda.stream(s_):
                 return forward()
     else:
-        eng.rows_per_wg = tuple(int(v) for v in args.rpw.split(",")) if args.rpw else (0, 0)
+        set_geometry(tuple(int(v) for v in args.rpw.split(",")) if args.rpw else (0, 0))
         step = forward
     dt = timed_region(step, args.steps, args.warmup)
     if eng.timers is not None:

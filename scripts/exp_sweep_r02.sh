@@ -8,3 +8,4 @@ for st in auto 0; do for inf in 8 12 16; do run --stack $st --inflight $inf; don
 run --stack auto --inflight 12 --rpw 8,16
 run --stack auto --inflight 24
 SFSN_OVERLAP_CHUNKS=0 run --stack auto --inflight 12
+for r in 8 16; do SFSN_FB_STACK_ROWS=$r run --stack auto --inflight 12; SFSN_FB_STACK_ROWS=$r run --stack auto --inflight 16; done

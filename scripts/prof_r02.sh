@@ -16,9 +16,9 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_IN
   tag=$(echo $c | cut -d' ' -f1)
   SFSN_OVERLAP_CHUNKS=0 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$tag -o p -- $B --sequential --steps 2 --warmup 1 --no-phase-a > $OUT/pmc_$tag.log 2>&1
 done
-# (4) HBM traffic of one forward in the timed region's geometry (sub-band scans at 16 rows per workgroup, fused input products)
+# (4) HBM traffic of one forward in the timed region's geometry (full-band stack at 8, sub-band scans at 16 rows per workgroup, fused input products)
 for c in FETCH_SIZE WRITE_SIZE; do
-  SFSN_OVERLAP_CHUNKS=0 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/job_$c -o p -- $B --sequential --rpw 4,16 --steps 3 --warmup 1 --no-phase-a > $OUT/job_$c.log 2>&1
+  SFSN_OVERLAP_CHUNKS=0 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/job_$c -o p -- $B --sequential --rpw 8,16 --steps 3 --warmup 1 --no-phase-a > $OUT/job_$c.log 2>&1
 done
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --streaming --no-cpu-baseline > $OUT/bench_streaming.json 2>> $OUT/bench_default.err

@@ -69,7 +69,7 @@ pj = dict(source_hash=src_hash, B=64, T=1000,
                                                                                       for kk, v in nf.items() if any(t in kk for t in OURS))),
           full_band_stack_mfma=mf,
           note="HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per dispatch (gfx950 FETCH_SIZE half-count correction); forward_hbm_bytes = all "
-               "kernels of one forward in the timed region's geometry (--rpw 4,16); sources: profiles/r02_pmc_summary.csv and gpurun_out/prof_r02/job_*")
+               "kernels of one forward in the timed region's geometry (--rpw 8,16: full-band stack at 8, sub-band scans at 16 rows per workgroup); sources: profiles/r02_pmc_summary.csv and gpurun_out/prof_r02/job_*")
 json.dump(pj, open(f"profiles/{rnd}_pmc.json", "w"), indent=1)
 rows = list(csv.DictReader(open(f"profiles/{rnd}_single_stream_whole_launch_kernel_stats.csv")))
 for r in rows[:14]:

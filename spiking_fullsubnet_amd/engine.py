@@ -231,6 +231,7 @@ class Engine:
         # by a few frames.  Shared gate weights only; membrane outputs (a test tap of the per-layer kernel) use the per-layer path.
         _ss = os.environ.get('SFSN_STACK_SCAN', 'auto')
         self.stack_scan = "auto" if _ss == "auto" else bool(int(_ss))
+        self.stack_rows_fb_auto = int(os.environ.get("SFSN_FB_STACK_ROWS", "4"))  # rows per workgroup of the full-band stack under "auto"
         self.stack_rows_per_wg = {"fb": 4, "sb": 8}  # rows per workgroup of every layer of a stack: sum of workgroups <= CUs
         self.stack_lag = 16
         # full-band / sub-band overlap of ONE forward: the sequence is cut into this many chunks, the full-band model runs them
@@ -430,7 +431,8 @@ class Engine:
         rows = sum(Rs)
         n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
         if H > 256:  # the full-band model: few rows, PROJ + gated scan roles
-            return (rows + 3) // 4 * nl + (rows + 15) // 16 <= n_cu, False, 4
+            rp = self.stack_rows_fb_auto
+            return (rows + rp - 1) // rp * nl + (rows + 15) // 16 <= n_cu, False, rp
         if rows <= n_cu:       # every layer's workgroups at 8 rows + the PROJ workgroups fit several times over
             return True, True, 8
         if rows <= 2 * n_cu:   # 8 rows per workgroup: both layers side by side still fit
