@@ -234,6 +234,9 @@ def test_modules_with_stack_scan_are_bit_identical_to_the_per_layer_schedule(fro
     eng.seq_chunk = 0
     eng.stack_scan = "auto"
     outs.append(eng.forward_stft(stft))
+    eng.stack_rows_fb_auto = 8  # the full-band stack's geometry in bench.py's timed region
+    outs.append(eng.forward_stft(stft))
+    eng.stack_rows_fb_auto = 4
     lean = eng.forward_stft(stft, want_layers=False, want_counts=True)
     eng.check_stack_errors()
     assert eng.launches.get("stack", 0) >= n0 + 8
