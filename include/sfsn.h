@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 4 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 5 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -330,6 +330,10 @@ typedef struct sfsn_hop_desc {
     float* spec_g;                 /* [B][F][4] scratch ({re, tag, im, tag} granules of the noisy frame), zeroed once */
     float* enh_g;                  /* [B][S][F][4] scratch (granules of the enhanced frame), zeroed once              */
     int frame_index;
+    unsigned* done;                /* nullable, [B][S]: word (b, s) is set to launch_index + 1 (system-scope release) once wave_out
+                                      (b, s) has been written.  wave_in, wave_out and done may be pinned host memory the device can
+                                      reach: samples in host memory -> enhanced samples in host memory with no copy launch and no
+                                      stream synchronisation (the caller spins on the words)                               */
 } sfsn_hop_desc;
 
 size_t sfsn_hop_scratch_bytes(const sfsn_hop_desc* desc /* host */);

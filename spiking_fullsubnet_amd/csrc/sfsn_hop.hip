@@ -100,6 +100,7 @@ struct HopParams {
     float* spec_g;
     float* enh_g;
     int frame_index;
+    unsigned* done;  // optional (host-visible): one word per (clip, speaker), set to launch + 1 when its samples are out
     float* hist;
     float* enh;
     float* mag;
@@ -779,6 +780,12 @@ __device__ __forceinline__ void hop_istft_role(const HopParams& p, const HopStag
         }
     const float2 out = make_float2(env.x > 1e-11f ? acc[0].x / env.x : 0.0f, env.y > 1e-11f ? acc[0].y / env.y : 0.0f);
     *reinterpret_cast<float2*>(p.wave_out + (size_t)pair * 128 + 2 * lane) = out;
+    if (p.done) {
+        // wave_out (and this word) may be host memory the device can reach: a caller that keeps its samples on the host spins on
+        // the word instead of synchronising the stream -- the samples are there when it changes (system-scope release)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(p.done + pair, p.launch + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int n = 2 * (lane + 64 * r);
@@ -868,6 +875,7 @@ static int hop_plan(HopParams& p, size_t& lds, const sfsn_hop_desc* d) {
     if (wave) {
         p.wave_in = d->wave_in; p.wave_state = d->wave_state; p.ola_state = d->ola_state; p.wave_out = d->wave_out;
         p.window = d->window; p.spec_g = d->spec_g; p.enh_g = d->enh_g; p.frame_index = d->frame_index;
+        p.done = d->done;
     }
     p.nseq = 1 + d->n_groups;
     int rc = hop_fill_seq(p.seq[0], d->fb, d->B, d->F, d->S, true, 0);

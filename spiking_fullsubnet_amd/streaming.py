@@ -22,6 +22,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import time
 from typing import Optional, Tuple
 
 import torch
@@ -42,7 +43,7 @@ class StreamingSession:
     """``step(frames [B, F, hop] complex64) -> (enh_stft [B, S, F, hop], enh_mag [B, S, F, hop])`` with state carried."""
 
     def __init__(self, engine: Engine, batch: int = 1, hop: int = 1, graph: bool = True, rows_per_wg=None, owner=None,
-                 one_launch="auto", waveform: bool = False):
+                 one_launch="auto", waveform: bool = False, host_io: bool = False):
         spec = engine.spec
         # the module the engine was packed from: reset() checks that its parameters have not changed since (the session's
         # captured graph holds pointers to THIS engine's packed weights)
@@ -93,6 +94,9 @@ class StreamingSession:
         self._hop = None
         self.waveform = bool(waveform)  # step_wave(): samples in, samples out (STFT and inverse STFT inside the launch)
         self._wave_calls = 0
+        self.host_io = bool(host_io)  # waveform mode: samples come from and go to (pinned) host memory, no copy launches
+        if self.host_io and not waveform:
+            raise ValueError("host_io goes with waveform=True")
         if self.waveform:
             if hop != 1 or spec.n_fft != 512:
                 raise NotImplementedError("waveform streaming: one 128-sample hop per call, 512-point frames")
@@ -235,6 +239,11 @@ class StreamingSession:
         enh = torch.zeros((B, S, F, hop, 2), dtype=torch.float32, device=dev)
         mag = torch.zeros((B, S, F, hop), dtype=torch.float32, device=dev)
         wave_out = torch.zeros((B, S, 128), dtype=torch.float32, device=dev) if self.waveform else None
+        host = None
+        if self.host_io:  # pinned host memory the kernel reads / writes directly (hipHostMalloc: device-reachable at the same address)
+            host = dict(inp=torch.zeros((B, 128), dtype=torch.float32).pin_memory(), out=torch.zeros((B, S, 128), dtype=torch.float32).pin_memory(),
+                        done=torch.zeros((B * S,), dtype=torch.int32).pin_memory())
+            host["done_np"] = host["done"].numpy()
         parts = []
         for b0 in range(0, B, per):
             nb = min(per, B - b0)
@@ -246,6 +255,8 @@ class StreamingSession:
             desc.enh_ri, desc.enh_mag = ptr(enh[b0:]), ptr(mag[b0:])
             if self.waveform:
                 desc.wave_in, desc.wave_out = probe.data_ptr(), ptr(wave_out[b0:])  # (wave_in: set per call)
+                if host is not None:
+                    desc.wave_out, desc.done = ptr(host["out"][b0:]), ptr(host["done"][b0 * S:])
             nbytes = L.sfsn_hop_scratch_bytes(ctypes.byref(desc))
             assert nbytes, "the sizing call accepted this geometry"
             scratch = torch.zeros((nbytes // 4 + 1,), dtype=torch.int32, device=dev)  # word 0: the error flag
@@ -254,7 +265,7 @@ class StreamingSession:
             parts.append(dict(desc=desc, ref=ctypes.byref(desc), b0=b0, nb=nb, st=st, spool=spool.buf, scratch=scratch,
                               err=torch.zeros((1,), dtype=torch.int32).pin_memory(), err_pending=False))
         return dict(parts=parts, desc=parts[0]["desc"], scratch=parts[0]["scratch"], wpool=wpool.buf, enh=torch.view_as_complex(enh),
-                    mag=mag, wave_out=wave_out)
+                    mag=mag, wave_out=wave_out, host=host)
 
     def _launch_hops(self, base_ptr: int, stride_bytes: int, field: str, frame_index=None) -> None:
         """One sfsn_stream_hop launch per part, back to back on torch's current stream; `field` of each descriptor is pointed at
@@ -420,3 +431,31 @@ class StreamingSession:
         if c < 3:  # padded positions torch.istft trims
             return torch.zeros_like(out)
         return out.clone() if copy else out
+
+
+    def step_wave_host(self, samples, timeout_s: float = 2.0) -> torch.Tensor:
+        """Waveform streaming with the samples on the HOST (``waveform=True, host_io=True``): ``samples`` = float32 [B, 128] CPU
+        tensor (or anything ``torch.as_tensor`` takes).  The launch reads them from pinned host memory and writes the enhanced
+        samples and a completion word per (clip, speaker) back into pinned host memory; the caller's thread spins on the words --
+        no copy launch, no stream synchronisation.  Returns a CPU tensor [B, S, 128] (a view of the session's pinned buffer, valid
+        until the next call); same three-hop delay as ``step_wave``."""
+        h = self._hop
+        if not self.host_io or h is None:
+            raise RuntimeError("open the session with waveform=True, host_io=True")
+        host = h["host"]
+        host["inp"].copy_(torch.as_tensor(samples, dtype=torch.float32).reshape(self.B, 128))
+        c = self._wave_calls
+        self._wave_calls += 1
+        if c == 0:
+            for part in h["parts"]:
+                part["st"]["state"][:, 384:].copy_(host["inp"][part["b0"]:part["b0"] + part["nb"]], non_blocking=True)
+            return torch.zeros_like(host["out"])
+        target = h["parts"][0]["desc"].launch_index + 1
+        self._launch_hops(host["inp"].data_ptr(), 128 * 4, "wave_in", frame_index=c - 1)
+        done, t_end = host["done_np"], None
+        while int(done.min()) != target:  # (all parts carry the same launch index)
+            if t_end is None:
+                t_end = time.perf_counter() + timeout_s
+            elif time.perf_counter() > t_end:
+                raise RuntimeError("sfsn_stream_hop: no completion word from the launch (see check_errors())")
+        return torch.zeros_like(host["out"]) if c < 3 else host["out"]

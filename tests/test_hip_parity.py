@@ -690,6 +690,30 @@ def test_waveform_streaming_equals_offline_forward(kw, seed, B):
         sess.reset()
 
 
+@pytest.mark.parametrize("kw,seed,B", [(rw.LIVE_M, 5, 1), (rw.LIVE_TINY_2SPK, 12, 3), (rw.LIVE_M, 5, 35)])
+def test_waveform_streaming_from_and_to_host_memory(kw, seed, B):
+    """host_io=True: the launch reads the new samples from pinned host memory and writes the enhanced samples and a completion
+    word per (clip, speaker) back into pinned host memory; the caller spins on the words (no copy launch, no stream
+    synchronisation).  Same samples as the device-side session and the offline forward, bit for bit."""
+    model = build_module("live", kw, rw.live_state_dict(kw, seed))
+    n_hops = 30
+    wave = torch.from_numpy(rw.synth_wave(B, n_hops + 1, seed))  # CPU [B, 128 * n_hops]
+    y = model(wave.to(DEV))[0]
+    y = y.reshape(B, -1, y.shape[-1]).cpu()
+    sess = model.streaming(batch=B, waveform=True, host_io=True)
+    outs = []
+    for c in range(n_hops):
+        o = sess.step_wave_host(wave[:, 128 * c:128 * (c + 1)])
+        assert o.device.type == "cpu"
+        if c >= 3:
+            outs.append(o.clone())
+    sess.check_errors()
+    got = torch.cat(outs, -1)
+    assert torch.equal(got, y[..., :got.shape[-1]])
+    with pytest.raises(ValueError):
+        model.streaming(batch=B, host_io=True)
+
+
 def test_stream_hop_argument_checks_and_fallback():
     """sfsn_stream_hop through the C ABI: malformed descriptors are refused, what the launch does not cover reports
     SFSN_EUNSUPPORTED (the session then replays the offline kernels), one_launch=True insists."""
