@@ -76,6 +76,10 @@ LIVE_M = dict(  # recipes/intel_ndns/spiking_fullsubnet/baseline_m.toml:33-56
     use_pre_layer_norm_fb=True, use_pre_layer_norm_sb=True, bn=True, shared_weights=True, sequence_model="GSN", num_spks=1,
 )
 
+LIVE_WSJ0 = dict(  # recipes/wsj0-mix/spiking_fullsubnet/default.toml [model.args]: 8 kHz, 256-point frames, two speakers
+    LIVE_M, n_fft=256, hop_length=64, win_length=256, fb_input_size=32, fb_proj_size=32, freq_cutoffs=[0, 16, 64, 128],
+    center_freq_sizes=[2, 16, 32], neighbor_freq_sizes=[7, 7, 7], num_spks=2)
+
 LIVE_TINY = dict(LIVE_M, fb_hidden_size=48, sb_hidden_size=32, df_orders=[2, 3, 1])
 LIVE_TINY_2SPK = dict(LIVE_TINY, num_spks=2, df_orders=[2, 1, 1])
 LIVE_TINY_UNSHARED = dict(LIVE_TINY, shared_weights=False, bn=False, use_pre_layer_norm_sb=False)

@@ -437,6 +437,35 @@ def test_module_vs_oracle_seeded(front, kw, seed, B, T):
         assert np.isfinite(out["enh_mag"]).all()
 
 
+def test_wsj0_separation_config_vs_oracle_and_streaming():
+    """The reference's other recipe for this model (recipes/wsj0-mix/spiking_fullsubnet/default.toml: 256-point frames at 8 kHz,
+    two speakers, 32-bin full-band input): HIP path against the CPU oracle on a seeded input, and the one-launch streaming
+    session against the offline forward, bit for bit."""
+    kw, seed, B, T = rw.LIVE_WSJ0, 17, 3, 48
+    sd = rw.live_state_dict(kw, seed)
+    spec = omodel.spec_from_live_kwargs(kw)
+    wave = torch.from_numpy(rw.synth_wave(B, T, seed, hop=kw["hop_length"], modulated=True))
+    stft_c = torch.stft(wave, kw["n_fft"], kw["hop_length"], kw["win_length"], window=torch.hann_window(kw["win_length"]), return_complex=True,
+                        pad_mode="constant")
+    ora = omodel.forward_from_stft(spec, sd, stft_c.numpy(), "f32", want_membrane=True)
+    model = build_module("live", kw, sd)
+    out = hip_result(model, stft_c.numpy())
+    stats = parity.check_model(out, parity.gold_from_oracle(ora), spec, tag="oracle:")
+    parity.report(f"oracle-seeded:live-wsj0:B{B}xT{T}", stats)
+    for st in stats:
+        assert st["spike_agreement"] > 0.999, st
+    stft = stft_c.to(DEV)[..., :T].contiguous()
+    off = model.engine().forward_stft(stft, want_layers=False)
+    sess = model.streaming(batch=B, hop=1)
+    assert sess._hop is not None
+    outs = [sess.step(stft[..., t:t + 1].contiguous()) for t in range(T)]
+    sess.check_errors()
+    assert torch.equal(torch.view_as_real(torch.cat([e for e, _ in outs], -1)), torch.view_as_real(off["enh_stft"]))
+    assert torch.equal(torch.cat([m for _, m in outs], -1), off["enh_mag"])
+    with pytest.raises(NotImplementedError):
+        model.streaming(batch=B, waveform=True)  # waveform streaming: 512-point frames only
+
+
 @pytest.mark.parametrize("fname,kw", [("frozen_m_zoo.npz", rw.FROZEN_M), ("frozen_s_zoo.npz", rw.FROZEN_S)])
 def test_thirty_second_clip_sits_on_the_fp32_noise_floor(fname, kw):
     """The recipes validate on 30 s clips = 3751 frames in one pass (dataloader.py:73-99).  Over thousands of steps
