@@ -690,7 +690,8 @@ def test_streaming_session_equals_offline_forward(kw, seed, B, hop, graph, one_l
 
 
 @pytest.mark.parametrize("kw,seed,B", [(rw.LIVE_TINY, 11, 2), (rw.LIVE_M, 5, 1), (rw.LIVE_TINY_2SPK, 12, 3), (rw.LIVE_M, 5, 17), (rw.LIVE_M, 5, 35),
-                                       (dict(rw.LIVE_TINY, df_orders=[1, 1, 1], use_pre_layer_norm_sb=False), 15, 1)])
+                                       (dict(rw.LIVE_TINY, df_orders=[1, 1, 1], use_pre_layer_norm_sb=False), 15, 1),
+                                       (dict(rw.LIVE_M, df_orders=[1, 1, 1]), 16, 2)])  # recipes/intel_ndns/.../baseline_m_no_df.toml
 def test_waveform_streaming_equals_offline_forward(kw, seed, B):
     """Samples in, samples out, 128 at a time (8 ms): the session with waveform=True -- STFT of the new frame, the whole model
     and the inverse STFT with its overlap-add state in ONE launch per hop -- reproduces the offline forward's waveform bit for
