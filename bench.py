@@ -48,6 +48,17 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np
 import torch
 
+# The contract is ONE JSON line on stdout.  RCCL (and anything else below us) writes banners to file descriptor 1 through C stdio:
+# keep the real stdout for the line and send every other writer of fd 1 to stderr.
+JSON_OUT = os.fdopen(os.dup(1), "w")
+os.dup2(2, 1)
+
+
+def _emit(text: str) -> None:
+    JSON_OUT.write(text + "\n")
+    JSON_OUT.flush()
+
+
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 INT8_PEAK_TOPS = 5000.0  # dense int8 MFMA peak = the dense fp8 figure of that guide (2x bf16; micro-benchmark ceiling 3944 TOPS)
 # API-faithful algorithmic bytes per clip-frame of the sub-band scan, baseline_m sizes:
@@ -68,7 +79,7 @@ def _self_launch(args):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    raise SystemExit(subprocess.call(cmd, env=env))
+    raise SystemExit(subprocess.call(cmd, env=env, stdout=JSON_OUT.fileno()))  # (the ranks get the real stdout as their fd 1)
 
 
 PROFILE_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
@@ -126,9 +137,12 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SFSN_BENCH_FORCE_DIST"):  # (forced: the RCCL all-gather with a single rank, a plumbing check)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
@@ -156,7 +170,7 @@ def main():
 
     def forward():
         res = eng.forward_stft(stft, want_layers=want_layers, pipeline=False)
-        if world > 1:
+        if dist is not None:
             # the one exchange of the path (the analogue of accelerator.gather_for_metrics, audiozen/trainer.py:511,555): enqueued on
             # the forward's own stream, so with several forwards in flight it overlaps the scans of the other lanes
             key = torch.cuda.current_stream(dev).cuda_stream
@@ -168,17 +182,17 @@ def main():
     def timed_region(step_fn, steps, warmup):
         for _ in range(warmup):
             step_fn()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             step_fn()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist is not None:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -352,12 +366,13 @@ def main():
                                 layer_outputs="api-faithful (fp32 spikes returned)" if want_layers else "skipped",
                                 in_flight=n_lanes, scan_rows_per_workgroup=list(eng.rows_per_wg),
                                 single_stream=single,
-                                world_size=(dist.get_world_size() if world > 1 else 1), backend=(backend if world > 1 else None),
+                                world_size=(dist.get_world_size() if dist is not None else 1), backend=(backend if dist is not None else None),
                                 library=dict(abi=_lib.ABI_VERSION, source_hash=_lib.source_hash(), stack_scan=str(eng.stack_scan)),
-                                parallelism=f"clip-sharded x{world}" + (" + RCCL all_gather(enh_mag) per step, on the forward's stream" if world > 1 else "")),
+                                parallelism=f"clip-sharded x{world}" + (" + RCCL all_gather(enh_mag) per step, on the forward's stream" if dist is not None else "")),
                     roofline=roofline, cpu_baseline=cpu)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        JSON_OUT.write(json.dumps(line) + "\n")
+        JSON_OUT.flush()
+    if dist is not None:
         dist.destroy_process_group()
 
 
@@ -396,7 +411,7 @@ def streaming_bench(args, model, dev, world, rank):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
-        print(json.dumps({
+        _emit(json.dumps({
             "metric": "streaming per-call latency p50 (BASELINE configs[4]: state carried on the device, hop frames per call)",
             "value": round(float(lat[len(lat) // 2]), 1), "unit": "us", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(float(lat.mean()) / 1e3, 4), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
@@ -440,7 +455,7 @@ def waveform_streaming_bench(args, model, dev, world, rank, B):
     lat = np.sort(np.asarray(lat)) * 1e6
     enq = np.sort(np.asarray(enq)) * 1e6
     if rank == 0:
-        print(json.dumps({
+        _emit(json.dumps({
             "metric": "waveform streaming per-call latency p50 (BASELINE configs[4] end to end: 128 samples in, 128 enhanced samples out" +
                       ("; host memory to host memory)" if args.host_io else ")"),
             "value": round(float(lat[len(lat) // 2]), 1), "unit": "us", "n_gpus": world, "steps": steps, "warmup": warmup,
