@@ -1068,3 +1068,23 @@ def test_bench_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo"
     assert d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 4
+
+
+def test_bench_rccl_path_with_a_single_rank():
+    """SFSN_BENCH_FORCE_DIST=1: bench.py initialises RCCL and runs the per-step all_gather_into_tensor of the enhanced magnitudes,
+    the barrier and the max-over-ranks reduction with ONE rank -- the N > 1 code path on the real backend, on a one-GPU box.
+    stdout carries the JSON line and nothing else (RCCL's banner goes to stderr)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SFSN_BENCH_FORCE_DIST="1", MASTER_PORT="29533")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-phase-a",
+                          "--inflight", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["backend"] == "nccl" and d["config"]["world_size"] == 1 and d["n_gpus"] == 1 and d["value"] > 0
