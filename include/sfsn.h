@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 5 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 6 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -205,6 +205,8 @@ int sfsn_spike_proj(const int8_t* s, const int8_t* w_packed, const float* w_dq, 
 #define SFSN_NORM_NONE 0
 #define SFSN_NORM_LAYERNORM 1 /* (x - mean) * rstd * ln_w + ln_b over the I features, eps inside the sqrt       */
 #define SFSN_NORM_LAPLACE 2   /* x / (mu[b] + 2.220446049250313e-16), mu from sfsn_laplace_means                 */
+#define SFSN_NORM_CUMLAPLACE 3 /* sfsn_stream_hop only: x / (running mean of the row + eps), state carried per row -- the offline
+                                  path runs sfsn_features with SFSN_NORM_NONE and then sfsn_cum_laplace_norm             */
 
 typedef struct sfsn_feature_group {
     float* x;           /* out [T][B*n_units][I]                                                             */
@@ -250,6 +252,17 @@ int sfsn_deepfilter(const float* stft_ri /* [B][F][T][2] */, int B, int F, int T
  * new frames of inp [rows][hop] are appended, in place, in one launch.  D + hop <= 16 (SFSN_EUNSUPPORTED beyond).
  * ---------------------------------------------------------------------------------------------------- */
 int sfsn_hist_shift(float* hist_ri, const float* inp_ri, int rows, int D, int hop, void* stream);
+
+/* ----------------------------------------------------------------------------------------------------
+ * cumulative_laplace_norm (FROZEN:172-202 in the form that accepts the 5-D sub-band tensor,
+ * recipes/intel_ndns/spiking_fullsubnet_freeze_phase/model_low_freq_count_time.py:182-204; FROZEN's own version raises on
+ * the sub-band input): every row (clip x unit) of x [T][R][I] is divided, frame by frame, by the mean of everything the row
+ * has seen so far: mean[r][t] = sum_{t' <= t} sum_i x[t'][r][i] / (I * (frames_before + t + 1)), x /= mean + 2.22e-16.
+ * In place.  cum_state [R] (nullable): the running sums, in/out -- a caller that feeds a sequence in pieces passes the same
+ * buffer and the number of frames already seen.  scratch: T * R floats.
+ * ---------------------------------------------------------------------------------------------------- */
+int sfsn_cum_laplace_norm(float* x /* [T][R][I] */, int T, int R, int I, float* cum_state /* [R], nullable */,
+                          int frames_before, float* scratch /* [T][R] */, void* stream);
 
 /* ----------------------------------------------------------------------------------------------------
  * Streaming hop -- BASELINE configs[4]: `hop` new frames of B clips through the WHOLE live model (features, every GSN layer

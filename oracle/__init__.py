@@ -144,6 +144,13 @@ class Oracle:
         self._fn("laplace_norm", [_P, _I, _I, _I, _I, _P])(_ptr(x), T, B, BN // B, I, _ptr(mu))
         return x, mu
 
+    def cum_laplace_norm(self, x):
+        """x [T, R, I] -> copy with every row divided by the running mean of what it has seen so far."""
+        x = self.arr(x).copy()
+        T, R, I = x.shape
+        self._fn("cum_laplace_norm", [_P, _I, _I, _I])(_ptr(x), T, R, I)
+        return x
+
     def deepfilter_group(self, stft, proj, enh, lo, N, fc, df, S):
         """Writes bins lo..lo+N*fc-1 of enh (complex [B,S,F,T]) in place."""
         stft = np.ascontiguousarray(stft, dtype=self.cdtype)

@@ -259,6 +259,27 @@ void ORA(laplace_norm)(real* x, int T, int B, int N, int I, real* mu_out) {
     }
 }
 
+/* cumulative_laplace_norm (FROZEN:172-202; the form that accepts the 5-D sub-band tensor:
+ * recipes/intel_ndns/spiking_fullsubnet_freeze_phase/model_low_freq_count_time.py:182-204 -- FROZEN's own
+ * version unpacks four dimensions and raises on the sub-band input): every row (clip x unit) is divided, frame by
+ * frame, by the mean of everything that row has seen so far:
+ *   step_sum[r][t] = sum_i x[t][r][i];  cum[r][t] = cumsum_t step_sum;  mean = cum / (I * (t + 1));  x /= mean + EPSILON.
+ * Sums in the working precision, sequentially over t (torch.cumsum on the CPU).  x [T][R][I], in place. */
+void ORA(cum_laplace_norm)(real* x, int T, int R, int I) {
+    for (int r = 0; r < R; ++r) {
+        real cum = 0;
+        for (int t = 0; t < T; ++t) {
+            real* p = x + ((size_t)t * R + r) * I;
+            real s = 0;
+            for (int i = 0; i < I; ++i) s += p[i];
+            cum += s;
+            const real mean = cum / (real)((double)I * (t + 1));
+            const real den = mean + (real)2.220446049250313e-16;
+            for (int i = 0; i < I; ++i) p[i] = p[i] / den;
+        }
+    }
+}
+
 /* Deep filtering of one group and write-back into the enhanced spectrum.
  * Output re-index MODEL:160-167 "(b n) (c fc df s) t -> b df s (n fc) t c" (frozen FROZEN:259-265 has
  * no s): projection channel p = ((ci*fc + fci)*df + di)*S + si, ci=0 real / 1 imag.

@@ -14,9 +14,9 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
-NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE = 0, 1, 2
+NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE, NORM_CUMLAPLACE = 0, 1, 2, 3
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
-ABI_VERSION = 5  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
+ABI_VERSION = 6  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -156,6 +156,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_deepfilter.argtypes = [_P, _I, _I, _I, _I, ctypes.POINTER(DfGroup), _I, _P, _P, _I, _I, _P]
     L.sfsn_hist_shift.restype = _I
     L.sfsn_hist_shift.argtypes = [_P, _P, _I, _I, _I, _P]
+    L.sfsn_cum_laplace_norm.restype = _I
+    L.sfsn_cum_laplace_norm.argtypes = [_P, _I, _I, _I, _P, _I, _P, _P]
     L.sfsn_hop_scratch_bytes.restype = ctypes.c_size_t
     L.sfsn_hop_scratch_bytes.argtypes = [ctypes.POINTER(HopDesc)]
     L.sfsn_hop_stages.restype = _I
@@ -177,7 +179,7 @@ def lib() -> ctypes.CDLL:
 EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
            "sfsn_w3_pack", "sfsn_w3_pack_bits", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_stack_scratch_bytes", "sfsn_gsn_stack_scan",
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
-           "sfsn_laplace_means", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
+           "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
 
 
 def check(rc: int, what: str = "") -> None:

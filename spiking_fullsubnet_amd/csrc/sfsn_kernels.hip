@@ -1330,6 +1330,47 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
     }
 }
 
+// ---- cumulative_laplace_norm (model_low_freq_count_time.py:182-204): three small launches ------------------------------------
+// (1) row sums of every (frame, row): a wave per row, the same lane assignment and wave reduction as the streaming hop's
+//     feature rows (slot u of lane l = element l + 64 u), so that both paths add the same numbers in the same order;
+// (2) one thread per row walks the T sums: running fp32 sum (torch.cumsum's arithmetic), mean, denominator;
+// (3) every element divided by its (frame, row) denominator.
+__global__ __launch_bounds__(256) void cumlap_rowsum_kernel(const float* __restrict__ x, float* __restrict__ s, int rows, int I) {
+    const int lane = threadIdx.x & 63, row = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;  // wave-uniform
+    const float* p = x + (size_t)row * I;
+    float sum = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sum += (lane + 64 * u < I) ? p[lane + 64 * u] : 0.0f;
+    sum = wave_sum(sum);
+    if (lane == 0) s[row] = sum;
+}
+
+__global__ __launch_bounds__(64) void cumlap_scan_kernel(float* __restrict__ s, float* __restrict__ cum_state, int T, int R, int I,
+                                                         int frames_before) {
+    const int r = (int)blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    float cum = cum_state ? cum_state[r] : 0.0f;
+    for (int t0 = 0; t0 < T; t0 += 8) {  // eight independent loads in flight, then the dependent chain
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = s[(size_t)(t0 + i < T ? t0 + i : T - 1) * R + r];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (t0 + i < T) {
+                cum += v[i];
+                const float mean = cum / (float)((double)I * (frames_before + t0 + i + 1));
+                s[(size_t)(t0 + i) * R + r] = mean + 2.220446049250313e-16f;
+            }
+    }
+    if (cum_state) cum_state[r] = cum;
+}
+
+__global__ __launch_bounds__(256) void cumlap_divide_kernel(float* __restrict__ x, const float* __restrict__ den, size_t n, int I) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = x[i] / den[i / (size_t)I];
+}
+
 // ---- spike counts (SynOPs, audiozen/metric.py:303-327) ---------------------------------------------------------
 struct CountParams {
     const int8_t* src[SFSN_MAX_COUNT_TENSORS];
@@ -2014,6 +2055,18 @@ extern "C" int sfsn_laplace_means(const float* stft_ri, const float* fb_tbf, int
     const int rows = B * (F - 1 + FB);
     hipLaunchKernelGGL(rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, stft_ri, fb_tbf, scratch, B, F, T, FB, fdrc);
     hipLaunchKernelGGL(laplace_mu_kernel, dim3(n_groups, B), dim3(64), 0, st, scratch, p, mu_out);
+    return hip_ok(hipGetLastError());
+}
+
+extern "C" int sfsn_cum_laplace_norm(float* x, int T, int R, int I, float* cum_state, int frames_before, float* scratch, void* stream) {
+    if (!x || !scratch || T <= 0 || R <= 0 || I <= 0 || frames_before < 0) return SFSN_EINVAL;
+    if (I > 256) return SFSN_EUNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rows = T * R;
+    hipLaunchKernelGGL(cumlap_rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, scratch, rows, I);
+    hipLaunchKernelGGL(cumlap_scan_kernel, dim3((R + 63) / 64), dim3(64), 0, st, scratch, cum_state, T, R, I, frames_before);
+    const size_t n = (size_t)rows * I;
+    hipLaunchKernelGGL(cumlap_divide_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, scratch, n, I);
     return hip_ok(hipGetLastError());
 }
 

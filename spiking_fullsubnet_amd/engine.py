@@ -46,6 +46,7 @@ class PathSpec:
     ln_fb: bool = True
     ln_sb: bool = True
     laplace: bool = False
+    cum_laplace: bool = False     # frozen front-end with cumulative_laplace_norm (causal: every row by its own running mean)
     proj_name: str = "proj"
 
     @property
@@ -700,7 +701,7 @@ class Engine:
         # sequential schedule: optionally still cut the sequence into chunks (single stream): the chunk-sized input-term
         # buffer is then produced and consumed while it is still in the 256 MB Infinity Cache instead of making a round
         # trip through HBM (745 MB per sub-band layer at B=64, T=1000)
-        overlap = bool(not pipeline and self.overlap_chunks > 1 and not spec.laplace and not (0 < self.seq_chunk < T)
+        overlap = bool(not pipeline and self.overlap_chunks > 1 and not spec.laplace and not spec.cum_laplace and not (0 < self.seq_chunk < T)
                        and T >= 96 * self.overlap_chunks)
         if overlap and self.stack_scan is True:
             # forced stack launches for both models: side by side on two streams they must not ask for more workgroups than the
@@ -848,13 +849,30 @@ class Engine:
                             done.append(ev)
             return done
 
+        cum = None
+        if spec.cum_laplace:
+            # cumulative_laplace_norm: the rows leave sfsn_features unnormalised and are divided by their running means (state per
+            # row, so a sequence fed in pieces continues where it stopped)
+            rows = [B] + [x.shape[1] for x in xs]
+            cum = dict(state=[torch.zeros((R,), **f32) for R in rows], scratch=torch.empty((nt_max * max(rows),), **f32))
+
+        def cum_norm(x, i, t0, nt, st):
+            R, I = x.shape[1], x.shape[2]
+            check(L.sfsn_cum_laplace_norm(ctypes.c_void_p(x.data_ptr() + t0 * R * I * 4), nt, R, I, _ptr(cum["state"][i]), t0,
+                                          _ptr(cum["scratch"]), st), "sfsn_cum_laplace_norm")
+
         def feat_fb(t0, nt, st):
             with self.timed("features:fb", st):
                 check(L.sfsn_features(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, t0, nt, st), "sfsn_features(fb)")
+                if cum is not None:
+                    cum_norm(x_fb, 0, t0, nt, st)
 
         def feat_sb(t0, nt, st):
             with self.timed("features:sb", st):
                 check(L.sfsn_features(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, fg_sb, ng, t0, nt, st), "sfsn_features(sb)")
+                if cum is not None:
+                    for g in range(ng):
+                        cum_norm(xs[g], 1 + g, t0, nt, st)
 
         def post_sb(t0, nt, st):
             with self.timed("deepfilter", st):

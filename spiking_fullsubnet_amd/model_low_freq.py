@@ -6,9 +6,10 @@ Same constructor keywords (:486-509), same state-dict names (``fc_output_layer``
 ``pre_layer_norm``; the zoo checkpoints load with ``strict=True``), same ``forward`` return tuple (:618).
 A frozen-recipe TOML switches over with ``[model_g] path = "spiking_fullsubnet_amd.model_low_freq.Separator"``.
 
-Input normalisation is the utterance-level ``offline_laplace_norm`` (:147-169) -- the setting of all zoo
-checkpoints.  ``cumulative_laplace_norm`` crashes on the 5-D sub-band tensor in the reference itself
- and is rejected here.
+Input normalisation: the utterance-level ``offline_laplace_norm`` (:147-169, the setting of all zoo checkpoints) or the causal
+``cumulative_laplace_norm`` of ``baseline_m_cumulative_laplace_norm.toml`` -- in the reference that one raises on the 5-D sub-band
+tensor (:172-202 unpacks four dimensions); it is built here in the form of ``model_low_freq_count_time.py:182-204`` (every row by its
+own running mean), which also makes this front-end streamable (``streaming()``).
 """
 from __future__ import annotations
 
@@ -67,10 +68,10 @@ class Separator(_EngineMixin, nn.Module):
                  sb_num_neighbor_freqs, fb_num_center_freqs, fb_num_neighbor_freqs, fb_hidden_size, sb_hidden_size, sb_df_orders,
                  sequence_model, fb_output_activate_function, sb_output_activate_function, norm_type, shared_weights=False, bn=False):
         super().__init__()
-        if norm_type != "offline_laplace_norm":
-            raise NotImplementedError(
-                f"norm_type={norm_type!r}: only offline_laplace_norm (all zoo checkpoints) is built; cumulative_laplace_norm "
-                "raises `too many values to unpack` on the sub-band tensor in the reference itself")
+        if norm_type not in ("offline_laplace_norm", "cumulative_laplace_norm"):
+            # (the reference: model_low_freq.py:216-231 norm_wrapper; offline_gaussian_norm is used by no recipe)
+            raise NotImplementedError(f"norm_type={norm_type!r}: offline_laplace_norm (all zoo checkpoints) and cumulative_laplace_norm "
+                                      "(recipes/.../baseline_m_cumulative_laplace_norm.toml) are built")
         self.n_fft, self.hop_length, self.win_length, self.fdrc = n_fft, hop_length, win_length, fdrc
         self.freq_cutoffs, self.sb_df_orders = freq_cutoffs, sb_df_orders
         self.num_repeats, self.fb_freqs = num_freqs // fb_freqs, fb_freqs
@@ -89,8 +90,8 @@ class Separator(_EngineMixin, nn.Module):
             front="frozen", n_fft=n_fft, fdrc=fdrc, fb_in=fb_freqs, fb_hidden=fb_hidden_size, fb_layers=2, fb_proj=fb_freqs,
             sb_hidden=sb_hidden_size, sb_layers=2, cutoffs=[0] + list(freq_cutoffs) + [num_freqs], ctr=list(sb_num_center_freqs),
             nbr=list(sb_num_neighbor_freqs), ctr_fb=list(fb_num_center_freqs), nbr_fb=list(fb_num_neighbor_freqs),
-            df=list(sb_df_orders), num_spks=1, shared=shared_weights, bn=bn, ln_fb=False, ln_sb=False, laplace=True,
-            proj_name="fc_output_layer")
+            df=list(sb_df_orders), num_spks=1, shared=shared_weights, bn=bn, ln_fb=False, ln_sb=False,
+            laplace=norm_type == "offline_laplace_norm", cum_laplace=norm_type == "cumulative_laplace_norm", proj_name="fc_output_layer")
 
     def _spec(self) -> PathSpec:
         return self._path_spec

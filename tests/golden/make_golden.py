@@ -229,8 +229,8 @@ def main():
         live_case("live_tiny_unshared.npz", rw.LIVE_TINY_UNSHARED, 13, 1, 20, True)
         live_case("live_m.npz", rw.LIVE_M, 21, 1, 40, False)
 
-    def frozen_case(fname, kw, sd, B, T, store_mem, store_weights):
-        model = frozen.Separator(**kw).eval()
+    def frozen_case(fname, kw, sd, B, T, store_mem, store_weights, module=None):
+        model = (module or frozen).Separator(**kw).eval()
         model.load_state_dict(to_torch_sd(sd), strict=True)
         res = run_model(model, neuron, rw.synth_wave(B, T, 1), frozen_front=True)
         out = {}
@@ -254,6 +254,23 @@ def main():
     if not only:
         frozen_case("frozen_tiny.npz", rw.FROZEN_TINY, rw.frozen_state_dict(rw.FROZEN_TINY, 31), 2, 24, True, False)
         frozen_case("frozen_s_zoo.npz", rw.FROZEN_S, zoo_weights("baseline_s"), 1, 126, False, True)
+    if not only or "frozen_cum" in only:
+        # cumulative_laplace_norm (recipes/.../baseline_m_cumulative_laplace_norm.toml): model_low_freq.Separator raises on the 5-D
+        # sub-band tensor (model_low_freq.py:172-202 unpacks four dimensions); the same class in model_low_freq_count_time.py
+        # carries the form that accepts it (:182-204) -- that one makes the fixture (it prints stage timings: silenced)
+        import importlib
+        frozen_ct = importlib.import_module("model_low_freq_count_time")
+        kw_c = dict(rw.FROZEN_TINY, norm_type="cumulative_laplace_norm")
+        _print = print
+        try:
+            import builtins
+            builtins.print = lambda *a, **k: None
+            frozen_case("frozen_tiny_cum.npz", kw_c, rw.frozen_state_dict(rw.FROZEN_TINY, 35), 3, 40, True, False, module=frozen_ct)
+            kw_m = dict(rw.FROZEN_M, norm_type="cumulative_laplace_norm")
+            frozen_case("frozen_m_cum.npz", kw_m, rw.frozen_state_dict(rw.FROZEN_M, 36), 1, 48, False, False, module=frozen_ct)
+        finally:
+            builtins.print = _print
+        print("frozen_tiny_cum.npz frozen_m_cum.npz")
     if not only or "frozen_l" in only:
         # baseline_l sizes: four sub-band groups (16 + 24 + 2 + 1 units), sub-band hidden size 256
         frozen_case("frozen_l.npz", rw.FROZEN_L, rw.frozen_state_dict(rw.FROZEN_L, 33), 1, 24, False, False)

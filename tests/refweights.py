@@ -93,6 +93,7 @@ FROZEN_S = dict(  # model_zoo/intel_ndns/spike_fsb/baseline_s/baseline_s.toml [m
 )
 
 FROZEN_M = dict(FROZEN_S, fb_hidden_size=320, sb_hidden_size=224, sb_df_orders=[5, 3, 1])  # .../baseline_m/baseline_m.toml [model_g.args]
+FROZEN_M_CUM = dict(FROZEN_M, norm_type="cumulative_laplace_norm")
 
 FROZEN_L = dict(FROZEN_S, fb_hidden_size=320, sb_hidden_size=256, freq_cutoffs=[32, 128, 192], sb_df_orders=[5, 3, 1, 1],
                 sb_num_center_freqs=[2, 4, 32, 64], sb_num_neighbor_freqs=[15, 15, 15, 15], fb_num_center_freqs=[2, 4, 32, 64],
@@ -101,6 +102,7 @@ FROZEN_L = dict(FROZEN_S, fb_hidden_size=320, sb_hidden_size=256, freq_cutoffs=[
 FROZEN_XL = dict(FROZEN_M, shared_weights=False)  # .../spiking_fullsubnet_freeze_phase/baseline_xl.toml: separate gate weights
 
 FROZEN_TINY = dict(FROZEN_S, fb_hidden_size=48, sb_hidden_size=32, sb_df_orders=[2, 1, 3])
+FROZEN_TINY_CUM = dict(FROZEN_TINY, norm_type="cumulative_laplace_norm")  # recipes/.../baseline_m_cumulative_laplace_norm.toml's norm
 
 
 def synth_wave(B: int, T: int, seed: int = 0, hop: int = 128, modulated: bool = False) -> np.ndarray:

@@ -71,6 +71,7 @@ CASES = [
     ("frozen_tiny.npz", "frozen", rw.FROZEN_TINY, 31),
     ("frozen_s_zoo.npz", "frozen", rw.FROZEN_S, None), ("frozen_m_zoo.npz", "frozen", rw.FROZEN_M, None),
     ("frozen_l.npz", "frozen", rw.FROZEN_L, 33), ("frozen_xl.npz", "frozen", rw.FROZEN_XL, 34),
+    ("frozen_tiny_cum.npz", "frozen", rw.FROZEN_TINY_CUM, 35), ("frozen_m_cum.npz", "frozen", rw.FROZEN_M_CUM, 36),
 ]
 
 
