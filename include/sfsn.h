@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 6 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 7 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -279,7 +279,7 @@ int sfsn_cum_laplace_norm(float* x /* [T][R][I] */, int T, int R, int I, float* 
  * Arithmetic is that of sfsn_features / sfsn_spike_proj / sfsn_gsn_layer_scan / sfsn_deepfilter expression by expression;
  * the real-valued input product is sfsn_input_proj_f32's fp32-MFMA form with four accumulators.
  *
- * Shared gate weights, LayerNorm or no normalisation, H % 16 == 0, H <= 320, I <= 192, P <= 256 (full-band P <= 128), at most
+ * Shared gate weights, LayerNorm / cumulative Laplace / no normalisation, H % 16 == 0, H <= 320, I <= 192, P <= 256 (full-band P <= 128), at most
  * SFSN_HOP_MAX_LAYERS layers and SFSN_HOP_MAX_GROUPS groups, D + hop <= 32, and few enough rows that every wave tile gets
  * its own compute unit (SFSN_EUNSUPPORTED otherwise: the caller then runs the per-kernel sequence).
  * ---------------------------------------------------------------------------------------------------- */
@@ -312,6 +312,8 @@ typedef struct sfsn_hop_seq {      /* one sequence model: the full-band model or
     const float* b_p;              /* [P]                                                                            */
     int df;                        /* deep-filter order of a sub-band group; 0 for the full-band model               */
     int fc;                        /* sub-band group: centre bins per unit (P == 2 * fc * df * S)                    */
+    float* cum[2];                 /* feat.norm == SFSN_NORM_CUMLAPLACE: [R] x 2, the rows' running sums, in/out (launch k reads
+                                      cum[k & 1], writes cum[(k + 1) & 1]; zero both to reset); NULL otherwise          */
 } sfsn_hop_seq;
 typedef struct sfsn_hop_desc {
     sfsn_hop_seq fb;
@@ -347,6 +349,8 @@ typedef struct sfsn_hop_desc {
                                       (b, s) has been written.  wave_in, wave_out and done may be pinned host memory the device can
                                       reach: samples in host memory -> enhanced samples in host memory with no copy launch and no
                                       stream synchronisation (the caller spins on the words)                               */
+    int frames_before;             /* frames this state has seen since it was zeroed (the caller adds `hop` after every launch):
+                                      SFSN_NORM_CUMLAPLACE's denominator                                             */
 } sfsn_hop_desc;
 
 size_t sfsn_hop_scratch_bytes(const sfsn_hop_desc* desc /* host */);

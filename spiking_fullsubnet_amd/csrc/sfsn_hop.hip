@@ -72,6 +72,7 @@ struct HopSeqDev {
     const float* b_p;
     const float* ln_w;
     const float* ln_b;
+    float* cum[2];  // SFSN_NORM_CUMLAPLACE: running sum of every row, double-buffered by launch parity
     int nl, H, P, R, KS, NT, PT, I, I1, KC;
     int lo, N, ctr, nbr, ctr_fb, nbr_fb, norm, df, fc;
     float eps;
@@ -89,6 +90,7 @@ struct HopParams {
     int B, F, S, hop, D, FB, fcov;
     float fdrc;
     unsigned launch;  // launches made on this state since it was zeroed: tag and state parity
+    int frames_before;  // frames the state has seen since it was zeroed (SFSN_NORM_CUMLAPLACE's denominator)
     const float* inp;
     // waveform mode (hop == 1): the new samples, the last 512 input samples, the output's overlap-add accumulator, the output,
     // the window, the noisy / enhanced frame as {re, tag, im, tag} granules, the index of the frame this launch computes
@@ -317,6 +319,14 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
     const int nf = p.F - 1;
     bool ok = true;
     unsigned pk = 0;
+    // cumulative_laplace_norm: the running sums of my rows (every workgroup of the row tile computes the same sequence; the first
+    // one stores it for the next launch, into the other half of the double buffer)
+    float cumr[HOP_ROWS_PER_WAVE];
+#pragma unroll
+    for (int ri = 0; ri < HOP_ROWS_PER_WAVE; ++ri) {
+        const int frow = 16 * rt + wave + HOP_WAVES * ri;
+        cumr[ri] = (L0 && sq.norm == SFSN_NORM_CUMLAPLACE && frow < R) ? sq.cum[p.launch & 1u][frow] : 0.0f;
+    }
 
     for (int t = 0; t < hop; ++t) {
         // ---- recurrent half: needs frame t-1 of my own layer only
@@ -427,6 +437,13 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
                     const float rstd = __builtin_amdgcn_rsqf(wave_sum(ss) * inv_I + sq.eps);
 #pragma unroll
                     for (int u = 0; u < HOP_NU_MAX; ++u) y[u] = ((v[ri][u] - mean) * rstd) * lw[u] + lb[u];
+                } else if (sq.norm == SFSN_NORM_CUMLAPLACE) {
+                    // cumlap_rowsum_kernel / cumlap_scan_kernel's arithmetic: fp32 row sum (same lanes, same reduction), fp32
+                    // running sum, mean over everything the row has seen, x / (mean + eps)
+                    cumr[ri] += wave_sum(sum);
+                    const float den = cumr[ri] / (float)((double)I * (p.frames_before + t + 1)) + 2.220446049250313e-16f;
+#pragma unroll
+                    for (int u = 0; u < HOP_NU_MAX; ++u) y[u] = v[ri][u] / den;
                 } else {
 #pragma unroll
                     for (int u = 0; u < HOP_NU_MAX; ++u) y[u] = v[ri][u];
@@ -487,6 +504,13 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
     if (active && row < R) {
         *reinterpret_cast<v4f*>(L.c + (size_t)row * H + cc) = c;
         *reinterpret_cast<unsigned*>(hnext + (size_t)row * HP + cc) = pk;
+    }
+    if (L0 && sq.norm == SFSN_NORM_CUMLAPLACE && wgl - rt * wpr == 0 && lane == 0) {
+#pragma unroll
+        for (int ri = 0; ri < HOP_ROWS_PER_WAVE; ++ri) {
+            const int frow = 16 * rt + wave + HOP_WAVES * ri;
+            if (frow < R) sq.cum[(p.launch + 1u) & 1u][frow] = cumr[ri];
+        }
     }
 }
 
@@ -837,13 +861,14 @@ static int hop_fill_seq(HopSeqDev& d, const sfsn_hop_seq& s, int B, int F, int S
     if (I > 16 * HOP_KC_MAX || I > 64 * HOP_NU_MAX) return SFSN_EUNSUPPORTED;
     if (g.lo + g.n_units * g.ctr > nf || g.nbr >= nf || (I2 && (FB <= 0 || g.nbr_fb >= nf))) return SFSN_EINVAL;
     if (g.norm == SFSN_NORM_LAPLACE) return SFSN_EUNSUPPORTED;  // utterance-level statistics: not causal
+    if (g.norm == SFSN_NORM_CUMLAPLACE && (!s.cum[0] || !s.cum[1])) return SFSN_EINVAL;
     if (g.norm == SFSN_NORM_LAYERNORM && (!g.ln_w || !g.ln_b)) return SFSN_EINVAL;
     if (!s.w_p || !s.w_p_dq || !s.b_p) return SFSN_EINVAL;
     memset(&d, 0, sizeof(d));
     d.nl = s.n_layers; d.H = s.H; d.P = s.P; d.R = B * g.n_units; d.KS = (s.H + 63) / 64; d.NT = s.H / 16; d.PT = (s.P + 15) / 16;
     d.I = I; d.I1 = I1; d.KC = (I + 15) / 16;
     d.lo = g.lo; d.N = g.n_units; d.ctr = g.ctr; d.nbr = g.nbr; d.ctr_fb = g.ctr_fb; d.nbr_fb = g.nbr_fb; d.norm = g.norm; d.eps = g.ln_eps;
-    d.ln_w = g.ln_w; d.ln_b = g.ln_b;
+    d.ln_w = g.ln_w; d.ln_b = g.ln_b; d.cum[0] = s.cum[0]; d.cum[1] = s.cum[1];
     d.w_p = s.w_p; d.w_p_dq = s.w_p_dq; d.b_p = s.b_p;
     d.df = is_fb ? 0 : s.df; d.fc = s.fc;
     if (!is_fb) {
@@ -983,6 +1008,7 @@ extern "C" int sfsn_stream_hop(const sfsn_hop_desc* desc, void* stream) {
     if (!desc->scratch || desc->scratch_bytes < hop_counter_bytes(local) + (size_t)local.nblocks * HOP_WAVES * 64) return SFSN_EINVAL;
     local.cnt = static_cast<unsigned*>(desc->scratch);
     local.launch = desc->launch_index;
+    local.frames_before = desc->frames_before;
     // per-wave time stamps behind the control words (written by -DSFSN_HOP_STAMPS builds only; scripts/exp_hop.py reads them)
     local.dbg = reinterpret_cast<unsigned long long*>(static_cast<char*>(desc->scratch) + hop_counter_bytes(local));
     int dev = 0;

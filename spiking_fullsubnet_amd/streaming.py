@@ -14,8 +14,9 @@ the frame from stage to stage through L2 (csrc/sfsn_hop.hip); its state is its o
 history).  Otherwise the ~15 launches of the offline kernels, captured once into a HIP graph and replayed per hop: at
 hop = 1 that step is launch-bound, not compute-bound.  Both are bit-identical to the offline forward (tested).
 
-The frozen front-end (``model_low_freq.Separator``) normalises with utterance-level Laplace means
-(model_low_freq.py:147-169), which are not causal: a session on it raises ``NotImplementedError``.
+The frozen front-end (``model_low_freq.Separator``) with ``offline_laplace_norm`` normalises with utterance-level means
+(model_low_freq.py:147-169), which are not causal: a session on it raises ``NotImplementedError``.  With
+``cumulative_laplace_norm`` (every row by its own running mean) it streams, through the one-launch hop only.
 """
 from __future__ import annotations
 
@@ -27,7 +28,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import DfGroup, HopDesc, HOP_MAX_GROUPS, HOP_MAX_LAYERS, check
+from ._lib import DfGroup, HopDesc, HOP_MAX_GROUPS, HOP_MAX_LAYERS, NORM_CUMLAPLACE, check
 from .engine import Engine, _ptr
 
 
@@ -97,6 +98,8 @@ class StreamingSession:
         self.host_io = bool(host_io)  # waveform mode: samples come from and go to (pinned) host memory, no copy launches
         if self.host_io and not waveform:
             raise ValueError("host_io goes with waveform=True")
+        if spec.cum_laplace:
+            one_launch = True  # the running means live in sfsn_stream_hop's state; the per-kernel sequence has no streaming form of it
         if self.waveform:
             if hop != 1 or spec.n_fft != 512:
                 raise NotImplementedError("waveform streaming: one 128-sample hop per call, 512-point frames")
@@ -196,6 +199,10 @@ class StreamingSession:
                 dst.feat = fg
                 if w["ln"] is not None:
                     dst.feat.ln_w, dst.feat.ln_b = w["ln"]
+                if spec.cum_laplace:  # the rows' running sums travel with the session
+                    dst.feat.norm = NORM_CUMLAPLACE
+                    c0, c1 = spool.zeros((R,), torch.float32), spool.zeros((R,), torch.float32)
+                    dst.cum[0], dst.cum[1] = (a, a) if a else (ptr(c0), ptr(c1))
                 dst.w_p, dst.w_p_dq, dst.b_p = w["p"]
                 for l, e in enumerate(w["layers"]):
                     o = dst.layer[l]
@@ -277,6 +284,7 @@ class StreamingSession:
             if part["err_pending"] and int(part["err"][0]) != 0:  # written behind an earlier launch; no blocking here
                 raise RuntimeError("sfsn_stream_hop: a bounded hand-off wait expired inside a launch (results invalid)")
             d = part["desc"]
+            d.frames_before = self.frames_done
             setattr(d, field, base_ptr + part["b0"] * stride_bytes)
             if frame_index is not None:
                 d.frame_index = frame_index

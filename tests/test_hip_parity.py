@@ -745,6 +745,37 @@ def test_waveform_streaming_from_and_to_host_memory(kw, seed, B):
         model.streaming(batch=B, host_io=True)
 
 
+TINY_CUM = dict(rw.FROZEN_TINY_CUM, sb_df_orders=[3, 2, 1])  # (the fixture's orders [2, 1, 3] give the last group 384 projections: one launch covers 256)
+
+
+@pytest.mark.parametrize("kw,seed,B,hop", [(TINY_CUM, 35, 3, 1), (rw.FROZEN_M_CUM, 36, 2, 1), (TINY_CUM, 35, 2, 3)])
+def test_frozen_front_end_with_cumulative_norm_streams(kw, seed, B, hop):
+    """cumulative_laplace_norm makes the frozen (model_zoo-architecture) front-end causal: the one-launch streaming session --
+    on spectra and on waveforms -- reproduces the offline forward bit for bit (running sums carried per row)."""
+    model = build_module("frozen", kw, rw.frozen_state_dict(kw, seed))
+    T = 36 * hop
+    wave = torch.from_numpy(rw.synth_wave(B, T, seed)).to(DEV)
+    stft = model._stft(wave)[..., :T].contiguous()
+    off = model.engine().forward_stft(stft, want_layers=False)
+    sess = model.streaming(batch=B, hop=hop)
+    assert sess._hop is not None
+    for rep in range(2):
+        outs = [sess.step(stft[..., t0:t0 + hop].contiguous()) for t0 in range(0, T, hop)]
+        sess.check_errors()
+        assert torch.equal(torch.view_as_real(torch.cat([e for e, _ in outs], -1)), torch.view_as_real(off["enh_stft"])), rep
+        assert torch.equal(torch.cat([m for _, m in outs], -1), off["enh_mag"])
+        sess.reset()
+    if hop == 1:
+        y = model(wave)[0].reshape(B, 1, -1)
+        ws = model.streaming(batch=B, waveform=True)
+        outs = [ws.step_wave(wave[:, 128 * c:128 * (c + 1)].contiguous()) for c in range((T - 1))]
+        ws.check_errors()
+        got = torch.cat(outs[3:], -1)
+        assert torch.equal(got, y[..., :got.shape[-1]])
+    with pytest.raises(NotImplementedError):  # 384 projections in the last group: no one-launch hop, and no per-kernel form of this norm
+        build_module("frozen", rw.FROZEN_TINY_CUM, rw.frozen_state_dict(rw.FROZEN_TINY_CUM, 35)).streaming(batch=1)
+
+
 def test_stream_hop_argument_checks_and_fallback():
     """sfsn_stream_hop through the C ABI: malformed descriptors are refused, what the launch does not cover reports
     SFSN_EUNSUPPORTED (the session then replays the offline kernels), one_launch=True insists."""
