@@ -574,14 +574,15 @@ def test_full_size_properties():
     # oracle on 8 clips spread over the batch (first, middle, last) x 300 frames: clips are independent and the model is causal
     # in T, so the long run restricted to those clips / frames must match the short oracle run -- for the default schedule
     # (full-band stack launch + per-layer sub-band scans at 4 rows per workgroup) AND for the geometry the bench's timed
-    # region uses (sub-band scans at 16 rows per workgroup with both fused-input variants)
+    # region uses (full-band stack at 8, sub-band scans at 16 rows per workgroup with both fused-input variants)
     Tc, clips = 300, [0, 1, 30, 31, 32, 33, 62, 63]
     spec = omodel.spec_from_live_kwargs(kw)
     ora = omodel.forward_from_stft(spec, sd, stft[clips, :, :Tc].cpu().numpy(), "f32", want_membrane=True)
     gold_sub = parity.gold_from_oracle(ora)
     eng = model.engine()
-    for label, rpw in (("default", (0, 0)), ("timed-region geometry", (4, 16))):
+    for label, rpw in (("default", (0, 0)), ("timed-region geometry", (8, 16))):
         eng.rows_per_wg = rpw
+        eng.stack_rows_fb_auto = 8 if rpw[0] == 8 else 4  # (bench.py's set_geometry: the full-band stack at 8 rows per workgroup)
         n0 = dict(eng.launches)
         rr = r1 if rpw == (0, 0) else model.forward_stft(stft)
         torch.cuda.synchronize()
@@ -598,7 +599,7 @@ def test_full_size_properties():
         for st in stats:
             assert st["spike_agreement"] > 0.999, st
         assert sum(st["diverged"] for st in stats) <= 4, stats  # 8 clips x 14 rows x 4 layers x 300 frames: (nearly) no flips at all
-    eng.rows_per_wg = (0, 0)
+    eng.rows_per_wg, eng.stack_rows_fb_auto = (0, 0), 4
     rates = [float(a.mean()) for a in r1["fb_all"][1:3]]
     assert all(0.02 < r < 0.98 for r in rates), rates  # the synthetic model is alive, not saturated
 
