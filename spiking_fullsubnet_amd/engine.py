@@ -243,6 +243,9 @@ class Engine:
         # chunks -- every chunk costs ~0.15 ms of launch boundaries, scan prologues and hand-off lag.  Off when several forwards
         # are in flight anyway (bench.py's timed region sets 0).
         self.overlap_chunks = int(os.environ.get("SFSN_OVERLAP_CHUNKS", "3"))
+        # frames of the first chunk: -1 = 0.24 T (measured, scripts/exp_overlap.py: 3.55 -> 3.40 ms at B=64, the same 3-4 % at B=4..32 and
+        # T=500; 64..128 frames and 0.32 T gain nothing), 0 = equal chunks
+        self.overlap_first = int(os.environ.get("SFSN_OVERLAP_FIRST", "-1"))
         self._ov_streams = None
         self.stack_wide = True
         self._stack_scratch: List[torch.Tensor] = []
@@ -718,10 +721,21 @@ class Engine:
             if b_fb and b_sb and b_fb + b_sb > n_cu:
                 overlap = False
         if overlap:
-            nt_max = -(-T // self.overlap_chunks)
+            # a short first chunk: the sub-band models can only start once the full-band model has finished a chunk, so the first
+            # one is the lead-in of the whole forward; the rest is cut evenly (the full-band model is ~2x faster per frame and
+            # stays ahead)
+            first = self.overlap_first if self.overlap_first >= 0 else int(round(0.24 * T / 8.0)) * 8
+            first = min(max(int(first), 0), T // 2)
+            if first:
+                rest = -(-(T - first) // (self.overlap_chunks - 1))
+                bounds = [(0, first)] + [(t0, min(rest, T - t0)) for t0 in range(first, T, rest)]
+            else:
+                nt = -(-T // self.overlap_chunks)
+                bounds = [(t0, min(nt, T - t0)) for t0 in range(0, T, nt)]
+            nt_max = max(n for _, n in bounds)
         else:
             nt_max = chunk if pipeline else (self.seq_chunk if 0 < self.seq_chunk < T else T)
-        bounds = [(t0, min(nt_max, T - t0)) for t0 in range(0, T, nt_max)]
+            bounds = [(t0, min(nt_max, T - t0)) for t0 in range(0, T, nt_max)]
         S, ng = spec.num_spks, spec.n_groups
         nl_fb, nl_sb = spec.fb_layers, spec.sb_layers
 

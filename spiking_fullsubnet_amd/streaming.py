@@ -456,7 +456,9 @@ class StreamingSession:
         self._wave_calls += 1
         if c == 0:
             for part in h["parts"]:
-                part["st"]["state"][:, 384:].copy_(host["inp"][part["b0"]:part["b0"] + part["nb"]], non_blocking=True)
+                # (blocking: the next call overwrites the pinned buffer right away)
+                part["st"]["state"][:, 384:].copy_(host["inp"][part["b0"]:part["b0"] + part["nb"]])
+            torch.cuda.current_stream(self.dev).synchronize()
             return torch.zeros_like(host["out"])
         target = h["parts"][0]["desc"].launch_index + 1
         self._launch_hops(host["inp"].data_ptr(), 128 * 4, "wave_in", frame_index=c - 1)
