@@ -44,6 +44,15 @@ def test_no_device_means_loud_failure_not_fallback():
         m(torch.zeros(1, 4096))
     with pytest.raises(RuntimeError):
         pkg.Engine(m._spec(), {k: v.numpy() for k, v in m.state_dict().items()}, "cpu")
+    # argument checks run before any launch: malformed calls are refused on a box without a GPU too
+    import ctypes
+    buf = ctypes.create_string_buffer(64)
+    a = ctypes.addressof(buf)
+    assert L.sfsn_cum_laplace_norm(None, 4, 2, 8, None, 0, a, None) == _lib.SFSN_EINVAL
+    assert L.sfsn_cum_laplace_norm(a, 4, 2, 8, None, -1, a, None) == _lib.SFSN_EINVAL
+    assert L.sfsn_cum_laplace_norm(a, 4, 2, 300, None, 0, a, None) == _lib.SFSN_EUNSUPPORTED  # rows wider than 256 features
+    c = pkg.Separator(**rw.FROZEN_TINY_CUM).eval()  # the cumulative-norm front-end constructs (the reference's raises at forward)
+    assert c._spec().cum_laplace and not c._spec().laplace
 
 
 @pytest.mark.parametrize("n,k", [(224, 224), (320, 320), (40, 224), (6, 48), (160, 38), (17, 65)])
