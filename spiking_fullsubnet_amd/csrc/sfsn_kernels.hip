@@ -23,6 +23,7 @@
 #include "sfsn.h"
 
 #include "sfsn_scan_dev.h"
+#include "sfsn_scan3_dev.h"
 #include "sfsn_feat_dev.h"
 
 // G = 1: shared gate weights (W [H][*] used for both gates); G = 2: separate forget / cell weights.
@@ -66,6 +67,24 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
     else
         scan_body<G, KS, NW, TPW, OUT, LP, TPW - 1>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state,
                                                 smem, T, H, NT, R, row0, rowc, n, q, tid, wave, rpw);
+}
+
+
+// ---- the scan with IO-specialised waves (sfsn_scan3_dev.h): shared gates, H <= 224, one layer per launch, any segments ----------
+template <int KS, int RPW, int OUT>
+__global__ __launch_bounds__(1024) void gsn_scan3_kernel(const ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char scan_smem[];
+    int s = 0;
+    for (int i = 1; i < p.nseg; ++i)
+        if ((int)blockIdx.x >= p.seg[i].tile0) s = i;
+    const ScanSegDev& sg = p.seg[s];
+    Scan3Role rl;
+    rl.zin = sg.zin; rl.w_hh = sg.w_hh; rl.w_dq = sg.w_dq; rl.bias = sg.bias; rl.bn_alpha = sg.bn_alpha; rl.bn_beta = sg.bn_beta;
+    rl.h_state = sg.h_state; rl.c_state = sg.c_state; rl.spikes_f32 = sg.spikes_f32; rl.spikes_i8 = sg.spikes_i8;
+    rl.R = sg.R; rl.row0 = ((int)blockIdx.x - sg.tile0) * RPW;
+    StackLink lk;
+    lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = nullptr; lk.lag = 0; lk.dbg = nullptr;
+    scan3_role<KS, RPW, OUT, 0>(rl, lk, scan_smem, p.T, p.H, p.NT);
 }
 
 // ---- fused-input scan (layers >= 1, shared gates, 128 < H <= 256, 16 rows per workgroup) -----------------------------------
@@ -1713,6 +1732,31 @@ static int launch_scan(const ScanParams& p, int tiles, int out, hipStream_t st) 
     }
 }
 
+
+template <int KS, int RPW, int OUT>
+static int launch_scan3_variant(const ScanParams& p, int tiles, hipStream_t st) {
+    using C = Scan3Cfg<KS, RPW, 0>;
+    auto kern = gsn_scan3_kernel<KS, RPW, OUT>;
+    const int lds = C::lds_bytes(p.NT);
+    if (lds > 64 * 1024) {
+        static int seen[SFSN_MAX_DEVICES] = {0};
+        if (raise_lds(reinterpret_cast<const void*>(kern), lds, seen) != SFSN_OK) return SFSN_EHIP;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(1024), lds, st, p);
+    return hip_ok(hipGetLastError());
+}
+
+static int launch_scan3(const ScanParams& p, int tiles, int out, int KS, hipStream_t st) {
+#define SCAN3_CASE(KS_, RPW_, OUT_) \
+    if (KS == KS_ && p.rpw == RPW_ && out == OUT_) return launch_scan3_variant<KS_, RPW_, OUT_>(p, tiles, st);
+#define SCAN3_KS(KS_) \
+    SCAN3_CASE(KS_, 4, 2) SCAN3_CASE(KS_, 4, 3) SCAN3_CASE(KS_, 8, 2) SCAN3_CASE(KS_, 8, 3) SCAN3_CASE(KS_, 16, 2) SCAN3_CASE(KS_, 16, 3)
+    SCAN3_KS(1) SCAN3_KS(2) SCAN3_KS(3) SCAN3_KS(4)
+#undef SCAN3_KS
+#undef SCAN3_CASE
+    return SFSN_EUNSUPPORTED;
+}
+
 extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, int T, int H, int shared, int rows_per_wg,
                                    void* stream) {
     if (!segs || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0) return SFSN_EINVAL;
@@ -1769,6 +1813,11 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
         hipLaunchKernelGGL(gsn_scan_stream_kernel<2>, dim3(tiles), dim3(512), lds, st, p);
         return hip_ok(hipGetLastError());
     }
+    // shared gates, at most 14 output tiles (two of the 16 waves are free for the input ring and the spike stores), no membrane
+    // output: the scan with IO-specialised waves (sfsn_scan3_dev.h).  SFSN_SCAN_V2=1 keeps round 2's body (A/B runs, tests).
+    // (at 16 rows per workgroup one loader wave issuing a DMA per output tile and step is slower than round 2's body, where
+    //  every wave fetches its own tile: 1.18 against 0.95 us per step at H = 224 -- that geometry keeps the old body)
+    if (shared && NT <= 14 && rpw <= 8 && (out == 2 || out == 3) && !getenv("SFSN_SCAN_V2")) return launch_scan3(p, tiles, out, KS, st);
     int NW, TPW;
     if (rpw == 4 && out <= 7) out |= 512;  // repacked-epilogue variant (see scan_body)
     if (shared) {

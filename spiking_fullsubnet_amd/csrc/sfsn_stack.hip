@@ -23,6 +23,7 @@
 
 #include "sfsn.h"
 #include "sfsn_scan_dev.h"
+#include "sfsn_scan3_dev.h"
 
 #define STACK_MAX_ROLES 24
 #define STACK_ZIN 0
@@ -56,6 +57,8 @@ struct StackParams {
     unsigned* dbg;   // optional [2 * block]: hand-off waits / poll iterations per workgroup (SFSN_STACK_DEBUG=1)
     int nroles, T, H, NT, lag;
     int gate_off;    // byte offset of the gate word in the dynamic LDS allocation (behind every role's layout)
+    int v2;          // 1: round 2's scan body in the wide flavour (SFSN_SCAN_V2=1: A/B runs)
+    int exp_flags;   // timing experiments (SFSN_STACK_EXP, wrong results): see proj3_role
 };
 
 
@@ -677,10 +680,31 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
     }
     const int T = p.T, H = p.H, NT = p.NT;
     if (rl.kind == STACK_PROJ) {
-        stack_proj16_role<KS>(rl, lk, scan_smem, gate_word_p, T, H, NT, blk);
+        if (NT <= 14 && !p.v2) {
+            Proj3Role r3;
+            r3.spikes_in = rl.spikes_in; r3.w_ih = rl.w_ih; r3.w_ih_dq = rl.w_ih_dq; r3.bias = rl.bias; r3.zin = rl.zin;
+            r3.R = rl.R; r3.row0 = blk * Proj3Layout<KS>::ROWS;
+            proj3_role<KS>(r3, lk, scan_smem, T, H, NT, p.exp_flags);
+        } else {
+            stack_proj16_role<KS>(rl, lk, scan_smem, gate_word_p, T, H, NT, blk);
+        }
     } else {
         const bool rp4 = rl.rpw == 4;
         const int flg = (rl.src >= 0 ? 1 : 0) | (rl.pub ? 2 : 0);
+        if (NT <= 14 && !p.v2) {
+            // the scan with IO-specialised waves (sfsn_scan3_dev.h): the loader wave alone polls the producers, the storer wave
+            // alone writes through and publishes -- the compute waves' step does not change with the role's links
+            Scan3Role r3;
+            r3.zin = rl.zin; r3.w_hh = rl.w_hh; r3.w_dq = rl.w_dq; r3.bias = rl.bias; r3.bn_alpha = rl.bn_alpha; r3.bn_beta = rl.bn_beta;
+            r3.h_state = rl.h_state; r3.c_state = rl.c_state; r3.spikes_f32 = rl.spikes_f32; r3.spikes_i8 = rl.spikes_i8;
+            r3.R = rl.R; r3.row0 = blk * rl.rpw;
+#define S3_CASE(RPW_, F) \
+    if (rl.rpw == RPW_ && flg == F) scan3_role<KS, RPW_, OUT, F>(r3, lk, scan_smem, T, H, NT, p.exp_flags);
+            S3_CASE(4, 0) S3_CASE(4, 1) S3_CASE(4, 2) S3_CASE(4, 3)
+            S3_CASE(8, 0) S3_CASE(8, 1) S3_CASE(8, 2) S3_CASE(8, 3)
+            S3_CASE(16, 0) S3_CASE(16, 1) S3_CASE(16, 2) S3_CASE(16, 3)
+#undef S3_CASE
+        } else {
 #define ZIN16_CASE(F)                                                                                     \
     if (flg == F) {                                                                                       \
         if (rp4)                                                                                          \
@@ -688,8 +712,9 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         else                                                                                              \
             stack_zin16_role<KS, OUT, F>(rl, lk, scan_smem, gate_word_p, T, H, NT, blk);                  \
     }
-        ZIN16_CASE(0) ZIN16_CASE(1) ZIN16_CASE(2) ZIN16_CASE(3)
+            ZIN16_CASE(0) ZIN16_CASE(1) ZIN16_CASE(2) ZIN16_CASE(3)
 #undef ZIN16_CASE
+        }
     }
     if (lk.dbg && threadIdx.x == 0) lk.dbg[3] = (unsigned)wall_clock64();
     stack_exit(p, gate_word_p);
@@ -830,7 +855,11 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
                 blocks = (blocks + r.nblocks + 7) & ~7;
                 prev_role[i] = nroles++;
                 int need = ProjLayout<5>::bytes(NT);
-                if (wide) need = KS == 1 ? Proj16Layout<1>::BYTES : KS == 2 ? Proj16Layout<2>::BYTES : KS == 3 ? Proj16Layout<3>::BYTES : Proj16Layout<4>::BYTES;
+                if (wide) {
+                    need = KS == 1 ? Proj16Layout<1>::BYTES : KS == 2 ? Proj16Layout<2>::BYTES : KS == 3 ? Proj16Layout<3>::BYTES : Proj16Layout<4>::BYTES;
+                    const int n3 = KS == 1 ? Proj3Layout<1>::BYTES : KS == 2 ? Proj3Layout<2>::BYTES : KS == 3 ? Proj3Layout<3>::BYTES : Proj3Layout<4>::BYTES;
+                    if (n3 > need) need = n3;
+                }
                 if (need > lds) lds = need;
             }
             StackRoleDev& r = p.role[nroles];
@@ -858,6 +887,11 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
                     case 3: need = ScanCfg<1, 3, 16, 1, 3, 0>::LDS_BYTES; break;
                     default: need = ScanCfg<1, 4, 16, 1, 3, 0>::LDS_BYTES; break;
                 }
+                if (NT <= 14) {  // the IO-wave scan's layout (ring of up to 9 frames of rpw rows + the state buffers)
+                    const int dfit = 65536 / (((rpw * 14 * 4 + 63) / 64) * 1024);
+                    const int n3 = (dfit < 9 ? dfit : 9) * (((rpw * NT * 4 + 63) / 64) * 1024) + 2 * 16 * (HP + 32) + 16;
+                    if (n3 > need) need = n3;
+                }
             } else if (r.kind == STACK_FUSED) {
                 switch (KS) {
                     case 1: need = FusedLayout<1>::bytes(rpw, NT); break;
@@ -883,6 +917,8 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
     p.dbg = nullptr;
     if (getenv("SFSN_STACK_DEBUG") && (size_t)(blocks + 2) * 5 * sizeof(unsigned) <= scratch_bytes) p.dbg = p.prog + blocks + 2;
     p.nroles = nroles; p.T = T; p.H = H; p.NT = NT; p.lag = lag; p.nblocks = blocks;
+    p.v2 = getenv("SFSN_SCAN_V2") ? 1 : 0;
+    p.exp_flags = getenv("SFSN_STACK_EXP") ? atoi(getenv("SFSN_STACK_EXP")) : 0;
     lds = (lds + 15) & ~15;
     p.gate_off = lds;
     lds += 16;
