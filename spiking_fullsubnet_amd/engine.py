@@ -246,6 +246,9 @@ class Engine:
         # frames of the first chunk: -1 = 0.24 T (measured, scripts/exp_overlap.py: 3.55 -> 3.40 ms at B=64, the same 3-4 % at B=4..32 and
         # T=500; 64..128 frames and 0.32 T gain nothing), 0 = equal chunks
         self.overlap_first = int(os.environ.get("SFSN_OVERLAP_FIRST", "-1"))
+        # True: forward_stft() returns only after the error words of its stack launches have been read (a launch whose bounded
+        # hand-off wait expired raises HERE instead of at the next forward); False: non-blocking, see check_stack_errors()
+        self.strict_errors = os.environ.get("SFSN_STRICT_ERRORS", "0") == "1"
         self._ov_streams = None
         self.stack_wide = True
         self._stack_scratch: List[torch.Tensor] = []
@@ -472,8 +475,14 @@ class Engine:
                     fin[l * ns + i].w_ih, fin[l * ns + i].w_ih_dq = pk.data_ptr(), dq.data_ptr()
         nbytes = L.sfsn_stack_scratch_bytes(nl, ns, rows)
         if scratch is None:  # (a streaming session owns its own: its captured graph must not outlive a cache entry)
-            scratch = self._workspace(("stack_scratch", tag, nl, ns, rows, torch.cuda.current_stream(self.device).cuda_stream),
-                                      lambda: dict(t=torch.zeros((nbytes // 4,), dtype=torch.int32, device=self.device)))["t"]
+            def make():
+                # zero-filled on the stream the kernel is launched on: on the overlapped schedule that is a side stream which
+                # only waits for the fork event, and a fill enqueued on the caller's stream after that event would not be
+                # ordered before the kernel that polls these counters (round-2 advisor finding)
+                with torch.cuda.stream(self._tstream(st)):
+                    return dict(t=torch.zeros((nbytes // 4,), dtype=torch.int32, device=self.device))
+            scratch = self._workspace(("stack_scratch", tag, nl, ns, rows, torch.cuda.current_stream(self.device).cuda_stream,
+                                       self._tstream(st).cuda_stream), make)["t"]
         assert scratch.numel() * 4 >= nbytes
         if not any(scratch is t for t in self._stack_scratch):
             self._stack_scratch.append(scratch)
@@ -492,21 +501,30 @@ class Engine:
                 pin.copy_(scratch[:1], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(stream)
-            self._stack_err_pending.append((ev, pin, f"{tag} rows={rows} frames={nt} wide={wide} rows_per_wg={rp} lag={self.stack_lag if lag is None else lag}"))
+            self._stack_err_pending.append((ev, pin, f"{tag} rows={rows} frames={nt} wide={wide} rows_per_wg={rp} lag={self.stack_lag if lag is None else lag}", scratch))
 
     def _poll_stack_errors(self, block: bool = False) -> None:
         keep = []
-        for ev, pin, what in self._stack_err_pending:
+        for ev, pin, what, scratch in self._stack_err_pending:
             if block:
                 ev.synchronize()
             if ev.query():
                 if int(pin[0]) != 0:
                     self._stack_err_pending = []
+                    self._clear_stack_scratch(scratch)
                     raise RuntimeError("sfsn_gsn_stack_scan: a layer-to-layer hand-off wait expired in an earlier launch "
                                        f"(that forward's results are invalid): {what}")
             else:
-                keep.append((ev, pin, what))
+                keep.append((ev, pin, what, scratch))
         self._stack_err_pending = keep
+
+    def _clear_stack_scratch(self, scratch) -> None:
+        """After a failed launch: the error word is sticky by design (nobody clears it on the device) and the progress counters
+        of a launch that gave up are not all zeroed by its last workgroup -- reset both, or every later launch on this scratch
+        buffer would report the old failure (round-2 advisor finding)."""
+        torch.cuda.synchronize(self.device)
+        scratch.zero_()
+        torch.cuda.synchronize(self.device)
 
     def check_stack_errors(self) -> None:
         """Raise if a hand-off wait of a stack launch expired (synchronises; tests and bench call it after a forward)."""
@@ -514,6 +532,7 @@ class Engine:
         self._poll_stack_errors(block=True)
         for t in self._stack_scratch:
             if int(t[0].item()) != 0:
+                self._clear_stack_scratch(t)
                 raise RuntimeError("sfsn_gsn_stack_scan: a layer-to-layer hand-off wait expired (results invalid)")
 
     def _stage_proj(self, seqs, s8s, projs, t0, nt, st, tag):
@@ -666,7 +685,13 @@ class Engine:
         with torch.cuda.device(self.device):
             if self._stack_err_pending:
                 self._poll_stack_errors()
-            return self._forward_stft(stft, want_layers, want_membrane, pipeline, want_counts)
+            out = self._forward_stft(stft, want_layers, want_membrane, pipeline, want_counts)
+            if self.strict_errors and self._stack_err_pending:
+                # results are only handed out once every stack launch of THIS forward is known to have completed its hand-offs
+                # (one stream synchronisation per forward: for callers that keep several forwards in flight leave it off and
+                # call check_stack_errors() at their own synchronisation points)
+                self._poll_stack_errors(block=True)
+            return out
 
     def _forward_stft(self, stft: torch.Tensor, want_layers: bool = True, want_membrane: bool = False, pipeline: Optional[bool] = None,
                       want_counts: bool = False) -> dict:
@@ -701,6 +726,8 @@ class Engine:
         chunk = self.pipeline_chunk
         if pipeline is None:
             pipeline = self.pipeline_default and chunk > 0 and T >= 2 * chunk
+        if spec.cum_laplace:
+            pipeline = False  # (the running-mean state and its scratch are per forward, not per stage: single-stream order only)
         # sequential schedule: optionally still cut the sequence into chunks (single stream): the chunk-sized input-term
         # buffer is then produced and consumed while it is still in the 256 MB Infinity Cache instead of making a round
         # trip through HBM (745 MB per sub-band layer at B=64, T=1000)

@@ -282,7 +282,7 @@ class StreamingSession:
         same = torch.cuda.current_device() == idx  # the C ABI launches on the calling thread's current device
         for part in self._hop["parts"]:
             if part["err_pending"] and int(part["err"][0]) != 0:  # written behind an earlier launch; no blocking here
-                raise RuntimeError("sfsn_stream_hop: a bounded hand-off wait expired inside a launch (results invalid)")
+                self.check_errors()  # (synchronises, clears the sticky words and raises)
             d = part["desc"]
             d.frames_before = self.frames_done
             setattr(d, field, base_ptr + part["b0"] * stride_bytes)
@@ -327,9 +327,18 @@ class StreamingSession:
         if self._hop is None:
             return
         torch.cuda.current_stream(self.dev).synchronize()
+        bad = False
         for part in self._hop["parts"]:
             if int(part["scratch"][0].item()) != 0:
-                raise RuntimeError("sfsn_stream_hop: a bounded hand-off wait expired inside a launch (results invalid)")
+                # the word is sticky on the device: clear it (and the pinned copy) when reporting, or every later check --
+                # reset() included -- would report this failure again (round-2 advisor finding)
+                part["scratch"][:1].zero_()
+                part["err"].zero_()
+                part["err_pending"] = False
+                bad = True
+        if bad:
+            torch.cuda.current_stream(self.dev).synchronize()
+            raise RuntimeError("sfsn_stream_hop: a bounded hand-off wait expired inside a launch (results invalid)")
 
     def _enqueue(self) -> None:
         """One hop on torch's current stream: history shift, then the offline forward's kernels on frames [D, D+hop)."""
@@ -463,7 +472,8 @@ class StreamingSession:
         target = h["parts"][0]["desc"].launch_index + 1
         self._launch_hops(host["inp"].data_ptr(), 128 * 4, "wave_in", frame_index=c - 1)
         done, t_end = host["done_np"], None
-        while int(done.min()) != target:  # (all parts carry the same launch index)
+        target &= 0xFFFFFFFF
+        while (int(done.min()) & 0xFFFFFFFF) != target or (int(done.max()) & 0xFFFFFFFF) != target:  # (all parts carry the same launch index; uint32 compare: the index wraps)
             if t_end is None:
                 t_end = time.perf_counter() + timeout_s
             elif time.perf_counter() > t_end:

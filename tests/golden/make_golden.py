@@ -205,11 +205,11 @@ def main():
         np.savez_compressed(os.path.join(HERE, "gsn_cells.npz"), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
         print("gsn_cells.npz", len(out))
 
-    def live_case(fname, kw, seed, B, T, store_mem, wave_seed=0):
+    def live_case(fname, kw, seed, B, T, store_mem, wave_seed=0, modulated=False):
         sd = rw.live_state_dict(kw, seed)
         model = live.SpikingFullSubNet(**kw).eval()
         model.load_state_dict(to_torch_sd(sd), strict=True)
-        res = run_model(model, neuron, rw.synth_wave(B, T, wave_seed), frozen_front=False)
+        res = run_model(model, neuron, rw.synth_wave(B, T, wave_seed, modulated=modulated), frozen_front=False)
         out = {}
         store_model_case(out, res, store_mem)
         out["weight_seed"] = np.asarray(seed)
@@ -228,6 +228,10 @@ def main():
         live_case("live_tiny_2spk.npz", rw.LIVE_TINY_2SPK, 12, 2, 20, True)
         live_case("live_tiny_unshared.npz", rw.LIVE_TINY_UNSHARED, 13, 1, 20, True)
         live_case("live_m.npz", rw.LIVE_M, 21, 1, 40, False)
+    if not only or "live_m_am" in only:
+        # the sizes bench.py runs (BASELINE configs[2]), two clips x 200 frames of the amplitude-modulated noise SURVEY 8d names
+        # (0.5 (1 + sin 2 pi 3 Hz t)): the spike rates swing with the envelope
+        live_case("live_m_am.npz", rw.LIVE_M, 21, 2, 200, False, wave_seed=4, modulated=True)
 
     def frozen_case(fname, kw, sd, B, T, store_mem, store_weights, module=None):
         model = (module or frozen).Separator(**kw).eval()
@@ -254,6 +258,10 @@ def main():
     if not only:
         frozen_case("frozen_tiny.npz", rw.FROZEN_TINY, rw.frozen_state_dict(rw.FROZEN_TINY, 31), 2, 24, True, False)
         frozen_case("frozen_s_zoo.npz", rw.FROZEN_S, zoo_weights("baseline_s"), 1, 126, False, True)
+    if not only or "frozen_s_zoo_4s" in only:
+        # BASELINE configs[0] as written: the trained baseline_s generator on ONE 4 s clip (T = 501 frames at 16 kHz / hop 128);
+        # the weights are those of frozen_s_zoo.npz (not stored twice)
+        frozen_case("frozen_s_zoo_4s.npz", rw.FROZEN_S, zoo_weights("baseline_s"), 1, 501, False, False)
     if not only or "frozen_cum" in only:
         # cumulative_laplace_norm (recipes/.../baseline_m_cumulative_laplace_norm.toml): model_low_freq.Separator raises on the 5-D
         # sub-band tensor (model_low_freq.py:172-202 unpacks four dimensions); the same class in model_low_freq_count_time.py

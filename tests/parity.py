@@ -88,6 +88,9 @@ def check_chain(spk, spk_ref, near_ref, t_up, name="", mem=None, mem_ref=None):
     return t_valid, stats
 
 
+_REPORT_STARTED = set()
+
+
 def report(case: str, stats, extra=None) -> None:
     """Append a per-fixture, per-layer divergence record (rows diverged, first-flip frames, explained / unexplained) to the
     JSON-lines report the GPU run leaves behind (gpurun_out/parity_report.jsonl, or $SFSN_PARITY_REPORT), so that a green
@@ -98,7 +101,10 @@ def report(case: str, stats, extra=None) -> None:
     path = os.environ.get("SFSN_PARITY_REPORT", os.path.join(root, "gpurun_out", "parity_report.jsonl"))
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        with open(path, "a") as fh:
+        # one report = one run of one build: the first record of a process truncates what an earlier run left behind
+        mode = "a" if path in _REPORT_STARTED else "w"
+        _REPORT_STARTED.add(path)
+        with open(path, mode) as fh:
             fh.write(json.dumps(dict(case=case, rows_diverged=sum(s["diverged"] for s in stats),
                                      unexplained=sum(s.get("own_unexplained", 0) for s in stats),
                                      min_spike_agreement=min((s["spike_agreement"] for s in stats), default=1.0),

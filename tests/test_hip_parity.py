@@ -363,6 +363,9 @@ MODEL_CASES = [
     ("frozen_m_zoo.npz", "frozen", rw.FROZEN_M, None), ("frozen_l.npz", "frozen", rw.FROZEN_L, 33),
     ("frozen_tiny_cum.npz", "frozen", rw.FROZEN_TINY_CUM, 35), ("frozen_m_cum.npz", "frozen", rw.FROZEN_M_CUM, 36),
     ("frozen_xl.npz", "frozen", rw.FROZEN_XL, 34),
+    # round 3: BASELINE configs[0] as written (trained baseline_s, ONE 4 s clip = 501 frames; weights: frozen_s_zoo.npz) and the
+    # bench's sizes on two clips x 200 frames of amplitude-modulated noise (SURVEY 8d's second input distribution)
+    ("frozen_s_zoo_4s.npz", "frozen", rw.FROZEN_S, "frozen_s_zoo.npz"), ("live_m_am.npz", "live", rw.LIVE_M, 21),
 ]
 
 
@@ -391,7 +394,10 @@ def case_setup(fname, front, kw, seed):
         spec, sd = omodel.spec_from_live_kwargs(kw), rw.live_state_dict(kw, seed)
     else:
         spec = omodel.spec_from_frozen_kwargs(kw)
-        sd = {k[3:]: v for k, v in gold.items() if k.startswith("sd/")} if seed is None else rw.frozen_state_dict(kw, seed)
+        if isinstance(seed, str):  # the weights live in another fixture (the trained zoo checkpoints are stored once)
+            sd = {k[3:]: v for k, v in load(seed).items() if k.startswith("sd/")}
+        else:
+            sd = {k[3:]: v for k, v in gold.items() if k.startswith("sd/")} if seed is None else rw.frozen_state_dict(kw, seed)
     return gold, spec, sd
 
 
@@ -571,11 +577,13 @@ def test_full_size_properties():
     torch.cuda.synchronize()
     assert torch.equal(torch.view_as_real(sub["enh_stft"]), torch.view_as_real(r1["enh_stft"][5:13]))
     assert torch.equal(sub["fb_all"][2], r1["fb_all"][2][:, 5:13])
-    # oracle on 8 clips spread over the batch (first, middle, last) x 300 frames: clips are independent and the model is causal
-    # in T, so the long run restricted to those clips / frames must match the short oracle run -- for the default schedule
-    # (full-band stack launch + per-layer sub-band scans at 4 rows per workgroup) AND for the geometry the bench's timed
-    # region uses (full-band stack at 8, sub-band scans at 16 rows per workgroup with both fused-input variants)
-    Tc, clips = 300, [0, 1, 30, 31, 32, 33, 62, 63]
+    # oracle on 8 clips spread over the batch (first, middle, last) x ALL 1000 frames: clips are independent, so the long run
+    # restricted to those clips must match the oracle run of those clips -- for the default schedule (full-band stack launch +
+    # per-layer sub-band scans at 4 rows per workgroup: the IO-wave scan of round 3) AND for the geometry the bench's timed
+    # region uses (full-band stack at 8, sub-band scans at 16 rows per workgroup with both fused-input variants).  The causal
+    # rule handles late divergence: a chain may leave the reference only where the reference membrane is inside the don't-care
+    # band (own_unexplained == 0 is asserted per layer; the per-layer first-flip frames go to the parity report).
+    Tc, clips = T, [0, 1, 30, 31, 32, 33, 62, 63]
     spec = omodel.spec_from_live_kwargs(kw)
     ora = omodel.forward_from_stft(spec, sd, stft[clips, :, :Tc].cpu().numpy(), "f32", want_membrane=True)
     gold_sub = parity.gold_from_oracle(ora)
@@ -595,10 +603,12 @@ def test_full_size_properties():
             rows = torch.cat([torch.arange(c * N, (c + 1) * N, device=DEV) for c in clips])
             out["sb_all"].append([a[:Tc, rows].cpu().numpy() for a in lst])
         stats = parity.check_model(out, gold_sub, spec, tag=f"full-size ({label}):")
-        parity.report(f"full-size:B64xT1000:{label}:clips{clips}:T{Tc}", stats)
+        parity.report(f"full-size:B64xT1000:{label}:clips{clips}:T{Tc}", stats, extra=dict(scan_kernels={k: v for k, v in eng.launches.items()}))
         for st in stats:
-            assert st["spike_agreement"] > 0.999, st
-        assert sum(st["diverged"] for st in stats) <= 4, stats  # 8 clips x 14 rows x 4 layers x 300 frames: (nearly) no flips at all
+            assert st.get("own_unexplained", 0) == 0, st  # every first flip sits inside the don't-care band of the reference membrane
+            assert st["valid_frac"] > 0.5, st             # ... and most chain-frames are compared strictly (a full-band flip voids the clip's sub-band rows from there on)
+        # 8 clips x 14 rows x 4 layers x 1000 frames: a handful of chains leave the reference at a near-threshold membrane
+        assert sum(st["diverged"] for st in stats) <= 0.1 * sum(st["rows"] for st in stats), stats
     eng.rows_per_wg, eng.stack_rows_fb_auto = (0, 0), 4
     rates = [float(a.mean()) for a in r1["fb_all"][1:3]]
     assert all(0.02 < r < 0.98 for r in rates), rates  # the synthetic model is alive, not saturated

@@ -72,6 +72,9 @@ CASES = [
     ("frozen_s_zoo.npz", "frozen", rw.FROZEN_S, None), ("frozen_m_zoo.npz", "frozen", rw.FROZEN_M, None),
     ("frozen_l.npz", "frozen", rw.FROZEN_L, 33), ("frozen_xl.npz", "frozen", rw.FROZEN_XL, 34),
     ("frozen_tiny_cum.npz", "frozen", rw.FROZEN_TINY_CUM, 35), ("frozen_m_cum.npz", "frozen", rw.FROZEN_M_CUM, 36),
+    # round 3: BASELINE configs[0] as written (trained baseline_s, ONE 4 s clip = 501 frames; weights: frozen_s_zoo.npz) and the
+    # bench's sizes on two clips x 200 frames of amplitude-modulated noise (SURVEY 8d's second input distribution)
+    ("frozen_s_zoo_4s.npz", "frozen", rw.FROZEN_S, "frozen_s_zoo.npz"), ("live_m_am.npz", "live", rw.LIVE_M, 21),
 ]
 
 
@@ -81,7 +84,10 @@ def case_inputs(fname, front, kw, seed):
         spec, sd = omodel.spec_from_live_kwargs(kw), rw.live_state_dict(kw, seed)
     else:
         spec = omodel.spec_from_frozen_kwargs(kw)
-        sd = {k[3:]: v for k, v in gold.items() if k.startswith("sd/")} if seed is None else rw.frozen_state_dict(kw, seed)
+        if isinstance(seed, str):  # the weights live in another fixture (the trained zoo checkpoints are stored once)
+            sd = {k[3:]: v for k, v in load(seed).items() if k.startswith("sd/")}
+        else:
+            sd = {k[3:]: v for k, v in gold.items() if k.startswith("sd/")} if seed is None else rw.frozen_state_dict(kw, seed)
     return gold, spec, sd
 
 
