@@ -533,65 +533,65 @@ def waveform_streaming_bench(args, model, dev, world, rank, B):
                        "min_us": round(float(lat[0]), 1), "real_time_factor_at_8ms_hop": round(8e3 / float(lat[len(lat) // 2]), 1)}}))
 
 
-def cpu_baseline(kw, sd, stft):
+def cpu_baseline(kw, sd, stft, weight_seed=21):
     """The CPU oracle (oracle/, the C restatement of the reference) on the host cores of this box, on the SAME workload: all B clips
-    x all T frames.  Clips are independent, so the batch is cut into groups of clips that run concurrently -- one Python thread per
-    group (the C calls and numpy release the GIL), each with its own OpenMP team over the rows of its clips (13 sub-band + 1
-    full-band row per clip): every core has work during all four sequence models, which the row-parallel oracle alone does not
-    manage on a 256-thread host (64 full-band rows, four models one after the other, Python glue in between: 3.6 x one core in
-    round 2).  Same arithmetic as the parity oracle (double accumulation, rounded once); a stated baseline, not the target."""
+    x all T frames, over and over for ~12 s.  Clips are independent, so the batch is cut into groups of clips that run side by side
+    -- one PROCESS per group (oracle/cpu_bench_worker.py), each with its own OpenMP team over the rows of its clips (13 sub-band +
+    1 full-band row per clip): every core has work during all four sequence models.  (The row-parallel oracle alone: 3.6 x one
+    core on a 256-thread host in round 2 -- 64 full-band rows, four models one after the other; groups as Python threads of one
+    process: 9 x, serialised by the interpreter lock around the numpy glue.)  Same arithmetic as the parity oracle (double
+    accumulation, rounded once); a stated baseline, not the target."""
     import ctypes
-    from concurrent.futures import ThreadPoolExecutor
+    import subprocess
+    import tempfile
     from oracle import model as omodel
     spec = omodel.spec_from_live_kwargs(kw)
     full = stft.cpu().numpy()
     B, _, T = full.shape
     ncpu = os.cpu_count() or 1
-    try:
-        gomp = ctypes.CDLL("libgomp.so.1")
-    except OSError:
-        gomp = None
     groups = max(1, min(B, ncpu // 4))                 # ~4 OpenMP threads per group of clips (14 rows per clip)
     per = max(1, ncpu // groups)
     cuts = [(B * i // groups, B * (i + 1) // groups) for i in range(groups)]
     cuts = [c for c in cuts if c[1] > c[0]]
-
-    def work(c):
-        if gomp is not None:
-            gomp.omp_set_num_threads(per)              # (per calling thread: the team of THIS group)
-        omodel.forward_from_stft(spec, sd, full[c[0]:c[1]], "f32")
-
-    with ThreadPoolExecutor(max_workers=len(cuts)) as pool:
-        list(pool.map(work, [(c[0], c[0] + 1) for c in cuts[:max(1, len(cuts) // 4)]]))  # warm the teams / page in
-        n, t0 = 0, time.perf_counter()
-        while True:
-            list(pool.map(work, cuts))
-            n += 1
-            el = time.perf_counter() - t0
-            if el > 12.0 or n >= 40:
-                break
-    frames = n * B * T
-    # one core, for calibration (SURVEY 8d): one clip, all T frames, OpenMP pinned to one thread
+    worker = os.path.join(ROOT, "oracle", "cpu_bench_worker.py")
+    value = el = None
+    n_total = 0
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "stft.npy")
+        np.save(path, full)
+        env = dict(os.environ, OMP_NUM_THREADS=str(per), OMP_PROC_BIND="false")
+        start = time.time() + 8.0 + 0.02 * len(cuts)   # every worker has imported numpy, built its weights and warmed its team by then
+        deadline = start + 12.0
+        procs = [subprocess.Popen([sys.executable, worker, path, str(lo), str(hi), repr(start), repr(deadline), str(weight_seed)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for lo, hi in cuts]
+        outs = []
+        for p in procs:
+            o, _ = p.communicate(timeout=300)
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+        el = max(o["t_end"] for o in outs) - start
+        frames = sum(o["forwards"] * (o["hi"] - o["lo"]) * T for o in outs)
+        n_total = sum(o["forwards"] for o in outs)
+        value = round(frames / el, 1)
+    # one core, for calibration (SURVEY 8d): one clip, all T frames, OpenMP pinned to one thread (in this process)
     single = cpu_model = None
     try:
-        if gomp is not None:
-            gomp.omp_set_num_threads(1)
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        omodel.forward_from_stft(spec, sd, full[:1, :, :16], "f32")
         t1 = time.perf_counter()
         omodel.forward_from_stft(spec, sd, full[:1], "f32")
         single = round(T / (time.perf_counter() - t1), 1)
-        if gomp is not None:
-            gomp.omp_set_num_threads(ncpu)
+        gomp.omp_set_num_threads(ncpu)
         with open("/proc/cpuinfo") as fh:
             cpu_model = next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), None)
     except Exception:  # the baseline is reported, never required
         pass
-    value = round(frames / el, 1)
     return dict(value=value, unit="frames/s", cores=ncpu, kind="port", single_core_value=single, cpu_model=cpu_model,
-                all_cores_over_one_core=(round(value / single, 1) if single else None),
-                scaling_note=f"{len(cuts)} groups of clips side by side (one Python thread each), {per} OpenMP threads per group over its rows; "
+                all_cores_over_one_core=(round(value / single, 1) if single and value else None),
+                scaling_note=f"{len(cuts)} groups of clips side by side, one process each with {per} OpenMP threads over the rows of its clips; "
                              "the T loop runs inside each row's thread (sfsn_oracle.c gsn_layer)",
-                sample=f"{n} x the whole workload (B={B}, T={T}, the timed region's input batch), {el:.1f} s of wall time, fp32 oracle "
-                       "(double accumulation, rounded once), all layer outputs produced")
+                sample=f"{n_total} group-forwards over the whole workload (B={B}, T={T}, the timed region's first input batch) in {el:.1f} s of "
+                       "wall time, fp32 oracle (double accumulation, rounded once), all layer outputs produced")
 
 
 if __name__ == "__main__":

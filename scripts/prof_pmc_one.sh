@@ -2,9 +2,10 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_one
+export SFSN_OVERLAP_CHUNKS=0
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/a -o p -- python bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/a.log 2>&1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/b -o p -- python bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/b.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/a -o p -- python bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-phase-a > $OUT/a.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/b -o p -- python bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-phase-a > $OUT/b.log 2>&1
 python - "$1" <<'PY'
 import csv, sys, re, collections
 pat = re.compile(sys.argv[1])

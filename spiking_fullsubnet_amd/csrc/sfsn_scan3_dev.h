@@ -207,10 +207,18 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
             }
             if constexpr (GATED) stop = flag[t & 1];  // written by the loader during step t-1 (or before)
             v4i a[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
+#ifdef SFSN_EXP_2PLANES  // timing experiment (wrong results unless the weights were packed with 16 bits: plane 0 is then zero): what
+            constexpr int D0 = 1;  // would a 16-bit-weight fast path that skips the zero plane buy?  
+#else
+            constexpr int D0 = 0;
+#endif
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int d = 0; d < 3; ++d) a[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[ks][d], b[ks], a[d], 0, 0, 0);
+                for (int d = D0; d < 3; ++d) a[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[ks][d], b[ks], a[d], 0, 0, 0);
+            // (tried in round 3: MFMA columns beyond the RPW rows as DUPLICATES of the live ones -- same LDS address, a broadcast -- so
+            //  that the re-deal below becomes a per-lane v_cndmask select instead of DPP row shifts: 0.611 / 0.744 us per step at
+            //  4 / 8 rows against 0.579 / 0.690 with zero columns and DPP; zero operands also cost the matrix pipe less power)
             int v[3][NV];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {

@@ -318,21 +318,33 @@ def _worker(rank, world, port, n_clips, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_clips", [8, 7])
-def test_gather_clips_world2_gloo(n_clips):
-    """N > 1 path on CPU: two gloo ranks shard the clips, all-gather and recover the batch in clip order (even and ragged)."""
+def _run_gather(world, n_clips):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_clips, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+@pytest.mark.parametrize("n_clips", [8, 7])
+def test_gather_clips_world2_gloo(n_clips):
+    """N > 1 path on CPU: two gloo ranks shard the clips, all-gather and recover the batch in clip order (even and ragged)."""
+    _run_gather(2, n_clips)
+
+
+@pytest.mark.parametrize("n_clips", [512, 21, 5])
+def test_gather_clips_world8_gloo(n_clips):
+    """BASELINE configs[3]'s shape of the exchange on CPU: EIGHT ranks (one node's worth), 512 clips = 64 per rank (even), 21 clips
+    (ragged: five ranks own three, three own two) and fewer clips than ranks (three ranks own none) -- every rank recovers the
+    batch in clip order."""
+    _run_gather(8, n_clips)
 
 
 REFERENCE = "/root/reference"
