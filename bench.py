@@ -112,8 +112,9 @@ def _pmc_matches(pj, B, T, geom, n_lanes):
     """PMC figures are attached only to the workload they were taken on (round-2 advisor finding: the source hash alone let a run
     with other arguments report mislabelled traffic)."""
     w = (pj or {}).get("workload") or {}
-    return bool(pj) and w.get("B") == B and w.get("T") == T and list(w.get("timed_region_rows_per_wg", [])) == list(geom) and \
-        w.get("in_flight") == n_lanes
+    # (the traffic of one forward does not depend on how many forwards are in flight: matched on the batch, the sequence length
+    #  and the launch geometry of the timed region)
+    return bool(pj) and w.get("B") == B and w.get("T") == T and list(w.get("timed_region_rows_per_wg", [])) == list(geom)
 
 
 def main():
@@ -533,14 +534,16 @@ def waveform_streaming_bench(args, model, dev, world, rank, B):
                        "min_us": round(float(lat[0]), 1), "real_time_factor_at_8ms_hop": round(8e3 / float(lat[len(lat) // 2]), 1)}}))
 
 
-def cpu_baseline(kw, sd, stft, weight_seed=21):
-    """The CPU oracle (oracle/, the C restatement of the reference) on the host cores of this box, on the SAME workload: all B clips
-    x all T frames, over and over for ~12 s.  Clips are independent, so the batch is cut into groups of clips that run side by side
-    -- one PROCESS per group (oracle/cpu_bench_worker.py), each with its own OpenMP team over the rows of its clips (13 sub-band +
-    1 full-band row per clip): every core has work during all four sequence models.  (The row-parallel oracle alone: 3.6 x one
-    core on a 256-thread host in round 2 -- 64 full-band rows, four models one after the other; groups as Python threads of one
-    process: 9 x, serialised by the interpreter lock around the numpy glue.)  Same arithmetic as the parity oracle (double
-    accumulation, rounded once); a stated baseline, not the target."""
+def cpu_baseline(kw, sd, stft, weight_seed=21, workers=None, threads=None):
+    """The CPU oracle (oracle/, the C restatement of the reference) on the host cores of this box, on the SAME workload: the B clips x
+    all T frames of the timed region's first input batch, over and over for ~12 s.  Clips are independent: `workers` processes
+    (oracle/cpu_bench_worker.py; default: as many as the cgroup CPU quota grants, else one per two hardware threads) each run whole clips
+    (clip w, w + workers, ... of as many copies of the batch as it takes to give every worker one), single-threaded, so no core
+    waits for another during the four sequence models; inside a worker the oracle takes the rows of a clip through the recurrence in
+    blocks of 8 with the inner loops compiled for AVX-512 / AVX2 (sfsn_oracle.c gsn_layer; same additions in the same order).
+    (Round 2: OpenMP over the rows of the whole batch, 3.6 x one core on a 256-thread host -- 64 full-band rows, four models one
+    after the other, every row streaming both weight matrices per step.)  Same arithmetic as the parity oracle (double accumulation,
+    rounded once); a stated baseline, not the target."""
     import ctypes
     import subprocess
     import tempfile
@@ -549,30 +552,40 @@ def cpu_baseline(kw, sd, stft, weight_seed=21):
     full = stft.cpu().numpy()
     B, _, T = full.shape
     ncpu = os.cpu_count() or 1
-    groups = max(1, min(B, ncpu // 4))                 # ~4 OpenMP threads per group of clips (14 rows per clip)
-    per = max(1, ncpu // groups)
-    cuts = [(B * i // groups, B * (i + 1) // groups) for i in range(groups)]
-    cuts = [c for c in cuts if c[1] > c[0]]
+    # what this process may actually use: the scheduler affinity and the cgroup CPU quota (the GPU boxes of this pool show 256
+    # hardware threads and a cpu.max of 16 CPUs: more runnable workers than that only time-slice -- 64 / 128 / 256 workers gave
+    # 13.7 / 10.2 / 5.3 x one core)
+    avail, quota = ncpu, None
+    try:
+        avail = min(avail, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+            avail = max(1, min(avail, int(quota + 0.5)))
+    except (OSError, ValueError):
+        pass
+    workers = int(os.environ.get("SFSN_CPU_WORKERS", workers or (avail if quota is not None else max(1, avail // 2))))
+    threads = int(os.environ.get("SFSN_CPU_THREADS", threads or 1))
     worker = os.path.join(ROOT, "oracle", "cpu_bench_worker.py")
-    value = el = None
-    n_total = 0
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "stft.npy")
         np.save(path, full)
-        env = dict(os.environ, OMP_NUM_THREADS=str(per), OMP_PROC_BIND="false")
-        start = time.time() + 8.0 + 0.02 * len(cuts)   # every worker has imported numpy, built its weights and warmed its team by then
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
+        start = time.time() + 8.0 + 0.03 * workers     # every worker has imported numpy, built its weights and warmed up by then
         deadline = start + 12.0
-        procs = [subprocess.Popen([sys.executable, worker, path, str(lo), str(hi), repr(start), repr(deadline), str(weight_seed)],
-                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for lo, hi in cuts]
+        procs = [subprocess.Popen([sys.executable, worker, path, str(w % B), str(w % B + 1), repr(start), repr(deadline), str(weight_seed)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for w in range(workers)]
         outs = []
         for p in procs:
-            o, _ = p.communicate(timeout=300)
+            o, _ = p.communicate(timeout=600)
             outs.append(json.loads(o.strip().splitlines()[-1]))
         el = max(o["t_end"] for o in outs) - start
-        frames = sum(o["forwards"] * (o["hi"] - o["lo"]) * T for o in outs)
         n_total = sum(o["forwards"] for o in outs)
-        value = round(frames / el, 1)
-    # one core, for calibration: one clip, all T frames, OpenMP pinned to one thread (in this process)
+        value = round(n_total * T / el, 1)
+    # one core, for calibration: one clip, all T frames, one thread (in this process)
     single = cpu_model = None
     try:
         gomp = ctypes.CDLL("libgomp.so.1")
@@ -586,12 +599,12 @@ def cpu_baseline(kw, sd, stft, weight_seed=21):
             cpu_model = next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), None)
     except Exception:  # the baseline is reported, never required
         pass
-    return dict(value=value, unit="frames/s", cores=ncpu, kind="port", single_core_value=single, cpu_model=cpu_model,
+    return dict(value=value, unit="frames/s", cores=workers * threads, hardware_threads=ncpu, cgroup_cpu_quota=quota, kind="port", single_core_value=single, cpu_model=cpu_model,
                 all_cores_over_one_core=(round(value / single, 1) if single and value else None),
-                scaling_note=f"{len(cuts)} groups of clips side by side, one process each with {per} OpenMP threads over the rows of its clips; "
-                             "the T loop runs inside each row's thread (sfsn_oracle.c gsn_layer)",
-                sample=f"{n_total} group-forwards over the whole workload (B={B}, T={T}, the timed region's first input batch) in {el:.1f} s of "
-                       "wall time, fp32 oracle (double accumulation, rounded once), all layer outputs produced")
+                scaling_note=f"{workers} single-clip worker processes side by side, {threads} thread(s) each; rows of a clip in blocks of 8 through "
+                             "the recurrence, AVX-512 / AVX2 inner loops (sfsn_oracle.c gsn_layer)",
+                sample=f"{n_total} clip-forwards of T={T} frames (clips of the timed region's first input batch, B={B}, cycled over the workers) in "
+                       f"{el:.1f} s of wall time, fp32 oracle (double accumulation, rounded once), all layer outputs produced")
 
 
 if __name__ == "__main__":

@@ -58,7 +58,14 @@ static inline real r_pow(real a, real b) { return sizeof(real) == 4 ? (real)powf
 int ORA(version)(void) { return 1; }
 
 /* acc[n] += sum_k x[k] * wT[k][n]; double accumulation, vectorisable over n without reassociation.
- * Zero inputs are skipped (exact: adding 0*w changes nothing) -- spikes are 25-58 % active. */
+ * Zero inputs are skipped (exact: adding 0*w changes nothing) -- spikes are 25-58 % active.
+ * (The inner loop is compiled for AVX-512 / AVX2 / baseline x86-64 and picked at run time: vector width changes how many of the
+ *  independent accumulators acc[n] advance per instruction, not the order of the additions into any one of them; with
+ *  -ffp-contract=off the multiply and the add stay separately rounded in every clone -- bit-identical results, checked against the
+ *  fixtures.  It is what makes the oracle a credible CPU baseline for bench.py: 2.4 x one core's speed of the SSE2 build.) */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
 static void matvec_acc(double* acc, const real* x, int K, const double* wT, int N) {
     for (int k = 0; k < K; ++k) {
         const double xk = (double)x[k];
@@ -66,6 +73,15 @@ static void matvec_acc(double* acc, const real* x, int K, const double* wT, int 
         const double* w = wT + (size_t)k * N;
         for (int n = 0; n < N; ++n) acc[n] += xk * w[n];
     }
+}
+
+/* acc[n] += xk * w[n] for one k (the inner loop of matvec_acc, for callers that walk k outside: gsn_layer's row blocks) */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+static void axpy_acc(double* acc, double xk, const double* w, int N) {
+    if (xk == 0.0) return; /* exact: adding 0*w changes nothing */
+    for (int n = 0; n < N; ++n) acc[n] += xk * w[n];
 }
 
 static double* transpose_to_double(const real* w, int N, int K) { /* w [N][K] -> wT [K][N] */
@@ -115,34 +131,51 @@ void ORA(gsn_layer)(const real* x, int T, int R, int I, int H, int shared, const
     }
     double* wihT = transpose_to_double(w_ih, GH, I);
     double* whhT = transpose_to_double(w_hh, GH, H);
-#pragma omp parallel for schedule(static)
-    for (int r = 0; r < R; ++r) {
-        real* hr = h + (size_t)r * H;
-        real* cr = c + (size_t)r * H;
-        double* zi = (double*)malloc(sizeof(double) * (size_t)GH);
-        double* zr = (double*)malloc(sizeof(double) * (size_t)GH);
+    /* Rows are independent; a thread takes a BLOCK of up to GSN_RB rows through all T steps and walks k in the outer loop of the
+     * two products, so that a row of W^T fetched once serves every row of the block (per row the additions into acc[n] still
+     * happen in the order k = 0, 1, ...: bit-identical to a row-at-a-time evaluation; checked against the fixtures).  Without the
+     * blocking every row streams both matrices (0.5-1.6 MB as double) per step and 256 threads are bound by the shared caches. */
+#define GSN_RB 8
+    const int nblk = (R + GSN_RB - 1) / GSN_RB;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int r0 = blk * GSN_RB, nr = (R - r0 < GSN_RB) ? R - r0 : GSN_RB;
+        double* zi = (double*)malloc(sizeof(double) * (size_t)GH * GSN_RB);
+        double* zr = (double*)malloc(sizeof(double) * (size_t)GH * GSN_RB);
         for (int t = 0; t < T; ++t) {
-            const real* xt = x + ((size_t)t * R + r) * I;
-            memset(zi, 0, sizeof(double) * (size_t)GH);
-            memset(zr, 0, sizeof(double) * (size_t)GH);
-            matvec_acc(zi, xt, I, wihT, GH); /* torch.mm(input, weight_ih.t())  NEURON:141 */
-            matvec_acc(zr, hr, H, whhT, GH); /* torch.mm(hx, weight_hh.t())     NEURON:143 */
-            for (int j = 0; j < H; ++j) {
-                const int jg = shared ? j : H + j;
-                real pf = ((real)zi[j] + bias[j]) + (real)zr[j];
-                real pg = ((real)zi[jg] + bias[H + j]) + (real)zr[jg];
-                real f = (real)1 / ((real)1 + r_exp(-pf));
-                real a = f * cr[j];
-                real b = (real)1 - f;
-                real d = b * pg;
-                real cy = a + d;
-                if (use_bn) cy = r_fma(cy, alpha[j], beta[j]);
-                cr[j] = cy;
-                size_t o = ((size_t)t * R + r) * H + j;
-                spikes[o] = (cy >= (real)0) ? (real)1 : (real)0;
-                if (membrane) membrane[o] = cy;
+            memset(zi, 0, sizeof(double) * (size_t)GH * nr);
+            memset(zr, 0, sizeof(double) * (size_t)GH * nr);
+            for (int k = 0; k < I; ++k) { /* torch.mm(input, weight_ih.t())  NEURON:141 */
+                const double* w = wihT + (size_t)k * GH;
+                for (int q = 0; q < nr; ++q) axpy_acc(zi + (size_t)q * GH, (double)x[((size_t)t * R + r0 + q) * I + k], w, GH);
             }
-            memcpy(hr, spikes + ((size_t)t * R + r) * H, sizeof(real) * (size_t)H);
+            for (int k = 0; k < H; ++k) { /* torch.mm(hx, weight_hh.t())     NEURON:143 */
+                const double* w = whhT + (size_t)k * GH;
+                for (int q = 0; q < nr; ++q) axpy_acc(zr + (size_t)q * GH, (double)h[(size_t)(r0 + q) * H + k], w, GH);
+            }
+            for (int q = 0; q < nr; ++q) {
+                const int r = r0 + q;
+                real* hr = h + (size_t)r * H;
+                real* cr = c + (size_t)r * H;
+                const double* zir = zi + (size_t)q * GH;
+                const double* zrr = zr + (size_t)q * GH;
+                for (int j = 0; j < H; ++j) {
+                    const int jg = shared ? j : H + j;
+                    real pf = ((real)zir[j] + bias[j]) + (real)zrr[j];
+                    real pg = ((real)zir[jg] + bias[H + j]) + (real)zrr[jg];
+                    real f = (real)1 / ((real)1 + r_exp(-pf));
+                    real a = f * cr[j];
+                    real b = (real)1 - f;
+                    real d = b * pg;
+                    real cy = a + d;
+                    if (use_bn) cy = r_fma(cy, alpha[j], beta[j]);
+                    cr[j] = cy;
+                    size_t o = ((size_t)t * R + r) * H + j;
+                    spikes[o] = (cy >= (real)0) ? (real)1 : (real)0;
+                    if (membrane) membrane[o] = cy;
+                }
+                memcpy(hr, spikes + ((size_t)t * R + r) * H, sizeof(real) * (size_t)H);
+            }
         }
         free(zi);
         free(zr);
