@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 7 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 8 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -120,6 +120,27 @@ typedef struct sfsn_scan_segment {
 
 int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs /* host array */, int n_segs, int T, int H, int shared,
                         int rows_per_wg /* 16, 8, 4, or 0 = choose so that the launch covers ~all CUs */, void* stream);
+
+/* ----------------------------------------------------------------------------------------------------
+ * Training-mode cell steps -- replace one iteration of GSULayer.forward's loop (NEURON:78-80) around
+ * GSUCell.forward (NEURON:132-153) with nn.BatchNorm1d in TRAINING mode (batch statistics of this step over all R rows, running
+ * statistics updated with `momentum`, NEURON:123,149-150), and the matching step of the backward pass through Triangle.backward
+ * (NEURON:94-101).  One launch per time step: the rows of a step are coupled by the normalisation.  All tensors fp32, device.
+ *   z [R][G*H]: x_t . W_ih^T WITHOUT bias (G = 1 shared: one product serves both gates; 2: forget | cell);  bias [2H];
+ *   w_hh [G*H][H] fp32;  h_prev, c_prev [R][H];  bn_w / bn_b [H] (both NULL: bn = False);  running_mean / running_var [H]
+ *   nullable (not updated).  Outputs of the forward step (saved for the backward step): spikes = h_t, u = c_t (post-BN
+ *   membrane), xhat (normalised, pre-affine; bn only), f (forget gate), g (pre-activation of the cell gate), invstd [H] (bn only).
+ * Backward step: dh_up (gradient w.r.t. h_t from above, nullable), dh_rec (gradient w.r.t. h_t through step t+1's recurrent
+ *   product, nullable), dc_next (gradient w.r.t. c_t from step t+1, nullable) -> d_gates [R][2H] (d pre_f | d pre_g), d_z [R][G*H]
+ *   (shared: their sum = the gradient of the shared product; unshared: pass NULL and use d_gates), dc_prev [R][H], and
+ *   d_bn_w / d_bn_b [H] ACCUMULATED (+=).  The caller forms dh_rec for step t-1 as d_z_t . W_hh (a library GEMM). */
+int sfsn_gsn_train_step_fwd(const float* z, const float* w_hh, const float* bias, const float* h_prev, const float* c_prev,
+                            const float* bn_w, const float* bn_b, float* running_mean, float* running_var, float momentum, float eps,
+                            int R, int H, int shared, float* spikes, float* u, float* xhat, float* f, float* g, float* invstd,
+                            void* stream);
+int sfsn_gsn_train_step_bwd(const float* dh_up, const float* dh_rec, const float* dc_next, const float* u, const float* xhat,
+                            const float* f, const float* g, const float* c_prev, const float* invstd, const float* bn_w, int R, int H,
+                            int shared, float* d_gates, float* d_z, float* dc_prev, float* d_bn_w, float* d_bn_b, void* stream);
 
 /* Fused-input variant for layers >= 1 (their input is the previous layer's spikes): the input term is computed inside
  * the scan from the int8 spikes and the packed input weights, so that sfsn_spike_proj's [T][R][H] fp32 result never makes

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
 NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE, NORM_CUMLAPLACE = 0, 1, 2, 3
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
-ABI_VERSION = 7  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
+ABI_VERSION = 8  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -74,7 +74,7 @@ class HopDesc(ctypes.Structure):
 def _sources():
     """The files the library is made of, in the order the Makefile hashes them (SRCS)."""
     return [os.path.join(_HERE, "..", "include", "sfsn.h")] + [
-        os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_scan3_dev.h", "sfsn_feat_dev.h", "sfsn_fft_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_hop.hip", "sfsn_fft.hip",
+        os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_scan3_dev.h", "sfsn_feat_dev.h", "sfsn_fft_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_hop.hip", "sfsn_fft.hip", "sfsn_train.hip",
                                   "sfsn_pack.cpp")]
 
 
@@ -135,6 +135,10 @@ def lib() -> ctypes.CDLL:
     L.sfsn_w3_unpack.argtypes = [_P, _P, _I, _I, _P]
     L.sfsn_gsn_layer_scan.restype = _I
     L.sfsn_gsn_layer_scan.argtypes = [ctypes.POINTER(ScanSegment), _I, _I, _I, _I, _I, _P]
+    L.sfsn_gsn_train_step_fwd.restype = _I
+    L.sfsn_gsn_train_step_fwd.argtypes = [_P] * 9 + [_F, _F, _I, _I, _I] + [_P] * 7
+    L.sfsn_gsn_train_step_bwd.restype = _I
+    L.sfsn_gsn_train_step_bwd.argtypes = [_P] * 10 + [_I, _I, _I] + [_P] * 6
     L.sfsn_gsn_layer_scan_fused.restype = _I
     L.sfsn_gsn_layer_scan_fused.argtypes = [ctypes.POINTER(ScanSegment), ctypes.POINTER(FusedInput), _I, _I, _I, _P]
     L.sfsn_gsn_layer_scan_fused_x.restype = _I
@@ -179,7 +183,7 @@ def lib() -> ctypes.CDLL:
 EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
            "sfsn_w3_pack", "sfsn_w3_pack_bits", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_stack_scratch_bytes", "sfsn_gsn_stack_scan",
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
-           "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft")
+           "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft", "sfsn_gsn_train_step_fwd", "sfsn_gsn_train_step_bwd")
 
 
 def check(rc: int, what: str = "") -> None:

@@ -63,17 +63,16 @@ class SequenceModel(nn.Module):
             self.pre_layer_norm = nn.LayerNorm(input_size)
         if sequence_model == "GSN":
             self.sequence_model = StackedGSU(input_size, hidden_size, num_layers, shared_weights, bn)
-        elif sequence_model == "LSTM":
-            raise NotImplementedError("sequence_model='LSTM' is the reference's nn.LSTM ablation, not the GSN hot path this "
-                                      "package accelerates; use the reference module for it")
+        elif sequence_model == "LSTM":  # the reference's nn.LSTM ablation (:38-45): served by the ATen path (training.py), not by the kernels
+            self.sequence_model = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, batch_first=True,
+                                          bidirectional=False)
         else:
             raise NotImplementedError(f"Sequence model {sequence_model} not implemented.")
-        if proj_size <= 0:
-            raise NotImplementedError("proj_size = 0 (Identity projection) is not used by any reference config")
-        self.proj = nn.Linear(hidden_size, proj_size)
-        if output_activate_function in ("tanh", "sigmoid", "relu"):
-            raise NotImplementedError("output activations are not fused yet; every reference config uses `false` (Identity)")
-        self.output_activate_function = nn.Identity()
+        self.proj = nn.Linear(hidden_size, proj_size) if proj_size > 0 else nn.Identity()
+        self.output_activate_function = {"tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "relu": nn.ReLU}.get(output_activate_function, nn.Identity)()
+        # what the inference kernels cover: GSN cells, a Linear projection, Identity output (every reference config); the rest
+        # runs on the ATen path in eval mode too (SURVEY 8b's torch fallback)
+        self.kernel_path = sequence_model == "GSN" and proj_size > 0 and isinstance(self.output_activate_function, nn.Identity)
         self.hidden_size, self.num_layers = hidden_size, num_layers
         self.use_pre_layer_norm, self.sequence_model_name = use_pre_layer_norm, sequence_model
 
@@ -114,6 +113,9 @@ class _EngineMixin:
     # win_length = n_fft, 1..4 hops per window: every reference config); "torch": torch.stft / torch.istft (rocFFT).  With
     # "device" a configuration the kernels do not cover falls back to torch -- that is the documented edge, not a CPU path.
     spectral_backend = "device"
+    # eval-mode forward() with gradients to the PARAMETERS (grad mode on): off by default -- parameters require grad by default, and an
+    # inference call that merely forgot torch.no_grad() should not leave the kernels; an input that requires grad always does
+    autograd_in_eval = False
 
     def _device_fft(self, t: torch.Tensor) -> bool:
         n_fft, hop = self.n_fft, self.hop_length
@@ -206,14 +208,25 @@ class _EngineMixin:
                                 waveform=waveform, host_io=host_io)
 
     def _check_mode(self, x=None):
+        """The inference kernels have no autograd graph and no training-mode BatchNorm: the entry points that use them
+        (forward_stft, streaming sessions) refuse a module in training mode or an input that requires grad.  forward() itself
+        routes such calls to the differentiable path (training.py)."""
         if x is not None and x.requires_grad:
-            raise RuntimeError(
-                "the input requires grad, but this package has no backward pass (SURVEY 8f rank 4) and no torch fallback: "
-                "detach the input, or keep the reference module for `-M train`")
+            raise RuntimeError("the input requires grad: the inference kernels have no backward pass -- call the module itself "
+                               "(forward() takes the differentiable path of training.py), or detach the input")
         if self.training:
-            raise RuntimeError(
-                "training-mode forward (per-time-step batch-statistics BatchNorm and BPTT through the spike surrogate, "
-                "efficient_spiking_neuron.py:94-101,149-150) is not built in this package (SURVEY 8f rank 4); call .eval()")
+            raise RuntimeError("the module is in training mode: the inference kernels evaluate BatchNorm with the running statistics -- "
+                               "call the module itself (forward() takes the training path of training.py), or .eval()")
+
+    def _wants_autograd(self, x) -> bool:
+        """forward() takes the differentiable ATen + training-step-kernel path when the module is in training mode, when gradients
+        can flow (grad mode on and the input or a parameter requires grad ... the recipes' validation runs under no_grad and stays on
+        the inference kernels), or when the constructor options are ones the inference kernels do not cover."""
+        if self.training:
+            return True
+        if torch.is_grad_enabled() and (x.requires_grad or self.autograd_in_eval):
+            return True  # (parameters always "require grad": an eval-mode call outside no_grad stays on the kernels unless asked)
+        return not self._kernel_path()
 
 
 class SpikingFullSubNet(_EngineMixin, nn.Module):
@@ -252,10 +265,18 @@ class SpikingFullSubNet(_EngineMixin, nn.Module):
         self._check_mode(noisy_cmp)
         return self.engine().forward_stft(noisy_cmp, want_layers=want_layers, want_membrane=want_membrane, want_counts=want_counts)
 
-    @torch.no_grad()
+    def _kernel_path(self) -> bool:
+        return self.fb_model.kernel_path and all(s.kernel_path for s in self.sb_model.sb_models)
+
     def forward(self, input):
         assert input.ndim == 2, f"Input tensor must be 2D, but got {input.ndim}D."
-        self._check_mode(input)
+        if self._wants_autograd(input):
+            from . import training
+            return training.forward_live(self, input)
+        with torch.no_grad():
+            return self._forward_inference(input)
+
+    def _forward_inference(self, input):
         batch_size, sequence_length = input.shape
         res = self.engine().forward_stft(self._stft(input), **self._layer_kwargs())
         enh_stft = res["enh_stft"]  # [B, S, F, T]

@@ -1,0 +1,238 @@
+"""Training-mode forward and backward of the live model (SURVEY 8b "autograd", 8f rank 4).
+
+What the recipes' training step needs (recipes/intel_ndns/spiking_fullsubnet/trainer.py:24-48: ``self.model(noisy)`` in
+``.train()`` mode, a loss on the enhanced waveform / magnitude, ``accelerator.backward(loss)``):
+
+* the recurrent cell loop with ``nn.BatchNorm1d`` in TRAINING mode inside the cell -- every time step normalises with that step's
+  batch statistics and updates the running statistics (efficient_spiking_neuron.py:123,149-150) -- and its backward pass through the
+  triangle surrogate of the spike (:94-101): ``GSNLayerTrainFn``, a ``torch.autograd.Function`` whose time steps are the HIP kernels
+  ``sfsn_gsn_train_step_fwd`` / ``sfsn_gsn_train_step_bwd`` (csrc/sfsn_train.hip: one launch per step, a workgroup owns 16 neurons
+  for all rows and reduces over the rows in LDS); the time-parallel products around them (input product, weight gradients, input
+  gradient) and the one sequential product of the backward pass (dh_{t-1} = dz_t . W_hh) are library GEMMs (``torch.mm``);
+* everything between ``stft`` and ``istft`` that is time-parallel (band selection, reflect-gathered sub-band features, LayerNorm,
+  projections, deep filter) as differentiable ATen operations on index tensors built once per module -- the kernels of the
+  inference engine have no backward.
+
+The same ATen path serves the constructor options the inference kernels do not cover (``sequence_model="LSTM"`` = ``nn.LSTM``,
+``proj_size=0``, output activations), in ``eval()`` mode too: SURVEY 8b's torch fallback.  HIP tensors only -- like the rest of the
+package this has no CPU path (a CPU module raises).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import check
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class GSNLayerTrainFn(torch.autograd.Function):
+    """One GSN layer over all T steps: x [T, R, I] -> spikes [T, R, H] (zero initial state, modeling_spiking_fullsubnet.py:100-106).
+
+    ``bn_w`` / ``bn_b`` None = no BatchNorm.  ``stats`` = (running_mean, running_var, num_batches_tracked) or None; with
+    ``batch_stats`` (the module is in training mode) every step uses its own batch statistics and updates ``stats`` in place;
+    without it (eval mode, gradients still wanted) the running statistics are folded into an affine map."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, bias, bn_w, bn_b, stats, shared, batch_stats, momentum, eps):
+        if not x.is_cuda:
+            raise RuntimeError("spiking_fullsubnet_amd has no CPU path: move the module and its input to a HIP device")
+        L = _lib.lib()
+        T, R, I = x.shape
+        GH, H = w_hh.shape
+        dev = x.device
+        x = x.contiguous().float()
+        w_ih_c, w_hh_c, bias_c = w_ih.detach().contiguous().float(), w_hh.detach().contiguous().float(), bias.detach().contiguous().float()
+        z = torch.mm(x.reshape(T * R, I), w_ih_c.t()).view(T, R, GH)  # x_t . W_ih^T for all t (bias is added inside the step)
+        f32 = dict(dtype=torch.float32, device=dev)
+        spikes, u = torch.empty((T, R, H), **f32), torch.empty((T, R, H), **f32)
+        fg, gg = torch.empty((T, R, H), **f32), torch.empty((T, R, H), **f32)
+        use_bn = bn_w is not None
+        fold = use_bn and not batch_stats  # eval-mode BatchNorm: y = x * alpha + beta with the running statistics
+        if fold:
+            rm, rv = stats[0].float(), stats[1].float()
+            alpha = bn_w.detach().float() / torch.sqrt(rv + eps)
+            beta = bn_b.detach().float() - rm * alpha
+        xhat = torch.empty((T, R, H), **f32) if (use_bn and not fold) else None
+        invstd = torch.empty((T, H), **f32) if (use_bn and not fold) else None
+        zero = torch.zeros((R, H), **f32)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        bw = bn_w.detach().contiguous().float() if (use_bn and not fold) else None
+        bb = bn_b.detach().contiguous().float() if (use_bn and not fold) else None
+        rmean = stats[0] if (use_bn and batch_stats and stats is not None) else None
+        rvar = stats[1] if (use_bn and batch_stats and stats is not None) else None
+        with torch.cuda.device(dev):
+            for t in range(T):
+                hp = zero if t == 0 else spikes[t - 1]
+                cp = zero if t == 0 else u[t - 1]
+                check(L.sfsn_gsn_train_step_fwd(_p(z[t]), _p(w_hh_c), _p(bias_c), _p(hp), _p(cp), _p(bw), _p(bb), _p(rmean), _p(rvar),
+                                                float(momentum), float(eps), R, H, int(shared), _p(spikes[t]), _p(u[t]),
+                                                _p(xhat[t]) if xhat is not None else None, _p(fg[t]), _p(gg[t]),
+                                                _p(invstd[t]) if invstd is not None else None, st), "sfsn_gsn_train_step_fwd")
+                if fold:  # (the folded affine map and the threshold, on the pre-normalisation membrane the step left in u)
+                    u[t].mul_(alpha).add_(beta)
+                    spikes[t].copy_((u[t] >= 0).float())
+        if use_bn and batch_stats and stats is not None and stats[2] is not None:
+            stats[2].add_(T)  # num_batches_tracked: one BatchNorm call per time step
+        ctx.save_for_backward(x, w_ih_c, w_hh_c, spikes, u, fg, gg, xhat if xhat is not None else zero, invstd if invstd is not None else zero,
+                              bw if bw is not None else zero, alpha if fold else zero)
+        ctx.meta = (bool(shared), use_bn, fold, T, R, I, H, GH)
+        return spikes
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_ih, w_hh, spikes, u, fg, gg, xhat, invstd, bw, alpha = ctx.saved_tensors
+        shared, use_bn, fold, T, R, I, H, GH = ctx.meta
+        L = _lib.lib()
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dy = dy.contiguous().float()
+        d_gates = torch.empty((T, R, 2 * H), **f32)
+        d_z = torch.empty((T, R, H), **f32) if shared else None
+        dc_buf = [torch.empty((R, H), **f32), torch.empty((R, H), **f32)]
+        d_bn_w, d_bn_b = torch.zeros((H,), **f32), torch.zeros((H,), **f32)
+        zero = torch.zeros((R, H), **f32)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        bn_kernel = use_bn and not fold
+        dh_rec = dc = None
+        with torch.cuda.device(dev):
+            for t in range(T - 1, -1, -1):
+                cp = zero if t == 0 else u[t - 1]
+                dh_up = dy[t]
+                if fold:
+                    # eval-mode BatchNorm folded into an affine map: du -> dc' is a per-neuron scale, applied by pre-scaling the
+                    # incoming gradients of u (the step kernel then runs without normalisation)
+                    tri = torch.clamp(1.0 - u[t].abs(), min=0.0)
+                    du = dh_up * tri if dh_rec is None else (dh_up + dh_rec) * tri
+                    if dc is not None:
+                        du = du + dc
+                    dcy = (du * alpha).contiguous()
+                    # reuse the step kernel with dc_next = dcy and no dh (tri(u) does not matter then): u is only read for tri
+                    check(L.sfsn_gsn_train_step_bwd(None, None, _p(dcy), _p(u[t]), None, _p(fg[t]), _p(gg[t]), _p(cp), None, None, R, H,
+                                                    int(shared), _p(d_gates[t]), _p(d_z[t]) if shared else None, _p(dc_buf[t & 1]), None, None, st),
+                          "sfsn_gsn_train_step_bwd")
+                else:
+                    check(L.sfsn_gsn_train_step_bwd(_p(dh_up), _p(dh_rec), _p(dc), _p(u[t]), _p(xhat[t]) if bn_kernel else None, _p(fg[t]),
+                                                    _p(gg[t]), _p(cp), _p(invstd[t]) if bn_kernel else None, _p(bw) if bn_kernel else None, R, H,
+                                                    int(shared), _p(d_gates[t]), _p(d_z[t]) if shared else None, _p(dc_buf[t & 1]),
+                                                    _p(d_bn_w) if bn_kernel else None, _p(d_bn_b) if bn_kernel else None, st),
+                          "sfsn_gsn_train_step_bwd")
+                dz_t = d_z[t] if shared else d_gates[t]
+                dh_rec = torch.mm(dz_t, w_hh)  # gradient w.r.t. h_{t-1} through this step's recurrent product
+                dc = dc_buf[t & 1]
+        dz = (d_z if shared else d_gates).reshape(T * R, GH)
+        dx = torch.mm(dz, w_ih).view(T, R, I)
+        dw_ih = torch.mm(dz.t(), x.reshape(T * R, I))
+        h_prev = torch.cat([zero.unsqueeze(0), spikes[:-1]], 0).reshape(T * R, H)
+        dw_hh = torch.mm(dz.t(), h_prev)
+        dbias = d_gates.reshape(T * R, 2 * H).sum(0)
+        if not use_bn:
+            d_bn_w = d_bn_b = None
+        elif fold:
+            d_bn_w = d_bn_b = None  # (eval-mode gradients of gamma / beta are not produced: parameters are frozen in eval use)
+        return dx, dw_ih, dw_hh, dbias, d_bn_w, d_bn_b, None, None, None, None, None
+
+
+def gsn_stack(x: torch.Tensor, stack, training: bool) -> List[torch.Tensor]:
+    """StackedGSU.forward (efficient_spiking_neuron.py:50-62) on the module's parameter containers: [x, S1, ..., SL]."""
+    outs = [x]
+    cur = x
+    for layer in stack.layers:
+        cell = layer.cell
+        bn = getattr(cell, "batchnorm", None) if cell.use_bn else None
+        stats = None
+        momentum, eps = 0.1, 1e-5
+        if bn is not None:
+            stats = (bn.running_mean, bn.running_var, bn.num_batches_tracked)
+            momentum = 0.1 if bn.momentum is None else bn.momentum
+            eps = bn.eps
+        cur = GSNLayerTrainFn.apply(cur, cell.weight_ih, cell.weight_hh, cell.bias_ih, None if bn is None else bn.weight,
+                                    None if bn is None else bn.bias, stats, cell.shared_weights, bool(training and bn is not None),
+                                    momentum, eps)
+        outs.append(cur)
+    return outs
+
+
+def sequence_model(seq, x_bft: torch.Tensor, training: bool):
+    """SequenceModel.forward (modeling_spiking_fullsubnet.py:81-125; LSTM variant :68-79): [R, I, T] -> ([R, P, T], all_layer_outputs)."""
+    if seq.sequence_model_name == "LSTM":
+        x = x_bft.permute(0, 2, 1)
+        if seq.use_pre_layer_norm:
+            x = seq.pre_layer_norm(x)
+        y, _ = seq.sequence_model(x)
+        y = seq.output_activate_function(seq.proj(y))
+        return y.permute(0, 2, 1), []
+    x = x_bft.permute(2, 0, 1)  # time-major
+    if seq.use_pre_layer_norm:
+        x = seq.pre_layer_norm(x)
+    outs = gsn_stack(x.contiguous(), seq.sequence_model, training)
+    y = seq.proj(outs[-1])
+    outs = outs + [y]
+    return seq.output_activate_function(y).permute(1, 2, 0), outs
+
+
+def _reflect(idx: torch.Tensor, nf: int) -> torch.Tensor:
+    idx = torch.where(idx < 0, -idx, idx)
+    return torch.where(idx > nf - 1, 2 * (nf - 1) - idx, idx)
+
+
+def forward_live(model, wave: torch.Tensor):
+    """SpikingFullSubNet.forward (modeling_spiking_fullsubnet.py:415-474) on differentiable operations."""
+    assert wave.ndim == 2, f"Input tensor must be 2D, but got {wave.ndim}D."
+    if not wave.is_cuda:
+        raise RuntimeError("spiking_fullsubnet_amd has no CPU path: move the module and its input to a HIP device")
+    B, length = wave.shape
+    dev = wave.device
+    window = torch.hann_window(model.n_fft, device=dev)
+    noisy = torch.stft(wave, model.n_fft, model.hop_length, model.win_length, window=window, return_complex=True, pad_mode="constant")
+    Fq, T = noisy.shape[1], noisy.shape[2]
+    nf = Fq - 1
+    mag = noisy.abs() ** model.fdrc
+    mag = mag[:, :nf]                                           # the Nyquist bin is passed through untouched
+    S = model.num_spks
+    training = model.training
+    fb_in = model.fb_input_size
+    fb_out, fb_all = sequence_model(model.fb_model, mag[:, :fb_in], training)  # [B, P, T]
+    P_fb = fb_out.shape[1]
+    sb = model.sb_model
+    cut = list(sb.freq_cutoffs)
+    enh_groups, sb_all = [], []
+    for g, seq in enumerate(sb.sb_models):
+        lo, hi, c, n, d = cut[g], cut[g + 1], sb.center_freq_sizes[g], sb.neighbor_freq_sizes[g], sb.df_orders[g]
+        if (hi - lo) % c != 0:
+            raise ValueError(f"Number of frequency bins must be divisible by the center frequency.GOT: ctr_freq={c}, "
+                             f"upper_cutoff_freq={hi}, lower_cutoff_freq={lo}")
+        N = (hi - lo) // c
+        k = torch.arange(N, device=dev)
+        idx_noisy = _reflect(lo + k[:, None] * c - n + torch.arange(c + 2 * n, device=dev)[None, :], nf)   # [N, c + 2n]
+        idx_fb = (lo + k[:, None] * c + torch.arange(c, device=dev)[None, :]) % P_fb                        # [N, c] (tiled full-band output)
+        x = torch.cat([mag[:, idx_noisy], fb_out[:, idx_fb]], dim=2)                                         # [B, N, I, T]
+        I = x.shape[2]
+        y, outs = sequence_model(seq, x.reshape(B * N, I, T), training)                                      # [B N, P, T]
+        sb_all.append(outs)
+        # projection channel p = ((ri * c + fci) * d + di) * S + si  ->  coefficient [B, di, si, n * c + fci, T] (re, im)
+        coef = y.reshape(B, N, 2, c, d, S, T)
+        cre = coef[:, :, 0].permute(0, 3, 4, 1, 2, 5).reshape(B, d, S, N * c, T)
+        cim = coef[:, :, 1].permute(0, 3, 4, 1, 2, 5).reshape(B, d, S, N * c, T)
+        xg = noisy[:, lo:hi]                                                                                 # [B, N c, T]
+        xp = F.pad(torch.view_as_real(xg), (0, 0, d - 1, 0))                                                 # causal: zeros on the left of T
+        xr, xi = xp[..., 0], xp[..., 1]
+        yr = yi = 0
+        for di in range(d):  # Y[f, t] = sum_d X[f, t - (d_order - 1) + d] * C[d, f, t]
+            a, b = xr[:, None, :, di:di + T], xi[:, None, :, di:di + T]
+            yr = yr + a * cre[:, di] - b * cim[:, di]
+            yi = yi + a * cim[:, di] + b * cre[:, di]
+        enh_groups.append(torch.complex(yr, yi))                                                             # [B, S, N c, T]
+    enh = torch.cat(enh_groups, dim=2)
+    enh_stft = torch.cat([enh, noisy[:, None, enh.shape[2]:].expand(B, S, Fq - enh.shape[2], T)], dim=2)     # bins past the groups pass through
+    enh_y = torch.istft(enh_stft.reshape(B * S, Fq, T), model.n_fft, model.hop_length, model.win_length, window=window, length=length)
+    if S > 1:
+        return enh_y.reshape(B, S, -1), fb_all, sb_all
+    return enh_y, enh_stft[:, 0].abs(), fb_all, sb_all

@@ -126,6 +126,55 @@ def gsn_cases(neuron, out):
     out["dims"] = np.array([m[1:] for m in meta], dtype=np.int64)
 
 
+
+def gsn_train_cases(neuron, out):
+    """The reference's StackedGSU in TRAINING mode (per-time-step batch-statistics BatchNorm that updates the running statistics T
+    times per forward, efficient_spiking_neuron.py:149-150) and the backward pass through the triangle surrogate (:94-101): a fixed
+    random cotangent `gy` on the last layer's spike train gives dL/dy = gy; recorded are the spike trains, the final states, the
+    BatchNorm buffers after the forward and the gradients of the input and of every parameter."""
+    import torch
+    import refweights
+    cases = [  # name, I, H, L, R, T, shared, bn
+        ("train_tiny_shared_bn", 12, 32, 2, 6, 10, True, True),
+        ("train_tiny_unshared_bn", 9, 16, 2, 5, 8, False, True),
+        ("train_tiny_shared_nobn", 10, 16, 1, 4, 9, True, False),
+        ("train_sb_shape", 38, 224, 2, 16, 6, True, True),
+    ]
+    meta = []
+    for ci, (name, I, H, L, R, T, shared, bn) in enumerate(cases):
+        rng = np.random.default_rng(300 + ci)
+        sd = {}
+        for l in range(L):
+            refweights._cell(rng, f"layers.{l}.cell.", I if l == 0 else H, H, shared, bn, sd)
+        net = neuron.efficient_spiking_neuron(I, H, L, shared_weights=shared, bn=bn).train()
+        net.load_state_dict(to_torch_sd(sd), strict=True)
+        x = torch.from_numpy(rng.standard_normal((T, R, I)).astype(np.float32)).requires_grad_(True)
+        gy = torch.from_numpy(rng.standard_normal((T, R, H)).astype(np.float32))
+        tap = CellTap(net, neuron)
+        states = [neuron.MemoryState(torch.zeros(R, H), torch.zeros(R, H)) for _ in range(L)]
+        y, out_states, all_out = net(x, states)
+        (y * gy).sum().backward()
+        mems = tap.stacked()
+        tap.close()
+        out[f"{name}/x"] = x.detach().numpy()
+        out[f"{name}/gy"] = gy.numpy()
+        for k, v in sd.items():
+            out[f"{name}/sd/{k}"] = v
+        for l in range(L):
+            out[f"{name}/spikes/{l}"] = all_out[l + 1].detach().numpy()
+            out[f"{name}/membrane/{l}"] = mems[f"layers.{l}.cell"]
+            out[f"{name}/hT/{l}"] = out_states[l][0].detach().numpy()
+            out[f"{name}/cT/{l}"] = out_states[l][1].detach().numpy()
+        out[f"{name}/grad/x"] = x.grad.numpy()
+        for k, p in net.named_parameters():
+            out[f"{name}/grad/{k}"] = p.grad.numpy()
+        for k, b in net.named_buffers():
+            out[f"{name}/buf/{k}"] = b.detach().numpy()
+        meta.append((name, I, H, L, R, T, int(shared), int(bn)))
+    out["cases"] = np.array([m[0] for m in meta])
+    out["dims"] = np.array([m[1:] for m in meta], dtype=np.int64)
+
+
 def run_model(model, neuron, wave, frozen_front):
     """Run a reference model on a waveform; return dict of path inputs/outputs."""
     import torch
@@ -204,6 +253,41 @@ def main():
         gsn_cases(neuron, out)
         np.savez_compressed(os.path.join(HERE, "gsn_cells.npz"), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
         print("gsn_cells.npz", len(out))
+
+    if not only or "gsn_train" in only:
+        out = {}
+        gsn_train_cases(neuron, out)
+        np.savez_compressed(os.path.join(HERE, "gsn_train_cells.npz"), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
+        print("gsn_train_cells.npz", len(out))
+
+    def live_train_case(fname, kw, seed, B, T, wave_seed=0):
+        """A whole live model in TRAINING mode on a waveform: forward outputs, a scalar loss (mean square of the enhanced waveform
+        + mean of the enhanced magnitude: both outputs of forward() carry gradient), every parameter's gradient, BatchNorm buffers
+        after the step's forward (the recipe's training step: recipes/intel_ndns/spiking_fullsubnet/trainer.py:24-48)."""
+        sd = rw.live_state_dict(kw, seed)
+        model = live.SpikingFullSubNet(**kw).train()
+        model.load_state_dict(to_torch_sd(sd), strict=True)
+        wave = torch.from_numpy(rw.synth_wave(B, T, wave_seed))
+        outs = model(wave)
+        enh_y, enh_mag = outs[0], outs[1]
+        loss = enh_y.pow(2).mean() + enh_mag.mean()
+        loss.backward()
+        out = dict(wave=wave.numpy(), enh_y=enh_y.detach().numpy(), enh_mag=enh_mag.detach().numpy(), loss=np.asarray(float(loss)))
+        for i, a in enumerate(outs[2]):
+            out[f"fb_all/{i}"] = a.detach().numpy()
+        for g, lst in enumerate(outs[3]):
+            for i, a in enumerate(lst):
+                out[f"sb_all/{g}/{i}"] = a.detach().numpy()
+        for k, p in model.named_parameters():
+            out[f"grad/{k}"] = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        for k, b in model.named_buffers():
+            out[f"buf/{k}"] = b.detach().numpy()
+        out["weight_seed"] = np.asarray(seed)
+        np.savez_compressed(os.path.join(HERE, fname), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
+        print(fname, float(loss))
+
+    if not only or "live_tiny_train" in only:
+        live_train_case("live_tiny_train.npz", rw.LIVE_TINY, 11, 3, 12)
 
     def live_case(fname, kw, seed, B, T, store_mem, wave_seed=0, modulated=False):
         sd = rw.live_state_dict(kw, seed)

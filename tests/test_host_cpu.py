@@ -188,18 +188,29 @@ def test_stream_hop_plan_on_the_host():
     assert L.sfsn_hop_stages(ctypes.byref(bad), out, 32) == _lib.SFSN_EUNSUPPORTED                   # utterance statistics: not causal
 
 
-def test_training_mode_and_grad_inputs_raise_instead_of_falling_back():
-    """The narrowing INTEGRATION.md states: no backward pass and no torch fallback -- a forward that the reference would
-    record for autograd (efficient_spiking_neuron.py:94-101,149-150) is refused before anything is launched."""
+def test_training_mode_and_grad_inputs_take_the_differentiable_path_or_raise():
+    """Round 3: the live module routes a training-mode call and an input that requires grad to the differentiable path
+    (training.py: HIP training-step kernels + ATen) -- which, like everything here, has no CPU path; the frozen competition model
+    (its recipe's trainers do not import in the reference either) still refuses both; the inference-only entry points refuse a
+    module in training mode."""
     import spiking_fullsubnet_amd as pkg
-    for m in (pkg.SpikingFullSubNet(**rw.LIVE_TINY), pkg.Separator(**rw.FROZEN_TINY)):
-        y = torch.zeros(1, 2048)
-        with pytest.raises(RuntimeError, match="training-mode"):
-            m.train()(y)
-        with pytest.raises(RuntimeError, match="requires grad"):
-            m.eval()(y.clone().requires_grad_())
-        with pytest.raises(RuntimeError, match="no CPU path"):
-            m.eval()(y)
+    y = torch.zeros(1, 2048)
+    live = pkg.SpikingFullSubNet(**rw.LIVE_TINY)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        live.train()(y)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        live.eval()(y.clone().requires_grad_())
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        live.eval()(y)
+    with pytest.raises(RuntimeError, match="training mode"):
+        live.train().forward_stft(torch.zeros(1, 257, 4, dtype=torch.complex64))
+    frozen = pkg.Separator(**rw.FROZEN_TINY)
+    with pytest.raises(RuntimeError, match="training mode"):
+        frozen.train()(y)
+    with pytest.raises(RuntimeError, match="requires grad"):
+        frozen.eval()(y.clone().requires_grad_())
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        frozen.eval()(y)
 
 
 def test_reference_init_is_reproduced():
