@@ -133,14 +133,21 @@ int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs /* host array */, int n_se
  * Backward step: dh_up (gradient w.r.t. h_t from above, nullable), dh_rec (gradient w.r.t. h_t through step t+1's recurrent
  *   product, nullable), dc_next (gradient w.r.t. c_t from step t+1, nullable) -> d_gates [R][2H] (d pre_f | d pre_g), d_z [R][G*H]
  *   (shared: their sum = the gradient of the shared product; unshared: pass NULL and use d_gates), dc_prev [R][H], and
- *   d_bn_w / d_bn_b [H] ACCUMULATED (+=).  The caller forms dh_rec for step t-1 as d_z_t . W_hh (a library GEMM). */
+ *   d_bn_w / d_bn_b [H] ACCUMULATED (+=).  The recurrent part of dL/dh_t is either handed in (dh_rec) or formed by the step itself
+ *   from the previous launch's d_z (dz_next . W_hh: no GEMM launch between the steps).
+ * Rows per step beyond ~64 are spread over several workgroups per neuron tile, which exchange their partial sums through `scratch`
+ * (sfsn_train_scratch_bytes(H) bytes, ZEROED by the caller before the first step of a layer call) and wait for each other inside
+ * the launch; `epoch` = 1, 2, ... counts the steps issued on that scratch buffer (forward and backward use their own buffers). */
+size_t sfsn_train_scratch_bytes(int H);
 int sfsn_gsn_train_step_fwd(const float* z, const float* w_hh, const float* bias, const float* h_prev, const float* c_prev,
                             const float* bn_w, const float* bn_b, float* running_mean, float* running_var, float momentum, float eps,
                             int R, int H, int shared, float* spikes, float* u, float* xhat, float* f, float* g, float* invstd,
-                            void* stream);
-int sfsn_gsn_train_step_bwd(const float* dh_up, const float* dh_rec, const float* dc_next, const float* u, const float* xhat,
+                            void* scratch, unsigned epoch, void* stream);
+int sfsn_gsn_train_step_bwd(const float* dz_next /* [R][G*H] d_z of step t+1, nullable */, const float* w_hh /* [G*H][H] */,
+                            const float* dh_up, const float* dh_rec, const float* dc_next, const float* u, const float* xhat,
                             const float* f, const float* g, const float* c_prev, const float* invstd, const float* bn_w, int R, int H,
-                            int shared, float* d_gates, float* d_z, float* dc_prev, float* d_bn_w, float* d_bn_b, void* stream);
+                            int shared, float* d_gates, float* d_z, float* dc_prev, float* d_bn_w, float* d_bn_b, void* scratch,
+                            unsigned epoch, void* stream);
 
 /* Fused-input variant for layers >= 1 (their input is the previous layer's spikes): the input term is computed inside
  * the scan from the int8 spikes and the packed input weights, so that sfsn_spike_proj's [T][R][H] fp32 result never makes

@@ -136,9 +136,11 @@ def lib() -> ctypes.CDLL:
     L.sfsn_gsn_layer_scan.restype = _I
     L.sfsn_gsn_layer_scan.argtypes = [ctypes.POINTER(ScanSegment), _I, _I, _I, _I, _I, _P]
     L.sfsn_gsn_train_step_fwd.restype = _I
-    L.sfsn_gsn_train_step_fwd.argtypes = [_P] * 9 + [_F, _F, _I, _I, _I] + [_P] * 7
+    L.sfsn_gsn_train_step_fwd.argtypes = [_P] * 9 + [_F, _F, _I, _I, _I] + [_P] * 7 + [ctypes.c_uint, _P]
+    L.sfsn_train_scratch_bytes.restype = ctypes.c_size_t
+    L.sfsn_train_scratch_bytes.argtypes = [_I]
     L.sfsn_gsn_train_step_bwd.restype = _I
-    L.sfsn_gsn_train_step_bwd.argtypes = [_P] * 10 + [_I, _I, _I] + [_P] * 6
+    L.sfsn_gsn_train_step_bwd.argtypes = [_P] * 12 + [_I, _I, _I] + [_P] * 6 + [ctypes.c_uint, _P]
     L.sfsn_gsn_layer_scan_fused.restype = _I
     L.sfsn_gsn_layer_scan_fused.argtypes = [ctypes.POINTER(ScanSegment), ctypes.POINTER(FusedInput), _I, _I, _I, _P]
     L.sfsn_gsn_layer_scan_fused_x.restype = _I
@@ -183,7 +185,7 @@ def lib() -> ctypes.CDLL:
 EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device_count", "sfsn_w3_packed_bytes", "sfsn_w3_padded_rows",
            "sfsn_w3_pack", "sfsn_w3_pack_bits", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_stack_scratch_bytes", "sfsn_gsn_stack_scan",
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
-           "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft", "sfsn_gsn_train_step_fwd", "sfsn_gsn_train_step_bwd")
+           "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft", "sfsn_gsn_train_step_fwd", "sfsn_gsn_train_step_bwd", "sfsn_train_scratch_bytes")
 
 
 def check(rc: int, what: str = "") -> None:

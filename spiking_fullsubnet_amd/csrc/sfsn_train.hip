@@ -42,6 +42,48 @@ __device__ __forceinline__ float reduce16(float v, float (*red)[TR_TILE], int rs
     return s;
 }
 
+
+// ---- several workgroups per neuron tile (round 3b): a launch is a grid of (H / 16 neuron tiles) x (RB row blocks); the row
+// blocks of a tile exchange 2 x 16 partial sums per step through `scratch` and a per-tile arrival counter (monotonic over the
+// steps of a layer: block b of step `epoch` waits for RB * epoch arrivals).  Payload: relaxed agent-scope stores, a block
+// barrier, then thread 0's release fence + arrival; readers: one polling lane (s_sleep between polls, bounded), a block
+// barrier, agent-scope loads.  Every block merges the partials in the same fixed order, so all blocks of a tile (and every
+// run) get the same bits.  All blocks of a launch are resident (a few hundred 256-thread blocks with little LDS).
+#define TR_PART 36  // floats per (tile, row block): [0] rows, [2..17] first partial per neuron, [18..33] second
+__device__ __forceinline__ bool tr_exchange(float* scratch, unsigned* counters, unsigned* err, int tile, int rb, int RB, unsigned epoch,
+                                            float p0, float p1, float nrows, int rsub, int j, float* out /* [RB][TR_PART] in LDS */) {
+    float* mine = scratch + ((size_t)tile * RB + rb) * TR_PART;
+    if (rsub == 0) {
+        __hip_atomic_store(mine + 2 + j, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 18 + j, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (j == 0) __hip_atomic_store(mine, nrows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = (unsigned)RB * epoch;
+        int good = 1;
+        for (unsigned spins = 0;; ++spins) {
+            if (__hip_atomic_load(counters + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+            if (spins > 4000000u) {  // ~1 s: a launch whose blocks are not all resident must not hang the device
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        ok = good;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RB * TR_PART; i += TR_THREADS)
+        out[i] = __hip_atomic_load(scratch + (size_t)tile * RB * TR_PART + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return ok != 0;
+}
+
 struct TrainFwdParams {
     const float* z;       // [R][G*H]
     const float* w_hh;    // [G*H][H]
@@ -60,16 +102,23 @@ struct TrainFwdParams {
     float* invstd;        // [H] (bn only)
     float momentum, eps;
     int R, H, shared, use_bn;
+    int RB, rpb;          // row blocks per neuron tile, rows per block
+    unsigned epoch;       // 1-based step count of this layer call (the arrival counters are monotonic)
+    float* scratch;       // [H/16][RB][TR_PART] partials
+    unsigned* counters;   // [H/16] arrivals, then [1] error word
 };
 
 __global__ __launch_bounds__(TR_THREADS) void gsn_train_step_fwd_kernel(const TrainFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char tr_smem[];
-    const int H = p.H, R = p.R, G = p.shared ? 1 : 2;
+    const int H = p.H, G = p.shared ? 1 : 2;
+    const int tile = blockIdx.x, rb = blockIdx.y;
+    const int r_lo = rb * p.rpb, r_hi = (r_lo + p.rpb < p.R) ? r_lo + p.rpb : p.R, nr = r_hi - r_lo;
     float* wt = reinterpret_cast<float*>(tr_smem);                       // [G][16][H + 1]
-    float* cbuf = wt + (size_t)G * TR_TILE * (H + 1);                     // [R][16] pre-normalisation membranes
+    float* cbuf = wt + (size_t)G * TR_TILE * (H + 1);                     // [rpb][16] pre-normalisation membranes of my rows
+    float* parts = cbuf + (size_t)p.rpb * TR_TILE;                        // [RB][TR_PART]
     __shared__ float red[TR_THREADS / TR_TILE][TR_TILE];
     const int tid = threadIdx.x, j = tid & 15, rsub = tid >> 4;
-    const int n0 = blockIdx.x * TR_TILE, nj = n0 + j;
+    const int n0 = tile * TR_TILE, nj = n0 + j;
     for (int i = tid; i < G * TR_TILE * H; i += TR_THREADS) {
         const int gi = i / (TR_TILE * H), rem = i - gi * TR_TILE * H, jj = rem / H, k = rem - jj * H;
         wt[(gi * TR_TILE + jj) * (H + 1) + k] = p.w_hh[((size_t)gi * H + n0 + jj) * H + k];
@@ -79,7 +128,7 @@ __global__ __launch_bounds__(TR_THREADS) void gsn_train_step_fwd_kernel(const Tr
     const float* wf = wt + (size_t)j * (H + 1);
     const float* wg = wt + (size_t)((G - 1) * TR_TILE + j) * (H + 1);
     float sum = 0.f;
-    for (int r = rsub; r < R; r += TR_THREADS / TR_TILE) {
+    for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
         const float* hp = p.h_prev + (size_t)r * H;
         float rf = 0.f, rg = 0.f;
         for (int k = 0; k < H; ++k) {
@@ -95,40 +144,59 @@ __global__ __launch_bounds__(TR_THREADS) void gsn_train_step_fwd_kernel(const Tr
         const float a = f * p.c_prev[(size_t)r * H + nj];
         const float b = (1.0f - f) * pre_g;
         const float cy = a + b;
-        cbuf[r * TR_TILE + j] = cy;
+        cbuf[(r - r_lo) * TR_TILE + j] = cy;
         p.f[(size_t)r * H + nj] = f;
         p.g[(size_t)r * H + nj] = pre_g;
         sum += cy;
     }
     if (!p.use_bn) {
         __syncthreads();
-        for (int r = rsub; r < R; r += TR_THREADS / TR_TILE) {
-            const float cy = cbuf[r * TR_TILE + j];
+        for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
+            const float cy = cbuf[(r - r_lo) * TR_TILE + j];
             p.u[(size_t)r * H + nj] = cy;
             p.spikes[(size_t)r * H + nj] = cy >= 0.f ? 1.f : 0.f;
         }
         return;
     }
-    const float mean = reduce16(sum, red, rsub, j) / (float)R;
+    // statistics of this step over ALL rows of the layer: per row block (count, mean, sum of squared deviations), merged pairwise in
+    // block order (the parallel-variance formula: exact in real arithmetic, a few ulp from a two-pass evaluation in fp32)
+    const float tot_b = reduce16(sum, red, rsub, j);
+    const float mean_b = nr > 0 ? tot_b / (float)nr : 0.f;
     float sq = 0.f;
-    for (int r = rsub; r < R; r += TR_THREADS / TR_TILE) {
-        const float d = cbuf[r * TR_TILE + j] - mean;
+    for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
+        const float d = cbuf[(r - r_lo) * TR_TILE + j] - mean_b;
         sq = __builtin_fmaf(d, d, sq);
     }
-    const float var = reduce16(sq, red, rsub, j) / (float)R;
+    const float m2_b = reduce16(sq, red, rsub, j);
+    float mean = mean_b, m2 = m2_b;
+    if (p.RB > 1) {
+        if (!tr_exchange(p.scratch, p.counters, p.counters + gridDim.x, tile, rb, p.RB, p.epoch, mean_b, m2_b, (float)nr, rsub, j, parts)) return;
+        float cnt = 0.f;
+        mean = 0.f; m2 = 0.f;
+        for (int b = 0; b < p.RB; ++b) {
+            const float nb = parts[b * TR_PART], mb = parts[b * TR_PART + 2 + j], qb = parts[b * TR_PART + 18 + j];
+            if (nb > 0.f) {
+                const float tot = cnt + nb, delta = mb - mean;
+                mean = mean + delta * (nb / tot);
+                m2 = m2 + qb + delta * delta * (cnt * nb / tot);
+                cnt = tot;
+            }
+        }
+    }
+    const float var = m2 / (float)p.R;
     const float invstd = 1.0f / sqrtf(var + p.eps);
     const float gam = p.bn_w[nj], bet = p.bn_b[nj];
-    for (int r = rsub; r < R; r += TR_THREADS / TR_TILE) {
-        const float xh = (cbuf[r * TR_TILE + j] - mean) * invstd;
+    for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
+        const float xh = (cbuf[(r - r_lo) * TR_TILE + j] - mean) * invstd;
         const float uu = xh * gam + bet;
         p.xhat[(size_t)r * H + nj] = xh;
         p.u[(size_t)r * H + nj] = uu;
         p.spikes[(size_t)r * H + nj] = uu >= 0.f ? 1.f : 0.f;
     }
-    if (rsub == 0) {
+    if (rsub == 0 && rb == 0) {
         p.invstd[nj] = invstd;
         if (p.running_mean) {
-            const float unb = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+            const float unb = p.R > 1 ? var * ((float)p.R / (float)(p.R - 1)) : var;
             p.running_mean[nj] = (1.0f - p.momentum) * p.running_mean[nj] + p.momentum * mean;
             p.running_var[nj] = (1.0f - p.momentum) * p.running_var[nj] + p.momentum * unb;
         }
@@ -136,8 +204,10 @@ __global__ __launch_bounds__(TR_THREADS) void gsn_train_step_fwd_kernel(const Tr
 }
 
 struct TrainBwdParams {
+    const float* dz_next;  // [R][G*H] or null: d_z of step t+1 -- the recurrent part of dL/dh_t is formed HERE (dz_next . W_hh)
+    const float* w_hh;     // [G*H][H]
     const float* dh_up;    // [R][H] or null
-    const float* dh_rec;   // [R][H] or null
+    const float* dh_rec;   // [R][H] or null (a caller-made recurrent part instead of dz_next)
     const float* dc_next;  // [R][H] or null
     const float* u;
     const float* xhat;
@@ -152,26 +222,47 @@ struct TrainBwdParams {
     float* d_bn_w;         // [H] +=
     float* d_bn_b;         // [H] +=
     int R, H, shared, use_bn;
+    int RB, rpb;
+    unsigned epoch;
+    float* scratch;
+    unsigned* counters;
 };
 
 __global__ __launch_bounds__(TR_THREADS) void gsn_train_step_bwd_kernel(const TrainBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char tr_smem[];
-    float* dbuf = reinterpret_cast<float*>(tr_smem);  // [R][16] du
     __shared__ float red[TR_THREADS / TR_TILE][TR_TILE];
-    const int H = p.H, R = p.R;
+    const int H = p.H, GH = (p.shared ? 1 : 2) * p.H;
+    const int tile = blockIdx.x, rb = blockIdx.y;
+    const int r_lo = rb * p.rpb, r_hi = (r_lo + p.rpb < p.R) ? r_lo + p.rpb : p.R;
     const int tid = threadIdx.x, j = tid & 15, rsub = tid >> 4;
-    const int nj = blockIdx.x * TR_TILE + j;
+    const int nj = tile * TR_TILE + j;
+    float* dbuf = reinterpret_cast<float*>(tr_smem);   // [rpb][16] du of my rows
+    float* parts = dbuf + (size_t)p.rpb * TR_TILE;      // [RB][TR_PART]
+    float* wcol = parts + (size_t)p.RB * TR_PART;       // [G*H][16]: the columns of W_hh that feed my 16 neurons of h_t
+    if (p.dz_next) {
+        for (int i = tid; i < GH * TR_TILE; i += TR_THREADS) {
+            const int nn = i / TR_TILE, jj = i - nn * TR_TILE;
+            wcol[i] = p.w_hh[(size_t)nn * H + tile * TR_TILE + jj];
+        }
+        __syncthreads();
+    }
     float s1 = 0.f, s2 = 0.f;
-    for (int r = rsub; r < R; r += TR_THREADS / TR_TILE) {
+    for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
         const size_t o = (size_t)r * H + nj;
         float dh = 0.f;
         if (p.dh_up) dh += p.dh_up[o];
         if (p.dh_rec) dh += p.dh_rec[o];
+        if (p.dz_next) {  // dL/dh_t through step t+1's recurrent product: sum_n dz_{t+1}[r][n] W_hh[n][my neuron]
+            const float* dz = p.dz_next + (size_t)r * GH;
+            float acc = 0.f;
+            for (int nn = 0; nn < GH; ++nn) acc = __builtin_fmaf(dz[nn], wcol[nn * TR_TILE + j], acc);
+            dh += acc;
+        }
         const float uu = p.u[o];
         const float tri = fmaxf(0.f, 1.0f - fabsf(uu));
         float du = dh * tri;
         if (p.dc_next) du += p.dc_next[o];
-        dbuf[r * TR_TILE + j] = du;
+        dbuf[(r - r_lo) * TR_TILE + j] = du;
         if (p.use_bn) {
             s1 += du;
             s2 = __builtin_fmaf(du, p.xhat[o], s2);
@@ -181,18 +272,26 @@ __global__ __launch_bounds__(TR_THREADS) void gsn_train_step_bwd_kernel(const Tr
     if (p.use_bn) {
         k1 = reduce16(s1, red, rsub, j);
         k2 = reduce16(s2, red, rsub, j);
-        scale = p.bn_w[nj] * p.invstd[nj] / (float)R;
-        if (rsub == 0) {
+        if (p.RB > 1) {
+            if (!tr_exchange(p.scratch, p.counters, p.counters + gridDim.x, tile, rb, p.RB, p.epoch, k1, k2, (float)(r_hi - r_lo), rsub, j, parts)) return;
+            k1 = 0.f; k2 = 0.f;
+            for (int b = 0; b < p.RB; ++b) {
+                k1 += parts[b * TR_PART + 2 + j];
+                k2 += parts[b * TR_PART + 18 + j];
+            }
+        }
+        scale = p.bn_w[nj] * p.invstd[nj] / (float)p.R;
+        if (rsub == 0 && rb == 0) {
             p.d_bn_w[nj] += k2;
             p.d_bn_b[nj] += k1;
         }
     } else {
         __syncthreads();
     }
-    for (int r = rsub; r < R; r += TR_THREADS / TR_TILE) {
+    for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
         const size_t o = (size_t)r * H + nj;
-        const float du = dbuf[r * TR_TILE + j];
-        const float dcy = p.use_bn ? scale * ((float)R * du - k1 - p.xhat[o] * k2) : du;
+        const float du = dbuf[(r - r_lo) * TR_TILE + j];
+        const float dcy = p.use_bn ? scale * ((float)p.R * du - k1 - p.xhat[o] * k2) : du;
         const float f = p.f[o], g = p.g[o], cp = p.c_prev[o];
         const float df = dcy * (cp - g);
         const float dpf = df * f * (1.0f - f);
@@ -204,47 +303,79 @@ __global__ __launch_bounds__(TR_THREADS) void gsn_train_step_bwd_kernel(const Tr
     }
 }
 
+// rows per workgroup: enough row blocks to put ~all compute units to work, at least 16 rows each; every block of a launch must be
+// resident (they wait for each other): the grid stays below ~220 blocks of 256 threads with < 40 KB of LDS
+static void train_geometry(int R, int H, int* RB, int* rpb) {
+    const int tiles = H / TR_TILE;
+    int rb = 220 / tiles;
+    if (rb < 1) rb = 1;
+    int per = (R + rb - 1) / rb;
+    if (per < 16) per = 16;
+    per = (per + 15) & ~15;
+    *rpb = per;
+    *RB = (R + per - 1) / per;
+}
+
+extern "C" size_t sfsn_train_scratch_bytes(int H) {
+    if (H <= 0 || H % TR_TILE) return 0;
+    const int tiles = H / TR_TILE;
+    return ((size_t)tiles * 16 * TR_PART) * sizeof(float) + ((size_t)tiles + 4) * sizeof(unsigned);  // partials (RB <= 16) + counters + error word
+}
+
 extern "C" int sfsn_gsn_train_step_fwd(const float* z, const float* w_hh, const float* bias, const float* h_prev, const float* c_prev,
                                        const float* bn_w, const float* bn_b, float* running_mean, float* running_var, float momentum,
                                        float eps, int R, int H, int shared, float* spikes, float* u, float* xhat, float* f, float* g,
-                                       float* invstd, void* stream) {
+                                       float* invstd, void* scratch, unsigned epoch, void* stream) {
     if (!z || !w_hh || !bias || !h_prev || !c_prev || !spikes || !u || !f || !g || R <= 0 || H <= 0) return SFSN_EINVAL;
     if (H % TR_TILE != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     const int use_bn = bn_w != nullptr;
     if (use_bn && (!bn_b || !xhat || !invstd)) return SFSN_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return SFSN_EINVAL;
-    const int G = shared ? 1 : 2;
-    const size_t lds = ((size_t)G * TR_TILE * (H + 1) + (size_t)R * TR_TILE) * sizeof(float);
-    if (lds > 150 * 1024) return SFSN_EUNSUPPORTED;  // rows of a layer per step: ~2000 at H = 320 (one workgroup holds them all)
+    const int G = shared ? 1 : 2, tiles = H / TR_TILE;
     TrainFwdParams p;
+    train_geometry(R, H, &p.RB, &p.rpb);
+    if (p.RB > 16) return SFSN_EUNSUPPORTED;  // (more than 16 x 220 / tiles x ... rows per layer and step)
+    if (p.RB > 1 && use_bn && (!scratch || epoch == 0)) return SFSN_EINVAL;
+    const size_t lds = ((size_t)G * TR_TILE * (H + 1) + (size_t)p.rpb * TR_TILE + (size_t)p.RB * TR_PART) * sizeof(float);
+    if (lds > 150 * 1024) return SFSN_EUNSUPPORTED;
     p.z = z; p.w_hh = w_hh; p.bias = bias; p.h_prev = h_prev; p.c_prev = c_prev; p.bn_w = bn_w; p.bn_b = bn_b;
     p.running_mean = running_mean; p.running_var = running_var; p.spikes = spikes; p.u = u; p.xhat = xhat; p.f = f; p.g = g;
     p.invstd = invstd; p.momentum = momentum; p.eps = eps; p.R = R; p.H = H; p.shared = shared; p.use_bn = use_bn;
+    p.epoch = epoch; p.scratch = static_cast<float*>(scratch);
+    p.counters = scratch ? reinterpret_cast<unsigned*>(static_cast<float*>(scratch) + (size_t)tiles * 16 * TR_PART) : nullptr;
     auto kern = gsn_train_step_fwd_kernel;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return SFSN_EHIP;
-    hipLaunchKernelGGL(kern, dim3(H / TR_TILE), dim3(TR_THREADS), lds, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.RB), dim3(TR_THREADS), lds, static_cast<hipStream_t>(stream), p);
     return hip_ok_tr(hipGetLastError());
 }
 
-extern "C" int sfsn_gsn_train_step_bwd(const float* dh_up, const float* dh_rec, const float* dc_next, const float* u, const float* xhat,
-                                       const float* f, const float* g, const float* c_prev, const float* invstd, const float* bn_w, int R,
-                                       int H, int shared, float* d_gates, float* d_z, float* dc_prev, float* d_bn_w, float* d_bn_b,
-                                       void* stream) {
+extern "C" int sfsn_gsn_train_step_bwd(const float* dz_next, const float* w_hh, const float* dh_up, const float* dh_rec, const float* dc_next,
+                                       const float* u, const float* xhat, const float* f, const float* g, const float* c_prev,
+                                       const float* invstd, const float* bn_w, int R, int H, int shared, float* d_gates, float* d_z,
+                                       float* dc_prev, float* d_bn_w, float* d_bn_b, void* scratch, unsigned epoch, void* stream) {
     if (!u || !f || !g || !c_prev || !d_gates || !dc_prev || R <= 0 || H <= 0) return SFSN_EINVAL;
     if (H % TR_TILE != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     const int use_bn = bn_w != nullptr;
     if (use_bn && (!xhat || !invstd || !d_bn_w || !d_bn_b)) return SFSN_EINVAL;
     if (shared && !d_z) return SFSN_EINVAL;
-    const size_t lds = (size_t)R * TR_TILE * sizeof(float);
-    if (lds > 150 * 1024) return SFSN_EUNSUPPORTED;
+    if (dz_next && !w_hh) return SFSN_EINVAL;
+    const int tiles = H / TR_TILE;
     TrainBwdParams p;
+    train_geometry(R, H, &p.RB, &p.rpb);
+    if (p.RB > 16) return SFSN_EUNSUPPORTED;
+    if (p.RB > 1 && use_bn && (!scratch || epoch == 0)) return SFSN_EINVAL;
+    const size_t lds = ((size_t)p.rpb * TR_TILE + (size_t)p.RB * TR_PART + (dz_next ? (size_t)(shared ? 1 : 2) * H * TR_TILE : 0)) * sizeof(float);
+    if (lds > 150 * 1024) return SFSN_EUNSUPPORTED;
+    p.dz_next = dz_next; p.w_hh = w_hh;
     p.dh_up = dh_up; p.dh_rec = dh_rec; p.dc_next = dc_next; p.u = u; p.xhat = xhat; p.f = f; p.g = g; p.c_prev = c_prev;
     p.invstd = invstd; p.bn_w = bn_w; p.d_gates = d_gates; p.d_z = d_z; p.dc_prev = dc_prev; p.d_bn_w = d_bn_w; p.d_bn_b = d_bn_b;
     p.R = R; p.H = H; p.shared = shared; p.use_bn = use_bn;
+    p.epoch = epoch; p.scratch = static_cast<float*>(scratch);
+    p.counters = scratch ? reinterpret_cast<unsigned*>(static_cast<float*>(scratch) + (size_t)tiles * 16 * TR_PART) : nullptr;
     auto kern = gsn_train_step_bwd_kernel;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return SFSN_EHIP;
-    hipLaunchKernelGGL(kern, dim3(H / TR_TILE), dim3(TR_THREADS), lds, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.RB), dim3(TR_THREADS), lds, static_cast<hipStream_t>(stream), p);
     return hip_ok_tr(hipGetLastError());
 }

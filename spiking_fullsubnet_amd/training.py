@@ -68,17 +68,29 @@ class GSNLayerTrainFn(torch.autograd.Function):
         bb = bn_b.detach().contiguous().float() if (use_bn and not fold) else None
         rmean = stats[0] if (use_bn and batch_stats and stats is not None) else None
         rvar = stats[1] if (use_bn and batch_stats and stats is not None) else None
+        # raw pointers per step (no tensor views: the interpreter's share of a step is what bounds small batches)
+        P = ctypes.c_void_p
+        sRH, sRG = R * H * 4, R * GH * 4
+        pz, psp, pu, pf, pg = z.data_ptr(), spikes.data_ptr(), u.data_ptr(), fg.data_ptr(), gg.data_ptr()
+        pxh = xhat.data_ptr() if xhat is not None else 0
+        pis = invstd.data_ptr() if invstd is not None else 0
+        pzero, pw, pb = zero.data_ptr(), w_hh_c.data_ptr(), bias_c.data_ptr()
+        a_bw, a_bb, a_rm, a_rv = _p(bw), _p(bb), _p(rmean), _p(rvar)
+        mom, ep, sh = float(momentum), float(eps), int(shared)
+        fwd = L.sfsn_gsn_train_step_fwd
+        scr = torch.zeros((L.sfsn_train_scratch_bytes(H) // 4,), dtype=torch.int32, device=dev)  # partial sums / arrival counters of the row blocks
+        p_scr = P(scr.data_ptr())
         with torch.cuda.device(dev):
             for t in range(T):
-                hp = zero if t == 0 else spikes[t - 1]
-                cp = zero if t == 0 else u[t - 1]
-                check(L.sfsn_gsn_train_step_fwd(_p(z[t]), _p(w_hh_c), _p(bias_c), _p(hp), _p(cp), _p(bw), _p(bb), _p(rmean), _p(rvar),
-                                                float(momentum), float(eps), R, H, int(shared), _p(spikes[t]), _p(u[t]),
-                                                _p(xhat[t]) if xhat is not None else None, _p(fg[t]), _p(gg[t]),
-                                                _p(invstd[t]) if invstd is not None else None, st), "sfsn_gsn_train_step_fwd")
+                rc = fwd(P(pz + t * sRG), P(pw), P(pb), P(pzero if t == 0 else psp + (t - 1) * sRH), P(pzero if t == 0 else pu + (t - 1) * sRH),
+                         a_bw, a_bb, a_rm, a_rv, mom, ep, R, H, sh, P(psp + t * sRH), P(pu + t * sRH), P(pxh + t * sRH) if pxh else None,
+                         P(pf + t * sRH), P(pg + t * sRH), P(pis + t * H * 4) if pis else None, p_scr, t + 1, st)
+                if rc:
+                    check(rc, "sfsn_gsn_train_step_fwd")
                 if fold:  # (the folded affine map and the threshold, on the pre-normalisation membrane the step left in u)
                     u[t].mul_(alpha).add_(beta)
                     spikes[t].copy_((u[t] >= 0).float())
+        ctx.scr = scr  # (its error word is read in backward: no synchronisation here)
         if use_bn and batch_stats and stats is not None and stats[2] is not None:
             stats[2].add_(T)  # num_batches_tracked: one BatchNorm call per time step
         ctx.save_for_backward(x, w_ih_c, w_hh_c, spikes, u, fg, gg, xhat if xhat is not None else zero, invstd if invstd is not None else zero,
@@ -101,32 +113,47 @@ class GSNLayerTrainFn(torch.autograd.Function):
         zero = torch.zeros((R, H), **f32)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         bn_kernel = use_bn and not fold
+        P = ctypes.c_void_p
+        sRH, s2H, sRG = R * H * 4, R * 2 * H * 4, R * GH * 4
+        pdy, pu, pf, pg = dy.data_ptr(), u.data_ptr(), fg.data_ptr(), gg.data_ptr()
+        pxh, pis = (xhat.data_ptr(), invstd.data_ptr()) if bn_kernel else (0, 0)
+        pdg = d_gates.data_ptr()
+        pdz = d_z.data_ptr() if shared else pdg      # the gradient of the (shared or per-gate) products: [T][R][G*H]
+        pzero, pw = zero.data_ptr(), w_hh.data_ptr()
+        a_bw = _p(bw) if bn_kernel else None
+        a_dw, a_db = (_p(d_bn_w), _p(d_bn_b)) if bn_kernel else (None, None)
+        pdc = [dc_buf[0].data_ptr(), dc_buf[1].data_ptr()]
+        sh = int(shared)
+        bwd = L.sfsn_gsn_train_step_bwd
+        scr = torch.zeros((L.sfsn_train_scratch_bytes(H) // 4,), dtype=torch.int32, device=dev)
+        p_scr = P(scr.data_ptr())
         dh_rec = dc = None
         with torch.cuda.device(dev):
             for t in range(T - 1, -1, -1):
-                cp = zero if t == 0 else u[t - 1]
-                dh_up = dy[t]
+                last = t == T - 1
+                p_cp = P(pzero if t == 0 else pu + (t - 1) * sRH)
+                p_dzn = None if last else P(pdz + (t + 1) * sRG)   # dL/dh_t through step t+1: formed inside the step from its d_z
                 if fold:
                     # eval-mode BatchNorm folded into an affine map: du -> dc' is a per-neuron scale, applied by pre-scaling the
-                    # incoming gradients of u (the step kernel then runs without normalisation)
+                    # incoming gradient of u (the step kernel then runs without normalisation, its dc_next carrying everything)
                     tri = torch.clamp(1.0 - u[t].abs(), min=0.0)
-                    du = dh_up * tri if dh_rec is None else (dh_up + dh_rec) * tri
+                    dh = dy[t] if last else dy[t] + torch.mm((d_z if shared else d_gates)[t + 1], w_hh)
+                    du = dh * tri
                     if dc is not None:
                         du = du + dc
                     dcy = (du * alpha).contiguous()
-                    # reuse the step kernel with dc_next = dcy and no dh (tri(u) does not matter then): u is only read for tri
-                    check(L.sfsn_gsn_train_step_bwd(None, None, _p(dcy), _p(u[t]), None, _p(fg[t]), _p(gg[t]), _p(cp), None, None, R, H,
-                                                    int(shared), _p(d_gates[t]), _p(d_z[t]) if shared else None, _p(dc_buf[t & 1]), None, None, st),
-                          "sfsn_gsn_train_step_bwd")
+                    rc = bwd(None, None, None, None, _p(dcy), P(pu + t * sRH), None, P(pf + t * sRH), P(pg + t * sRH), p_cp, None, None, R, H, sh,
+                             P(pdg + t * s2H), P(pdz + t * sRG) if shared else None, P(pdc[t & 1]), None, None, p_scr, T - t, st)
+                    dc = dc_buf[t & 1]
                 else:
-                    check(L.sfsn_gsn_train_step_bwd(_p(dh_up), _p(dh_rec), _p(dc), _p(u[t]), _p(xhat[t]) if bn_kernel else None, _p(fg[t]),
-                                                    _p(gg[t]), _p(cp), _p(invstd[t]) if bn_kernel else None, _p(bw) if bn_kernel else None, R, H,
-                                                    int(shared), _p(d_gates[t]), _p(d_z[t]) if shared else None, _p(dc_buf[t & 1]),
-                                                    _p(d_bn_w) if bn_kernel else None, _p(d_bn_b) if bn_kernel else None, st),
-                          "sfsn_gsn_train_step_bwd")
-                dz_t = d_z[t] if shared else d_gates[t]
-                dh_rec = torch.mm(dz_t, w_hh)  # gradient w.r.t. h_{t-1} through this step's recurrent product
-                dc = dc_buf[t & 1]
+                    rc = bwd(p_dzn, P(pw), P(pdy + t * sRH), None, None if last else P(pdc[(t + 1) & 1]), P(pu + t * sRH),
+                             P(pxh + t * sRH) if bn_kernel else None, P(pf + t * sRH), P(pg + t * sRH), p_cp,
+                             P(pis + t * H * 4) if bn_kernel else None, a_bw, R, H, sh, P(pdg + t * s2H),
+                             P(pdz + t * sRG) if shared else None, P(pdc[t & 1]), a_dw, a_db, p_scr, T - t, st)
+                if rc:
+                    check(rc, "sfsn_gsn_train_step_bwd")
+        if int(scr[-4:].max().item()) != 0 or int(ctx.scr[-4:].max().item()) != 0:
+            raise RuntimeError("sfsn_gsn_train_step: the row blocks of a step did not all arrive (a launch's workgroups were not co-resident)")
         dz = (d_z if shared else d_gates).reshape(T * R, GH)
         dx = torch.mm(dz, w_ih).view(T, R, I)
         dw_ih = torch.mm(dz.t(), x.reshape(T * R, I))
