@@ -110,6 +110,12 @@ struct HopParams {
     unsigned long long* dbg;  // -DSFSN_HOP_STAMPS builds + SFSN_HOP_DEBUG: 8 time stamps (100 MHz) per wave
 };
 
+// what changes from hop to hop (a launch takes them from its kernel arguments; the resident kernel counts them up itself)
+struct HopStep {
+    unsigned launch;
+    int frame_index, frames_before;
+};
+
 #ifdef SFSN_HOP_STAMPS
 // (every lane stores the same value to the same word: no branch, so the compiler's wait-count bookkeeping is not disturbed;
 // a stamps build always has a valid dbg pointer)
@@ -210,7 +216,7 @@ __device__ __forceinline__ float2 hop_in_bin(const HopParams& p, int b, int f, i
 // ---------------------------------------------------------------------------------------------------------------------
 // ONE: hop == 1 (the configuration that matters): no frame loop, so nothing stays live across it.
 template <bool L0, bool ONE>
-__device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStageDev& sd, const HopSeqDev& sq, char* smem) {
+__device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStep& hs, const HopStageDev& sd, const HopSeqDev& sq, char* smem) {
     const int l = sd.layer;
     const HopLayerDev& L = sq.layer[l];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -224,7 +230,7 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
     const int row = 16 * rt + n, rowc = row < R ? row : R - 1;
     const int cc = 16 * tile + 4 * q;
     const int hop = ONE ? 1 : p.hop;
-    const unsigned tagw = hop_tag(p.launch) * 0x02020202u;
+    const unsigned tagw = hop_tag(hs.launch) * 0x02020202u;
     char* hbA = smem + 64;
     char* hbB = hbA + HOP_KS_MAX * 1024;
     float* fbl = reinterpret_cast<float*>(hbB + HOP_KS_MAX * 1024);
@@ -255,8 +261,8 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
     }
     // ---- everything this wave will need is requested now (the stages upstream are still at work); the recurrent half's
     // operands first
-    const int8_t* hprev = L.h[p.launch & 1u];
-    int8_t* hnext = L.h[(p.launch + 1u) & 1u];
+    const int8_t* hprev = L.h[hs.launch & 1u];
+    int8_t* hnext = L.h[(hs.launch + 1u) & 1u];
     v4i h0[HOP_KS_MAX];  // h of the last frame of the previous launch (plain bytes 0/1)
     v4i Whh[3][HOP_KS_MAX], Wih[3][HOP_KS_MAX];
 #pragma unroll
@@ -325,7 +331,7 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
 #pragma unroll
     for (int ri = 0; ri < HOP_ROWS_PER_WAVE; ++ri) {
         const int frow = 16 * rt + wave + HOP_WAVES * ri;
-        cumr[ri] = (L0 && sq.norm == SFSN_NORM_CUMLAPLACE && frow < R) ? sq.cum[p.launch & 1u][frow] : 0.0f;
+        cumr[ri] = (L0 && sq.norm == SFSN_NORM_CUMLAPLACE && frow < R) ? sq.cum[hs.launch & 1u][frow] : 0.0f;
     }
 
     for (int t = 0; t < hop; ++t) {
@@ -441,7 +447,7 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
                     // cumlap_rowsum_kernel / cumlap_scan_kernel's arithmetic: fp32 row sum (same lanes, same reduction), fp32
                     // running sum, mean over everything the row has seen, x / (mean + eps)
                     cumr[ri] += wave_sum(sum);
-                    const float den = cumr[ri] / (float)((double)I * (p.frames_before + t + 1)) + 2.220446049250313e-16f;
+                    const float den = cumr[ri] / (float)((double)I * (hs.frames_before + t + 1)) + 2.220446049250313e-16f;
 #pragma unroll
                     for (int u = 0; u < HOP_NU_MAX; ++u) y[u] = v[ri][u] / den;
                 } else {
@@ -509,7 +515,7 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
 #pragma unroll
         for (int ri = 0; ri < HOP_ROWS_PER_WAVE; ++ri) {
             const int frow = 16 * rt + wave + HOP_WAVES * ri;
-            if (frow < R) sq.cum[(p.launch + 1u) & 1u][frow] = cumr[ri];
+            if (frow < R) sq.cum[(hs.launch + 1u) & 1u][frow] = cumr[ri];
         }
     }
 }
@@ -520,14 +526,14 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStag
 // last frame) the history shift of those bins.  LDS: [64 B][hb: KS_MAX KB][16 x (P + 4) floats].
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool ONE>
-__device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStageDev& sd, const HopSeqDev& sq, char* smem) {
+__device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStep& hs, const HopStageDev& sd, const HopSeqDev& sq, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     const int rt = (int)blockIdx.x - sd.wg0;
     const int H = sq.H, KS = sq.KS, R = sq.R, HP = KS * 64, P = sq.P, PT = sq.PT;
     const int hop = ONE ? 1 : p.hop, D = p.D, S = p.S, F = p.F;
-    const unsigned tagw = hop_tag(p.launch) * 0x02020202u;
+    const unsigned tagw = hop_tag(hs.launch) * 0x02020202u;
     const int LDP = P + 4;
     char* hb = smem + 64;
     float* pbuf = reinterpret_cast<float*>(hb + HOP_KS_MAX * 1024);
@@ -694,12 +700,12 @@ __device__ __forceinline__ void hop_proj_role(const HopParams& p, const HopStage
 // the last 384 samples of the state followed by the 128 new ones; sfsn_fft.hip's transform (same code, same bits); the bins
 // leave as granules; then the state moves on by one hop.  LDS: [64 B][unit table 4 KB][8 x 2 KB exchange].
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void hop_stft_role(const HopParams& p, const HopStageDev& sd, char* smem) {
+__device__ __forceinline__ void hop_stft_role(const HopParams& p, const HopStep& hs, const HopStageDev& sd, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rt = (int)blockIdx.x - sd.wg0;
     const int nclip = (p.B - 16 * rt) < 16 ? (p.B - 16 * rt) : 16;
-    const unsigned tagw = hop_tag(p.launch) * 0x02020202u;
+    const unsigned tagw = hop_tag(hs.launch) * 0x02020202u;
     float2* unit = reinterpret_cast<float2*>(smem + 64);
     float2(*fbuf)[FFT_N] = reinterpret_cast<float2(*)[FFT_N]>(smem + 64 + FFT_NFFT * 8);
     fill_unit_table(unit, tid, HOP_THREADS);
@@ -753,11 +759,11 @@ __device__ __forceinline__ void hop_stft_role(const HopParams& p, const HopStage
 // complete divided by the squared-window envelope of the frames that exist (t - q >= 0), accumulator moved on by one hop.
 // LDS: [64 B][unit table 4 KB][8 x 2 KB exchange][8 x 264 float2 spectrum rows].
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void hop_istft_role(const HopParams& p, const HopStageDev& sd, char* smem) {
+__device__ __forceinline__ void hop_istft_role(const HopParams& p, const HopStep& hs, const HopStageDev& sd, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pair = ((int)blockIdx.x - sd.wg0) * HOP_WAVES + wave;  // clip * S + speaker
-    const unsigned tagw = hop_tag(p.launch) * 0x02020202u;
+    const unsigned tagw = hop_tag(hs.launch) * 0x02020202u;
     float2* unit = reinterpret_cast<float2*>(smem + 64);
     float2(*fbuf)[FFT_N] = reinterpret_cast<float2(*)[FFT_N]>(smem + 64 + FFT_NFFT * 8);
     float2(*xs)[264] = reinterpret_cast<float2(*)[264]>(smem + 64 + FFT_NFFT * 8 + HOP_WAVES * FFT_N * 8);
@@ -798,7 +804,7 @@ __device__ __forceinline__ void hop_istft_role(const HopParams& p, const HopStag
     float2 env = make_float2(0.0f, 0.0f);
 #pragma unroll
     for (int q = 3; q >= 0; --q)
-        if (p.frame_index - q >= 0) {
+        if (hs.frame_index - q >= 0) {
             env.x += win[q].x * win[q].x;
             env.y += win[q].y * win[q].y;
         }
@@ -808,7 +814,7 @@ __device__ __forceinline__ void hop_istft_role(const HopParams& p, const HopStag
         // wave_out (and this word) may be host memory the device can reach: a caller that keeps its samples on the host spins on
         // the word instead of synchronising the stream -- the samples are there when it changes (system-scope release)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(p.done + pair, p.launch + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) __hip_atomic_store(p.done + pair, hs.launch + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -817,16 +823,13 @@ __device__ __forceinline__ void hop_istft_role(const HopParams& p, const HopStag
     }
 }
 
+// one hop of one workgroup: the role its block index selects
 template <bool ONE>
-__global__ __launch_bounds__(HOP_THREADS) void stream_hop_kernel(const HopParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    HOP_STAMP(0);
+__device__ __forceinline__ void hop_dispatch(const HopParams& p, const HopStep& hs, char* smem) {
     if ((int)blockIdx.x < p.st[0].nwg) {
         // layer 0 of the full-band model is the head of the frame's critical path: its descriptors sit at fixed kernarg
         // offsets, so every scalar load is issued at once instead of table -> stage -> sequence
-        hop_layer_role<true, ONE>(p, p.st[0], p.seq[0], smem);
-        HOP_STAMP(7);
+        hop_layer_role<true, ONE>(p, hs, p.st[0], p.seq[0], smem);
         return;
     }
     const int si = (int)((p.stage_of_block[blockIdx.x >> 2] >> (8 * (blockIdx.x & 3))) & 0xffu);
@@ -834,17 +837,73 @@ __global__ __launch_bounds__(HOP_THREADS) void stream_hop_kernel(const HopParams
     const HopSeqDev& sq = p.seq[sd.seq];
     if (sd.layer >= 0) {
         if (sd.layer == 0)
-            hop_layer_role<true, ONE>(p, sd, sq, smem);
+            hop_layer_role<true, ONE>(p, hs, sd, sq, smem);
         else
-            hop_layer_role<false, ONE>(p, sd, sq, smem);
+            hop_layer_role<false, ONE>(p, hs, sd, sq, smem);
     } else if (sd.layer == -1) {
-        hop_proj_role<ONE>(p, sd, sq, smem);
+        hop_proj_role<ONE>(p, hs, sd, sq, smem);
     } else if (ONE && sd.layer == -2) {
-        hop_stft_role(p, sd, smem);
+        hop_stft_role(p, hs, sd, smem);
     } else if (ONE) {
-        hop_istft_role(p, sd, smem);
+        hop_istft_role(p, hs, sd, smem);
     }
+}
+
+template <bool ONE>
+__global__ __launch_bounds__(HOP_THREADS) void stream_hop_kernel(const HopParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    HOP_STAMP(0);
+    HopStep hs;
+    hs.launch = p.launch; hs.frame_index = p.frame_index; hs.frames_before = p.frames_before;
+    hop_dispatch<ONE>(p, hs, smem);
     HOP_STAMP(7);
+}
+
+// ---- the RESIDENT form (BASELINE configs[4]: "persistent kernel", round 3): one launch serves hop after hop.  The host rings a
+// doorbell word in pinned host memory (value k + 1 for hop k, 0xFFFFFFFF = stop) after it has put the hop's samples into the
+// pinned input buffer; workgroup 0's first lane polls it over PCIe (system scope) and forwards it to a device word every other
+// workgroup polls (agent scope), so the host memory sees one reader.  Within a hop the stages hand over exactly as in a launch
+// (tagged granules, tag = launch index + k); the completion word per (clip, speaker) tells the host the enhanced samples are in
+// its memory, and only then may it ring the next hop (every consumer of hop k has read its inputs by then: the last stage
+// depends on all of them).  Bounded: a doorbell that stays silent for `idle_polls` polls ends the kernel (it must never outlive
+// its host thread), as does a hand-off wait that expires inside a hop.  Waveform mode, one-frame hops.
+__global__ __launch_bounds__(HOP_THREADS) void stream_hop_resident_kernel(const HopParams p, const unsigned* doorbell, unsigned idle_polls) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned go_lds;
+    unsigned* go = p.cnt + 1;  // device word: hops released so far (0xFFFFFFFF: stop)
+    for (unsigned k = 0;; ++k) {
+        if (threadIdx.x == 0) {
+            unsigned v = 0;
+            if (blockIdx.x == 0) {
+                for (unsigned spins = 0;; ++spins) {
+                    v = __hip_atomic_load(doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (v >= k + 1u) break;
+                    if (spins > idle_polls || ld_agent(p.cnt) != 0u) {
+                        v = 0xFFFFFFFFu;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                __hip_atomic_store(go, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                for (;;) {
+                    v = __hip_atomic_load(go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v >= k + 1u) break;
+                    __builtin_amdgcn_s_sleep(2);  // (bounded by workgroup 0's watchdog: it publishes the stop value)
+                }
+            }
+            go_lds = v;
+        }
+        __syncthreads();
+        const unsigned v = go_lds;
+        __syncthreads();
+        if (v == 0xFFFFFFFFu) break;
+        HopStep hs;
+        hs.launch = p.launch + k; hs.frame_index = p.frame_index + (int)k; hs.frames_before = p.frames_before + (int)k * p.hop;
+        hop_dispatch<true>(p, hs, smem);
+        __syncthreads();
+    }
 }
 
 // =====================================================================================================================
@@ -1027,5 +1086,29 @@ extern "C" int sfsn_stream_hop(const sfsn_hop_desc* desc, void* stream) {
         hipLaunchKernelGGL(stream_hop_kernel<true>, dim3(local.nblocks), dim3(HOP_THREADS), lds, static_cast<hipStream_t>(stream), local);
     else
         hipLaunchKernelGGL(stream_hop_kernel<false>, dim3(local.nblocks), dim3(HOP_THREADS), lds, static_cast<hipStream_t>(stream), local);
+    return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;
+}
+
+extern "C" int sfsn_stream_hop_resident(const sfsn_hop_desc* desc, const void* doorbell, unsigned idle_ms, void* stream) {
+    HopParams local;
+    size_t lds;
+    const int rc = hop_plan(local, lds, desc);
+    if (rc != SFSN_OK) return rc;
+    if (!doorbell || !desc->wave_in || !desc->done || desc->hop != 1) return SFSN_EINVAL;  // waveform mode with host completion words
+    if (!desc->scratch || desc->scratch_bytes < hop_counter_bytes(local) + (size_t)local.nblocks * HOP_WAVES * 64) return SFSN_EINVAL;
+    local.cnt = static_cast<unsigned*>(desc->scratch);
+    local.launch = desc->launch_index;
+    local.frames_before = desc->frames_before;
+    local.dbg = reinterpret_cast<unsigned long long*>(static_cast<char*>(desc->scratch) + hop_counter_bytes(local));
+    const int fit = hop_fits_device(local.nblocks);
+    if (fit != SFSN_OK) return fit;
+    if (lds > 160 * 1024) return SFSN_EUNSUPPORTED;
+    const void* kern = reinterpret_cast<const void*>(stream_hop_resident_kernel);
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SFSN_EHIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(local.cnt + 1, 0, sizeof(unsigned), st) != hipSuccess) return SFSN_EHIP;  // the device-side doorbell copy
+    // a poll of host memory takes ~1.5 us (PCIe round trip + s_sleep): idle_ms -> polls
+    const unsigned polls = idle_ms > 60000u ? 40000000u : idle_ms * 650u + 1000u;
+    hipLaunchKernelGGL(stream_hop_resident_kernel, dim3(local.nblocks), dim3(HOP_THREADS), lds, st, local, static_cast<const unsigned*>(doorbell), polls);
     return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;
 }
