@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="streaming: launch the kernels one by one instead of replaying the HIP graph")
     ap.add_argument("--no-one-launch", action="store_true", help="streaming: the offline kernels per hop (HIP graph) instead of sfsn_stream_hop")
     ap.add_argument("--waveform", action="store_true", help="streaming: samples in, samples out (STFT and inverse STFT inside the launch)")
+    ap.add_argument("--resident", action="store_true", help="with --host-io: one resident launch serves every hop (doorbell in pinned memory) instead of one launch per hop")
     ap.add_argument("--host-io", action="store_true", help="waveform streaming with the samples in host memory on both sides (pinned, read / written by the launch)")
     ap.add_argument("--no-streaming-leg", action="store_true", help="skip the 2,000-hop streaming measurement (config.streaming) behind the timed region")
     args = ap.parse_args()
@@ -497,7 +498,7 @@ def waveform_streaming_bench(args, model, dev, world, rank, B):
     """Streaming on waveforms: 128 new samples (8 ms) per call, enhanced samples back (three hops late: the look-ahead of the
     centred 32 ms analysis + the overlap-add); per-call latency as in streaming_bench."""
     steps, warmup = max(args.steps, 2000), max(args.warmup, 200)
-    sess = model.streaming(batch=B, waveform=True, host_io=args.host_io)
+    sess = model.streaming(batch=B, waveform=True, host_io=args.host_io, resident=args.resident)
     g = torch.Generator(device="cpu").manual_seed(3)
     chunks = 0.05 * torch.randn((steps + warmup, B, 128), generator=g)
     if not args.host_io:
@@ -505,7 +506,8 @@ def waveform_streaming_bench(args, model, dev, world, rank, B):
     lat, enq = [], []
     for i in range(steps + warmup):
         x = chunks[i]
-        torch.cuda.synchronize()
+        if not args.resident:  # (a device-wide synchronise would wait for the resident kernel's watchdog)
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         if args.host_io:  # samples in a CPU tensor -> enhanced samples in a CPU tensor (the call returns when they are there)
             sess.step_wave_host(x)
@@ -517,6 +519,7 @@ def waveform_streaming_bench(args, model, dev, world, rank, B):
         if i >= warmup:
             lat.append(time.perf_counter() - t0)
             enq.append(t1 - t0)
+    sess.close()
     sess.check_errors()
     lat = np.sort(np.asarray(lat)) * 1e6
     enq = np.sort(np.asarray(enq)) * 1e6
@@ -528,8 +531,9 @@ def waveform_streaming_bench(args, model, dev, world, rank, B):
             "ms_per_step": round(float(lat.mean()) / 1e3, 4), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (0.05*randn samples; seeded random weights, randomised BN stats)",
             "config": {"workload": "configs[4]: streaming on waveforms, live baseline_m sizes, fp32 parity mode", "clips_per_gpu": B,
-                       "hop_samples": 128, "algorithmic_delay_samples": 384, "host_io": bool(args.host_io),
-                       "schedule": "one launch per hop: STFT of the new frame, the whole model, inverse STFT with overlap-add state",
+                       "hop_samples": 128, "algorithmic_delay_samples": 384, "host_io": bool(args.host_io), "resident": bool(args.resident),
+                       "schedule": ("one resident launch, a doorbell per hop" if args.resident else "one launch per hop") +
+                                   ": STFT of the new frame, the whole model, inverse STFT with overlap-add state",
                        "host_enqueue_p50_us": round(float(enq[len(enq) // 2]), 1), "p99_us": round(float(lat[int(len(lat) * 0.99)]), 1),
                        "min_us": round(float(lat[0]), 1), "real_time_factor_at_8ms_hop": round(8e3 / float(lat[len(lat) // 2]), 1)}}))
 

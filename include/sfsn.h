@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 8 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 9 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -383,6 +383,20 @@ typedef struct sfsn_hop_desc {
 
 size_t sfsn_hop_scratch_bytes(const sfsn_hop_desc* desc /* host */);
 int sfsn_stream_hop(const sfsn_hop_desc* desc /* host */, void* stream);
+
+/* The RESIDENT form of the waveform hop (BASELINE.json configs[4] names a "persistent kernel"; round 3).  One launch serves hop
+ * after hop of a waveform session with host completion words (wave_in, wave_out and done in pinned host memory, hop == 1):
+ * for hop k = 0, 1, ... the host writes the 128 samples per clip into wave_in, then stores k + 1 into the 32-bit `doorbell`
+ * word (pinned host memory too), then waits until every done word reads desc->launch_index + k + 1 -- only then may it ring
+ * hop k + 1.  The kernel uses launch index desc->launch_index + k, frame index desc->frame_index + k and
+ * desc->frames_before + k for hop k (what k separate sfsn_stream_hop calls would have been given).  Storing 0xFFFFFFFF ends the
+ * kernel; so does a doorbell silent for about `idle_ms` milliseconds and an expired hand-off wait (error word set, as for a
+ * launch): the kernel never outlives its caller by more than that.  The caller keeps `stream` free of other work while
+ * the kernel is resident (it holds the hop's workgroups -- 23 of 256 CUs for the M model at B = 1) and adds the hops served to
+ * its own launch / frame counters afterwards; doorbell[1] (zeroed by the caller before the call) is set to 1 by the kernel when it
+ * leaves.  Same results as the launches, bit for bit. */
+int sfsn_stream_hop_resident(const sfsn_hop_desc* desc /* host */, void* doorbell /* pinned host, u32[2] */, unsigned idle_ms,
+                             void* stream);
 /* Diagnostic: the launch's stages in block order, out[4 * i] = {sequence (0 = full-band, 1 + g = group g), layer (-1 = projection
  * [+ deep filter]), first workgroup, workgroups}; returns the number of stages (or a negative status).  With SFSN_HOP_DEBUG set
  * in the environment a launch leaves eight 100 MHz time stamps per wave (4 waves per workgroup) in `scratch`, behind the

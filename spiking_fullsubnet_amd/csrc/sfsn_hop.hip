@@ -509,7 +509,7 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStep
     }
     if (active && row < R) {
         *reinterpret_cast<v4f*>(L.c + (size_t)row * H + cc) = c;
-        *reinterpret_cast<unsigned*>(hnext + (size_t)row * HP + cc) = pk;
+        st_agent(hnext + (size_t)row * HP + cc, pk);  // (write-through: the resident form has no launch boundary to write L2 back)
     }
     if (L0 && sq.norm == SFSN_NORM_CUMLAPLACE && wgl - rt * wpr == 0 && lane == 0) {
 #pragma unroll
@@ -862,48 +862,60 @@ __global__ __launch_bounds__(HOP_THREADS) void stream_hop_kernel(const HopParams
 
 // ---- the RESIDENT form (BASELINE configs[4]: "persistent kernel", round 3): one launch serves hop after hop.  The host rings a
 // doorbell word in pinned host memory (value k + 1 for hop k, 0xFFFFFFFF = stop) after it has put the hop's samples into the
-// pinned input buffer; workgroup 0's first lane polls it over PCIe (system scope) and forwards it to a device word every other
-// workgroup polls (agent scope), so the host memory sees one reader.  Within a hop the stages hand over exactly as in a launch
+// pinned input buffer; one wave of every workgroup polls it over PCIe (forwarding it through a device word polled by the
+// others cost 2 us more per hop).  Within a hop the stages hand over exactly as in a launch
 // (tagged granules, tag = launch index + k); the completion word per (clip, speaker) tells the host the enhanced samples are in
 // its memory, and only then may it ring the next hop (every consumer of hop k has read its inputs by then: the last stage
 // depends on all of them).  Bounded: a doorbell that stays silent for `idle_polls` polls ends the kernel (it must never outlive
 // its host thread), as does a hand-off wait that expires inside a hop.  Waveform mode, one-frame hops.
-__global__ __launch_bounds__(HOP_THREADS) void stream_hop_resident_kernel(const HopParams p, const unsigned* doorbell, unsigned idle_polls) {
+__global__ __launch_bounds__(HOP_THREADS) void stream_hop_resident_kernel(const HopParams p, unsigned* doorbell, unsigned idle_ticks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ unsigned go_lds;
-    unsigned* go = p.cnt + 1;  // device word: hops released so far (0xFFFFFFFF: stop)
+    unsigned* fin = p.cnt + 2;  // workgroups that have finished (and released) a hop, counted up over the hops
     for (unsigned k = 0;; ++k) {
-        if (threadIdx.x == 0) {
-            unsigned v = 0;
-            if (blockIdx.x == 0) {
-                for (unsigned spins = 0;; ++spins) {
-                    v = __hip_atomic_load(doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (v >= k + 1u) break;
-                    if (spins > idle_polls || ld_agent(p.cnt) != 0u) {
-                        v = 0xFFFFFFFFu;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(4);
+        // one wave per workgroup waits, the other waves sleep at the barrier.  Relaxed polls (an acquire per poll would
+        // invalidate the caches under the stages that are still computing) of two words at once: the host's doorbell, over
+        // PCIe, and the count of workgroups that have released hop k - 1 -- the state a hop leaves for the next one (last
+        // spikes, read by every workgroup of the layer) crosses compute units without a launch boundary here.
+        if (threadIdx.x < 64) {
+            unsigned v;
+            const unsigned long long t0 = wall_clock64();  // 100 MHz
+            for (unsigned spins = 0;; ++spins) {
+                v = __hip_atomic_load(doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned f = ld_agent(fin);
+                if (v == 0xFFFFFFFFu || (v >= k + 1u && f >= k * gridDim.x)) break;
+                if ((spins & 63u) == 63u && (wall_clock64() - t0 > (unsigned long long)idle_ticks || ld_agent(p.cnt) != 0u)) {
+                    v = 0xFFFFFFFFu;
+                    break;
                 }
-                __hip_atomic_store(go, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                for (;;) {
-                    v = __hip_atomic_load(go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v >= k + 1u) break;
-                    __builtin_amdgcn_s_sleep(2);  // (bounded by workgroup 0's watchdog: it publishes the stop value)
-                }
+                __builtin_amdgcn_s_sleep(2);
             }
-            go_lds = v;
+            if (threadIdx.x == 0) *reinterpret_cast<unsigned*>(smem) = v;  // (the hop's LDS is free between hops)
         }
         __syncthreads();
-        const unsigned v = go_lds;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the hop's samples sit in host memory
+        unsigned v = *reinterpret_cast<const unsigned*>(smem);
         __syncthreads();
+        v = __builtin_amdgcn_readfirstlane(v);
         if (v == 0xFFFFFFFFu) break;
+#ifdef SFSN_HOP_STAMPS
+        const int wave = threadIdx.x >> 6;
+        HOP_STAMP(0);
+#endif
         HopStep hs;
         hs.launch = p.launch + k; hs.frame_index = p.frame_index + (int)k; hs.frames_before = p.frames_before + (int)k * p.hop;
         hop_dispatch<true>(p, hs, smem);
+#ifdef SFSN_HOP_STAMPS
+        HOP_STAMP(7);
+#endif
+        // the state that crosses compute units between hops (the last spikes) left as write-through stores: once they have
+        // completed they are visible to the agent -- no L2 write-back (a release fence here cost the hops 4 us: buffer_wbl2
+        // stalls the L2 under the stages that are still computing)
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
         __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(fin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // the host learns that the kernel has left (watchdog, error word or its own stop) without a runtime call
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(doorbell + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // =====================================================================================================================
@@ -1089,7 +1101,7 @@ extern "C" int sfsn_stream_hop(const sfsn_hop_desc* desc, void* stream) {
     return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;
 }
 
-extern "C" int sfsn_stream_hop_resident(const sfsn_hop_desc* desc, const void* doorbell, unsigned idle_ms, void* stream) {
+extern "C" int sfsn_stream_hop_resident(const sfsn_hop_desc* desc, void* doorbell, unsigned idle_ms, void* stream) {
     HopParams local;
     size_t lds;
     const int rc = hop_plan(local, lds, desc);
@@ -1106,9 +1118,8 @@ extern "C" int sfsn_stream_hop_resident(const sfsn_hop_desc* desc, const void* d
     const void* kern = reinterpret_cast<const void*>(stream_hop_resident_kernel);
     if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SFSN_EHIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(local.cnt + 1, 0, sizeof(unsigned), st) != hipSuccess) return SFSN_EHIP;  // the device-side doorbell copy
-    // a poll of host memory takes ~1.5 us (PCIe round trip + s_sleep): idle_ms -> polls
-    const unsigned polls = idle_ms > 60000u ? 40000000u : idle_ms * 650u + 1000u;
-    hipLaunchKernelGGL(stream_hop_resident_kernel, dim3(local.nblocks), dim3(HOP_THREADS), lds, st, local, static_cast<const unsigned*>(doorbell), polls);
+    if (hipMemsetAsync(local.cnt + 1, 0, 2 * sizeof(unsigned), st) != hipSuccess) return SFSN_EHIP;  // (word 2: the hop-finished count)
+    const unsigned polls = (idle_ms > 30000u ? 30000u : idle_ms) * 100000u;  // ticks of the 100 MHz wall clock
+    hipLaunchKernelGGL(stream_hop_resident_kernel, dim3(local.nblocks), dim3(HOP_THREADS), lds, st, local, static_cast<unsigned*>(doorbell), polls);
     return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;
 }

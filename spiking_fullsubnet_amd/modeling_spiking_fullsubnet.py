@@ -198,14 +198,14 @@ class _EngineMixin:
         return self._engine
 
     def streaming(self, batch: int = 1, hop: int = 1, graph: bool = True, rows_per_wg=None, one_launch="auto", waveform: bool = False,
-                  host_io: bool = False):
+                  host_io: bool = False, resident: bool = False, idle_ms: int = 1000):
         """Frame-by-frame session (``streaming.StreamingSession``): state and deep-filter history stay on the device between
         calls; one launch per hop (``sfsn_stream_hop``) where the library covers the model, else the offline kernels replayed
         from a HIP graph.  ``waveform=True``: samples in, samples out (``step_wave``).  Live front-end only."""
         from .streaming import StreamingSession
         self._check_mode()
         return StreamingSession(self.engine(), batch=batch, hop=hop, graph=graph, rows_per_wg=rows_per_wg, owner=self, one_launch=one_launch,
-                                waveform=waveform, host_io=host_io)
+                                waveform=waveform, host_io=host_io, resident=resident, idle_ms=idle_ms)
 
     def _check_mode(self, x=None):
         """The inference kernels have no autograd graph and no training-mode BatchNorm: the entry points that use them

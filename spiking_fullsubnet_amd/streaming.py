@@ -44,7 +44,7 @@ class StreamingSession:
     """``step(frames [B, F, hop] complex64) -> (enh_stft [B, S, F, hop], enh_mag [B, S, F, hop])`` with state carried."""
 
     def __init__(self, engine: Engine, batch: int = 1, hop: int = 1, graph: bool = True, rows_per_wg=None, owner=None,
-                 one_launch="auto", waveform: bool = False, host_io: bool = False):
+                 one_launch="auto", waveform: bool = False, host_io: bool = False, resident: bool = False, idle_ms: int = 1000):
         spec = engine.spec
         # the module the engine was packed from: reset() checks that its parameters have not changed since (the session's
         # captured graph holds pointers to THIS engine's packed weights)
@@ -98,6 +98,13 @@ class StreamingSession:
         self.host_io = bool(host_io)  # waveform mode: samples come from and go to (pinned) host memory, no copy launches
         if self.host_io and not waveform:
             raise ValueError("host_io goes with waveform=True")
+        # host_io only: ONE resident launch serves hop after hop (sfsn_stream_hop_resident), rung through a doorbell word in pinned
+        # memory; it starts with the first hop that computes a frame and ends with reset(), close(), or idle_ms of silence
+        self.resident = bool(resident)
+        self.idle_ms = int(idle_ms)
+        self._res = None
+        if self.resident and not self.host_io:
+            raise ValueError("resident goes with waveform=True, host_io=True")
         if spec.cum_laplace:
             one_launch = True  # the running means live in sfsn_stream_hop's state; the per-kernel sequence has no streaming form of it
         if self.waveform:
@@ -251,6 +258,8 @@ class StreamingSession:
             host = dict(inp=torch.zeros((B, 128), dtype=torch.float32).pin_memory(), out=torch.zeros((B, S, 128), dtype=torch.float32).pin_memory(),
                         done=torch.zeros((B * S,), dtype=torch.int32).pin_memory())
             host["done_np"] = host["done"].numpy()
+            host["bell"] = torch.zeros((16,), dtype=torch.int32).pin_memory()  # the resident kernel's doorbell (word 0)
+            host["bell_np"] = host["bell"].numpy().view("uint32")
         parts = []
         for b0 in range(0, B, per):
             nb = min(per, B - b0)
@@ -315,6 +324,7 @@ class StreamingSession:
                     h.zero_()
                     c.zero_()
         self.hist.zero_()
+        self._stop_resident()
         if self._hop is not None:
             self.check_errors()
             for part in self._hop["parts"]:
@@ -450,6 +460,57 @@ class StreamingSession:
         return out.clone() if copy else out
 
 
+    # ---- the resident launch (host_io, resident=True) ---------------------------------------------------------------------------
+    def _start_resident(self, c: int) -> None:
+        h = self._hop
+        if len(h["parts"]) != 1:
+            raise NotImplementedError("resident streaming: batches one launch covers (one part)")
+        part, host = h["parts"][0], h["host"]
+        d = part["desc"]
+        d.frames_before, d.frame_index, d.wave_in = self.frames_done, c - 1, host["inp"].data_ptr()
+        host["bell_np"][:2] = 0  # word 0: the doorbell; word 1: set by the kernel when it leaves
+        with torch.cuda.device(self.dev):
+            side = torch.cuda.Stream(self.dev)  # non-blocking: the kernel stays resident behind everything else the caller does
+            side.wait_stream(torch.cuda.current_stream(self.dev))  # (state fills / the first call's copy come first)
+            rc = self.eng.lib.sfsn_stream_hop_resident(part["ref"], ctypes.c_void_p(host["bell"].data_ptr()), self.idle_ms,
+                                                       ctypes.c_void_p(side.cuda_stream))
+        if rc:
+            check(rc, "sfsn_stream_hop_resident")
+        self._res = dict(k=0, stream=side)
+
+    def _stop_resident(self) -> None:
+        """End the resident launch (no-op without one) and fold the hops it served into the descriptor's launch counter."""
+        r = self._res
+        if r is None:
+            return
+        self._res = None
+        self._hop["host"]["bell_np"][0] = 0xFFFFFFFF
+        r["stream"].synchronize()
+        self._hop["parts"][0]["desc"].launch_index += r["k"]
+
+    def _ring_resident(self, c: int) -> int:
+        r = self._res
+        if r is not None and self._hop["host"]["bell_np"][1] != 0:
+            self._stop_resident()  # the doorbell stayed silent long enough for the kernel to leave: start another
+            r = None
+        if r is None:
+            self._start_resident(c)
+            r = self._res
+        r["k"] += 1
+        self._hop["host"]["bell_np"][0] = r["k"]
+        self.frames_done += self.hop
+        return self._hop["parts"][0]["desc"].launch_index + r["k"]
+
+    def close(self) -> None:
+        """End a resident launch, if one is running (reset() does the same)."""
+        self._stop_resident()
+
+    def __del__(self):
+        try:
+            self._stop_resident()
+        except Exception:
+            pass
+
     def step_wave_host(self, samples, timeout_s: float = 2.0) -> torch.Tensor:
         """Waveform streaming with the samples on the HOST (``waveform=True, host_io=True``): ``samples`` = float32 [B, 128] CPU
         tensor (or anything ``torch.as_tensor`` takes).  The launch reads them from pinned host memory and writes the enhanced
@@ -469,13 +530,25 @@ class StreamingSession:
                 part["st"]["state"][:, 384:].copy_(host["inp"][part["b0"]:part["b0"] + part["nb"]])
             torch.cuda.current_stream(self.dev).synchronize()
             return torch.zeros_like(host["out"])
-        target = h["parts"][0]["desc"].launch_index + 1
-        self._launch_hops(host["inp"].data_ptr(), 128 * 4, "wave_in", frame_index=c - 1)
+        if self.resident:
+            target = self._ring_resident(c)
+        else:
+            target = h["parts"][0]["desc"].launch_index + 1
+            self._launch_hops(host["inp"].data_ptr(), 128 * 4, "wave_in", frame_index=c - 1)
         done, t_end = host["done_np"], None
         target &= 0xFFFFFFFF
         while (int(done.min()) & 0xFFFFFFFF) != target or (int(done.max()) & 0xFFFFFFFF) != target:  # (all parts carry the same launch index; uint32 compare: the index wraps)
             if t_end is None:
                 t_end = time.perf_counter() + timeout_s
             elif time.perf_counter() > t_end:
+                if self.resident:
+                    self._stop_resident()
                 raise RuntimeError("sfsn_stream_hop: no completion word from the launch (see check_errors())")
+            if self._res is not None and host["bell_np"][1] != 0 and (int(done.min()) & 0xFFFFFFFF) != target:
+                # the resident kernel's watchdog fired just as this hop was rung: the hop was not served -- start another kernel on it
+                self.frames_done -= self.hop
+                self._res["k"] -= 1
+                self._stop_resident()
+                self.check_errors()
+                target = self._ring_resident(c) & 0xFFFFFFFF
         return torch.zeros_like(host["out"]) if c < 3 else host["out"]

@@ -4,6 +4,7 @@ full sizes -- through size-independent properties (state carry across chunks, ba
 run-to-run bit stability).  Tolerances and the causal comparison rule live in tests/parity.py."""
 import ctypes
 import os
+import time
 
 import numpy as np
 import pytest
@@ -763,6 +764,84 @@ def test_waveform_streaming_from_and_to_host_memory(kw, seed, B):
     assert torch.equal(got, y[..., :got.shape[-1]])
     with pytest.raises(ValueError):
         model.streaming(batch=B, host_io=True)
+
+
+def test_streaming_hops_beside_a_saturated_chip_are_right_or_loud():
+    """A one-launch hop assumes its ~20 workgroups get compute units promptly.  Here they do not: B = 64 x T = 1000
+    forwards are in flight on six other streams (every CU held by scan workgroups that stay for the whole launch) while a
+    B = 1 session streams 200 hops.  The contract: every hop is either bit-identical to the offline forward or the session
+    raises (a bounded hand-off wait expired -> error word -> check_errors()); it never returns wrong samples silently, the
+    sticky word is cleared by the report, and after reset() on a quiet chip the session is exact again."""
+    kw, seed = rw.LIVE_M, 5
+    model = build_module("live", kw, rw.live_state_dict(kw, seed))
+    T = 200
+    wave = torch.from_numpy(rw.synth_wave(1, T + 1, seed)).to(DEV)
+    stft = torch.stft(wave, 512, 128, 512, window=torch.hann_window(512, device=DEV), return_complex=True, pad_mode="constant")[..., :T].contiguous()
+    off = model.engine().forward_stft(stft, want_layers=False)
+    load_model = build_module("live", kw, rw.live_state_dict(kw, seed + 1))
+    big = torch.from_numpy(rw.synth_wave(64, 1001, 77)).to(DEV)
+    big = torch.stft(big, 512, 128, 512, window=torch.hann_window(512, device=DEV), return_complex=True, pad_mode="constant")[..., :1000].contiguous()
+    leng = load_model.engine()
+    leng.forward_stft(big, want_layers=False)  # (scratch allocated, weights packed)
+    sess = model.streaming(batch=1)
+    torch.cuda.synchronize()
+    lanes = [torch.cuda.Stream(device=DEV) for _ in range(6)]
+    for rep in range(3):  # ~3 x 6 forwards of ~3 ms: the hops below overlap them
+        for s_ in lanes:
+            with torch.cuda.stream(s_):
+                leng.forward_stft(big, want_layers=False)
+    outs, raised = [], False
+    t_begin = time.perf_counter()
+    try:
+        for t in range(T):
+            e, _ = sess.step(stft[..., t:t + 1].contiguous())
+            outs.append(e)
+        sess.check_errors()
+    except RuntimeError as err:
+        raised = True
+        assert "hand-off wait expired" in str(err)
+    busy_ms = (time.perf_counter() - t_begin) * 1e3
+    torch.cuda.synchronize()
+    if not raised:
+        e = torch.cat(outs, -1)
+        assert torch.equal(torch.view_as_real(e), torch.view_as_real(off["enh_stft"]))
+    parity.report("streaming-beside-saturated-chip", [], extra=dict(hops=T, raised=raised, wall_ms_for_the_hops=round(busy_ms, 2),
+                                                                     load="6 streams x 3 forwards of B=64 x T=1000 in flight"))
+    # quiet chip, new utterance: exact again, and no stale error word
+    sess.reset()
+    outs = [sess.step(stft[..., t:t + 1].contiguous())[0] for t in range(T)]
+    sess.check_errors()
+    assert torch.equal(torch.view_as_real(torch.cat(outs, -1)), torch.view_as_real(off["enh_stft"]))
+
+
+@pytest.mark.parametrize("kw,seed,B", [(rw.LIVE_M, 5, 1), (rw.LIVE_TINY_2SPK, 12, 3)])
+def test_waveform_streaming_resident_launch(kw, seed, B):
+    """resident=True: ONE launch serves hop after hop, rung through a doorbell word in pinned host memory
+    (sfsn_stream_hop_resident).  Same samples as the offline forward, bit for bit -- across a doorbell left silent until the
+    kernel's watchdog ended it (the session starts another), and again after reset()."""
+    import time
+    model = build_module("live", kw, rw.live_state_dict(kw, seed))
+    n_hops = 30
+    wave = torch.from_numpy(rw.synth_wave(B, n_hops + 1, seed))
+    y = model(wave.to(DEV))[0]
+    y = y.reshape(B, -1, y.shape[-1]).cpu()
+    sess = model.streaming(batch=B, waveform=True, host_io=True, resident=True, idle_ms=200)
+    for rep in range(2):
+        outs = []
+        for c in range(n_hops):
+            if rep == 0 and c == 17:
+                time.sleep(0.6)  # well past idle_ms: the resident kernel has left by now
+                assert sess._hop["host"]["bell_np"][1] == 1
+            o = sess.step_wave_host(wave[:, 128 * c:128 * (c + 1)])
+            if c >= 3:
+                outs.append(o.clone())
+        got = torch.cat(outs, -1)
+        assert torch.equal(got, y[..., :got.shape[-1]]), rep
+        sess.reset()  # ends the resident launch, checks the error word
+        assert sess._res is None
+    sess.close()
+    with pytest.raises(ValueError):
+        model.streaming(batch=B, waveform=True, resident=True)
 
 
 TINY_CUM = dict(rw.FROZEN_TINY_CUM, sb_df_orders=[3, 2, 1])  # (the fixture's orders [2, 1, 3] give the last group 384 projections: one launch covers 256)
