@@ -190,10 +190,12 @@ __global__ __launch_bounds__(NW * 64) void step_v1_kernel(const StepArgs p) {
     constexpr int NTL = (NT + NW - 1) / NW, NV = Deal<RPW>::NV;
     __shared__ __attribute__((aligned(16))) int8_t hbuf[2 * 16 * LDH];
     __shared__ float zl[16][HP];
+    __shared__ __attribute__((aligned(16))) int cntw[4];  // ORDER == 2: tiles completed per k-slice, counted up over the steps
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 2 * 16 * LDH / 4; i += NW * 64) reinterpret_cast<int*>(hbuf)[i] = 0;
     for (int i = tid; i < 16 * HP; i += NW * 64) zl[i / HP][i % HP] = (i % HP) < H ? p.zin[(size_t)(((int)blockIdx.x * RPW + (i / HP) % RPW) % p.R) * H + i % HP] : 0.f;
+    if (tid < 4) cntw[tid] = 0;
     __syncthreads();
     // my row and my neurons within a tile after the re-deal
     const int row = RPW == 16 ? n : RPW == 8 ? (n & 7) : (n & 3);
@@ -290,16 +292,62 @@ __global__ __launch_bounds__(NW * 64) void step_v1_kernel(const StepArgs p) {
     };
 
     const long long t0 = __builtin_readcyclecounter();
-    long long st_last[4] = {0, 0, 0, 0}, st_sum[3] = {0, 0, 0};
+    long long st_last[4] = {0, 0, 0, 0}, st_sum[3] = {0, 0, 0}, st_early = 0;
+    v4i eacc[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
+    unsigned edm = 0;
     auto loop = [&](auto ntag) __attribute__((always_inline)) {
         constexpr int NTW = decltype(ntag)::value;  // tiles of THIS wave: compile time, so that a step is one basic block
 #pragma unroll 1
         for (int t = 0; t < p.T; ++t) {
             const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
             int8_t* hn = hbuf + ((t & 1) ^ 1) * 16 * LDH;
-            long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            long long s0 = 0, s1 = 0, s2 = 0, s2b = 0, s3 = 0;
             if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(s0)); __builtin_amdgcn_sched_barrier(0); }
-            if constexpr (NTW > 0) {
+            if constexpr (NTW == 1 && ORDER == 2) {
+                // EARLY: the k-slices of h(t) whose four tiles have finished go through the products of step t+1 before the barrier
+                constexpr int LAST = (NT - 1) >> 2;
+                const int mys = wave >> 2;
+                v4i b[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    if (!((edm >> ks) & 1u)) b[ks] = *reinterpret_cast<const v4i*>(hc + n * LDH + ks * 64 + q * 16);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if ((edm >> ks) & 1u) continue;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) eacc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[0][ks][d], b[ks], eacc[d], 0, 0, 0);
+                }
+                if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(s1)); __builtin_amdgcn_sched_barrier(0); }
+                epi_tile(0, eacc, hn);
+                eacc[0] = eacc[1] = eacc[2] = v4i{0, 0, 0, 0};
+                edm = 0;
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&cntw[mys], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(s2)); __builtin_amdgcn_sched_barrier(0); }
+                if (mys < LAST && t + 1 < p.T) {
+                    const unsigned want = (1u << LAST) - 1u;
+                    const int need = 4 * (t + 1), need_last = (NT - 4 * LAST) * (t + 1);
+                    const unsigned caddr = (unsigned)(size_t)cntw;
+#pragma unroll 1
+                    for (int spins = 0; spins < 64; ++spins) {
+                        v4i cn;
+                        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cn) : "v"(caddr) : "memory");
+#pragma unroll
+                        for (int ks = 0; ks < LAST; ++ks) {
+                            if (!((edm >> ks) & 1u) && __builtin_amdgcn_readfirstlane(cn[ks]) >= need) {
+                                const v4i bb = *reinterpret_cast<const v4i*>(hn + n * LDH + ks * 64 + q * 16);
+#pragma unroll
+                                for (int d = 0; d < 3; ++d) eacc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[0][ks][d], bb, eacc[d], 0, 0, 0);
+                                edm |= 1u << ks;
+                            }
+                        }
+                        if (edm == want) break;
+                        if (__builtin_amdgcn_readfirstlane(cn[LAST]) >= need_last) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(s2b)); __builtin_amdgcn_sched_barrier(0); }
+            } else if constexpr (NTW > 0) {
                 v4i b[KS];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(hc + n * LDH + ks * 64 + q * 16);
@@ -335,7 +383,7 @@ __global__ __launch_bounds__(NW * 64) void step_v1_kernel(const StepArgs p) {
             __builtin_amdgcn_s_barrier();
             if constexpr (STAMP) {
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s3));
-                st_last[0] = s0; st_last[1] = s1; st_last[2] = s2; st_last[3] = s3;
+                st_last[0] = s0; st_last[1] = s1; st_last[2] = s2; st_last[3] = s3; st_early = s2b;
                 st_sum[0] += s1 - s0; st_sum[1] += s2 - s0; st_sum[2] += s3 - s0;
             }
         }
@@ -347,6 +395,7 @@ __global__ __launch_bounds__(NW * 64) void step_v1_kernel(const StepArgs p) {
     if constexpr (STAMP) if (blockIdx.x == 0 && lane == 0) {
         for (int k = 0; k < 4; ++k) p.stamps[wave * 8 + k] = st_last[k];
         for (int k = 0; k < 3; ++k) p.stamps[wave * 8 + 4 + k] = st_sum[k];
+        p.stamps[wave * 8 + 7] = st_early;
     }
 #pragma unroll
     for (int i = 0; i < NTL; ++i)
@@ -767,8 +816,9 @@ int main(int argc, char** argv) {
 #define V1S(NW, RPW, ORDER, GRID) { timeit("v1 STAMPED waves=" #NW " rows/wg=" #RPW " order=" #ORDER, GRID, T, dclk, [&](int it) { \
         StepArgs b = a; b.T = it; hipLaunchKernelGGL((step_v1_kernel<NW, RPW, 0, 0, 3, 0, 1, ORDER>), dim3(GRID), dim3(NW * 64), 0, 0, b); }); \
         long long hs[16 * 8]; CK(hipMemcpy(hs, a.stamps, sizeof(hs), hipMemcpyDeviceToHost)); long long m0 = hs[0]; for (int w = 0; w < NW; ++w) if (hs[w * 8] < m0) m0 = hs[w * 8]; \
-        for (int w = 0; w < NW; ++w) printf("   wave %2d (simd slot %d): last step: top +%4lld  mfma-issued +%4lld  epi-issued +%4lld  past-barrier +%4lld | mean: mfma %6.1f epi %6.1f barrier %6.1f\n", w, w >> 2, \
-            hs[w * 8] - m0, hs[w * 8 + 1] - m0, hs[w * 8 + 2] - m0, hs[w * 8 + 3] - m0, (double)hs[w * 8 + 4] / T, (double)hs[w * 8 + 5] / T, (double)hs[w * 8 + 6] / T); }
+        for (int w = 0; w < NW; ++w) printf("   wave %2d (simd slot %d): last step: top +%4lld  mfma-issued +%4lld  epi-issued +%4lld  early-done +%4lld  past-barrier +%4lld | mean: mfma %6.1f epi %6.1f barrier %6.1f\n", w, w >> 2, \
+            hs[w * 8] - m0, hs[w * 8 + 1] - m0, hs[w * 8 + 2] - m0, hs[w * 8 + 7] ? hs[w * 8 + 7] - m0 : 0ll, hs[w * 8 + 3] - m0, (double)hs[w * 8 + 4] / T, (double)hs[w * 8 + 5] / T, (double)hs[w * 8 + 6] / T); }
+    if (argc > 1 && !strcmp(argv[1], "early")) { V1S(16, 4, 0, 208); V1S(16, 4, 2, 208); V1S(16, 8, 0, 104); V1S(16, 8, 2, 104); return 0; }
     V1S(16, 8, 0, 104); V1S(16, 4, 0, 208); V1S(8, 8, 0, 104); V1S(8, 8, 1, 104); V1S(4, 8, 1, 104);
 #define V1O(NW, RPW, ORDER, PRIO, GRID) timeit("v1 waves=" #NW " rows/wg=" #RPW " order=" #ORDER " prio=" #PRIO, GRID, T, dclk, [&](int it) { \
         StepArgs b = a; b.T = it; hipLaunchKernelGGL((step_v1_kernel<NW, RPW, 0, 0, 3, PRIO, 0, ORDER>), dim3(GRID), dim3(NW * 64), 0, 0, b); })
