@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--waveform", action="store_true", help="streaming: samples in, samples out (STFT and inverse STFT inside the launch)")
     ap.add_argument("--resident", action="store_true", help="with --host-io: one resident launch serves every hop (doorbell in pinned memory) instead of one launch per hop")
     ap.add_argument("--host-io", action="store_true", help="waveform streaming with the samples in host memory on both sides (pinned, read / written by the launch)")
+    ap.add_argument("--training", action="store_true", help="SURVEY 8f-4: one training step (forward in train() mode + backward) of the live model, own JSON line")
     ap.add_argument("--no-streaming-leg", action="store_true", help="skip the 2,000-hop streaming measurement (config.streaming) behind the timed region")
     args = ap.parse_args()
 
@@ -188,6 +189,8 @@ def main():
         x = model._stft(wave).contiguous()  # untimed: the STFT is the edge of the path
         assert x.shape == (B, 257, T)
         return x
+    if args.training:
+        return training_bench(args, model, dev, world, rank, rw, B, T)
     stft = make_input(0)
     eng = model.engine()
     eng.stack_scan = "auto" if args.stack == "auto" else bool(int(args.stack))
@@ -492,6 +495,47 @@ def streaming_bench(args, model, dev, world, rank):
             "ms_per_step": round(m["mean_us"] / 1e3, 4), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (0.05*randn complex frames; seeded random weights, randomised BN stats)",
             "config": cfg}))
+
+
+def training_bench(args, model, dev, world, rank, rw, B, T):
+    """a training step of the live baseline_m model -- forward in train() mode (BatchNorm on the batch statistics
+    of every time step inside every cell, efficient_spiking_neuron.py:123,149-150) and backward through the triangle surrogate
+    (:94-101) -- on this package's differentiable path (training.py: one HIP launch per cell step and direction, library GEMMs for the
+    time-parallel products).  The recipe's batch is 64 clips (baseline_m.toml:72); the loss here is a stand-in of the same shape
+    class (a mean over the enhanced waveform and magnitude).  Wall time per step, synchronised, no optimiser step (the optimiser,
+    losses and trainer stay the reference's: out of scope)."""
+    steps, warmup = min(args.steps, 5), min(args.warmup, 2)
+    model.train()
+    wave = torch.from_numpy(rw.synth_wave(B, T, seed=1000 * rank + 7)).to(dev)
+
+    def one():
+        for p_ in model.parameters():
+            p_.grad = None
+        out = model(wave)
+        loss = out[0].pow(2).mean() + out[1].mean()
+        loss.backward()
+        return loss
+
+    for _ in range(max(warmup, 1)):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    gn = float(torch.sqrt(sum((p_.grad.float() ** 2).sum() for p_ in model.parameters() if p_.grad is not None)))
+    if rank == 0:
+        _emit(json.dumps({
+            "metric": "training step wall time (forward in train() mode + backward), live baseline_m", "value": round(ms, 2), "unit": "ms",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 2), "higher_is_better": False, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (0.05*randn waveform; seeded random weights, randomised BN stats)",
+            "config": {"workload": "SURVEY 8f-4: training-mode forward + backward, per-step batch-statistics BatchNorm, triangle surrogate",
+                       "clips_per_gpu": B, "frames": T, "clip_frames_per_s": round(B * T / (ms / 1e3), 1), "loss": float(loss.detach()),
+                       "grad_norm": gn, "optimizer_step": "not included (the reference's optimiser; out of scope)",
+                       "cell_steps_per_training_step": 2 * 4 * T,
+                       "note": "the same loop written as ATen operations per cell step (the reference's structure) takes 2.65 s at B=16 and "
+                               "2.8 s at B=64 (scripts/exp_train.py)"}}))
 
 
 def waveform_streaming_bench(args, model, dev, world, rank, B):

@@ -1,5 +1,5 @@
 # Round-3 profiling recipe (run on the GPU box via gpurun).  Kernel-trace stats first, then PMC passes in their own runs (never
-# combined with sys/runtime/hip tracing).  scripts/summarize_profiles_r03.py turns the raw outputs into profiles/r02_*.
+# combined with sys/runtime/hip tracing).  scripts/summarize_profiles_r03.py turns the raw outputs into profiles/r03_*.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_r03
@@ -22,5 +22,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --streaming --no-cpu-baseline > $OUT/bench_streaming.json 2>> $OUT/bench_default.err
+python bench.py --streaming --waveform --host-io > $OUT/bench_streaming_waveform_host.json 2>> $OUT/bench_default.err
+# (5) the training step: the line at the recipe's batch, kernel stats of one step at B = 16
+python bench.py --training --batch 64 > $OUT/bench_training.json 2>> $OUT/bench_default.err
+python bench.py --training --batch 16 > $OUT/bench_training_b16.json 2>> $OUT/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/training -o t -- python bench.py --training --batch 16 --steps 2 --warmup 1 > $OUT/training.log 2>&1
+# what goes back is capped at 64 MiB: the big per-dispatch traces are not needed (the stats files are)
+rm -f $OUT/default/d_kernel_trace.csv $OUT/training/t_kernel_trace.csv $OUT/single_whole/s_kernel_trace.csv
 python -c "from spiking_fullsubnet_amd import _lib; print(_lib.source_hash())" > $OUT/source_hash.txt
 tail -c 600 $OUT/bench_default.json

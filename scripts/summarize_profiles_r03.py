@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_r03 (scratch, from scripts/prof_r03.sh) -> profiles/r02_* (tracked): kernel stats of the three commands, a PMC
-summary per kernel, and profiles/r02_pmc.json -- the PMC-derived figures bench.py attaches to its line when the library build
+"""gpurun_out/prof_r03 (scratch, from scripts/prof_r03.sh) -> profiles/r03_* (tracked): kernel stats of the three commands, a PMC
+summary per kernel, and profiles/r03_pmc.json -- the PMC-derived figures bench.py attaches to its line when the library build
 (source hash) matches."""
 import collections, csv, json, os, shutil, sys
 base = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r03"
@@ -11,6 +11,10 @@ shutil.copy(f"{base}/single_whole/s_kernel_stats.csv", f"profiles/{rnd}_single_s
 shutil.copy(f"{base}/default/d_kernel_stats.csv", f"profiles/{rnd}_default_kernel_stats.csv")
 shutil.copy(f"{base}/bench_default.json", f"profiles/{rnd}_bench_line.json")
 shutil.copy(f"{base}/bench_streaming.json", f"profiles/{rnd}_streaming_line.json")
+for src, dst in (("bench_streaming_waveform_host.json", "streaming_waveform_host_line.json"), ("bench_training.json", "training_line.json"),
+                 ("bench_training_b16.json", "training_line_b16.json"), ("training/t_kernel_stats.csv", "training_kernel_stats.csv")):
+    if os.path.exists(f"{base}/{src}"):
+        shutil.copy(f"{base}/{src}", f"profiles/{rnd}_{dst}")
 if os.path.exists("gpurun_out/parity_report.jsonl"):
     shutil.copy("gpurun_out/parity_report.jsonl", f"profiles/{rnd}_parity_report.jsonl")
 src_hash = open(f"{base}/source_hash.txt").read().strip()

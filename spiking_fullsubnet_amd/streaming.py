@@ -535,11 +535,18 @@ class StreamingSession:
         else:
             target = h["parts"][0]["desc"].launch_index + 1
             self._launch_hops(host["inp"].data_ptr(), 128 * 4, "wave_in", frame_index=c - 1)
-        done, t_end = host["done_np"], None
+        done, t_end, t_soft = host["done_np"], None, None
         target &= 0xFFFFFFFF
         while (int(done.min()) & 0xFFFFFFFF) != target or (int(done.max()) & 0xFFFFFFFF) != target:  # (all parts carry the same launch index; uint32 compare: the index wraps)
             if t_end is None:
                 t_end = time.perf_counter() + timeout_s
+                t_soft = t_end - timeout_s + 0.02
+            elif t_soft is not None and not self.resident and time.perf_counter() > t_soft:
+                # 20 ms without the words (a hop takes tens of microseconds): a hand-off wait inside the launch has probably
+                # expired -- the launch has ended by now, its error word says so, and check_errors() raises it (round-2 advisor:
+                # a failed launch used to show up only as the 2 s timeout)
+                t_soft = None
+                self.check_errors()
             elif time.perf_counter() > t_end:
                 if self.resident:
                     self._stop_resident()
