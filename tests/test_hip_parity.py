@@ -1122,7 +1122,8 @@ def spec_units(spec, g):
 
 
 def test_errors_match_reference_behaviour():
-    """ValueError for an indivisible band (modeling:283-287), AssertionError for a non-2D input (:426), loud failure on CPU."""
+    """ValueError for an indivisible band (modeling:283-287), AssertionError for a non-2D input (:426), loud failure on CPU;
+    train() is served by the differentiable path, not by the inference kernels."""
     import spiking_fullsubnet_amd as pkg
     bad = dict(rw.LIVE_TINY, freq_cutoffs=[0, 30, 128, 256])
     m = pkg.SpikingFullSubNet(**bad).eval().to(DEV)
@@ -1133,8 +1134,11 @@ def test_errors_match_reference_behaviour():
         m(torch.zeros(1, 1, 2048, device=DEV))
     with pytest.raises(RuntimeError):
         pkg.SpikingFullSubNet(**rw.LIVE_TINY).eval()(torch.zeros(1, 2048))
+    # training mode is the differentiable path (tests/test_training.py); the inference-only entry points refuse it
+    mt = pkg.SpikingFullSubNet(**rw.LIVE_TINY).to(DEV).train()
+    assert mt(torch.zeros(1, 2048, device=DEV))[0].requires_grad
     with pytest.raises(RuntimeError):
-        pkg.SpikingFullSubNet(**rw.LIVE_TINY).to(DEV).train()(torch.zeros(1, 2048, device=DEV))
+        mt.streaming(batch=1)
 
 
 def test_fused_scan_entry_points_reject_what_they_do_not_cover(hip):
