@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 9 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 10 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -127,7 +127,7 @@ int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs /* host array */, int n_se
  * statistics updated with `momentum`, NEURON:123,149-150), and the matching step of the backward pass through Triangle.backward
  * (NEURON:94-101).  One launch per time step: the rows of a step are coupled by the normalisation.  All tensors fp32, device.
  *   z [R][G*H]: x_t . W_ih^T WITHOUT bias (G = 1 shared: one product serves both gates; 2: forget | cell);  bias [2H];
- *   w_hh [G*H][H] fp32;  h_prev, c_prev [R][H];  bn_w / bn_b [H] (both NULL: bn = False);  running_mean / running_var [H]
+ *   w_hh [G*H][H] fp32;  h_prev [R][H] spikes (0 / 1: anything non-zero counts as 1), c_prev [R][H];  bn_w / bn_b [H] (both NULL: bn = False);  running_mean / running_var [H]
  *   nullable (not updated).  Outputs of the forward step (saved for the backward step): spikes = h_t, u = c_t (post-BN
  *   membrane), xhat (normalised, pre-affine; bn only), f (forget gate), g (pre-activation of the cell gate), invstd [H] (bn only).
  * Backward step: dh_up (gradient w.r.t. h_t from above, nullable), dh_rec (gradient w.r.t. h_t through step t+1's recurrent
@@ -136,8 +136,8 @@ int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs /* host array */, int n_se
  *   d_bn_w / d_bn_b [H] ACCUMULATED (+=).  The recurrent part of dL/dh_t is either handed in (dh_rec) or formed by the step itself
  *   from the previous launch's d_z (dz_next . W_hh: no GEMM launch between the steps).
  * Rows per step beyond ~64 are spread over several workgroups per neuron tile, which exchange their partial sums through `scratch`
- * (sfsn_train_scratch_bytes(H) bytes, ZEROED by the caller before the first step of a layer call) and wait for each other inside
- * the launch; `epoch` = 1, 2, ... counts the steps issued on that scratch buffer (forward and backward use their own buffers). */
+ * (sfsn_train_scratch_bytes(H) bytes, ZEROED by the caller before the first step of a layer call: 8-byte {value, epoch} granules)
+ * and wait for each other inside the launch; `epoch` = 1, 2, ... counts the steps issued on that scratch buffer (forward and backward use their own buffers). */
 size_t sfsn_train_scratch_bytes(int H);
 int sfsn_gsn_train_step_fwd(const float* z, const float* w_hh, const float* bias, const float* h_prev, const float* c_prev,
                             const float* bn_w, const float* bn_b, float* running_mean, float* running_var, float momentum, float eps,
@@ -148,6 +148,19 @@ int sfsn_gsn_train_step_bwd(const float* dz_next /* [R][G*H] d_z of step t+1, nu
                             const float* f, const float* g, const float* c_prev, const float* invstd, const float* bn_w, int R, int H,
                             int shared, float* d_gates, float* d_z, float* dc_prev, float* d_bn_w, float* d_bn_b, void* scratch,
                             unsigned epoch, void* stream);
+
+/* A whole layer call: the T step launches of a layer, forward (t = 0 .. T-1) or backward (t = T-1 .. 0), enqueued back to back by
+ * the library (one call from the host language per layer and direction instead of T).  Tensors as for the step entries with a
+ * leading [T]: z [T][R][G*H]; spikes, u, xhat, f, g, dh_up [T][R][H]; invstd [T][H]; d_gates [T][R][2H]; d_z [T][R][H] (shared;
+ * NULL otherwise).  Zero initial state (MODEL:100-106): `zero` = [R][H] zeros.  dc_work: 2 * R * H floats of workspace.
+ * `scratch` as for the step entries (zeroed by the caller before the call; epochs 1 .. T are used). */
+int sfsn_gsn_train_seq_fwd(const float* z, const float* w_hh, const float* bias, const float* bn_w, const float* bn_b,
+                           float* running_mean, float* running_var, float momentum, float eps, int T, int R, int H, int shared,
+                           const float* zero, float* spikes, float* u, float* xhat, float* f, float* g, float* invstd, void* scratch,
+                           void* stream);
+int sfsn_gsn_train_seq_bwd(const float* w_hh, const float* dh_up, const float* u, const float* xhat, const float* f, const float* g,
+                           const float* invstd, const float* bn_w, int T, int R, int H, int shared, const float* zero, float* d_gates,
+                           float* d_z, float* dc_work, float* d_bn_w, float* d_bn_b, void* scratch, void* stream);
 
 /* Fused-input variant for layers >= 1 (their input is the previous layer's spikes): the input term is computed inside
  * the scan from the int8 spikes and the packed input weights, so that sfsn_spike_proj's [T][R][H] fp32 result never makes

@@ -44,44 +44,45 @@ __device__ __forceinline__ float reduce16(float v, float (*red)[TR_TILE], int rs
 
 
 // ---- several workgroups per neuron tile (round 3b): a launch is a grid of (H / 16 neuron tiles) x (RB row blocks); the row
-// blocks of a tile exchange 2 x 16 partial sums per step through `scratch` and a per-tile arrival counter (monotonic over the
-// steps of a layer: block b of step `epoch` waits for RB * epoch arrivals).  Payload: relaxed agent-scope stores, a block
-// barrier, then thread 0's release fence + arrival; readers: one polling lane (s_sleep between polls, bounded), a block
-// barrier, agent-scope loads.  Every block merges the partials in the same fixed order, so all blocks of a tile (and every
-// run) get the same bits.  All blocks of a launch are resident (a few hundred 256-thread blocks with little LDS).
-#define TR_PART 36  // floats per (tile, row block): [0] rows, [2..17] first partial per neuron, [18..33] second
-__device__ __forceinline__ bool tr_exchange(float* scratch, unsigned* counters, unsigned* err, int tile, int rb, int RB, unsigned epoch,
+// blocks of a tile exchange 2 x 16 partial sums (+ a row count) per step through `scratch`.  Transport: DATA-TAGGED GRANULES
+// (MI355X_MICROARCH.md, handoff-1to1): a value travels as one naturally aligned 8-byte {value, tag} written by ONE write-through
+// store, tag = the step's epoch (1, 2, ... over the steps issued on this scratch buffer; the buffer starts zeroed) -- data and
+// "ready" arrive together, so there is no flag, no drained store queue, no arrival counter.  Every granule of a tile is polled
+// by exactly one thread of every reading workgroup (relaxed agent loads, s_sleep between polls, bounded), the values land in
+// LDS, one barrier.  The first form (sc1 payload, release fence, per-tile arrival counter, one polling lane, agent loads of the
+// payload) cost ~5 of a step launch's 16 us.  Every block merges the partials in the same fixed order, so all blocks of a tile
+// (and every run) get the same bits.  All blocks of a launch are resident (a few hundred 256-thread blocks with little LDS).
+#define TR_PART 36   // LDS floats per (tile, row block): [0] rows, [2..17] first partial per neuron, [18..33] second
+#define TR_PARTG 40  // granules (8 bytes) per (tile, row block) in `scratch`, same indices
+__device__ __forceinline__ bool tr_exchange(float* scratch, unsigned* /*counters*/, unsigned* err, int tile, int rb, int RB, unsigned epoch,
                                             float p0, float p1, float nrows, int rsub, int j, float* out /* [RB][TR_PART] in LDS */) {
-    float* mine = scratch + ((size_t)tile * RB + rb) * TR_PART;
+    unsigned long long* gran = reinterpret_cast<unsigned long long*>(scratch) + (size_t)tile * 16 * TR_PARTG;  // [16][TR_PARTG]
+    unsigned long long* mine = gran + (size_t)rb * TR_PARTG;
+    const unsigned long long tag = (unsigned long long)epoch << 32;
     if (rsub == 0) {
-        __hip_atomic_store(mine + 2 + j, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mine + 18 + j, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (j == 0) __hip_atomic_store(mine, nrows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 2 + j, tag | __float_as_uint(p0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 18 + j, tag | __float_as_uint(p1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (j == 0) __hip_atomic_store(mine, tag | __float_as_uint(nrows), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    __shared__ int ok;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned want = (unsigned)RB * epoch;
-        int good = 1;
+    int good = 1;
+    for (int i = threadIdx.x; i < RB * 34; i += TR_THREADS) {
+        const int b = i / 34, k = i - b * 34;
+        if (k == 1) continue;
+        const unsigned long long* g = gran + (size_t)b * TR_PARTG + k;
+        unsigned long long v = 0;
         for (unsigned spins = 0;; ++spins) {
-            if (__hip_atomic_load(counters + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
-            if (spins > 4000000u) {  // ~1 s: a launch whose blocks are not all resident must not hang the device
+            v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == epoch) break;
+            if (spins > 2000000u) {  // ~1 s: a launch whose blocks are not all resident must not hang the device
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 good = 0;
                 break;
             }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
         }
-        ok = good;
+        out[b * TR_PART + k] = __uint_as_float((unsigned)v);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < RB * TR_PART; i += TR_THREADS)
-        out[i] = __hip_atomic_load(scratch + (size_t)tile * RB * TR_PART + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    return ok != 0;
+    return __syncthreads_and(good) != 0;
 }
 
 struct TrainFwdParams {
@@ -116,9 +117,18 @@ __global__ __launch_bounds__(TR_THREADS) void gsn_train_step_fwd_kernel(const Tr
     float* wt = reinterpret_cast<float*>(tr_smem);                       // [G][16][H + 1]
     float* cbuf = wt + (size_t)G * TR_TILE * (H + 1);                     // [rpb][16] pre-normalisation membranes of my rows
     float* parts = cbuf + (size_t)p.rpb * TR_TILE;                        // [RB][TR_PART]
+    unsigned* hb = reinterpret_cast<unsigned*>(parts + (size_t)p.RB * TR_PART);  // [rpb][H / 4] h_{t-1} of my rows, a byte per neuron
     __shared__ float red[TR_THREADS / TR_TILE][TR_TILE];
     const int tid = threadIdx.x, j = tid & 15, rsub = tid >> 4;
     const int n0 = tile * TR_TILE, nj = n0 + j;
+    // the last spikes of my rows: whole rows, 16 bytes per request, all requests of a thread in flight together (the round-3a
+    // kernel read them element by element inside the product loop: 224 dependent-latency loads per row -- most of its 15.9 us)
+    const int H4 = H >> 2;
+    for (int i = tid; i < nr * H4; i += TR_THREADS) {
+        const int rr = i / H4, c4 = i - rr * H4;
+        const float4 h = *reinterpret_cast<const float4*>(p.h_prev + (size_t)(r_lo + rr) * H + 4 * c4);
+        hb[rr * H4 + c4] = (h.x != 0.f ? 1u : 0u) | (h.y != 0.f ? 0x100u : 0u) | (h.z != 0.f ? 0x10000u : 0u) | (h.w != 0.f ? 0x1000000u : 0u);
+    }
     for (int i = tid; i < G * TR_TILE * H; i += TR_THREADS) {
         const int gi = i / (TR_TILE * H), rem = i - gi * TR_TILE * H, jj = rem / H, k = rem - jj * H;
         wt[(gi * TR_TILE + jj) * (H + 1) + k] = p.w_hh[((size_t)gi * H + n0 + jj) * H + k];
@@ -129,12 +139,16 @@ __global__ __launch_bounds__(TR_THREADS) void gsn_train_step_fwd_kernel(const Tr
     const float* wg = wt + (size_t)((G - 1) * TR_TILE + j) * (H + 1);
     float sum = 0.f;
     for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
-        const float* hp = p.h_prev + (size_t)r * H;
+        const unsigned* hp = hb + (size_t)(r - r_lo) * H4;
         float rf = 0.f, rg = 0.f;
-        for (int k = 0; k < H; ++k) {
-            const float hk = hp[k];
-            rf = __builtin_fmaf(hk, wf[k], rf);
-            if (G == 2) rg = __builtin_fmaf(hk, wg[k], rg);
+        for (int k4 = 0; k4 < H4; ++k4) {  // (h is 0 / 1: fma(h, w, acc) in k order, as before)
+            const unsigned hw = hp[k4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float hk = (float)((hw >> (8 * e)) & 1u);
+                rf = __builtin_fmaf(hk, wf[4 * k4 + e], rf);
+                if (G == 2) rg = __builtin_fmaf(hk, wg[4 * k4 + e], rg);
+            }
         }
         if (G == 1) rg = rf;
         const float zf = p.z[(size_t)r * G * H + nj], zg = p.z[(size_t)r * G * H + (G - 1) * H + nj];
@@ -239,7 +253,13 @@ __global__ __launch_bounds__(TR_THREADS) void gsn_train_step_bwd_kernel(const Tr
     float* dbuf = reinterpret_cast<float*>(tr_smem);   // [rpb][16] du of my rows
     float* parts = dbuf + (size_t)p.rpb * TR_TILE;      // [RB][TR_PART]
     float* wcol = parts + (size_t)p.RB * TR_PART;       // [G*H][16]: the columns of W_hh that feed my 16 neurons of h_t
+    float* dzb = wcol + (size_t)GH * TR_TILE;           // [rpb][G*H]: d_z of step t+1, my rows (whole rows, 16 bytes per request)
     if (p.dz_next) {
+        const int G4 = GH >> 2, nrw = r_hi - r_lo;
+        for (int i = tid; i < nrw * G4; i += TR_THREADS) {
+            const int rr = i / G4, c4 = i - rr * G4;
+            *reinterpret_cast<float4*>(dzb + (size_t)rr * GH + 4 * c4) = *reinterpret_cast<const float4*>(p.dz_next + (size_t)(r_lo + rr) * GH + 4 * c4);
+        }
         for (int i = tid; i < GH * TR_TILE; i += TR_THREADS) {
             const int nn = i / TR_TILE, jj = i - nn * TR_TILE;
             wcol[i] = p.w_hh[(size_t)nn * H + tile * TR_TILE + jj];
@@ -253,7 +273,7 @@ __global__ __launch_bounds__(TR_THREADS) void gsn_train_step_bwd_kernel(const Tr
         if (p.dh_up) dh += p.dh_up[o];
         if (p.dh_rec) dh += p.dh_rec[o];
         if (p.dz_next) {  // dL/dh_t through step t+1's recurrent product: sum_n dz_{t+1}[r][n] W_hh[n][my neuron]
-            const float* dz = p.dz_next + (size_t)r * GH;
+            const float* dz = dzb + (size_t)(r - r_lo) * GH;
             float acc = 0.f;
             for (int nn = 0; nn < GH; ++nn) acc = __builtin_fmaf(dz[nn], wcol[nn * TR_TILE + j], acc);
             dh += acc;
@@ -319,7 +339,7 @@ static void train_geometry(int R, int H, int* RB, int* rpb) {
 extern "C" size_t sfsn_train_scratch_bytes(int H) {
     if (H <= 0 || H % TR_TILE) return 0;
     const int tiles = H / TR_TILE;
-    return ((size_t)tiles * 16 * TR_PART) * sizeof(float) + ((size_t)tiles + 4) * sizeof(unsigned);  // partials (RB <= 16) + counters + error word
+    return ((size_t)tiles * 16 * TR_PARTG) * sizeof(unsigned long long) + ((size_t)tiles + 4) * sizeof(unsigned);  // granules (RB <= 16) + [unused] + error word
 }
 
 extern "C" int sfsn_gsn_train_step_fwd(const float* z, const float* w_hh, const float* bias, const float* h_prev, const float* c_prev,
@@ -336,13 +356,13 @@ extern "C" int sfsn_gsn_train_step_fwd(const float* z, const float* w_hh, const 
     train_geometry(R, H, &p.RB, &p.rpb);
     if (p.RB > 16) return SFSN_EUNSUPPORTED;  // (more than 16 x 220 / tiles x ... rows per layer and step)
     if (p.RB > 1 && use_bn && (!scratch || epoch == 0)) return SFSN_EINVAL;
-    const size_t lds = ((size_t)G * TR_TILE * (H + 1) + (size_t)p.rpb * TR_TILE + (size_t)p.RB * TR_PART) * sizeof(float);
+    const size_t lds = ((size_t)G * TR_TILE * (H + 1) + (size_t)p.rpb * TR_TILE + (size_t)p.RB * TR_PART) * sizeof(float) + (size_t)p.rpb * H;
     if (lds > 150 * 1024) return SFSN_EUNSUPPORTED;
     p.z = z; p.w_hh = w_hh; p.bias = bias; p.h_prev = h_prev; p.c_prev = c_prev; p.bn_w = bn_w; p.bn_b = bn_b;
     p.running_mean = running_mean; p.running_var = running_var; p.spikes = spikes; p.u = u; p.xhat = xhat; p.f = f; p.g = g;
     p.invstd = invstd; p.momentum = momentum; p.eps = eps; p.R = R; p.H = H; p.shared = shared; p.use_bn = use_bn;
     p.epoch = epoch; p.scratch = static_cast<float*>(scratch);
-    p.counters = scratch ? reinterpret_cast<unsigned*>(static_cast<float*>(scratch) + (size_t)tiles * 16 * TR_PART) : nullptr;
+    p.counters = scratch ? reinterpret_cast<unsigned*>(static_cast<float*>(scratch) + (size_t)tiles * 16 * TR_PARTG * 2) : nullptr;
     auto kern = gsn_train_step_fwd_kernel;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return SFSN_EHIP;
@@ -365,17 +385,55 @@ extern "C" int sfsn_gsn_train_step_bwd(const float* dz_next, const float* w_hh, 
     train_geometry(R, H, &p.RB, &p.rpb);
     if (p.RB > 16) return SFSN_EUNSUPPORTED;
     if (p.RB > 1 && use_bn && (!scratch || epoch == 0)) return SFSN_EINVAL;
-    const size_t lds = ((size_t)p.rpb * TR_TILE + (size_t)p.RB * TR_PART + (dz_next ? (size_t)(shared ? 1 : 2) * H * TR_TILE : 0)) * sizeof(float);
+    const size_t lds = ((size_t)p.rpb * TR_TILE + (size_t)p.RB * TR_PART + (dz_next ? (size_t)(shared ? 1 : 2) * H * (TR_TILE + p.rpb) : 0)) * sizeof(float);
     if (lds > 150 * 1024) return SFSN_EUNSUPPORTED;
     p.dz_next = dz_next; p.w_hh = w_hh;
     p.dh_up = dh_up; p.dh_rec = dh_rec; p.dc_next = dc_next; p.u = u; p.xhat = xhat; p.f = f; p.g = g; p.c_prev = c_prev;
     p.invstd = invstd; p.bn_w = bn_w; p.d_gates = d_gates; p.d_z = d_z; p.dc_prev = dc_prev; p.d_bn_w = d_bn_w; p.d_bn_b = d_bn_b;
     p.R = R; p.H = H; p.shared = shared; p.use_bn = use_bn;
     p.epoch = epoch; p.scratch = static_cast<float*>(scratch);
-    p.counters = scratch ? reinterpret_cast<unsigned*>(static_cast<float*>(scratch) + (size_t)tiles * 16 * TR_PART) : nullptr;
+    p.counters = scratch ? reinterpret_cast<unsigned*>(static_cast<float*>(scratch) + (size_t)tiles * 16 * TR_PARTG * 2) : nullptr;
     auto kern = gsn_train_step_bwd_kernel;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return SFSN_EHIP;
     hipLaunchKernelGGL(kern, dim3(tiles, p.RB), dim3(TR_THREADS), lds, static_cast<hipStream_t>(stream), p);
     return hip_ok_tr(hipGetLastError());
+}
+
+// ---- a whole layer call: the T step launches enqueued from here (the interpreter's share of a step launch was ~10 us of the
+// 15 it took at small batches).  Tensors as for the step entries with a leading [T]; zero initial state (`zero` = [R][H] zeros).
+extern "C" int sfsn_gsn_train_seq_fwd(const float* z, const float* w_hh, const float* bias, const float* bn_w, const float* bn_b,
+                                      float* running_mean, float* running_var, float momentum, float eps, int T, int R, int H,
+                                      int shared, const float* zero, float* spikes, float* u, float* xhat, float* f, float* g,
+                                      float* invstd, void* scratch, void* stream) {
+    if (T <= 0 || !zero) return SFSN_EINVAL;
+    const size_t RH = (size_t)R * H, RG = (size_t)R * (shared ? 1 : 2) * H;
+    for (int t = 0; t < T; ++t) {
+        const int rc = sfsn_gsn_train_step_fwd(z + t * RG, w_hh, bias, t ? spikes + (t - 1) * RH : zero, t ? u + (t - 1) * RH : zero, bn_w, bn_b,
+                                               running_mean, running_var, momentum, eps, R, H, shared, spikes + t * RH, u + t * RH,
+                                               xhat ? xhat + t * RH : nullptr, f + t * RH, g + t * RH, invstd ? invstd + (size_t)t * H : nullptr,
+                                               scratch, (unsigned)(t + 1), stream);
+        if (rc != SFSN_OK) return rc;
+    }
+    return SFSN_OK;
+}
+
+// d_gates [T][R][2H], d_z [T][R][H] (shared) or NULL; dc_work [2][R][H] scratch for the carried membrane gradient
+extern "C" int sfsn_gsn_train_seq_bwd(const float* w_hh, const float* dh_up, const float* u, const float* xhat, const float* f,
+                                      const float* g, const float* invstd, const float* bn_w, int T, int R, int H, int shared,
+                                      const float* zero, float* d_gates, float* d_z, float* dc_work, float* d_bn_w, float* d_bn_b,
+                                      void* scratch, void* stream) {
+    if (T <= 0 || !zero || !dc_work || !d_gates || (shared && !d_z)) return SFSN_EINVAL;
+    const size_t RH = (size_t)R * H, RG = (size_t)R * (shared ? 1 : 2) * H;
+    float* dzs = shared ? d_z : d_gates;  // the gradient of the (shared or per-gate) products: [T][R][G*H]
+    for (int t = T - 1; t >= 0; --t) {
+        const bool last = t == T - 1;
+        const int rc = sfsn_gsn_train_step_bwd(last ? nullptr : dzs + (t + 1) * RG, w_hh, dh_up + t * RH, nullptr,
+                                               last ? nullptr : dc_work + ((t + 1) & 1) * RH, u + t * RH, xhat ? xhat + t * RH : nullptr,
+                                               f + t * RH, g + t * RH, t ? u + (t - 1) * RH : zero, invstd ? invstd + (size_t)t * H : nullptr, bn_w,
+                                               R, H, shared, d_gates + (size_t)t * R * 2 * H, shared ? d_z + t * RH : nullptr,
+                                               dc_work + (t & 1) * RH, d_bn_w, d_bn_b, scratch, (unsigned)(T - t), stream);
+        if (rc != SFSN_OK) return rc;
+    }
+    return SFSN_OK;
 }

@@ -80,8 +80,13 @@ class GSNLayerTrainFn(torch.autograd.Function):
         fwd = L.sfsn_gsn_train_step_fwd
         scr = torch.zeros((L.sfsn_train_scratch_bytes(H) // 4,), dtype=torch.int32, device=dev)  # partial sums / arrival counters of the row blocks
         p_scr = P(scr.data_ptr())
+        seq = not fold
+        if seq:  # the T step launches enqueued by the library (one call per layer; the interpreter's share of a step was ~10 us)
+            with torch.cuda.device(dev):
+                check(L.sfsn_gsn_train_seq_fwd(P(pz), P(pw), P(pb), a_bw, a_bb, a_rm, a_rv, mom, ep, T, R, H, sh, P(pzero), P(psp), P(pu),
+                                               P(pxh) if pxh else None, P(pf), P(pg), P(pis) if pis else None, p_scr, st), "sfsn_gsn_train_seq_fwd")
         with torch.cuda.device(dev):
-            for t in range(T):
+            for t in (() if seq else range(T)):
                 rc = fwd(P(pz + t * sRG), P(pw), P(pb), P(pzero if t == 0 else psp + (t - 1) * sRH), P(pzero if t == 0 else pu + (t - 1) * sRH),
                          a_bw, a_bb, a_rm, a_rv, mom, ep, R, H, sh, P(psp + t * sRH), P(pu + t * sRH), P(pxh + t * sRH) if pxh else None,
                          P(pf + t * sRH), P(pg + t * sRH), P(pis + t * H * 4) if pis else None, p_scr, t + 1, st)
@@ -128,8 +133,15 @@ class GSNLayerTrainFn(torch.autograd.Function):
         scr = torch.zeros((L.sfsn_train_scratch_bytes(H) // 4,), dtype=torch.int32, device=dev)
         p_scr = P(scr.data_ptr())
         dh_rec = dc = None
+        seq = not fold
+        if seq:
+            dcw = torch.empty((2, R, H), **f32)
+            with torch.cuda.device(dev):
+                check(L.sfsn_gsn_train_seq_bwd(P(pw), P(pdy), P(pu), P(pxh) if bn_kernel else None, P(pf), P(pg), P(pis) if bn_kernel else None, a_bw,
+                                               T, R, H, sh, P(pzero), P(pdg), P(pdz) if shared else None, P(dcw.data_ptr()), a_dw, a_db, p_scr, st),
+                      "sfsn_gsn_train_seq_bwd")
         with torch.cuda.device(dev):
-            for t in range(T - 1, -1, -1):
+            for t in (() if seq else range(T - 1, -1, -1)):
                 last = t == T - 1
                 p_cp = P(pzero if t == 0 else pu + (t - 1) * sRH)
                 p_dzn = None if last else P(pdz + (t + 1) * sRG)   # dL/dh_t through step t+1: formed inside the step from its d_z
