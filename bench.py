@@ -251,7 +251,7 @@ def main():
         (8, 16): half / a quarter of the workgroups per forward, so that more forwards' scans fit side by side."""
         eng.rows_per_wg = g
         eng.stack_rows_fb_auto = g[0] if g[0] in (4, 8, 16) else 4
-    n_lanes = 1 if args.sequential else max(1, min(args.inflight, args.steps // 2))  # a short run cannot amortise many lanes
+    n_lanes = 1 if args.sequential else max(1, min(args.inflight, args.steps))  # (--steps 20: 12 lanes measured 36-37 M, 10 lanes 34.5-35.8 M frames/s)
 
     # ---- phase S (untimed for `value`): THE STRICT NUMBER -- one forward at a time on one stream, B clips x T frames per step,
     #      nothing else in flight.  Launch geometry = the engine's default for a forward alone (full-band stack in one
