@@ -398,3 +398,23 @@ def test_reference_plugin_loader_instantiates_the_dropins_with_bit_identical_ini
         mine.load_state_dict(a, strict=True)  # and a reference checkpoint loads strictly
     finally:
         sys.path.remove(REFERENCE)
+
+
+def test_training_entry_points_check_their_arguments_without_a_gpu():
+    """sfsn_gsn_train_step_* / _seq_*: argument errors come back as codes before anything is launched (runs on a box without a GPU)."""
+    import ctypes
+    from spiking_fullsubnet_amd import _lib
+    L = _lib.lib()
+    P, one = ctypes.c_void_p, ctypes.c_void_p(64)  # (a non-null pointer that is never dereferenced on these paths)
+    assert L.sfsn_train_scratch_bytes(0) == 0 and L.sfsn_train_scratch_bytes(24) == 0 and L.sfsn_train_scratch_bytes(224) > 0
+    # missing tensors
+    assert L.sfsn_gsn_train_step_fwd(None, one, one, one, one, None, None, None, None, 0.1, 1e-5, 4, 32, 1, one, one, None, one, one, None, None, 1, None) == _lib.SFSN_EINVAL
+    # H not a multiple of the 16-neuron tile
+    assert L.sfsn_gsn_train_step_fwd(one, one, one, one, one, None, None, None, None, 0.1, 1e-5, 4, 24, 1, one, one, None, one, one, None, None, 1, None) == _lib.SFSN_EUNSUPPORTED
+    # BatchNorm weight without its bias / outputs
+    assert L.sfsn_gsn_train_step_fwd(one, one, one, one, one, one, None, None, None, 0.1, 1e-5, 4, 32, 1, one, one, None, one, one, None, None, 1, None) == _lib.SFSN_EINVAL
+    # shared gates need d_z; no frames; no zero state
+    assert L.sfsn_gsn_train_step_bwd(None, None, one, None, None, one, None, one, one, one, None, None, 4, 32, 1, one, None, one, None, None, None, 1, None) == _lib.SFSN_EINVAL
+    assert L.sfsn_gsn_train_seq_fwd(one, one, one, None, None, None, None, 0.1, 1e-5, 0, 4, 32, 1, one, one, one, None, one, one, None, None, None) == _lib.SFSN_EINVAL
+    assert L.sfsn_gsn_train_seq_fwd(one, one, one, None, None, None, None, 0.1, 1e-5, 5, 4, 32, 1, None, one, one, None, one, one, None, None, None) == _lib.SFSN_EINVAL
+    assert L.sfsn_gsn_train_seq_bwd(one, one, one, None, one, one, None, None, 5, 4, 32, 1, one, one, None, one, None, None, None, None) == _lib.SFSN_EINVAL
