@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 10 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 11 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -120,6 +120,12 @@ typedef struct sfsn_scan_segment {
 
 int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs /* host array */, int n_segs, int T, int H, int shared,
                         int rows_per_wg /* 16, 8, 4, or 0 = choose so that the launch covers ~all CUs */, void* stream);
+
+/* The same scan for weights packed with 16 bits (sfsn_w3_pack_bits(.., 16): digit plane 0 is zero): the zero plane's matrix
+ * instructions are skipped (8 instead of 12 per tile and step; the sums are the same, so the results equal sfsn_gsn_layer_scan's
+ * on the same packed weights).  Covers what the IO-specialised scan covers (shared gates, H <= 224, 4 or 8 rows per workgroup, no
+ * membrane output); SFSN_EUNSUPPORTED otherwise -- the caller then uses sfsn_gsn_layer_scan.  BASELINE configs[2]'s 16-bit mode. */
+int sfsn_gsn_layer_scan_w16(const sfsn_scan_segment* segs /* host */, int n_segs, int T, int H, int shared, int rows_per_wg, void* stream);
 
 /* ----------------------------------------------------------------------------------------------------
  * Training-mode cell steps -- replace one iteration of GSULayer.forward's loop (NEURON:78-80) around

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
 
 
 // ---- the scan with IO-specialised waves (sfsn_scan3_dev.h): shared gates, H <= 224, one layer per launch, any segments ----------
-template <int KS, int RPW, int OUT>
+template <int KS, int RPW, int OUT, int D0 = 0>
 __global__ __launch_bounds__(1024) void gsn_scan3_kernel(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char scan_smem[];
     int s = 0;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(1024) void gsn_scan3_kernel(const ScanParams p) {
     rl.R = sg.R; rl.row0 = ((int)blockIdx.x - sg.tile0) * RPW;
     StackLink lk;
     lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = nullptr; lk.lag = 0; lk.dbg = nullptr;
-    scan3_role<KS, RPW, OUT, 0>(rl, lk, scan_smem, p.T, p.H, p.NT);
+    scan3_role<KS, RPW, OUT, 0, D0>(rl, lk, scan_smem, p.T, p.H, p.NT);
 }
 
 // ---- fused-input scan (layers >= 1, shared gates, 128 < H <= 256, 16 rows per workgroup) -----------------------------------
@@ -1736,8 +1736,17 @@ static int launch_scan(const ScanParams& p, int tiles, int out, hipStream_t st) 
 template <int KS, int RPW, int OUT>
 static int launch_scan3_variant(const ScanParams& p, int tiles, hipStream_t st) {
     using C = Scan3Cfg<KS, RPW, 0>;
-    auto kern = gsn_scan3_kernel<KS, RPW, OUT>;
     const int lds = C::lds_bytes(p.NT);
+    if (p.w16) {
+        auto k16 = gsn_scan3_kernel<KS, RPW, OUT, 1>;
+        if (lds > 64 * 1024) {
+            static int seen16[SFSN_MAX_DEVICES] = {0};
+            if (raise_lds(reinterpret_cast<const void*>(k16), lds, seen16) != SFSN_OK) return SFSN_EHIP;
+        }
+        hipLaunchKernelGGL(k16, dim3(tiles), dim3(1024), lds, st, p);
+        return hip_ok(hipGetLastError());
+    }
+    auto kern = gsn_scan3_kernel<KS, RPW, OUT>;
     if (lds > 64 * 1024) {
         static int seen[SFSN_MAX_DEVICES] = {0};
         if (raise_lds(reinterpret_cast<const void*>(kern), lds, seen) != SFSN_OK) return SFSN_EHIP;
@@ -1757,11 +1766,11 @@ static int launch_scan3(const ScanParams& p, int tiles, int out, int KS, hipStre
     return SFSN_EUNSUPPORTED;
 }
 
-extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, int T, int H, int shared, int rows_per_wg,
-                                   void* stream) {
+static int layer_scan_impl(const sfsn_scan_segment* segs, int n_segs, int T, int H, int shared, int rows_per_wg, int w16, void* stream) {
     if (!segs || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0) return SFSN_EINVAL;
     if (H % 16 != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     ScanParams p;
+    p.w16 = w16;
     // rows per workgroup: as few as it takes to spread the launch over ~all 256 CUs (see the kernel comment)
     int rows_total = 0;
     for (int i = 0; i < n_segs; ++i) rows_total += segs[i].R > 0 ? segs[i].R : 0;
@@ -1818,6 +1827,7 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
     // (at 16 rows per workgroup one loader wave issuing a DMA per output tile and step is slower than round 2's body, where
     //  every wave fetches its own tile: 1.18 against 0.95 us per step at H = 224 -- that geometry keeps the old body)
     if (shared && NT <= 14 && rpw <= 8 && (out == 2 || out == 3) && !getenv("SFSN_SCAN_V2")) return launch_scan3(p, tiles, out, KS, st);
+    if (w16) return SFSN_EUNSUPPORTED;  // only the scan3 kernels have the two-plane form: the caller uses sfsn_gsn_layer_scan
     int NW, TPW;
     if (rpw == 4 && out <= 7) out |= 512;  // repacked-epilogue variant (see scan_body)
     if (shared) {
@@ -1837,12 +1847,23 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
     return SFSN_EUNSUPPORTED;
 }
 
+extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, int T, int H, int shared, int rows_per_wg,
+                                   void* stream) {
+    return layer_scan_impl(segs, n_segs, T, H, shared, rows_per_wg, 0, stream);
+}
+
+extern "C" int sfsn_gsn_layer_scan_w16(const sfsn_scan_segment* segs, int n_segs, int T, int H, int shared, int rows_per_wg,
+                                       void* stream) {
+    return layer_scan_impl(segs, n_segs, T, H, shared, rows_per_wg, 1, stream);
+}
+
 extern "C" int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, int n_segs, int T, int H,
                                          void* stream) {
     if (!segs || !fin || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0) return SFSN_EINVAL;
     if (H % 16 != 0 || H <= 128 || H > 256) return SFSN_EUNSUPPORTED;  // two output tiles per wave: 8 < H/16 <= 16
     ScanParams p;
     p.rpw = 16;
+    p.w16 = 0;
     int tiles = 0;
     const int out = 2 | (segs[0].spikes_f32 ? 1 : 0);
     for (int i = 0; i < n_segs; ++i) {
@@ -1885,6 +1906,7 @@ extern "C" int sfsn_gsn_layer_scan_fused_x(const sfsn_scan_segment* segs, const 
     if (H % 16 != 0 || H <= 128 || H > 256) return SFSN_EUNSUPPORTED;
     ScanParams p;
     p.rpw = 16;
+    p.w16 = 0;
     int tiles = 0, imax = 0;
     const int out = 2 | (segs[0].spikes_f32 ? 1 : 0);
     for (int i = 0; i < n_segs; ++i) {

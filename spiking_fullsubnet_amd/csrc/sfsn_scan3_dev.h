@@ -129,7 +129,9 @@ struct Scan3Role {
 
 // FLG bit 0: the input term is written by other workgroups of this launch (gated on lk.in, sc1 loads); bit 1: the int8 spikes
 // feed other workgroups of this launch (sc1 stores, progress in lk.out).  OUT bit 0: fp32 spikes, bit 1: int8 spikes.
-template <int KS, int RPW, int OUT, int FLG>
+// D0 = 1: the weights were packed with 16 bits (sfsn_w3_pack_bits): digit plane 0 is zero and its products are skipped -- 8 instead
+// of 12 matrix instructions per tile and step, the same sums.
+template <int KS, int RPW, int OUT, int FLG, int D0 = 0>
 __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink& lk, char* smem, int T, int H, int NT, int exp_flags = 0) {
     using C = Scan3Cfg<KS, RPW, FLG>;
     constexpr int LDH = C::LDH, HP = C::HP, D = C::D, NV = C::NV;
@@ -207,11 +209,6 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
             }
             if constexpr (GATED) stop = flag[t & 1];  // written by the loader during step t-1 (or before)
             v4i a[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
-#ifdef SFSN_EXP_2PLANES  // timing experiment (wrong results unless the weights were packed with 16 bits: plane 0 is then zero): what
-            constexpr int D0 = 1;  // would a 16-bit-weight fast path that skips the zero plane buy?  
-#else
-            constexpr int D0 = 0;
-#endif
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll

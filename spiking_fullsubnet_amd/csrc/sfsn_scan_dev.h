@@ -44,6 +44,7 @@ struct ScanParams {
     ScanSegDev seg[SFSN_MAX_SEGMENTS];
     int nseg, T, H, NT;  // NT = H / 16 output tiles per gate
     int rpw;             // rows per workgroup (16, 8 or 4): fewer rows per CU = less HBM traffic per CU per step
+    int w16;             // 1: 16-bit weights, digit plane 0 is zero (sfsn_gsn_layer_scan_w16): the scan3 kernels skip it
 };
 
 __device__ __forceinline__ float recombine3(int a0, int a1, int a2) {

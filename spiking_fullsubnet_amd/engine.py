@@ -199,6 +199,7 @@ class Engine:
         if weight_bits not in (24, 16):
             raise ValueError("weight_bits must be 24 (exact) or 16")
         self.weight_bits = weight_bits
+        self.w16_fast = os.environ.get("SFSN_W16_FAST", "1") != "0"  # 16-bit mode: skip the zero digit plane in the scans that can
         self.spec = spec
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -360,7 +361,13 @@ class Engine:
             sg.spikes_i8 = ctypes.c_void_p(s8s[i].data_ptr() + t0 * R * HP)
             sg.R = R
         with self.timed("scan:" + tag, st):
-            check(L.sfsn_gsn_layer_scan(segs, len(seqs), nt, H, int(spec.shared), rpw, st), "sfsn_gsn_layer_scan")
+            rc = _lib.SFSN_EUNSUPPORTED
+            if self.weight_bits == 16 and self.w16_fast:  # the two-plane scan where the library has it (same results)
+                rc = L.sfsn_gsn_layer_scan_w16(segs, len(seqs), nt, H, int(spec.shared), rpw, st)
+                if rc not in (0, _lib.SFSN_EUNSUPPORTED):
+                    check(rc, "sfsn_gsn_layer_scan_w16")
+            if rc != 0:
+                check(L.sfsn_gsn_layer_scan(segs, len(seqs), nt, H, int(spec.shared), rpw, st), "sfsn_gsn_layer_scan")
 
     def _fusable(self, seqs, rpw, want_membrane) -> bool:
         """Layers >= 1 can take their input term inside the scan (sfsn_gsn_layer_scan_fused): shared gates, 128 < H <= 256,

@@ -1141,6 +1141,30 @@ def test_errors_match_reference_behaviour():
         mt.streaming(batch=1)
 
 
+def test_sixteen_bit_weights_take_the_two_plane_scan_with_the_same_results():
+    """weight_bits = 16 leaves digit plane 0 of every packed matrix zero; sfsn_gsn_layer_scan_w16 skips its matrix instructions in the
+    scans it covers (8 instead of 12 per tile and step).  Same sums: the forward equals the three-plane kernels' on the same weights."""
+    kw, seed, B, T = rw.LIVE_M, 5, 4, 180
+    model = build_module("live", kw, rw.live_state_dict(kw, seed))
+    model.weight_bits = 16
+    wave = torch.from_numpy(rw.synth_wave(B, T + 1, seed)).to(DEV)
+    stft = torch.stft(wave, 512, 128, 512, window=torch.hann_window(512, device=DEV), return_complex=True, pad_mode="constant")[..., :T].contiguous()
+    eng = model.engine()
+    assert eng.weight_bits == 16
+    eng.stack_scan = False  # per-layer launches: the path that has the two-plane form
+    res = {}
+    for fast in (False, True):
+        eng.w16_fast = fast
+        eng.launches = {}
+        res[fast] = eng.forward_stft(stft)
+        torch.cuda.synchronize()
+    a, b = res[False], res[True]
+    assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(b["enh_stft"]))
+    for x, y in zip(a["fb_all"] + sum(a["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])):
+        assert torch.equal(x, y)
+    assert float(b["sb_all"][0][2].mean()) > 0.01  # (the cells do spike)
+
+
 def test_fused_scan_entry_points_reject_what_they_do_not_cover(hip):
     """sfsn_gsn_layer_scan_fused / _fused_x return SFSN_EUNSUPPORTED (the caller then uses the two-call form) or SFSN_EINVAL."""
     from spiking_fullsubnet_amd._lib import FusedInput, FusedX, ScanSegment, SFSN_EINVAL, SFSN_EUNSUPPORTED
