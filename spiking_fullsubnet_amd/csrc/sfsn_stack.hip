@@ -15,6 +15,9 @@
 //          (shared gates, H <= 256: both weight matrices fit one CU)
 //   PROJ   the time-parallel input product S.W_ih^T + b of a layer >= 1 whose two matrices do not fit one CU together
 //          (H = 320, the full-band model): 16 rows per workgroup, no recurrence, feeds a ZIN role
+//   FUSED3 (round 4) the IO-wave scan of a layer >= 1 with its input product inside, batched over two frames in the MFMA columns
+//          8 rows leave idle (sfsn_scan3i_dev.h): H <= 224, shared gates, 8 rows per workgroup; what H <= 224 stacks without
+//          input-term buffers run (the 8-wave FUSED role keeps 224 < H <= 256 and other row counts)
 // Arithmetic is that of the per-layer kernels, instruction for instruction: results are bit-identical to
 // sfsn_spike_proj + sfsn_gsn_layer_scan (tested).
 #include <hip/hip_runtime.h>
@@ -24,11 +27,13 @@
 #include "sfsn.h"
 #include "sfsn_scan_dev.h"
 #include "sfsn_scan3_dev.h"
+#include "sfsn_scan3i_dev.h"
 
 #define STACK_MAX_ROLES 24
 #define STACK_ZIN 0
 #define STACK_FUSED 1
 #define STACK_PROJ 2
+#define STACK_FUSED3 3  // the IO-wave scan with its input product inside (sfsn_scan3i_dev.h): wide kernel, 8 rows per workgroup
 
 struct StackRoleDev {
     const int8_t* w_hh;
@@ -679,7 +684,21 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         lk.n_in = b1 - b0 + 1;
     }
     const int T = p.T, H = p.H, NT = p.NT;
-    if (rl.kind == STACK_PROJ) {
+    if (rl.kind == STACK_FUSED3) {
+        Scan3iRole ri;
+        ri.spikes_in = rl.spikes_in; ri.w_ih = rl.w_ih; ri.w_ih_dq = rl.w_ih_dq; ri.w_hh = rl.w_hh; ri.w_dq = rl.w_dq; ri.bias = rl.bias;
+        ri.bn_alpha = rl.bn_alpha; ri.bn_beta = rl.bn_beta; ri.h_state = rl.h_state; ri.c_state = rl.c_state;
+        ri.spikes_f32 = rl.spikes_f32; ri.spikes_i8 = rl.spikes_i8; ri.R = rl.R; ri.row0 = blk * 8;
+        const bool tl = (H & 63) != 0 && (H & 63) <= 32;  // the k tail as one 16x16x32 step
+        // (KS = 4 with at most 14 tiles is H = 208 or 224: always the tail form -- four full k-steps of both matrices do not fit)
+        if (rl.pub) {
+            if (tl) scan3i_role<KS, 1, OUT, 3>(ri, lk, scan_smem, T, H, NT, p.exp_flags);
+            else if constexpr (KS < 4) scan3i_role<KS, 0, OUT, 3>(ri, lk, scan_smem, T, H, NT, p.exp_flags);
+        } else {
+            if (tl) scan3i_role<KS, 1, OUT, 1>(ri, lk, scan_smem, T, H, NT, p.exp_flags);
+            else if constexpr (KS < 4) scan3i_role<KS, 0, OUT, 1>(ri, lk, scan_smem, T, H, NT, p.exp_flags);
+        }
+    } else if (rl.kind == STACK_PROJ) {
         if (NT <= 14 && !p.v2) {
             Proj3Role r3;
             r3.spikes_in = rl.spikes_in; r3.w_ih = rl.w_ih; r3.w_ih_dq = rl.w_ih_dq; r3.bias = rl.bias; r3.zin = rl.zin;
@@ -816,8 +835,14 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
             if (!segs[l * n_segs + i].zin) wide = false;
     if (n_layers == 1 && fused) wide = true;
     if (getenv("SFSN_STACK_NARROW")) wide = false;
+    // round 4: no input-term buffers, H <= 224, 8 rows per workgroup in the layers >= 1: the wide kernel with FUSED3 roles (the input
+    // product inside the IO-wave scan) instead of the 8-wave FUSED roles (SFSN_STACK_FUSED8=1 keeps those: A/B runs)
+    bool inscan = fused && !wide && NT <= 14 && n_layers >= 2 && !getenv("SFSN_STACK_FUSED8") && !getenv("SFSN_SCAN_V2");
+    for (int l = 1; l < n_layers && inscan; ++l)
+        if ((rows_per_wg ? rows_per_wg[l] : 8) != 8) inscan = false;
+    if (inscan) wide = true;
     if (wide) fused = false;
-    const int roles_per_layer = fused ? 1 : 2;
+    const int roles_per_layer = (fused || inscan) ? 1 : 2;
     if (n_segs * (1 + (n_layers - 1) * roles_per_layer) > STACK_MAX_ROLES) return SFSN_EUNSUPPORTED;
     if (lag < 0) return SFSN_EINVAL;
     StackParams p;
@@ -842,10 +867,10 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
                 if (!f.w_ih || !f.w_ih_dq || !aligned16(f.w_ih)) return SFSN_EINVAL;
                 if (f.spikes_in != segs[(l - 1) * n_segs + i].spikes_i8) return SFSN_EINVAL;  // the layer below, same segment
             }
-            if (l == 0 || !fused) {
+            if (l == 0 || !(fused || inscan)) {
                 if (!s.zin) return SFSN_EINVAL;  // layer 0: the precomputed input term; H > 256: the PROJ role's output buffer
             }
-            if (l > 0 && !fused) {  // PROJ role first (lower block indices than the scan it feeds)
+            if (l > 0 && !fused && !inscan) {  // PROJ role first (lower block indices than the scan it feeds)
                 StackRoleDev& r = p.role[nroles];
                 r = StackRoleDev{};
                 r.bias = s.bias; r.zin = const_cast<float*>(s.zin); r.spikes_in = f.spikes_in; r.w_ih = f.w_ih; r.w_ih_dq = f.w_ih_dq;
@@ -871,8 +896,8 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
             r.pub = last ? 0 : 1;
             if (l == 0) {
                 r.kind = STACK_ZIN; r.src = -1; r.src_rpw = rpw;
-            } else if (fused) {
-                r.kind = STACK_FUSED; r.spikes_in = f.spikes_in; r.w_ih = f.w_ih; r.w_ih_dq = f.w_ih_dq;
+            } else if (fused || inscan) {
+                r.kind = inscan ? STACK_FUSED3 : STACK_FUSED; r.spikes_in = f.spikes_in; r.w_ih = f.w_ih; r.w_ih_dq = f.w_ih_dq;
                 r.src = prev_role[i]; r.src_rpw = p.role[prev_role[i]].rpw;
             } else {
                 r.kind = STACK_ZIN; r.src = prev_role[i]; r.src_rpw = wide ? 32 : 16;
@@ -891,6 +916,11 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
                     const int dfit = 65536 / (((rpw * 14 * 4 + 63) / 64) * 1024);
                     const int n3 = (dfit < 9 ? dfit : 9) * (((rpw * NT * 4 + 63) / 64) * 1024) + 2 * 16 * (HP + 32) + 16;
                     if (n3 > need) need = n3;
+                }
+                if (r.kind == STACK_FUSED3) {  // + the input-spike ring, two digit planes of W_ih and the product's constants
+                    const int n3i = KS == 1 ? Scan3iCfg<1, 3>::lds_bytes(NT) : KS == 2 ? Scan3iCfg<2, 3>::lds_bytes(NT)
+                                  : KS == 3 ? Scan3iCfg<3, 3>::lds_bytes(NT) : Scan3iCfg<4, 3>::lds_bytes(NT);
+                    if (n3i > need) need = n3i;
                 }
             } else if (r.kind == STACK_FUSED) {
                 switch (KS) {

@@ -92,6 +92,12 @@ STACKS = [  # I, H, layers, rows per segment, T, rows per workgroup
     (38, 224, 2, [40, 9, 17], 50, 8), (38, 224, 3, [33], 41, 4), (64, 320, 2, [21], 37, 4), (64, 320, 3, [35, 6], 30, 8),
     (12, 32, 3, [5, 20], 33, 16), (38, 160, 2, [64], 64, 8), (30, 256, 2, [18, 3], 26, 16), (64, 240, 4, [7], 29, 4),
     (20, 96, 2, [1], 19, 8),
+    # round 4: layers >= 1 at 8 rows per workgroup without an input-term buffer run the FUSED3 role (input product inside the
+    # IO-wave scan, sfsn_scan3i_dev.h): every k-step form (H mod 64 in (0, 32]: the 32-wide tail step; otherwise full steps), three
+    # layers (a FUSED3 role that publishes), T = 1 / 2 / odd, ragged row tiles
+    (38, 224, 3, [33, 8], 41, 8), (16, 192, 2, [19], 23, 8), (24, 128, 2, [9], 31, 8), (12, 48, 2, [5, 20], 33, 8),
+    (12, 64, 3, [11], 7, 8), (38, 224, 2, [8], 1, 8), (38, 224, 2, [13], 2, 8), (10, 16, 2, [3], 9, 8), (38, 208, 2, [24], 21, 8),
+    (38, 176, 2, [10], 12, 8), (38, 144, 4, [17], 15, 8),
 ]
 
 
@@ -124,6 +130,24 @@ def test_stack_scan_vs_oracle_and_per_layer_calls(hip, I, H, nl, Rs, T, rpw, wid
             np.testing.assert_array_equal(got[l][i][0], spk)
             np.testing.assert_array_equal(got[l][i][2], hT)
             np.testing.assert_array_equal(got[l][i][3], cT)
+
+
+def test_fused3_role_equals_the_eight_wave_fused_role(hip, monkeypatch):
+    """A/B of the two ways a stack without input-term buffers runs its layers >= 1 at 8 rows per workgroup: the FUSED3 role
+    (round 4: 16 waves, input product batched over two frames) against the 8-wave FUSED role it replaced (SFSN_STACK_FUSED8=1),
+    full-size sub-band geometry: every word equal."""
+    rng = np.random.default_rng(17)
+    I, H, nl, Rs, T = 38, 224, 2, [512, 192, 128], 96
+    cells = _cells(rng, I, H, nl)
+    zin0 = [rng.standard_normal((T, R, H)).astype(np.float32) * 0.5 for R in Rs]
+    new = run_stack(hip, zin0, cells, T, H, 8, lag=8, wide=False)
+    monkeypatch.setenv("SFSN_STACK_FUSED8", "1")
+    old = run_stack(hip, zin0, cells, T, H, 8, lag=8, wide=False)
+    monkeypatch.delenv("SFSN_STACK_FUSED8")
+    for l in range(nl):
+        for i in range(len(Rs)):
+            for k in range(4):
+                np.testing.assert_array_equal(new[l][i][k], old[l][i][k])
 
 
 def _spike_proj(hip, s8, w, H):
