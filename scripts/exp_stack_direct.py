@@ -53,7 +53,7 @@ def run(H, nl, rpw, lag, T=1000, Rs=None, reps=5):
         blk, roles = 0, []
         for l in range(nl):
             for i, R in enumerate(Rs):
-                if l > 0:
+                if l > 0 and not os.environ.get('NOZIN'):
                     n = (R + 31) // 32; roles.append((f"PROJ l{l} seg{i}", blk, blk + n)); blk = (blk + n + 7) & ~7
                 n = (R + rpw - 1) // rpw; roles.append((f"scan l{l} seg{i}", blk, blk + n)); blk = (blk + n + 7) & ~7
         dbg = w[blk + 2: blk + 2 + 4 * blk].reshape(-1, 4); t0 = min(dbg[b0:b1, 2].min() for _, b0, b1 in roles)

@@ -30,6 +30,23 @@
 //   * publishing: the write-through int8 stores take ~5 us to retire and vmcnt retires in order, so they get a queue of their
 //     own (the storer wave: 2 stores per frame, 8 frames in flight) and the fp32 spike stores move to the loader wave, whose
 //     ring is deep enough that the DMA it waits for is older than any store it has issued in the last 4 steps.
+#ifndef SFSN_S3_LSF
+#define SFSN_S3_LSF 1  // 1: a publishing role's fp32 spikes are written by the loader wave (its storer's queue holds the write-through int8 stores only)
+#endif
+#ifndef SFSN_S3_CWF
+// 1: the COMPUTE waves write the fp32 spikes themselves, one small store per wave and step (the 64-byte row segments of a tile; the
+// L2 merges them into lines) -- a round-4 experiment, OFF.  Why it was tried: a wave has at most 63 memory operations in flight and
+// a store takes 4-6 us to retire here, so an 8-row role whose stores all leave through one or two IO waves cannot go below
+// (stores per frame) x (retire time) / 63 per step: the publishing layer-1 role of a pair launch runs at 0.9 us per step on an
+// idle chip whichever IO wave carries the seven fp32 stores of a frame (scripts/exp_stack_direct.py, ROWS=64), and the plain
+// 8-row scan (nine stores per frame through the storer) sits at 0.69.  With fourteen store queues the publishing role ran at
+// 0.63 -- but the compute-bound roles lost far more than that: one VMEM store per compute wave and step in front of the step
+// barrier cost them 0.1-0.2 us per step, at the top of the next step (under the LDS wait) 0.5-0.9 us (4-row scan 0.55 -> 1.4).
+#define SFSN_S3_CWF 0
+#endif
+#ifndef SFSN_S3_PFMAX
+#define SFSN_S3_PFMAX 8   // frames of a publishing storer's stores that may be in flight (24 measured the same: the limit is elsewhere)
+#endif
 template <int KS, int RPW, int FLG = 0>
 struct Scan3Cfg {
     static constexpr int HP = KS * 64, LDH = HP + 32;
@@ -40,7 +57,7 @@ struct Scan3Cfg {
     __host__ __device__ static constexpr int slot_bytes(int NT) { return pieces(NT) * 1024; }
     static constexpr int MAXP = (RPW * 14 * 4 + 63) / 64;  // pieces at NT = 14
     static constexpr bool GATED = (FLG & 1) != 0, PUB = (FLG & 2) != 0;
-    static constexpr int DWANT = PUB ? 6 : (GATED ? 9 : 4);
+    static constexpr int DWANT = (PUB && SFSN_S3_LSF) ? 6 : ((GATED || PUB) ? 9 : 4);
     static constexpr int DFIT = 65536 / (MAXP * 1024);       // LDS-DMA destinations stay below 64 KiB
     static constexpr int D = DWANT < DFIT ? DWANT : DFIT;    // input-term ring depth (frames)
     __host__ __device__ static constexpr int hbuf_off(int NT) { return D * slot_bytes(NT); }
@@ -48,6 +65,27 @@ struct Scan3Cfg {
     __host__ __device__ static constexpr int lds_bytes(int NT) { return flag_off(NT) + 16; }
     static constexpr int NV = RPW == 16 ? 4 : RPW == 8 ? 2 : 1;  // live values per lane and tile
 };
+
+// fp32 spikes of a compute wave: NV consecutive floats per lane at byte offset `off` of the frame's block (saddr form: the frame base
+// is wave-uniform).  Fire and forget: compute waves never wait on vmcnt.  Issued at the TOP of the next step, while the wave waits
+// for its state fragments from LDS anyway: a store in front of the step barrier cost the compute-bound roles 0.1-0.2 us per step
+// (the issue of a VMEM instruction, address + data registers through the texture path, sits on every wave's way to the barrier).
+template <int NV>
+__device__ __forceinline__ void s3_store_spikes(const float* base_uniform, unsigned off, const float (&sp)[NV]) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base_uniform);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned long long base = ((unsigned long long)hi << 32) | lo;
+    if constexpr (NV == 1) {
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(sp[0]), "s"(base));
+    } else if constexpr (NV == 2) {
+        typedef float v2f_ __attribute__((ext_vector_type(2)));
+        const v2f_ d = {sp[0], sp[1]};
+        asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(d), "s"(base));
+    } else {
+        const v4f d = {sp[0], sp[1], sp[2], sp[3]};
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base));  // (see store16_sc1)
+    }
+}
 
 // The gate of a loader wave: frames [0, need) published by ALL producers in lk.in[0 .. n_in)?  Polled by lane 0 with relaxed
 // agent-scope loads and s_sleep between polls; the other waves of the workgroup never see the counters.  `avail` caches the
@@ -136,7 +174,11 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
     using C = Scan3Cfg<KS, RPW, FLG>;
     constexpr int LDH = C::LDH, HP = C::HP, D = C::D, NV = C::NV;
     constexpr bool GATED = (FLG & 1) != 0, PUB = (FLG & 2) != 0;
-    constexpr bool LSF = PUB && (OUT & 1);  // the loader wave also writes the fp32 spikes (see Scan3Cfg)
+#ifndef SFSN_S3_LSF
+#define SFSN_S3_LSF 0
+#endif
+    constexpr bool CWF = SFSN_S3_CWF && (OUT & 1);  // the compute waves write the fp32 spikes (see SFSN_S3_CWF)
+    constexpr bool LSF = !CWF && SFSN_S3_LSF && PUB && (OUT & 1);  // the loader wave also writes the fp32 spikes (round 3; see Scan3Cfg)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
@@ -151,12 +193,13 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
     __syncthreads();
     for (int idx = tid; idx < RPW * (H / 4); idx += 1024) {
         const int rr = idx / (H / 4), j4 = (idx - rr * (H / 4)) * 4;
-        if (row0 + rr < R) {
-            const v4f h = *reinterpret_cast<const v4f*>(rl.h_state + (size_t)(row0 + rr) * H + j4);
-            const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
-                                (h.w > 0.5f ? 0x1000000u : 0u);
-            *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
-        }
+        // (rows past R are duplicates of row R-1 in every value -- input term, membrane, last spikes --, so that whatever a lane of
+        //  such a row stores goes to row R-1's address with row R-1's value)
+        const int rsrc = row0 + rr < R ? row0 + rr : R - 1;
+        const v4f h = *reinterpret_cast<const v4f*>(rl.h_state + (size_t)rsrc * H + j4);
+        const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
+                            (h.w > 0.5f ? 0x1000000u : 0u);
+        *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
     }
 
     if (wave < NT) {
@@ -185,9 +228,14 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
         const unsigned zoff = (unsigned)(((ct * 4 + q) * RPW + row) * 16 + sub * 4);  // my input-term bytes within a ring slot
         const unsigned boff = (unsigned)(n * LDH + q * 16);
         const unsigned hoff = (unsigned)(row * LDH + cj);
+        const unsigned foff = (unsigned)(((size_t)grow * H + cj) * 4);  // my fp32 spikes within a frame of [T][R][H] (R * H * 4 < 4 GiB)
+        const size_t fframe = (size_t)R * H;
         __syncthreads();                       // initial state in hbuf[0]
         __builtin_amdgcn_s_barrier();          // the loader's prologue frames have landed
         int stop = 0;
+        float sp[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) sp[j] = 0.f;
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
@@ -195,6 +243,7 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
             v4i b[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(hc + boff + ks * 64);
+            if constexpr (CWF) if (t > 0) s3_store_spikes<NV>(rl.spikes_f32 + (size_t)(t - 1) * fframe, foff, sp);  // (under the LDS wait)
             const char* zp = smem + (t % D) * SLOT + zoff;
             float z[NV];
             if constexpr (NV == 4) {
@@ -245,6 +294,7 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
                 const float y = __builtin_fmaf(m, al[j], be[j]);
                 c[j] = y;
                 pk |= (y >= 0.0f) ? (1u << (8 * j)) : 0u;
+                sp[j] = (y >= 0.0f) ? 1.0f : 0.0f;
             }
             if constexpr (NV == 4) *reinterpret_cast<unsigned*>(hn + hoff) = pk;
             else if constexpr (NV == 2) *reinterpret_cast<unsigned short*>(hn + hoff) = (unsigned short)pk;
@@ -253,6 +303,7 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
             __builtin_amdgcn_s_barrier();
             if constexpr (GATED) if (__builtin_amdgcn_readfirstlane(stop)) break;
         }
+        if constexpr (CWF) if (T > 0 && !(GATED && __builtin_amdgcn_readfirstlane(stop))) s3_store_spikes<NV>(rl.spikes_f32 + (size_t)(T - 1) * fframe, foff, sp);
         // final state
         const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
         if (live) {
@@ -330,7 +381,7 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
         // ================================================= storer wave =================================================
         constexpr int MAX8 = (RPW * KS * 4 + 63) / 64;
         constexpr int nu8 = RPW * (HP / 16), ns8 = (nu8 + 63) / 64;
-        constexpr bool F32 = (OUT & 1) && !LSF;  // (when this role publishes, the loader wave writes the fp32 spikes)
+        constexpr bool F32 = (OUT & 1) && !LSF && !CWF;  // (else the loader wave or the compute waves write the fp32 spikes)
         S3FlushF<RPW, LDH> ff;
         if constexpr (F32) ff.init(lane, row0, R, H);
         int l8[MAX8];
@@ -361,7 +412,7 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
         // counts on at least this many per frame being in the queue (an instruction without live lanes may or may not be issued)
         const int rows_live = (R - row0 < RPW) ? R - row0 : RPW;
         const int spf = (F32 ? ff.nsf : 0) + ((OUT & 2) ? (rows_live * (HP / 16) + 63) / 64 : 0);
-        const int pf = spf > 0 ? (62 / spf < 8 ? 62 / spf : 8) : 8;  // frames of my stores that may be in flight
+        const int pf = spf > 0 ? (62 / spf < SFSN_S3_PFMAX ? 62 / spf : SFSN_S3_PFMAX) : 8;  // frames of my stores that may be in flight
         __syncthreads();
         __builtin_amdgcn_s_barrier();
         int stop = 0;

@@ -70,7 +70,8 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
     using C = Scan3iCfg<KS, FLG>;
     constexpr int RPW = 8, LDH = C::LDH, HP = C::HP, D = C::D, A = C::A, SLOT = C::SLOT, NP = C::NP, NCH = C::NCH;
     constexpr bool GATED = C::GATED, PUB = C::PUB;
-    constexpr bool LSF = PUB && (OUT & 1);  // the loader wave also writes the fp32 spikes (see Scan3Cfg)
+    constexpr bool CWF = SFSN_S3_CWF && (OUT & 1);  // the compute waves write the fp32 spikes (see SFSN_S3_CWF)
+    constexpr bool LSF = !CWF && SFSN_S3_LSF && PUB && (OUT & 1);
     constexpr int KSF = TL ? KS - 1 : KS;   // full 64-wide k-steps
     constexpr int NK = KS;                  // k-steps in all
     constexpr int NKA = NK < 2 ? NK : 2;    // k-steps [0, NKA) of an input product run in the even step, the rest (at most two) in the odd one
@@ -97,12 +98,11 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
     __syncthreads();
     for (int idx = tid; idx < RPW * (H / 4); idx += 1024) {
         const int rr = idx / (H / 4), j4 = (idx - rr * (H / 4)) * 4;
-        if (row0 + rr < R) {
-            const v4f h = *reinterpret_cast<const v4f*>(rl.h_state + (size_t)(row0 + rr) * H + j4);
-            const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
-                                (h.w > 0.5f ? 0x1000000u : 0u);
-            *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
-        }
+        const int rsrc = row0 + rr < R ? row0 + rr : R - 1;  // (rows past R duplicate row R-1 in every value: see scan3_role)
+        const v4f h = *reinterpret_cast<const v4f*>(rl.h_state + (size_t)rsrc * H + j4);
+        const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
+                            (h.w > 0.5f ? 0x1000000u : 0u);
+        *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
     }
 
     if (wave < NT) {
@@ -144,6 +144,8 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
         for (int ks = 0; ks < KS; ++ks) soff[ks] = (unsigned)((n >> 3) * SLOT + row * 256 + ((ks * 4 + q + 2 * row) & 15) * 16);
         const unsigned woff = (unsigned)(C::WIH_OFF + (ct * KS) * 1024 + lane * 16);
         const unsigned cqoff = (unsigned)(C::csti_off(NT) + (cj >> 1) * 16);
+        const unsigned foff = (unsigned)(((size_t)grow * H + cj) * 4);  // my fp32 spikes within a frame of [T][R][H]
+        const size_t fframe = (size_t)R * H;
         float zc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // the input term of my two neurons at the two frames of the current pair
         v4i e[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
         v4i pfb[2], pfw0[2], pfw1[2];
@@ -215,6 +217,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
         if constexpr (NK > 2) { pf_load(0, 2, 0); pf_load(0, 2, 1); pf_mfma(2); }
         in_finish(*reinterpret_cast<const v4f*>(smem + cqoff));
         int stop = 0;
+        float sp[2] = {0.f, 0.f};
 #pragma unroll 1
         for (int t2 = 0; t2 < T && !stop; t2 += 2) {
 #pragma unroll
@@ -229,6 +232,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
                 for (int ks = 0; ks < KSF; ++ks) b[ks] = *reinterpret_cast<const v4i*>(hc + boff + ks * 64);
                 long bt = 0;
                 if constexpr (TL) bt = *reinterpret_cast<const long*>(hc + boft);
+                if constexpr (CWF) if (t > 0) s3_store_spikes<2>(rl.spikes_f32 + (size_t)(t - 1) * fframe, foff, sp);  // (under the LDS wait)
                 v4i a[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
                 if constexpr (TL) {
                     // The 32-wide tail step FIRST, from zero accumulators, as one block the compiler cannot reorder, with the wait
@@ -277,6 +281,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
                     const float y = __builtin_fmaf(m, al[j], be[j]);
                     c[j] = y;
                     pk |= (y >= 0.0f) ? (1u << (8 * j)) : 0u;
+                    sp[j] = (y >= 0.0f) ? 1.0f : 0.0f;
                 }
                 *reinterpret_cast<unsigned short*>(hn + hoff) = (unsigned short)pk;
                 __builtin_amdgcn_sched_barrier(0);
@@ -293,6 +298,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
                 }
             }
         }
+        if constexpr (CWF) if (T > 0 && !stop) s3_store_spikes<2>(rl.spikes_f32 + (size_t)(T - 1) * fframe, foff, sp);
         // final state
         const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
         if (live) {
@@ -366,7 +372,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
         // ================================================= storer wave (scan3_role's) =================================================
         constexpr int MAX8 = (RPW * KS * 4 + 63) / 64;
         constexpr int nu8 = RPW * (HP / 16), ns8 = (nu8 + 63) / 64;
-        constexpr bool F32 = (OUT & 1) && !LSF;
+        constexpr bool F32 = (OUT & 1) && !LSF && !CWF;
         S3FlushF<RPW, LDH> ff;
         if constexpr (F32) ff.init(lane, row0, R, H);
         int l8[MAX8];
@@ -395,7 +401,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
         };
         const int rows_live = (R - row0 < RPW) ? R - row0 : RPW;
         const int spf = (F32 ? ff.nsf : 0) + ((OUT & 2) ? (rows_live * (HP / 16) + 63) / 64 : 0);
-        const int pf = spf > 0 ? (62 / spf < 8 ? 62 / spf : 8) : 8;  // frames of my stores that may be in flight
+        const int pf = spf > 0 ? (62 / spf < SFSN_S3_PFMAX ? 62 / spf : SFSN_S3_PFMAX) : 8;  // frames of my stores that may be in flight
         __syncthreads();
         __builtin_amdgcn_s_barrier();
         int stop = 0;

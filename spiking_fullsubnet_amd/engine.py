@@ -234,6 +234,7 @@ class Engine:
         _ss = os.environ.get('SFSN_STACK_SCAN', 'auto')
         self.stack_scan = "auto" if _ss == "auto" else bool(int(_ss))
         self.stack_rows_fb_auto = int(os.environ.get("SFSN_FB_STACK_ROWS", "4"))  # rows per workgroup of the full-band stack under "auto"
+        self.pair_scan = os.environ.get("SFSN_PAIR_SCAN", "1") != "0"  # H <= 224 stacks as one launch of FUSED3 roles (see _stack_choice)
         self.stack_rows_per_wg = {"fb": 4, "sb": 8}  # rows per workgroup of every layer of a stack: sum of workgroups <= CUs
         self.stack_lag = 16
         # full-band / sub-band overlap of ONE forward: the sequence is cut into this many chunks, the full-band model runs them
@@ -447,6 +448,15 @@ class Engine:
         if H > 256:  # the full-band model: few rows, PROJ + gated scan roles
             rp = self.stack_rows_fb_auto
             return (rows + rp - 1) // rp * nl + (rows + 15) // 16 <= n_cu, False, rp
+        # round 4: H <= 224 stacks without input-term buffers run their layers >= 1 as FUSED3 roles (the input product inside the
+        # 8-row IO-wave scan): all layers side by side in one launch, no fp32 input term for the layers >= 1.  Every workgroup of
+        # the launch has to be resident beside the full-band stack of the same forward (<= 40 workgroups), and the forward has
+        # to be alone on the chip -- `rows_per_wg` (0 or 8 for the sub-band models) says so: bench.py's timed region, with a
+        # dozen forwards in flight, sets 16 and keeps its per-layer launches.  Measured at B = 64, T = 1000 (scripts/exp_pair.py):
+        # 1.03 ms against 1.43 (scan3 at 4 rows + sfsn_spike_proj), 1.72 (8-wave FUSED roles), 2.4 (PROJ roles).
+        wgs8 = nl * sum((R + 7) // 8 for R in Rs)
+        if self.pair_scan and H <= 224 and self.rows_per_wg[1] in (0, 8) and wgs8 <= n_cu - 40:
+            return True, False, 8
         if rows <= n_cu:       # every layer's workgroups at 8 rows + the PROJ workgroups fit several times over
             return True, True, 8
         if rows <= 2 * n_cu:   # 8 rows per workgroup: both layers side by side still fit
