@@ -272,10 +272,12 @@ def main():
         t_s = eng.timer_summary()
         eng.timers = None
         eng.overlap_chunks = ov
+        sb_how = ("sub-band layers side by side in one launch (layer 2 forms its input product inside the scan)" if "stack:sb" in t_s and "scan:sb" not in t_s
+                  else "sub-band layers as full-chip launches")
         single = dict(ms_per_step=round(1e3 * dt_a / ka, 4), value=round(world * B * T * ka / dt_a, 1), steps=ka, in_flight=1,
-                      schedule=f"full-band stack in one layer-pipelined launch; sub-band layers as full-chip launches; the sequence in "
+                      schedule=f"full-band stack in one layer-pipelined launch; {sb_how}; the sequence in "
                                f"{eng.overlap_chunks} chunks with the sub-band models one chunk behind the full-band model on a second stream"
-                      if eng.overlap_chunks > 1 else "full-band stack in one layer-pipelined launch; sub-band layers as full-chip launches")
+                      if eng.overlap_chunks > 1 else f"full-band stack in one layer-pipelined launch; {sb_how}")
         # ---- phase K (untimed): the scan kernels of the timed region's geometry, each alone on the chip (one forward at a time)
         if n_lanes > 1:
             set_geometry(geom_b)
@@ -363,6 +365,19 @@ def main():
                               launches=ss["n"], algorithmic_bytes_per_launch=int(alg),
                               traffic=(pj or {}).get("sb_scan_single_hbm_bytes_per_launch"),
                               measured_in="one forward at a time, the whole sequence in one launch per layer (HIP events on the launch stream)")
+            # --- round 4: the sub-band LAYERS SIDE BY SIDE in one launch (sfsn_gsn_stack_scan, layer 1 = the IO-wave scan at 8 rows
+            #     publishing its int8 spikes, layer 2 = the FUSED3 role that forms its input product inside the scan): the
+            #     algorithmic bytes of BOTH layers over the launch's time
+            sp = t_s.get("stack:sb")
+            if sp and not ss:
+                nl_sb = kw["sb_num_layers"]
+                strict = dict(kernel=f"gsn_stack_wide_kernel<KS={(Hs + 63) // 64}> (all {nl_sb} sub-band layers in ONE launch: layer 1 = IO-wave scan role, "
+                                     f"8 rows per workgroup, int8 spikes handed to layer 2 inside the launch; layers >= 2 = FUSED3 role, input "
+                                     f"product inside the scan, two frames per matrix instruction), {nl_sb * wgs(sb_rows, 8)} workgroups of 8 rows",
+                              **hbm(sp["mean_ms"], nl_sb * alg), per_step_us=round(1e3 * sp["mean_ms"] / T, 3),
+                              launches=sp["n"], layers_per_launch=nl_sb, algorithmic_bytes_per_launch=int(nl_sb * alg),
+                              traffic=(pj or {}).get("sb_pair_hbm_bytes_per_launch"),
+                              measured_in="one forward at a time, the whole sequence in one launch for all layers (HIP events on the launch stream)")
             # --- the full-band stack (phase S): both layers + the layer-2 input product in ONE layer-pipelined launch
             fb = t_s.get("stack:fb")
             full_band = None

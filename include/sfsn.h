@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 11 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 12 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -145,6 +145,8 @@ int sfsn_gsn_layer_scan_w16(const sfsn_scan_segment* segs /* host */, int n_segs
  * (sfsn_train_scratch_bytes(H) bytes, ZEROED by the caller before the first step of a layer call: 8-byte {value, epoch} granules)
  * and wait for each other inside the launch; `epoch` = 1, 2, ... counts the steps issued on that scratch buffer (forward and backward use their own buffers). */
 size_t sfsn_train_scratch_bytes(int H);
+/* SFSN_OK when BOTH step kernels take this geometry (their LDS needs differ): call once per layer before the first forward step. */
+int sfsn_gsn_train_check(int R, int H, int shared);
 int sfsn_gsn_train_step_fwd(const float* z, const float* w_hh, const float* bias, const float* h_prev, const float* c_prev,
                             const float* bn_w, const float* bn_b, float* running_mean, float* running_var, float momentum, float eps,
                             int R, int H, int shared, float* spikes, float* u, float* xhat, float* f, float* g, float* invstd,

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
 NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE, NORM_CUMLAPLACE = 0, 1, 2, 3
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
-ABI_VERSION = 11  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
+ABI_VERSION = 12  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -141,6 +141,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_gsn_train_step_fwd.argtypes = [_P] * 9 + [_F, _F, _I, _I, _I] + [_P] * 7 + [ctypes.c_uint, _P]
     L.sfsn_train_scratch_bytes.restype = ctypes.c_size_t
     L.sfsn_train_scratch_bytes.argtypes = [_I]
+    L.sfsn_gsn_train_check.restype = _I
+    L.sfsn_gsn_train_check.argtypes = [_I, _I, _I]
     L.sfsn_gsn_train_step_bwd.restype = _I
     L.sfsn_gsn_train_step_bwd.argtypes = [_P] * 12 + [_I, _I, _I] + [_P] * 6 + [ctypes.c_uint, _P]
     L.sfsn_gsn_train_seq_fwd.restype = _I  # z, w_hh, bias, bn_w, bn_b, running_mean, running_var | momentum, eps | T, R, H, shared | zero, 6 outputs, scratch, stream
@@ -194,7 +196,7 @@ EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device
            "sfsn_w3_pack", "sfsn_w3_pack_bits", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_stack_scratch_bytes", "sfsn_gsn_stack_scan",
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
            "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_stream_hop_resident", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft", "sfsn_gsn_train_step_fwd", "sfsn_gsn_train_step_bwd", "sfsn_train_scratch_bytes",
-           "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16")
+           "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16", "sfsn_gsn_train_check")
 
 
 def check(rc: int, what: str = "") -> None:

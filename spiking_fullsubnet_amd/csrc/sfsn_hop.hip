@@ -331,7 +331,9 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStep
 #pragma unroll
     for (int ri = 0; ri < HOP_ROWS_PER_WAVE; ++ri) {
         const int frow = 16 * rt + wave + HOP_WAVES * ri;
-        cumr[ri] = (L0 && sq.norm == SFSN_NORM_CUMLAPLACE && frow < R) ? sq.cum[hs.launch & 1u][frow] : 0.0f;
+        // (agent-scope load: in the resident form the previous hop's sum was written by ANOTHER workgroup of the same launch --
+        //  no launch boundary has made it visible to this CU's L1 / this XCD's L2)
+        cumr[ri] = (L0 && sq.norm == SFSN_NORM_CUMLAPLACE && frow < R) ? __uint_as_float(ld_agent(&sq.cum[hs.launch & 1u][frow])) : 0.0f;
     }
 
     for (int t = 0; t < hop; ++t) {
@@ -515,7 +517,7 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStep
 #pragma unroll
         for (int ri = 0; ri < HOP_ROWS_PER_WAVE; ++ri) {
             const int frow = 16 * rt + wave + HOP_WAVES * ri;
-            if (frow < R) sq.cum[(hs.launch + 1u) & 1u][frow] = cumr[ri];
+            if (frow < R) st_agent(&sq.cum[(hs.launch + 1u) & 1u][frow], __float_as_uint(cumr[ri]));  // (write-through, as the last spikes are)
         }
     }
 }
@@ -882,8 +884,12 @@ __global__ __launch_bounds__(HOP_THREADS) void stream_hop_resident_kernel(const 
             for (unsigned spins = 0;; ++spins) {
                 v = __hip_atomic_load(doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const unsigned f = ld_agent(fin);
-                if (v == 0xFFFFFFFFu || (v >= k + 1u && f >= k * gridDim.x)) break;
-                if ((spins & 63u) == 63u && (wall_clock64() - t0 > (unsigned long long)idle_ticks || ld_agent(p.cnt) != 0u)) {
+                // (wrap-safe compares: hop and completion counts are 32-bit and a stream may outlive them)
+                const bool rung = (int)(v - (k + 1u)) >= 0;
+                if (v == 0xFFFFFFFFu || (rung && (int)(f - k * gridDim.x) >= 0)) break;
+                // the idle watchdog only fires while the doorbell is silent: once a hop has been rung this workgroup serves it (a peer
+                // that is still finishing the previous hop is waited for; the hop's own bounded hand-off spins report a peer that left)
+                if ((spins & 63u) == 63u && ((!rung && wall_clock64() - t0 > (unsigned long long)idle_ticks) || ld_agent(p.cnt) != 0u)) {
                     v = 0xFFFFFFFFu;
                     break;
                 }

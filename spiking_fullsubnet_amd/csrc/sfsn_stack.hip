@@ -948,7 +948,14 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
     if (getenv("SFSN_STACK_DEBUG") && (size_t)(blocks + 2) * 5 * sizeof(unsigned) <= scratch_bytes) p.dbg = p.prog + blocks + 2;
     p.nroles = nroles; p.T = T; p.H = H; p.NT = NT; p.lag = lag; p.nblocks = blocks;
     p.v2 = getenv("SFSN_SCAN_V2") ? 1 : 0;
+    // timing switches of the hand-off roles (wrong results by design: stores dropped, waits skipped): compiled in only with
+    // -DSFSN_EXPERIMENTS (make EXTRA=-DSFSN_EXPERIMENTS, scripts/exp_stack_r03.sh) -- a stray environment variable must not be
+    // able to corrupt a production launch
+#ifdef SFSN_EXPERIMENTS
     p.exp_flags = getenv("SFSN_STACK_EXP") ? atoi(getenv("SFSN_STACK_EXP")) : 0;
+#else
+    p.exp_flags = 0;
+#endif
     lds = (lds + 15) & ~15;
     p.gate_off = lds;
     lds += 16;

@@ -342,6 +342,21 @@ extern "C" size_t sfsn_train_scratch_bytes(int H) {
     return ((size_t)tiles * 16 * TR_PARTG) * sizeof(unsigned long long) + ((size_t)tiles + 4) * sizeof(unsigned);  // granules (RB <= 16) + [unused] + error word
 }
 
+// Will both step kernels take (R, H)?  The forward and the backward step have different LDS needs (the backward one stages H x
+// (16 + rows per block) floats of W_hh columns and d_z rows): a layer call checks BOTH before its first forward launch, so that a
+// forward pass cannot succeed where the backward pass would be refused (round-3 advisor finding: R ~ 2048).
+extern "C" int sfsn_gsn_train_check(int R, int H, int shared) {
+    if (R <= 0 || H <= 0) return SFSN_EINVAL;
+    if (H % TR_TILE != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
+    int RB, rpb;
+    train_geometry(R, H, &RB, &rpb);
+    if (RB > 16) return SFSN_EUNSUPPORTED;
+    const int G = shared ? 1 : 2;
+    const size_t lds_f = ((size_t)G * TR_TILE * (H + 1) + (size_t)rpb * TR_TILE + (size_t)RB * TR_PART) * sizeof(float) + (size_t)rpb * H;
+    const size_t lds_b = ((size_t)rpb * TR_TILE + (size_t)RB * TR_PART + (size_t)G * H * (TR_TILE + rpb)) * sizeof(float);
+    return (lds_f > 150 * 1024 || lds_b > 150 * 1024) ? SFSN_EUNSUPPORTED : SFSN_OK;
+}
+
 extern "C" int sfsn_gsn_train_step_fwd(const float* z, const float* w_hh, const float* bias, const float* h_prev, const float* c_prev,
                                        const float* bn_w, const float* bn_b, float* running_mean, float* running_var, float momentum,
                                        float eps, int R, int H, int shared, float* spikes, float* u, float* xhat, float* f, float* g,

@@ -33,6 +33,26 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_EXCHANGE_FAILED = ("sfsn_gsn_train_step: the row blocks of a step did not all arrive (a launch's workgroups were not co-resident); "
+                    "the outputs of that layer call are invalid")
+_pending: list = []  # (event, pinned copy of a forward call's error word): looked at, without blocking, by the next layer call
+
+
+def _poll_pending(block: bool = False) -> None:
+    """Raise if an earlier forward-only layer call (no backward followed it) reported a failed row-block exchange."""
+    keep = []
+    for ev, pin in _pending:
+        if block:
+            ev.synchronize()
+        if ev.query():
+            if int(pin.max().item()) != 0:
+                _pending.clear()
+                raise RuntimeError(_EXCHANGE_FAILED)
+        else:
+            keep.append((ev, pin))
+    _pending[:] = keep
+
+
 class GSNLayerTrainFn(torch.autograd.Function):
     """One GSN layer over all T steps: x [T, R, I] -> spikes [T, R, H] (zero initial state, modeling_spiking_fullsubnet.py:100-106).
 
@@ -45,9 +65,23 @@ class GSNLayerTrainFn(torch.autograd.Function):
         if not x.is_cuda:
             raise RuntimeError("spiking_fullsubnet_amd has no CPU path: move the module and its input to a HIP device")
         L = _lib.lib()
+        _poll_pending()
         T, R, I = x.shape
         GH, H = w_hh.shape
         dev = x.device
+        # both directions' geometry up front: the backward step needs more LDS than the forward one at large R
+        check(L.sfsn_gsn_train_check(R, H, int(shared)), f"sfsn_gsn_train_check(R={R}, H={H})")
+        if bn_w is not None and batch_stats:
+            if R == 1:  # nn.BatchNorm1d in training mode (torch/nn/functional.py: _verify_batch_size)
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([{R}, {H}])")
+            if momentum is None:
+                raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative moving average) is not implemented by the HIP training step")
+            if stats is not None:
+                for nm, t_ in (("running_mean", stats[0]), ("running_var", stats[1])):
+                    # the step kernel updates these in place through raw float pointers
+                    if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != dev or t_.numel() != H:
+                        raise TypeError(f"BatchNorm {nm} must be a contiguous float32 tensor of {H} elements on {dev}, got "
+                                        f"{t_.dtype} {tuple(t_.shape)} on {t_.device}")
         x = x.contiguous().float()
         w_ih_c, w_hh_c, bias_c = w_ih.detach().contiguous().float(), w_hh.detach().contiguous().float(), bias.detach().contiguous().float()
         z = torch.mm(x.reshape(T * R, I), w_ih_c.t()).view(T, R, GH)  # x_t . W_ih^T for all t (bias is added inside the step)
@@ -76,7 +110,7 @@ class GSNLayerTrainFn(torch.autograd.Function):
         pis = invstd.data_ptr() if invstd is not None else 0
         pzero, pw, pb = zero.data_ptr(), w_hh_c.data_ptr(), bias_c.data_ptr()
         a_bw, a_bb, a_rm, a_rv = _p(bw), _p(bb), _p(rmean), _p(rvar)
-        mom, ep, sh = float(momentum), float(eps), int(shared)
+        mom, ep, sh = float(0.1 if momentum is None else momentum), float(eps), int(shared)
         fwd = L.sfsn_gsn_train_step_fwd
         scr = torch.zeros((L.sfsn_train_scratch_bytes(H) // 4,), dtype=torch.int32, device=dev)  # partial sums / arrival counters of the row blocks
         p_scr = P(scr.data_ptr())
@@ -95,7 +129,21 @@ class GSNLayerTrainFn(torch.autograd.Function):
                 if fold:  # (the folded affine map and the threshold, on the pre-normalisation membrane the step left in u)
                     u[t].mul_(alpha).add_(beta)
                     spikes[t].copy_((u[t] >= 0).float())
-        ctx.scr = scr  # (its error word is read in backward: no synchronisation here)
+        ctx.scr = scr  # (its error word is read in backward: no synchronisation there until the gradients are assembled)
+        if seq:
+            if not any(ctx.needs_input_grad):
+                # nothing will call backward() (BatchNorm recalibration, validation with the module left in train()): an exchange that
+                # timed out leaves spikes / u / running statistics unwritten -- find out before handing them out
+                if int(scr[-4:].max().item()) != 0:
+                    raise RuntimeError(_EXCHANGE_FAILED)
+            else:
+                # backward() reads the word too, but a forward that is never followed by one must not go unnoticed either: the word
+                # travels to pinned host memory behind the launches and the next layer call looks at it without blocking
+                pin = torch.empty((4,), dtype=torch.int32, pin_memory=True)
+                pin.copy_(scr[-4:], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                _pending.append((ev, pin))
         if use_bn and batch_stats and stats is not None and stats[2] is not None:
             stats[2].add_(T)  # num_batches_tracked: one BatchNorm call per time step
         ctx.save_for_backward(x, w_ih_c, w_hh_c, spikes, u, fg, gg, xhat if xhat is not None else zero, invstd if invstd is not None else zero,
@@ -165,7 +213,7 @@ class GSNLayerTrainFn(torch.autograd.Function):
                 if rc:
                     check(rc, "sfsn_gsn_train_step_bwd")
         if int(scr[-4:].max().item()) != 0 or int(ctx.scr[-4:].max().item()) != 0:
-            raise RuntimeError("sfsn_gsn_train_step: the row blocks of a step did not all arrive (a launch's workgroups were not co-resident)")
+            raise RuntimeError(_EXCHANGE_FAILED)
         dz = (d_z if shared else d_gates).reshape(T * R, GH)
         dx = torch.mm(dz, w_ih).view(T, R, I)
         dw_ih = torch.mm(dz.t(), x.reshape(T * R, I))
@@ -190,7 +238,7 @@ def gsn_stack(x: torch.Tensor, stack, training: bool) -> List[torch.Tensor]:
         momentum, eps = 0.1, 1e-5
         if bn is not None:
             stats = (bn.running_mean, bn.running_var, bn.num_batches_tracked)
-            momentum = 0.1 if bn.momentum is None else bn.momentum
+            momentum = bn.momentum  # (None = cumulative moving average: rejected by GSNLayerTrainFn in training mode)
             eps = bn.eps
         cur = GSNLayerTrainFn.apply(cur, cell.weight_ih, cell.weight_hh, cell.bias_ih, None if bn is None else bn.weight,
                                     None if bn is None else bn.bias, stats, cell.shared_weights, bool(training and bn is not None),

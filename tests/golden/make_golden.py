@@ -139,9 +139,15 @@ def gsn_train_cases(neuron, out):
         ("train_tiny_unshared_bn", 9, 16, 2, 5, 8, False, True),
         ("train_tiny_shared_nobn", 10, 16, 1, 4, 9, True, False),
         ("train_sb_shape", 38, 224, 2, 16, 6, True, True),
+        # recipe scale (round-3 review): the sub-band stack of group 0 at the recipe's batch of 64 (baseline_m.toml:72: 512 rows ->
+        # 11 row blocks per neuron tile exchange their BatchNorm partial sums inside every step launch) and the full-band stack
+        # (64 rows, H = 320: 4 row blocks).  Spike trains stored packed, the cotangent regenerated from its seed, no membranes.
+        ("train_sb_recipe", 38, 224, 2, 512, 24, True, True),
+        ("train_fb_recipe", 64, 320, 2, 64, 24, True, True),
     ]
     meta = []
     for ci, (name, I, H, L, R, T, shared, bn) in enumerate(cases):
+        big = T * R * H > 200000
         rng = np.random.default_rng(300 + ci)
         sd = {}
         for l in range(L):
@@ -149,7 +155,9 @@ def gsn_train_cases(neuron, out):
         net = neuron.efficient_spiking_neuron(I, H, L, shared_weights=shared, bn=bn).train()
         net.load_state_dict(to_torch_sd(sd), strict=True)
         x = torch.from_numpy(rng.standard_normal((T, R, I)).astype(np.float32)).requires_grad_(True)
-        gy = torch.from_numpy(rng.standard_normal((T, R, H)).astype(np.float32))
+        gy_np = (np.random.default_rng(7000 + ci).standard_normal((T, R, H)).astype(np.float32) if big
+                 else rng.standard_normal((T, R, H)).astype(np.float32))
+        gy = torch.from_numpy(gy_np)
         tap = CellTap(net, neuron)
         states = [neuron.MemoryState(torch.zeros(R, H), torch.zeros(R, H)) for _ in range(L)]
         y, out_states, all_out = net(x, states)
@@ -157,14 +165,26 @@ def gsn_train_cases(neuron, out):
         mems = tap.stacked()
         tap.close()
         out[f"{name}/x"] = x.detach().numpy()
-        out[f"{name}/gy"] = gy.numpy()
+        if big:
+            out[f"{name}/gy_seed"] = np.asarray(7000 + ci)
+        else:
+            out[f"{name}/gy"] = gy.numpy()
         for k, v in sd.items():
             out[f"{name}/sd/{k}"] = v
         for l in range(L):
-            out[f"{name}/spikes/{l}"] = all_out[l + 1].detach().numpy()
-            out[f"{name}/membrane/{l}"] = mems[f"layers.{l}.cell"]
-            out[f"{name}/hT/{l}"] = out_states[l][0].detach().numpy()
-            out[f"{name}/cT/{l}"] = out_states[l][1].detach().numpy()
+            spk = all_out[l + 1].detach().numpy()
+            if big:
+                assert set(np.unique(spk)) <= {0.0, 1.0}
+                out[f"{name}/spikes_packed/{l}"] = np.packbits(spk.astype(np.uint8).reshape(-1))
+                out[f"{name}/spike_rate/{l}"] = np.asarray(float(spk.mean()))
+                # where the reference's own (post-BatchNorm) membrane is within 1e-4 of the threshold: a first spike disagreement is
+                # only acceptable there (two correct fp32 evaluations of the layer's input product differ in the last bits)
+                out[f"{name}/near1e-4/{l}"] = np.packbits((np.abs(mems[f"layers.{l}.cell"]) < 1e-4).reshape(-1))
+            else:
+                out[f"{name}/spikes/{l}"] = spk
+                out[f"{name}/membrane/{l}"] = mems[f"layers.{l}.cell"]
+                out[f"{name}/hT/{l}"] = out_states[l][0].detach().numpy()
+                out[f"{name}/cT/{l}"] = out_states[l][1].detach().numpy()
         out[f"{name}/grad/x"] = x.grad.numpy()
         for k, p in net.named_parameters():
             out[f"{name}/grad/{k}"] = p.grad.numpy()
@@ -260,7 +280,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, "gsn_train_cells.npz"), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
         print("gsn_train_cells.npz", len(out))
 
-    def live_train_case(fname, kw, seed, B, T, wave_seed=0):
+    def live_train_case(fname, kw, seed, B, T, wave_seed=0, pack=False):
         """A whole live model in TRAINING mode on a waveform: forward outputs, a scalar loss (mean square of the enhanced waveform
         + mean of the enhanced magnitude: both outputs of forward() carry gradient), every parameter's gradient, BatchNorm buffers
         after the step's forward (the recipe's training step: recipes/intel_ndns/spiking_fullsubnet/trainer.py:24-48)."""
@@ -273,11 +293,21 @@ def main():
         loss = enh_y.pow(2).mean() + enh_mag.mean()
         loss.backward()
         out = dict(wave=wave.numpy(), enh_y=enh_y.detach().numpy(), enh_mag=enh_mag.detach().numpy(), loss=np.asarray(float(loss)))
+        def put(key, a, is_spikes):
+            a = a.detach().numpy()
+            if pack and is_spikes:
+                assert set(np.unique(a)) <= {0.0, 1.0}
+                out[key + "/packed"] = np.packbits(a.astype(np.uint8).reshape(-1))
+                out[key + "/shape"] = np.asarray(a.shape, dtype=np.int64)
+            elif pack:
+                out[key + "/head"] = a[:4].copy()  # (layer inputs / projections at this size: the first four frames only)
+            else:
+                out[key] = a
         for i, a in enumerate(outs[2]):
-            out[f"fb_all/{i}"] = a.detach().numpy()
+            put(f"fb_all/{i}", a, 0 < i < len(outs[2]) - 1)
         for g, lst in enumerate(outs[3]):
             for i, a in enumerate(lst):
-                out[f"sb_all/{g}/{i}"] = a.detach().numpy()
+                put(f"sb_all/{g}/{i}", a, 0 < i < len(lst) - 1)
         for k, p in model.named_parameters():
             out[f"grad/{k}"] = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
         for k, b in model.named_buffers():
@@ -288,6 +318,10 @@ def main():
 
     if not only or "live_tiny_train" in only:
         live_train_case("live_tiny_train.npz", rw.LIVE_TINY, 11, 3, 12)
+    if not only or "live_m_train" in only:
+        # one training step of the whole model at baseline_m sizes, B = 16, T = 32 (sub-band rows 128 / 48 / 32, H = 224; full band 16
+        # rows, H = 320): spike trains packed, layer inputs / projections by their first frames, every parameter's gradient
+        live_train_case("live_m_train.npz", rw.LIVE_M, 21, 16, 32, wave_seed=4, pack=True)
 
     def live_case(fname, kw, seed, B, T, store_mem, wave_seed=0, modulated=False):
         sd = rw.live_state_dict(kw, seed)

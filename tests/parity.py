@@ -101,7 +101,13 @@ def report(case: str, stats, extra=None) -> None:
     path = os.environ.get("SFSN_PARITY_REPORT", os.path.join(root, "gpurun_out", "parity_report.jsonl"))
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        # one report = one run of one build: the first record of a process truncates what an earlier run left behind
+        # one report = one run of one build.  Parallel test workers (pytest-xdist) each write their OWN file (suffix = worker id),
+        # so that one worker's first record cannot truncate what another has written; a process's first record truncates what an
+        # earlier run left in its file
+        worker = os.environ.get("PYTEST_XDIST_WORKER")
+        if worker:
+            base, ext = os.path.splitext(path)
+            path = f"{base}.{worker}{ext}"
         mode = "a" if path in _REPORT_STARTED else "w"
         _REPORT_STARTED.add(path)
         with open(path, mode) as fh:

@@ -875,6 +875,33 @@ def test_frozen_front_end_with_cumulative_norm_streams(kw, seed, B, hop):
         build_module("frozen", rw.FROZEN_TINY_CUM, rw.frozen_state_dict(rw.FROZEN_TINY_CUM, 35)).streaming(batch=1)
 
 
+@pytest.mark.parametrize("kw,seed,B", [(TINY_CUM, 35, 3), (rw.FROZEN_M_CUM, 36, 2)])
+def test_resident_launch_carries_the_cumulative_norm_sums(kw, seed, B):
+    """The resident form of the hop with cumulative_laplace_norm (round-3 advisor finding): the running sum of a row is written by
+    one workgroup of a hop and read by the others in the next hop with NO launch boundary in between -- it travels write-through
+    with agent-scope loads, like the last spikes.  Enhanced samples equal the offline forward's, bit for bit, over 60 hops, after
+    a watchdog exit and after reset()."""
+    import time
+    model = build_module("frozen", kw, rw.frozen_state_dict(kw, seed))
+    n_hops = 60
+    wave = torch.from_numpy(rw.synth_wave(B, n_hops + 1, seed))
+    y = model(wave.to(DEV))[0]
+    y = y.reshape(B, -1, y.shape[-1]).cpu()
+    sess = model.streaming(batch=B, waveform=True, host_io=True, resident=True, idle_ms=200)
+    for rep in range(2):
+        outs = []
+        for c in range(n_hops):
+            if rep == 0 and c == 23:
+                time.sleep(0.6)  # the resident kernel has left: the next hop starts another one, the sums continue from device memory
+            o = sess.step_wave_host(wave[:, 128 * c:128 * (c + 1)])
+            if c >= 3:
+                outs.append(o.clone())
+        got = torch.cat(outs, -1)
+        assert torch.equal(got, y[..., :got.shape[-1]]), rep
+        sess.reset()
+    sess.close()
+
+
 def test_stream_hop_argument_checks_and_fallback():
     """sfsn_stream_hop through the C ABI: malformed descriptors are refused, what the launch does not cover reports
     SFSN_EUNSUPPORTED (the session then replays the offline kernels), one_launch=True insists."""

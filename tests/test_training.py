@@ -26,10 +26,12 @@ def _close(a, b, name, rtol=2e-3, atol_frac=2e-4):
     assert not bad.any(), f"{name}: {int(bad.sum())} of {a.size} outside tolerance, max abs err {np.abs(a - b).max():.3g} (scale {np.abs(b).max():.3g})"
 
 
-@pytest.mark.parametrize("ci", range(4))
+@pytest.mark.parametrize("ci", range(6))
 def test_gsn_stack_training_forward_and_backward_match_the_reference(ci):
     """StackedGSU in training mode: spike trains of every layer, BatchNorm buffers after the forward (running statistics updated once
-    per time step), and the gradients of the input and of every parameter for a fixed cotangent on the last layer's spikes."""
+    per time step), and the gradients of the input and of every parameter for a fixed cotangent on the last layer's spikes.
+    Cases 4 / 5 are at RECIPE scale (baseline_m.toml:72, batch 64): the sub-band stack of group 0 with 512 rows -- 11 row blocks per
+    neuron tile exchange their BatchNorm partial sums inside every step launch -- and the full-band stack (64 rows, H = 320)."""
     import spiking_fullsubnet_amd.modeling_spiking_fullsubnet as M
     from spiking_fullsubnet_amd import training
     g = np.load(os.path.join(GOLD, "gsn_train_cells.npz"))
@@ -41,21 +43,47 @@ def test_gsn_stack_training_forward_and_backward_match_the_reference(ci):
     stack = stack.to(DEV).train()
     x = _t(g[f"{name}/x"]).requires_grad_(True)
     outs = training.gsn_stack(x, stack, training=True)
+    flipped = False
     for l in range(L):
-        ref = g[f"{name}/spikes/{l}"]
         got = outs[l + 1].detach().cpu().numpy()
+        if f"{name}/spikes/{l}" in g.files:
+            ref = g[f"{name}/spikes/{l}"]
+        else:  # recipe-scale cases: packed spike trains
+            ref = np.unpackbits(g[f"{name}/spikes_packed/{l}"])[:T * R * H].reshape(T, R, H).astype(np.float32)
         assert got.shape == ref.shape
-        assert (got == ref).all(), f"{name} layer {l}: {(got != ref).sum()} spikes differ from the reference's training-mode forward"
-    (outs[-1] * _t(g[f"{name}/gy"])).sum().backward()
-    _close(x.grad.cpu().numpy(), g[f"{name}/grad/x"], f"{name}: dL/dx")
+        d = got != ref
+        if d.any() and f"{name}/near1e-4/{l}" in g.files and not flipped:
+            # The causal rule of tests/parity.py for a layer whose rows are coupled by the batch statistics: every frame before the
+            # first disagreement is exact, and the disagreeing neurons of that frame sit within 1e-4 of the threshold in the
+            # reference (the layer's input product is a library GEMM here and an ATen CPU GEMM there: last-bit differences).
+            # From that frame on the statistics of EVERY row are perturbed, so later frames and the layers above are not compared.
+            near = np.unpackbits(g[f"{name}/near1e-4/{l}"])[:T * R * H].reshape(T, R, H).astype(bool)
+            t0 = int(np.nonzero(d.any(axis=(1, 2)))[0][0])
+            assert near[t0][d[t0]].all(), f"{name} layer {l}: first disagreement at frame {t0} on a neuron outside the don't-care band"
+            print(f"{name} layer {l}: exact up to frame {t0} of {T}; {int(d[t0].sum())} near-threshold flip(s) there, {int(d.sum())} in all")
+            flipped = True
+        elif not flipped:
+            assert not d.any(), f"{name} layer {l}: {d.sum()} spikes differ from the reference's training-mode forward"
+    gy = g[f"{name}/gy"] if f"{name}/gy" in g.files else \
+        np.random.default_rng(int(g[f"{name}/gy_seed"])).standard_normal((T, R, H)).astype(np.float32)
+    (outs[-1] * _t(gy)).sum().backward()
+    # (after an accepted near-threshold flip the spike trains differ in a few dozen of ~10^5..10^6 entries: gradients are sums over
+    #  all of them and stay close, but no longer to the 2e-3 of identical trains)
+    def close(a, b, nm):
+        if not flipped:
+            return _close(a, b, nm)
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        err = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+        assert err < 2e-2, f"{nm}: relative L2 error {err:.3g} after an accepted near-threshold flip"
+    close(x.grad.cpu().numpy(), g[f"{name}/grad/x"], f"{name}: dL/dx")
     for k, p in stack.named_parameters():
-        _close(p.grad.cpu().numpy(), g[f"{name}/grad/{k}"], f"{name}: grad {k}")
+        close(p.grad.cpu().numpy(), g[f"{name}/grad/{k}"], f"{name}: grad {k}")
     for k, b in stack.named_buffers():
         ref = g[f"{name}/buf/{k}"]
         if k.endswith("num_batches_tracked"):
             assert int(b) == int(ref), (k, int(b), int(ref))
         else:
-            _close(b.cpu().numpy(), ref, f"{name}: buffer {k}", rtol=1e-4, atol_frac=1e-5)
+            _close(b.cpu().numpy(), ref, f"{name}: buffer {k}", rtol=1e-4 if not flipped else 1e-2, atol_frac=1e-5 if not flipped else 1e-3)
 
 
 def test_live_module_training_step_matches_the_reference():
@@ -105,6 +133,81 @@ def test_live_module_training_step_matches_the_reference():
     with torch.no_grad():
         y = m(_t(g["wave"]))
     assert y[0].shape == enh_y.shape and torch.isfinite(y[0]).all()
+
+
+def test_live_m_training_step_matches_the_reference():
+    """One training step of the whole model at baseline_m sizes (B = 16, T = 32: sub-band rows 128 / 48 / 32 at H = 224, full band
+    16 rows at H = 320) against the reference's: every spike train equal, the loss, every parameter's gradient, BatchNorm buffers."""
+    import spiking_fullsubnet_amd as pkg
+    g = np.load(os.path.join(GOLD, "live_m_train.npz"))
+    kw = rw.LIVE_M
+    sd = rw.live_state_dict(kw, int(g["weight_seed"]))
+    m = pkg.SpikingFullSubNet(**kw)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).train()
+    outs = m(_t(g["wave"]))
+
+    def check_list(prefix, lst):
+        for i, a in enumerate(lst):
+            a = a.detach().cpu().numpy()
+            if 0 < i < len(lst) - 1:
+                shape = tuple(int(v) for v in g[f"{prefix}/{i}/shape"])
+                ref = np.unpackbits(g[f"{prefix}/{i}/packed"])[:int(np.prod(shape))].reshape(shape).astype(np.float32)
+                assert a.shape == ref.shape and (a == ref).all(), f"{prefix}[{i}]: {(a != ref).sum()} spikes differ"
+            else:
+                _close(a[:4], g[f"{prefix}/{i}/head"], f"{prefix}[{i}][:4]", rtol=1e-4, atol_frac=1e-5)
+    check_list("fb_all", outs[2])
+    for gi, lst in enumerate(outs[3]):
+        check_list(f"sb_all/{gi}", lst)
+    _close(outs[1].detach().cpu().numpy(), g["enh_mag"], "enh_mag", rtol=1e-4, atol_frac=1e-5)
+    _close(outs[0].detach().cpu().numpy(), g["enh_y"], "enh_y", rtol=1e-3, atol_frac=1e-4)
+    loss = outs[0].pow(2).mean() + outs[1].mean()
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-5)
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        _close(p.grad.cpu().numpy(), g[f"grad/{k}"], f"grad {k}")
+    for k, b in m.named_buffers():
+        if f"buf/{k}" not in g.files:
+            continue
+        if k.endswith("num_batches_tracked"):
+            assert int(b) == int(g[f"buf/{k}"]), k
+        else:
+            _close(b.cpu().numpy(), g[f"buf/{k}"], f"buffer {k}", rtol=1e-4, atol_frac=1e-5)
+
+
+def test_training_layer_call_checks_before_it_launches():
+    """Round-3 advisor findings: (a) both step kernels' geometry is validated before the first forward launch (the backward step
+    needs more LDS than the forward one: R = 2048 at H = 224 used to pass forward and fail in backward()); (b) BatchNorm running
+    statistics are handed to the kernel as raw float pointers: anything but contiguous float32 on the input's device is refused;
+    (c) R = 1 in training mode raises like nn.BatchNorm1d; momentum = None is refused; (d) a forward with nothing to differentiate
+    (no backward will follow) has its row-block exchange checked before the outputs are handed out."""
+    import spiking_fullsubnet_amd.modeling_spiking_fullsubnet as M
+    from spiking_fullsubnet_amd import _lib, training
+    L = _lib.lib()
+    assert L.sfsn_gsn_train_check(512, 224, 1) == _lib.SFSN_OK and L.sfsn_gsn_train_check(64, 320, 1) == _lib.SFSN_OK
+    assert L.sfsn_gsn_train_check(4096, 224, 1) == _lib.SFSN_EUNSUPPORTED and L.sfsn_gsn_train_check(8, 30, 1) == _lib.SFSN_EUNSUPPORTED
+    stack = M.StackedGSU(12, 32, 1, True, True).to(DEV).train()
+    rm = stack.layers[0].cell.batchnorm.running_mean.clone()
+    with pytest.raises(NotImplementedError):  # refused up front: nothing was launched, the statistics are untouched
+        training.gsn_stack(torch.randn(3, 70000, 12, device=DEV), stack, training=True)
+    assert torch.equal(rm, stack.layers[0].cell.batchnorm.running_mean)
+    with pytest.raises(ValueError):
+        training.gsn_stack(torch.randn(5, 1, 12, device=DEV), stack, training=True)
+    stack.layers[0].cell.batchnorm.momentum = None
+    with pytest.raises(NotImplementedError):
+        training.gsn_stack(torch.randn(5, 4, 12, device=DEV), stack, training=True)
+    stack.layers[0].cell.batchnorm.momentum = 0.1
+    half = M.StackedGSU(12, 32, 1, True, True).to(DEV).train()
+    half.layers[0].cell.batchnorm.running_var = half.layers[0].cell.batchnorm.running_var.double()
+    with pytest.raises(TypeError):
+        training.gsn_stack(torch.randn(5, 4, 12, device=DEV), half, training=True)
+    # no_grad forward in training mode (BatchNorm recalibration): runs, updates the statistics, hands out finite spikes
+    with torch.no_grad():
+        outs = training.gsn_stack(torch.randn(6, 40, 12, device=DEV), stack, training=True)
+    assert outs[-1].shape == (6, 40, 32) and set(outs[-1].unique().tolist()) <= {0.0, 1.0}
+    assert int(stack.layers[0].cell.batchnorm.num_batches_tracked) == 6
+    training._poll_pending(block=True)
 
 
 def test_lstm_and_output_activation_options_run_on_the_aten_path():
