@@ -101,8 +101,19 @@ class Separator(_EngineMixin, nn.Module):
         self._check_mode(complex_stft)
         return self.engine().forward_stft(complex_stft, want_layers=want_layers, want_membrane=want_membrane, want_counts=want_counts)
 
-    @torch.no_grad()
+    def _kernel_path(self) -> bool:
+        return True  # (every constructor option that is accepted is served by the kernels)
+
     def forward(self, noisy_y):
+        """model_low_freq.py:561-618.  In training mode, or when gradients can flow into the input, the differentiable path of
+        training.py (``forward_frozen``: ATen front / back end, HIP training-step kernels for the cell loop); else the kernels."""
+        if self._wants_autograd(noisy_y):
+            from . import training
+            return training.forward_frozen(self, noisy_y)
+        with torch.no_grad():
+            return self._forward_inference(noisy_y)
+
+    def _forward_inference(self, noisy_y):
         ndim = noisy_y.dim()
         assert ndim in (2, 3), "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
         if ndim == 3:

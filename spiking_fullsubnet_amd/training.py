@@ -323,3 +323,82 @@ def forward_live(model, wave: torch.Tensor):
     if S > 1:
         return enh_y.reshape(B, S, -1), fb_all, sb_all
     return enh_y, enh_stft[:, 0].abs(), fb_all, sb_all
+
+
+_LAPLACE_EPS = 2.220446049250313e-16  # audiozen/constant.py:11 (np.finfo(np.float32).eps is NOT what the reference adds)
+
+
+def _frozen_sequence_model(seq, x_bft: torch.Tensor, training: bool):
+    """The frozen SequenceModel.forward (model_low_freq.py:100-139): no LayerNorm, ``fc_output_layer``, no activation in any config."""
+    x = x_bft.permute(2, 0, 1).contiguous()  # [B, F, T] => [T, B, F]
+    outs = gsn_stack(x, seq.sequence_model, training)
+    y = seq.fc_output_layer(outs[-1])
+    return y.permute(1, 2, 0), outs + [y]
+
+
+def forward_frozen(model, wave: torch.Tensor):
+    """Separator.forward (recipes/intel_ndns/spiking_fullsubnet_freeze_phase/model_low_freq.py:561-618) on differentiable
+    operations, for a module in training mode or an input that requires grad: the utterance-level ``offline_laplace_norm`` (:147-169:
+    x / (mean over every non-batch dimension + EPSILON)) on the full-band input (:578) and on every group's concatenated sub-band
+    input (:475), reflect-unfolded noisy AND full-band features (:350-431: the tiled full-band output has its own centre / neighbour
+    sizes), the cell loop on the HIP training-step kernels (GSNLayerTrainFn), deep filtering and reconstruction as in forward_live."""
+    ndim = wave.dim()
+    assert ndim in (2, 3), "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
+    if ndim == 3:
+        assert wave.size(1) == 1, "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
+        wave = wave.squeeze(1)
+    if not wave.is_cuda:
+        raise RuntimeError("spiking_fullsubnet_amd has no CPU path: move the module and its input to a HIP device")
+    spec = model._spec()
+    if spec.cum_laplace:
+        raise NotImplementedError("cumulative_laplace_norm has no differentiable path (the reference's own Separator raises on it, "
+                                  "model_low_freq.py:172-202); train with offline_laplace_norm")
+    B, length = wave.shape
+    dev = wave.device
+    window = torch.hann_window(model.win_length, device=dev)
+    noisy = torch.stft(wave, model.n_fft, model.hop_length, model.win_length, window=window, return_complex=True, pad_mode="constant")
+    Fq, T = noisy.shape[1], noisy.shape[2]
+    nf = Fq - 1
+    mag = (noisy.abs() ** model.fdrc)[:, :nf]                      # [B, nf, T]: the Nyquist bin is passed through untouched
+    training = model.training
+
+    def laplace(x):  # one scalar per batch item over everything else (non-causal)
+        mu = x.mean(dim=tuple(range(1, x.dim())), keepdim=True)
+        return x / (mu + _LAPLACE_EPS)
+    fb_in = model.fb_freqs
+    fb_out, fb_all = _frozen_sequence_model(model.fb_model, laplace(mag[:, :fb_in]), training)   # [B, P, T]
+    P_fb = fb_out.shape[1]
+    sbm = model.sb_model
+    cut = [0] + list(sbm.freq_cutoffs) + [nf]
+    enh_groups, sb_all = [], []
+    for g, seq in enumerate(sbm.sb_models):
+        lo, hi = cut[g], cut[g + 1]
+        c, n = sbm.sb_num_center_freqs[g], sbm.sb_num_neighbor_freqs[g]
+        cf, nfb = sbm.fb_num_center_freqs[g], sbm.fb_num_neighbor_freqs[g]
+        d = seq.df_order
+        if (hi - lo) % c != 0 or (hi - lo) % cf != 0 or (hi - lo) // cf != (hi - lo) // c:
+            raise ValueError(f"Number of frequency bins must be divisible by the center frequency.GOT: ctr_freq={c}, "
+                             f"upper_cutoff_freq={hi}, lower_cutoff_freq={lo}")
+        N = (hi - lo) // c
+        k = torch.arange(N, device=dev)
+        idx_noisy = _reflect(lo + k[:, None] * c - n + torch.arange(c + 2 * n, device=dev)[None, :], nf)        # [N, c + 2n]
+        idx_fb = _reflect(lo + k[:, None] * cf - nfb + torch.arange(cf + 2 * nfb, device=dev)[None, :], nf) % P_fb  # tiled full-band output
+        x = laplace(torch.cat([mag[:, idx_noisy], fb_out[:, idx_fb]], dim=2))                                    # [B, N, I, T]
+        I = x.shape[2]
+        y, outs = _frozen_sequence_model(seq, x.reshape(B * N, I, T), training)                                  # [B N, P, T]
+        sb_all.append(outs)
+        coef = y.reshape(B, N, 2, c, d, T)   # channel p = (ri * c + fci) * d + di  (:262-268)
+        cre = coef[:, :, 0].permute(0, 3, 1, 2, 4).reshape(B, d, N * c, T)
+        cim = coef[:, :, 1].permute(0, 3, 1, 2, 4).reshape(B, d, N * c, T)
+        xp = F.pad(torch.view_as_real(noisy[:, lo:hi]), (0, 0, d - 1, 0))                                        # causal: zeros on the left of T
+        xr, xi = xp[..., 0], xp[..., 1]
+        yr = yi = 0
+        for di in range(d):
+            a, b = xr[:, :, di:di + T], xi[:, :, di:di + T]
+            yr = yr + a * cre[:, di] - b * cim[:, di]
+            yi = yi + a * cim[:, di] + b * cre[:, di]
+        enh_groups.append(torch.complex(yr, yi))                                                                 # [B, N c, T]
+    enh = torch.cat(enh_groups, dim=1)
+    enh_stft = torch.cat([enh, noisy[:, enh.shape[1]:]], dim=1)                                                  # bins past the groups pass through
+    enh_y = torch.istft(enh_stft, model.n_fft, model.hop_length, model.win_length, window=window, length=length)
+    return enh_y, enh_stft.abs(), fb_all, sb_all

@@ -376,6 +376,28 @@ def main():
     if not only:
         frozen_case("frozen_tiny.npz", rw.FROZEN_TINY, rw.frozen_state_dict(rw.FROZEN_TINY, 31), 2, 24, True, False)
         frozen_case("frozen_s_zoo.npz", rw.FROZEN_S, zoo_weights("baseline_s"), 1, 126, False, True)
+    if not only or "frozen_tiny_train" in only:
+        # the frozen Separator as an ordinary trainable module (model_low_freq.py:485-618): one training step in .train() mode
+        sd = rw.frozen_state_dict(rw.FROZEN_TINY, 31)
+        model = frozen.Separator(**rw.FROZEN_TINY).train()
+        model.load_state_dict(to_torch_sd(sd), strict=True)
+        wave = torch.from_numpy(rw.synth_wave(3, 14, 2))
+        outs = model(wave)
+        loss = outs[0].pow(2).mean() + outs[1].mean()
+        loss.backward()
+        out = dict(wave=wave.numpy(), enh_y=outs[0].detach().numpy(), enh_mag=outs[1].detach().numpy(), loss=np.asarray(float(loss.detach())))
+        for i, a in enumerate(outs[2]):
+            out[f"fb_all/{i}"] = a.detach().numpy()
+        for g_, lst in enumerate(outs[3]):
+            for i, a in enumerate(lst):
+                out[f"sb_all/{g_}/{i}"] = a.detach().numpy()
+        for k, p_ in model.named_parameters():
+            out[f"grad/{k}"] = p_.grad.numpy() if p_.grad is not None else np.zeros(tuple(p_.shape), np.float32)
+        for k, b in model.named_buffers():
+            out[f"buf/{k}"] = b.detach().numpy()
+        out["weight_seed"] = np.asarray(31)
+        np.savez_compressed(os.path.join(HERE, "frozen_tiny_train.npz"), **out, **{f"meta/{k}": np.asarray(v) for k, v in meta.items()})
+        print("frozen_tiny_train.npz", float(loss))
     if not only or "frozen_s_zoo_4s" in only:
         # BASELINE configs[0] as written: the trained baseline_s generator on ONE 4 s clip (T = 501 frames at 16 kHz / hop 128);
         # the weights are those of frozen_s_zoo.npz (not stored twice)

@@ -176,6 +176,43 @@ def test_live_m_training_step_matches_the_reference():
             _close(b.cpu().numpy(), g[f"buf/{k}"], f"buffer {k}", rtol=1e-4, atol_frac=1e-5)
 
 
+def test_frozen_separator_training_step_matches_the_reference():
+    """The frozen recipe's generator (model_low_freq.Separator) is an ordinary trainable module in the reference: one training step
+    in .train() mode (offline Laplace norm, reflect-unfolded noisy and full-band features, batch-statistics BatchNorm in every cell)
+    against the reference's own -- spike trains equal, loss, every parameter's gradient, BatchNorm buffers."""
+    import spiking_fullsubnet_amd as pkg
+    g = np.load(os.path.join(GOLD, "frozen_tiny_train.npz"))
+    kw = rw.FROZEN_TINY
+    sd = rw.frozen_state_dict(kw, int(g["weight_seed"]))
+    m = pkg.Separator(**kw)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).train()
+    outs = m(_t(g["wave"]))
+    assert len(outs) == 4
+    for prefix, lst in [("fb_all", outs[2])] + [(f"sb_all/{gi}", l_) for gi, l_ in enumerate(outs[3])]:
+        for i, a in enumerate(lst):
+            ref = g[f"{prefix}/{i}"]
+            if 0 < i < len(lst) - 1:
+                assert (a.detach().cpu().numpy() == ref).all(), f"{prefix}[{i}]: spike tensor differs"
+            else:
+                _close(a.detach().cpu().numpy(), ref, f"{prefix}[{i}]", rtol=1e-4, atol_frac=1e-5)
+    _close(outs[1].detach().cpu().numpy(), g["enh_mag"], "enh_mag", rtol=1e-4, atol_frac=1e-5)
+    _close(outs[0].detach().cpu().numpy(), g["enh_y"], "enh_y", rtol=1e-3, atol_frac=1e-4)
+    loss = outs[0].pow(2).mean() + outs[1].mean()
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-5)
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        _close(p.grad.cpu().numpy(), g[f"grad/{k}"], f"grad {k}")
+    for k, b in m.named_buffers():
+        if f"buf/{k}" in g.files and not k.endswith("num_batches_tracked"):
+            _close(b.cpu().numpy(), g[f"buf/{k}"], f"buffer {k}", rtol=1e-4, atol_frac=1e-5)
+    m.eval()  # back on the inference kernels with the statistics the step has just updated; a 3-D input as the reference accepts
+    with torch.no_grad():
+        y = m(_t(g["wave"]).unsqueeze(1))
+    assert y[0].shape == outs[0].shape and torch.isfinite(y[0]).all()
+
+
 def test_training_layer_call_checks_before_it_launches():
     """Round-3 advisor findings: (a) both step kernels' geometry is validated before the first forward launch (the backward step
     needs more LDS than the forward one: R = 2048 at H = 224 used to pass forward and fail in backward()); (b) BatchNorm running
