@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 12 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 13 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -220,6 +220,14 @@ size_t sfsn_stack_scratch_bytes(int n_layers, int n_segs, int rows_total);
 int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs /* host [n_layers][n_segs] */, const sfsn_fused_input* fin /* host, same shape;
                         layer-0 entries ignored */, int n_layers, int n_segs, int T, int H, const int* rows_per_wg /* host [n_layers] */,
                         int lag, void* scratch, size_t scratch_bytes, void* stream);
+/* The same with layer 0's real-valued input product inside the scan for the segments whose fx[i].x is given (round 4; fx NULL or
+ * fx[i].x NULL: the segment's layer 0 reads `zin` as above): x [T][R][I] fp32 and W_ih [H][I] fp32 as for
+ * sfsn_gsn_layer_scan_fused_x -- the bf16 3-way split of sfsn_input_proj_f32, bit-identical to that call + the scan.  Needs the
+ * layout this entry point gives stacks of H <= 224 without input-term buffers (or a single layer): 8 rows per workgroup in every
+ * layer, even I <= 64, R a multiple of 8, x 16-byte aligned; SFSN_EUNSUPPORTED otherwise (use `zin`). */
+int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, const sfsn_fused_x* fx /* host [n_segs], nullable */,
+                          int n_layers, int n_segs, int T, int H, const int* rows_per_wg, int lag, void* scratch, size_t scratch_bytes,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Time-parallel products.

@@ -75,11 +75,23 @@ nb = L.sfsn_stack_scratch_bytes(nl, ns, sum(Rs))
 scratch = torch.zeros((nb // 4,), dtype=torch.int32, device=DEV)
 
 
-def stack(rpw, wide=False):
+xg0 = torch.randn((T, Rs[0], I), device=DEV)
+w_ih0 = torch.randn((H, I), device=DEV) / I ** 0.5
+
+
+def stack(rpw, wide=False, x_groups=()):
     segs, fin = (ScanSegment * (nl * ns))(), (FusedInput * (nl * ns))()
     fill(segs, fin, wide)
     rp = (ctypes.c_int * nl)(*rpw)
-    check(L.sfsn_gsn_stack_scan(segs, fin, nl, ns, T, H, rp, LAG, p_(scratch), nb, None), "stack")
+    if x_groups:
+        from spiking_fullsubnet_amd._lib import FusedX
+        fx = (FusedX * ns)()
+        for i in x_groups:
+            fx[i].x, fx[i].w_ih, fx[i].I = xg0.data_ptr(), w_ih0.data_ptr(), I
+            segs[i].zin = None
+        check(L.sfsn_gsn_stack_scan_x(segs, fin, fx, nl, ns, T, H, rp, LAG, p_(scratch), nb, None), "stack_x")
+    else:
+        check(L.sfsn_gsn_stack_scan(segs, fin, nl, ns, T, H, rp, LAG, p_(scratch), nb, None), "stack")
 
 
 def per_layer(rpw):
@@ -117,6 +129,7 @@ for l in range(nl):
     for i in range(ns):
         assert torch.equal(ref[l][i], a[l][i]), (l, i)
 print("pair launch == per-layer launches, bit for bit")
+timeit("pair launch, group 0's layer-1 input product inside (FUSEDX3)", lambda: stack((8, 8), x_groups=(0,)))
 timeit("pair launch: layer 1 scan3 4 rows | layer 2 FUSED3", lambda: stack((4, 8)))
 timeit("pair launch: layer 1 scan3 16 rows | layer 2 FUSED3", lambda: stack((16, 8)))
 os.environ["SFSN_STACK_FUSED8"] = "1"

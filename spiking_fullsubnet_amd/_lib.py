@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
 NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE, NORM_CUMLAPLACE = 0, 1, 2, 3
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
-ABI_VERSION = 12  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
+ABI_VERSION = 13  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -74,7 +74,7 @@ class HopDesc(ctypes.Structure):
 def _sources():
     """The files the library is made of, in the order the Makefile hashes them (SRCS)."""
     return [os.path.join(_HERE, "..", "include", "sfsn.h")] + [
-        os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_scan3_dev.h", "sfsn_scan3i_dev.h", "sfsn_feat_dev.h", "sfsn_fft_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_hop.hip", "sfsn_fft.hip", "sfsn_train.hip",
+        os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_scan3_dev.h", "sfsn_scan3i_dev.h", "sfsn_scan3x_dev.h", "sfsn_feat_dev.h", "sfsn_fft_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_hop.hip", "sfsn_fft.hip", "sfsn_train.hip",
                                   "sfsn_pack.cpp")]
 
 
@@ -158,6 +158,9 @@ def lib() -> ctypes.CDLL:
     L.sfsn_gsn_stack_scan.restype = _I
     L.sfsn_gsn_stack_scan.argtypes = [ctypes.POINTER(ScanSegment), ctypes.POINTER(FusedInput), _I, _I, _I, _I, ctypes.POINTER(_I), _I, _P,
                                       ctypes.c_size_t, _P]
+    L.sfsn_gsn_stack_scan_x.restype = _I
+    L.sfsn_gsn_stack_scan_x.argtypes = [ctypes.POINTER(ScanSegment), ctypes.POINTER(FusedInput), ctypes.POINTER(FusedX), _I, _I, _I, _I,
+                                        ctypes.POINTER(_I), _I, _P, ctypes.c_size_t, _P]
     L.sfsn_input_proj_f32.restype = _I
     L.sfsn_input_proj_f32.argtypes = [_P, _P, _P, _P, _I, _I, _I, _I, _P]
     L.sfsn_spike_proj.restype = _I
@@ -196,7 +199,7 @@ EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device
            "sfsn_w3_pack", "sfsn_w3_pack_bits", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_stack_scratch_bytes", "sfsn_gsn_stack_scan",
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
            "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_stream_hop_resident", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft", "sfsn_gsn_train_step_fwd", "sfsn_gsn_train_step_bwd", "sfsn_train_scratch_bytes",
-           "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16", "sfsn_gsn_train_check")
+           "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16", "sfsn_gsn_train_check", "sfsn_gsn_stack_scan_x")
 
 
 def check(rc: int, what: str = "") -> None:

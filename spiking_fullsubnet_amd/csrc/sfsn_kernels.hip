@@ -789,22 +789,7 @@ __global__ __launch_bounds__(512) void input_proj_fast_kernel(const float* __res
 // x1w1, x1w2, x2w1, x1w3, x2w2, x3w1 carry x.w to 2^-26 |x||w| per term -- below half an fp32 ulp of the term -- and the
 // matrix core accumulates them in fp32.  The five small products go to their own accumulator (not swamped by the large
 // one; two independent MFMA chains) and are added once at the end.  6 MFMAs of 16 clk per 32 k instead of 8 of 32 clk.
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pack_bf16_rne(float a, float b) {
-    const v2f v = {a, b};
-    const bf2 p = __builtin_convertvector(v, bf2);  // v_cvt_pk_bf16_f32
-    return *reinterpret_cast<const unsigned*>(&p);
-}
-// (a, b) -> three packed bf16 pairs (low half = a's piece, high half = b's piece)
-__device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
-    p1 = pack_bf16_rne(a, b);
-    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
-    p2 = pack_bf16_rne(ra, rb);
-    p3 = pack_bf16_rne(ra - __uint_as_float(p2 << 16), rb - __uint_as_float(p2 & 0xffff0000u));
-}
+// (bf8 / split3: sfsn_scan_dev.h -- shared with the FUSEDX3 role of the stack launch)
 
 template <int TPW, int KS>
 __global__ __launch_bounds__(512) void input_proj_bf3_kernel(const float* __restrict__ x, const float* __restrict__ w,

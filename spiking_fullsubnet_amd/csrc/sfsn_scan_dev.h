@@ -53,6 +53,24 @@ __device__ __forceinline__ float recombine3(int a0, int a1, int a2) {
     return __builtin_fmaf((float)a2, 65536.0f, (float)(a1 * 256 + a0));
 }
 
+// ---- fp32 -> three bf16 pieces (the real-valued input products: input_proj_bf3_kernel, the fused-x scans) ---------------------
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16_rne(float a, float b) {
+    const v2f v = {a, b};
+    const bf2 p = __builtin_convertvector(v, bf2);  // v_cvt_pk_bf16_f32
+    return *reinterpret_cast<const unsigned*>(&p);
+}
+// (a, b) -> three packed bf16 pairs (low half = a's piece, high half = b's piece)
+__device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = pack_bf16_rne(a, b);
+    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pack_bf16_rne(ra, rb);
+    p3 = pack_bf16_rne(ra - __uint_as_float(p2 << 16), rb - __uint_as_float(p2 & 0xffff0000u));
+}
+
 // ---- input-term prefetch: LDS-DMA ring, hidden from the compiler's s_waitcnt bookkeeping -------------------------
 // What the profile showed: vmcnt retires in order and counts STORES too, and a spike store takes about a microsecond
 // to retire here, so any wait for a prefetched register that was issued after a store stalls the step for the store

@@ -28,11 +28,13 @@
 #include "sfsn_scan_dev.h"
 #include "sfsn_scan3_dev.h"
 #include "sfsn_scan3i_dev.h"
+#include "sfsn_scan3x_dev.h"
 
 #define STACK_MAX_ROLES 24
 #define STACK_ZIN 0
 #define STACK_FUSED 1
 #define STACK_PROJ 2
+#define STACK_FUSEDX3 4  // layer 0 with its real-valued input product inside the IO-wave scan (sfsn_scan3x_dev.h): wide kernel, 8 rows
 #define STACK_FUSED3 3  // the IO-wave scan with its input product inside (sfsn_scan3i_dev.h): wide kernel, 8 rows per workgroup
 
 struct StackRoleDev {
@@ -49,6 +51,9 @@ struct StackRoleDev {
     const int8_t* spikes_in;  // FUSED / PROJ: the previous layer's int8 spikes
     const int8_t* w_ih;       // FUSED / PROJ: packed input weights
     const float* w_ih_dq;
+    const float* x;           // FUSEDX3: the layer input [T][R][I]
+    const float* w_ih_f32;    // FUSEDX3: [H][I]
+    int I;
     int R, block0, nblocks, kind, rpw;
     int src;      // producer role (-1: the input is complete before the launch)
     int src_rpw;  // rows per workgroup of the producer role
@@ -684,7 +689,26 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         lk.n_in = b1 - b0 + 1;
     }
     const int T = p.T, H = p.H, NT = p.NT;
-    if (rl.kind == STACK_FUSED3) {
+    if (rl.kind == STACK_FUSEDX3) {
+        Scan3xRole rx;
+        rx.x = rl.x; rx.w_ih = rl.w_ih_f32; rx.I = rl.I; rx.w_hh = rl.w_hh; rx.w_dq = rl.w_dq; rx.bias = rl.bias;
+        rx.bn_alpha = rl.bn_alpha; rx.bn_beta = rl.bn_beta; rx.h_state = rl.h_state; rx.c_state = rl.c_state;
+        rx.spikes_f32 = rl.spikes_f32; rx.spikes_i8 = rl.spikes_i8; rx.R = rl.R; rx.row0 = blk * 8;
+        const bool tl = (H & 63) != 0 && (H & 63) <= 32;
+#define X3_CASE(TL_, F_)                                                                    \
+    {                                                                                       \
+        if (rl.I > 32) scan3x_role<KS, TL_, OUT, F_, 2>(rx, lk, scan_smem, T, H, NT);       \
+        else scan3x_role<KS, TL_, OUT, F_, 1>(rx, lk, scan_smem, T, H, NT);                 \
+    }
+        if (rl.pub) {
+            if (tl) X3_CASE(1, 2)
+            else if constexpr (KS < 4) X3_CASE(0, 2)
+        } else {
+            if (tl) X3_CASE(1, 0)
+            else if constexpr (KS < 4) X3_CASE(0, 0)
+        }
+#undef X3_CASE
+    } else if (rl.kind == STACK_FUSED3) {
         Scan3iRole ri;
         ri.spikes_in = rl.spikes_in; ri.w_ih = rl.w_ih; ri.w_ih_dq = rl.w_ih_dq; ri.w_hh = rl.w_hh; ri.w_dq = rl.w_dq; ri.bias = rl.bias;
         ri.bn_alpha = rl.bn_alpha; ri.bn_beta = rl.bn_beta; ri.h_state = rl.h_state; ri.c_state = rl.c_state;
@@ -823,6 +847,12 @@ static int launch_stack(const StackParams& p, int blocks, int lds, hipStream_t s
 
 extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, int n_layers, int n_segs, int T, int H,
                                    const int* rows_per_wg, int lag, void* scratch, size_t scratch_bytes, void* stream) {
+    return sfsn_gsn_stack_scan_x(segs, fin, nullptr, n_layers, n_segs, T, H, rows_per_wg, lag, scratch, scratch_bytes, stream);
+}
+
+extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, const sfsn_fused_x* fx, int n_layers,
+                                     int n_segs, int T, int H, const int* rows_per_wg, int lag, void* scratch, size_t scratch_bytes,
+                                     void* stream) {
     if (!segs || !fin || n_layers <= 0 || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0 || !scratch) return SFSN_EINVAL;
     if (H % 16 != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     const int KS = (H + 63) / 64, NT = H / 16, HP = KS * 64;
@@ -867,7 +897,16 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
                 if (!f.w_ih || !f.w_ih_dq || !aligned16(f.w_ih)) return SFSN_EINVAL;
                 if (f.spikes_in != segs[(l - 1) * n_segs + i].spikes_i8) return SFSN_EINVAL;  // the layer below, same segment
             }
-            if (l == 0 || !(fused || inscan)) {
+            // layer 0 of a segment with fx[i].x: the real-valued input product inside the scan (FUSEDX3) -- the wide kernel's IO-wave
+            // roles only, 8 rows per workgroup, even I <= 64, whole 8-row blocks, 16-byte aligned rows
+            const bool xrole = l == 0 && fx && fx[i].x;
+            if (xrole) {
+                const sfsn_fused_x& g = fx[i];
+                const bool can = (inscan || (n_layers == 1 && wide)) && NT <= 14 && rpw == 8 && !getenv("SFSN_SCAN_V2");
+                if (!g.w_ih || g.I <= 0) return SFSN_EINVAL;
+                if (!can || g.I > 64 || (g.I & 1) || (s.R & 7) || !aligned16(g.x)) return SFSN_EUNSUPPORTED;
+            }
+            if (!xrole && (l == 0 || !(fused || inscan))) {
                 if (!s.zin) return SFSN_EINVAL;  // layer 0: the precomputed input term; H > 256: the PROJ role's output buffer
             }
             if (l > 0 && !fused && !inscan) {  // PROJ role first (lower block indices than the scan it feeds)
@@ -894,7 +933,9 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
             r.zin = const_cast<float*>(s.zin);
             r.R = s.R; r.rpw = rpw; r.block0 = blocks; r.nblocks = (s.R + rpw - 1) / rpw;
             r.pub = last ? 0 : 1;
-            if (l == 0) {
+            if (xrole) {
+                r.kind = STACK_FUSEDX3; r.src = -1; r.src_rpw = rpw; r.x = fx[i].x; r.w_ih_f32 = fx[i].w_ih; r.I = fx[i].I; r.zin = nullptr;
+            } else if (l == 0) {
                 r.kind = STACK_ZIN; r.src = -1; r.src_rpw = rpw;
             } else if (fused || inscan) {
                 r.kind = inscan ? STACK_FUSED3 : STACK_FUSED; r.spikes_in = f.spikes_in; r.w_ih = f.w_ih; r.w_ih_dq = f.w_ih_dq;
@@ -916,6 +957,11 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
                     const int dfit = 65536 / (((rpw * 14 * 4 + 63) / 64) * 1024);
                     const int n3 = (dfit < 9 ? dfit : 9) * (((rpw * NT * 4 + 63) / 64) * 1024) + 2 * 16 * (HP + 32) + 16;
                     if (n3 > need) need = n3;
+                }
+                if (r.kind == STACK_FUSEDX3) {
+                    const int n3x = KS == 1 ? Scan3xCfg<1, 2>::lds_bytes(NT) : KS == 2 ? Scan3xCfg<2, 2>::lds_bytes(NT)
+                                  : KS == 3 ? Scan3xCfg<3, 2>::lds_bytes(NT) : Scan3xCfg<4, 2>::lds_bytes(NT);
+                    if (n3x > need) need = n3x;
                 }
                 if (r.kind == STACK_FUSED3) {  // + the input-spike ring, two digit planes of W_ih and the product's constants
                     const int n3i = KS == 1 ? Scan3iCfg<1, 3>::lds_bytes(NT) : KS == 2 ? Scan3iCfg<2, 3>::lds_bytes(NT)

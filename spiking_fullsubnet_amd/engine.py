@@ -463,13 +463,28 @@ class Engine:
             return True, False, 8
         return False, False, 0
 
-    def _stage_stack(self, seqs, d, t0, nt, st, tag, wide, rpw_stack, lag=None, scratch=None):
-        """Every layer of the given sequence models in one launch (layer 0's input term is already in d["zin"][0])."""
+    def _stack_x_groups(self, seqs, xs_, nt, wide, rpw_stack, want_membrane=False):
+        """Groups whose LAYER 0 takes its real-valued input product inside the stack launch (FUSEDX3 role, sfsn_gsn_stack_scan_x):
+        the layout H <= 224 stacks without input-term buffers get (8 rows per workgroup), even I <= 64, whole 8-row blocks, and at
+        least 64 row-frames (below that sfsn_input_proj_f32 itself takes its fp32-MFMA form: the schedules would differ in the last bit)."""
+        if not (self.fuse_input and self.pair_scan and self.spec.shared and not wide and rpw_stack == 8 and not want_membrane
+                and seqs[0].H <= 224 and len(seqs[0].cells) >= 2 and not os.environ.get("SFSN_STACK_FUSED8")):
+            return []
+        return [i for i, (seq, x) in enumerate(zip(seqs, xs_))
+                if seq.I % 2 == 0 and seq.I <= 64 and x.shape[1] % 8 == 0 and nt * x.shape[1] >= 64]
+
+    def _stage_stack(self, seqs, d, t0, nt, st, tag, wide, rpw_stack, lag=None, scratch=None, xs_=None, xg=()):
+        """Every layer of the given sequence models in one launch (layer 0's input term is already in d["zin"][0]; for the groups
+        in `xg` the launch forms it itself from the feature rows xs_[i])."""
         L = self.lib
         H, nl, ns = seqs[0].H, len(seqs[0].cells), len(seqs)
         HP = (H + 63) // 64 * 64
         segs = (ScanSegment * (nl * ns))()
         fin = (FusedInput * (nl * ns))()
+        fx = (FusedX * ns)() if xg else None
+        for i in xg:
+            x, cell = xs_[i], seqs[i].cells[0]
+            fx[i].x, fx[i].w_ih, fx[i].I = x.data_ptr() + t0 * x.shape[1] * seqs[i].I * 4, cell.w_ih_f32.data_ptr(), seqs[i].I
         rows = 0
         for l in range(nl):
             for i, seq in enumerate(seqs):
@@ -477,7 +492,7 @@ class Engine:
                 rows += R if l == 0 else 0
                 # layers >= 1: an input-term buffer selects the wide flavour for H <= 256 (16-wave scans fed by PROJ workgroups
                 # of the same launch); without it the 8-wave fused-input roles run
-                sg.zin = _ptr(d["zin"][l][i]) if (l == 0 or H > 256 or wide) else None
+                sg.zin = _ptr(d["zin"][l][i]) if ((l == 0 and i not in xg) or (l > 0 and (H > 256 or wide))) else None
                 sg.w_hh, sg.w_dq, sg.bias = _ptr(cell.w_hh_q), _ptr(cell.w_hh_dq), _ptr(cell.bias)
                 sg.bn_alpha, sg.bn_beta = _ptr(cell.alpha), _ptr(cell.beta)
                 sg.h_state, sg.c_state = _ptr(d["states"][l][i][0]), _ptr(d["states"][l][i][1])
@@ -507,8 +522,12 @@ class Engine:
         rpw = (ctypes.c_int * nl)(*([rp] * nl))
         self.launches["stack"] = self.launches.get("stack", 0) + 1
         with self.timed("stack:" + tag, st):
-            check(L.sfsn_gsn_stack_scan(segs, fin, nl, ns, nt, H, rpw, self.stack_lag if lag is None else lag, _ptr(scratch), nbytes, st),
-                  "sfsn_gsn_stack_scan")
+            if xg:
+                check(L.sfsn_gsn_stack_scan_x(segs, fin, fx, nl, ns, nt, H, rpw, self.stack_lag if lag is None else lag, _ptr(scratch), nbytes, st),
+                      "sfsn_gsn_stack_scan_x")
+            else:
+                check(L.sfsn_gsn_stack_scan(segs, fin, nl, ns, nt, H, rpw, self.stack_lag if lag is None else lag, _ptr(scratch), nbytes, st),
+                      "sfsn_gsn_stack_scan")
         # the launch's error word (a bounded hand-off wait expired) travels to pinned host memory behind the launch; it is looked
         # at without blocking at the next forward (and by check_stack_errors): a failed launch cannot go unnoticed for long
         if not torch.cuda.is_current_stream_capturing():
@@ -853,8 +872,11 @@ class Engine:
                     if staged and gate_events is not None:
                         gstreams[first].wait_event(gate_events[c])
                     feat_fn(t0, nt, hG[first])
-                    self._stage_input(seqs, 0, xs_, d["zin"][0], t0, nt, hG[first], tag)
-                    self._stage_stack(seqs, d, t0, nt, hS[first], tag, wide, rpw_stack)
+                    xg = self._stack_x_groups(seqs, xs_, nt, wide, rpw_stack or self.stack_rows_per_wg[tag], want_membrane)
+                    zr = [i for i in range(len(seqs)) if i not in xg]
+                    if zr:
+                        self._stage_input(pick(seqs, zr), 0, pick(xs_, zr), pick(d["zin"][0], zr), t0, nt, hG[first], tag)
+                    self._stage_stack(seqs, d, t0, nt, hS[first], tag, wide, rpw_stack, xs_=xs_, xg=xg)
                     self._stage_proj(seqs, d["s8"][nl - 1], d["proj"], t0, nt, hG[first], tag)
                     if post_fn is not None:
                         post_fn(t0, nt, hG[first])

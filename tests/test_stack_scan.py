@@ -46,7 +46,7 @@ def _cells(rng, I, H, nl):
     return out
 
 
-def run_stack(hip, zin0s, cells, T, H, rpw, lag=4, want_f32=True, h0=None, c0=None, wide=True):
+def run_stack(hip, zin0s, cells, T, H, rpw, lag=4, want_f32=True, h0=None, c0=None, wide=True, xs=None):
     """zin0s: per segment [T, R, H] = x . W_ih^T of layer 0 (bias added here).  Returns per layer / segment fp32 spikes,
     int8 spikes and the final states.  wide: give the layers >= 1 an input-term buffer (H <= 256: selects the 16-wave flavour
     with PROJ workgroups; without it the 8-wave fused-input roles run; H > 256 always needs the buffer)."""
@@ -82,7 +82,21 @@ def run_stack(hip, zin0s, cells, T, H, rpw, lag=4, want_f32=True, h0=None, c0=No
     nb = hip.sfsn_stack_scratch_bytes(nl, ns, sum(z.shape[1] for z in zin0s))
     scratch = torch.zeros((nb // 4,), dtype=torch.int32, device=DEV)
     rp = (ctypes.c_int * nl)(*([rpw] * nl))
-    check(hip.sfsn_gsn_stack_scan(segs, fin, nl, ns, T, H, rp, lag, _p(scratch), nb, None), "sfsn_gsn_stack_scan")
+    if xs is not None:
+        # xs[i] = layer-0 input [T, R, I] of segment i (or None: that segment's layer 0 reads zin0s[i]): sfsn_gsn_stack_scan_x
+        from spiking_fullsubnet_amd._lib import FusedX
+        fx = (FusedX * ns)()
+        w0 = _t(cells[0][0]["weight_ih"])
+        keep.append(w0)
+        for i, x in enumerate(xs):
+            if x is not None:
+                tx = _t(x)
+                keep.append(tx)
+                fx[i].x, fx[i].w_ih, fx[i].I = tx.data_ptr(), w0.data_ptr(), x.shape[2]
+                segs[i].zin = None
+        check(hip.sfsn_gsn_stack_scan_x(segs, fin, fx, nl, ns, T, H, rp, lag, _p(scratch), nb, None), "sfsn_gsn_stack_scan_x")
+    else:
+        check(hip.sfsn_gsn_stack_scan(segs, fin, nl, ns, T, H, rp, lag, _p(scratch), nb, None), "sfsn_gsn_stack_scan")
     torch.cuda.synchronize()
     assert int(scratch[0].item()) == 0, "a hand-off wait expired"
     return [[tuple(None if x is None else x.cpu().numpy() for x in out[l][i]) for i in range(ns)] for l in range(nl)]
@@ -148,6 +162,59 @@ def test_fused3_role_equals_the_eight_wave_fused_role(hip, monkeypatch):
         for i in range(len(Rs)):
             for k in range(4):
                 np.testing.assert_array_equal(new[l][i][k], old[l][i][k])
+
+
+def _input_proj(hip, x, w):
+    """sfsn_input_proj_f32(bias = NULL): x [T, R, I] -> [T, R, H] (numpy)."""
+    from spiking_fullsubnet_amd._lib import check
+    T, R, I = x.shape
+    H = w.shape[0]
+    tx, tw = _t(x), _t(w)
+    z = torch.empty((T * R, H), device=DEV)
+    check(hip.sfsn_input_proj_f32(_p(tx), _p(tw), None, _p(z), T * R, I, H, H, None), "input_proj")
+    torch.cuda.synchronize()
+    return z.cpu().numpy().reshape(T, R, H)
+
+
+FUSEDX3 = [  # I, H, layers, rows per segment (multiples of 8), which segments take x, T
+    (38, 224, 2, [40, 16, 24], [True, True, True], 45), (38, 224, 2, [64, 8], [True, False], 33), (64, 160, 2, [32], [True], 30),
+    (30, 96, 3, [16, 8], [True, True], 21), (38, 224, 1, [24], [True], 17), (12, 32, 2, [8], [True], 9), (38, 224, 2, [64], [True], 1),
+    (38, 224, 2, [32], [True], 2), (2, 48, 2, [8], [True], 11), (62, 192, 2, [24], [True], 14),
+]  # (T x R >= 64 everywhere: below that sfsn_input_proj_f32 itself takes its fp32-MFMA form, whose roundings differ in the last bit)
+
+
+@pytest.mark.parametrize("I,H,nl,Rs,use_x,T", FUSEDX3)
+def test_fusedx3_layer0_role_equals_input_proj_plus_scan(hip, I, H, nl, Rs, use_x, T):
+    """Round 4: layer 0 with its real-valued input product INSIDE the 8-row IO-wave scan (sfsn_gsn_stack_scan_x, the bf16 3-way
+    split batched over two frames) against sfsn_input_proj_f32 + the per-layer scan, bit for bit -- every layer of the stack (the
+    layers above consume its spikes inside the same launch), final states, segments with and without x in one launch, one and two
+    k-chunks of the product, T = 1 / 2 / odd."""
+    from test_hip_parity import run_scan
+    rng = np.random.default_rng(I * 1000 + H + T)
+    cells = _cells(rng, I, H, nl)
+    xs = [rng.standard_normal((T, R, I)).astype(np.float32) for R in Rs]
+    zin0 = [_input_proj(hip, x, cells[0][0]["weight_ih"]) for x in xs]
+    got = run_stack(hip, zin0, cells, T, H, 8, wide=False, xs=[x if u else None for x, u in zip(xs, use_x)])
+    for i in range(len(Rs)):
+        for l, (sd, alpha, beta, _) in enumerate(cells):
+            zin = zin0[i] if l == 0 else _spike_proj(hip, got[l - 1][i][1], sd["weight_ih"], H)
+            spk, _, s8, hT, cT = run_scan(hip, zin, sd["weight_hh"], sd["bias_ih"], alpha, beta, True, want_mem=False)
+            np.testing.assert_array_equal(got[l][i][0], spk)
+            np.testing.assert_array_equal(got[l][i][1], s8)
+            np.testing.assert_array_equal(got[l][i][2], hT)
+            np.testing.assert_array_equal(got[l][i][3], cT)
+
+
+def test_fusedx3_refuses_what_it_does_not_cover(hip):
+    from spiking_fullsubnet_amd import _lib
+    rng = np.random.default_rng(4)
+    cells = _cells(rng, 38, 224, 2)
+    T = 6
+    for R, I, rpw in ((12, 38, 8), (16, 37, 8), (16, 38, 4), (16, 66, 8)):  # ragged block, odd I, other rows per workgroup, I > 64
+        cells_ = cells if I == 38 else _cells(rng, I, 224, 2)
+        x = rng.standard_normal((T, R, I)).astype(np.float32)
+        with pytest.raises(NotImplementedError):
+            run_stack(hip, [np.zeros((T, R, 224), np.float32)], cells_, T, 224, rpw, wide=False, xs=[x])
 
 
 def _spike_proj(hip, s8, w, H):
