@@ -1163,7 +1163,9 @@ def test_errors_match_reference_behaviour():
         pkg.SpikingFullSubNet(**rw.LIVE_TINY).eval()(torch.zeros(1, 2048))
     # training mode is the differentiable path (tests/test_training.py); the inference-only entry points refuse it
     mt = pkg.SpikingFullSubNet(**rw.LIVE_TINY).to(DEV).train()
-    assert mt(torch.zeros(1, 2048, device=DEV))[0].requires_grad
+    assert mt(torch.zeros(2, 2048, device=DEV))[0].requires_grad
+    with pytest.raises(ValueError, match="more than 1 value per channel"):  # one clip = one full-band row: nn.BatchNorm1d's own refusal
+        mt(torch.zeros(1, 2048, device=DEV))
     with pytest.raises(RuntimeError):
         mt.streaming(batch=1)
 
