@@ -29,7 +29,7 @@ Prints ONE JSON line on rank 0 (see the task contract), carrying
                    HIP-event launch duration -- the north star's "HBM roofline on the sub-band scan"), `dominant_kernel_timed_region`
                    (the fused sub-band scan of the timed region's geometry, alone on the chip and as a time share inside the
                    region), `full_band_stack` (MFMA utilisation).  PMC-derived fields (`traffic`, `mfma.pmc`) come from
-                   profiles/r03_pmc.json and are attached only when that file was taken with the library build that is running
+                   profiles/r04_pmc.json and are attached only when that file was taken with the library build that is running
                    (source hash) on this workload (B, T, geometry, forwards in flight);
   cpu_baseline  -- the CPU oracle (oracle/, a C restatement of the reference) timed on this host's cores on the whole workload
                    (all B clips x all T frames, groups of clips side by side; rank 0, N=1 only).
@@ -91,7 +91,7 @@ def _self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env, stdout=JSON_OUT.fileno()))  # (the ranks get the real stdout as their fd 1)
 
 
-PROFILE_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r04_pmc.json")
 
 
 def _pmc_profile():
