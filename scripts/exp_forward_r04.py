@@ -32,3 +32,16 @@ for pair in (False, True):
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 8
             eng.check_stack_errors()
             print(f"pair={int(pair)} overlap_chunks={n} first={first}: {'bit-identical' if ok else 'MISMATCH'}  {dt*1e3:.3f} ms per forward (B={B}, T={T}) launches {la}", flush=True)
+
+if os.environ.get("FRACS"):
+    eng.pair_scan, eng.overlap_chunks, eng.overlap_first = True, 3, -1
+    for spec in os.environ["FRACS"].split(";"):
+        eng.overlap_fracs = [float(v) for v in spec.split(",")]
+        out = eng.forward_stft(stft); eng.check_stack_errors()
+        ok = torch.equal(torch.view_as_real(ref["enh_stft"]), torch.view_as_real(out["enh_stft"]))
+        for _ in range(3): eng.forward_stft(stft)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(8): eng.forward_stft(stft)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 8
+        print(f"chunk fractions {spec}: {'bit-identical' if ok else 'MISMATCH'}  {dt*1e3:.3f} ms per forward, chunks={out['n_chunks']}", flush=True)
+    eng.overlap_fracs = None

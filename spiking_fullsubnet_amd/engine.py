@@ -245,6 +245,7 @@ class Engine:
         # chunks -- every chunk costs ~0.15 ms of launch boundaries, scan prologues and hand-off lag.  Off when several forwards
         # are in flight anyway (bench.py's timed region sets 0).
         self.overlap_chunks = int(os.environ.get("SFSN_OVERLAP_CHUNKS", "3"))
+        self.overlap_fracs = None  # optional explicit chunk lengths (fractions of T) of the overlapped schedule
         # frames of the first chunk: -1 = 0.24 T (measured, scripts/exp_overlap.py: 3.55 -> 3.40 ms at B=64, the same 3-4 % at B=4..32 and
         # T=500; 64..128 frames and 0.32 T gain nothing), 0 = equal chunks
         self.overlap_first = int(os.environ.get("SFSN_OVERLAP_FIRST", "-1"))
@@ -789,7 +790,15 @@ class Engine:
             # stays ahead)
             first = self.overlap_first if self.overlap_first >= 0 else int(round(0.24 * T / 8.0)) * 8
             first = min(max(int(first), 0), T // 2)
-            if first:
+            if self.overlap_fracs:  # explicit chunk lengths as fractions of T (experiments: scripts/exp_forward_r04.py)
+                cuts = [int(round(f * T / 8.0)) * 8 for f in self.overlap_fracs]
+                lens = [c for c in cuts if c > 0]
+                lens = lens[:-1] + [T - sum(lens[:-1])] if sum(lens[:-1]) < T else [T]
+                bounds, t0 = [], 0
+                for n_ in lens:
+                    bounds.append((t0, n_))
+                    t0 += n_
+            elif first:
                 rest = -(-(T - first) // (self.overlap_chunks - 1))
                 bounds = [(0, first)] + [(t0, min(rest, T - t0)) for t0 in range(first, T, rest)]
             else:
