@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 13 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 14 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -157,11 +157,37 @@ int sfsn_gsn_train_step_bwd(const float* dz_next /* [R][G*H] d_z of step t+1, nu
                             int shared, float* d_gates, float* d_z, float* dc_prev, float* d_bn_w, float* d_bn_b, void* scratch,
                             unsigned epoch, void* stream);
 
-/* A whole layer call: the T step launches of a layer, forward (t = 0 .. T-1) or backward (t = T-1 .. 0), enqueued back to back by
- * the library (one call from the host language per layer and direction instead of T).  Tensors as for the step entries with a
- * leading [T]: z [T][R][G*H]; spikes, u, xhat, f, g, dh_up [T][R][H]; invstd [T][H]; d_gates [T][R][2H]; d_z [T][R][H] (shared;
- * NULL otherwise).  Zero initial state (MODEL:100-106): `zero` = [R][H] zeros.  dc_work: 2 * R * H floats of workspace.
- * `scratch` as for the step entries (zeroed by the caller before the call; epochs 1 .. T are used). */
+/* A whole layer call in ONE launch (ABI 14; ABI <= 13 enqueued T step launches): forward (t = 0 .. T-1) or backward (t = T-1 .. 0).
+ * The workgroups stay resident for all T steps -- weight tile, carried membrane (forward) / its gradient (backward) in LDS -- and
+ * exchange what a step needs from other workgroups through the L2 (csrc/sfsn_train.hip: packed spikes / d_z written through, one
+ * publish counter per row block; the BatchNorm partial sums as for the step entries).  Arithmetic is the step entries', value for
+ * value.  Tensors as for the step entries with a leading [T]: z [T][R][G*H]; spikes, u, xhat, f, g, dh_up [T][R][H]; invstd [T][H];
+ * d_gates [T][R][2H]; d_z [T][R][H] (shared; NULL otherwise).  Zero initial state (MODEL:100-106).  `zero` and `dc_work` are unused
+ * (kept for the ABI-13 call shape; may be NULL).  `scratch`: sfsn_train_seq_scratch_bytes(R, H) bytes, ZEROED by the caller before the
+ * call, one buffer per call (forward and backward use their own); its last four 32-bit words hold the error word as before. */
+size_t sfsn_train_seq_scratch_bytes(int R, int H);
+/* Several layer calls of the same (T, H, gate sharing) in ONE launch per direction -- the sub-band groups of a model are independent
+ * of one another, and a layer call leaves most of the chip idle: their workgroups sit side by side in one grid.  Per call the
+ * tensors of sfsn_gsn_train_seq_fwd / _bwd and its own zeroed scratch buffer.  n <= 8.  All calls with BatchNorm or all without.
+ * SFSN_EUNSUPPORTED when the launch could not hold every call's workgroups resident together (sfsn_gsn_train_multi_check says so
+ * up front; it needs the device): issue the calls separately then. */
+typedef struct {
+    const float *z, *w_hh, *bias, *bn_w, *bn_b;
+    float *running_mean, *running_var;
+    float momentum, eps;
+    int R;
+    float *spikes, *u, *xhat, *f, *g, *invstd;
+    void* scratch;
+} SfsnTrainSeqFwd;
+typedef struct {
+    const float *w_hh, *dh_up, *u, *xhat, *f, *g, *invstd, *bn_w;
+    int R;
+    float *d_gates, *d_z, *d_bn_w, *d_bn_b;
+    void* scratch;
+} SfsnTrainSeqBwd;
+int sfsn_gsn_train_multi_check(const int* R, int n, int H, int shared);
+int sfsn_gsn_train_seq_fwd_multi(const SfsnTrainSeqFwd* calls, int n, int T, int H, int shared, void* stream);
+int sfsn_gsn_train_seq_bwd_multi(const SfsnTrainSeqBwd* calls, int n, int T, int H, int shared, void* stream);
 int sfsn_gsn_train_seq_fwd(const float* z, const float* w_hh, const float* bias, const float* bn_w, const float* bn_b,
                            float* running_mean, float* running_var, float momentum, float eps, int T, int R, int H, int shared,
                            const float* zero, float* spikes, float* u, float* xhat, float* f, float* g, float* invstd, void* scratch,

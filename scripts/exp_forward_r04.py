@@ -1,6 +1,6 @@
 """Round 4: one forward alone (B x T, live baseline_m) with the sub-band stack as one pair launch (FUSED3 roles) against round 3's
 per-layer schedule, by number of full-band / sub-band overlap chunks; every returned tensor compared with the per-layer forward.
-usage: python scripts/exp_forward_r04.py [B] [T]   (CHUNKS=0,2,3,4  FIRST=-1)"""
+usage: python scripts/exp_forward_r04.py [B] [T]   (CHUNKS=0,2,3,4  FIRST=-1  PAIRS=0,1  AHEAD=1  FRACS="a,b,c;...")"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -17,10 +17,11 @@ eng.overlap_chunks, eng.pair_scan = 0, False
 ref = eng.forward_stft(stft); torch.cuda.synchronize()
 chunks = [int(v) for v in os.environ.get("CHUNKS", "0,2,3,4").split(",")]
 firsts = [int(v) for v in os.environ.get("FIRST", "-1").split(",")]
-for pair in (False, True):
+aheads = [int(v) for v in os.environ.get("AHEAD", "1").split(",")]
+for pair, ahead in [(bool(int(p_)), bool(a_)) for p_ in os.environ.get("PAIRS", "0,1").split(",") for a_ in aheads]:
     for n in chunks:
         for first in (firsts if n > 1 else [-1]):
-            eng.pair_scan, eng.overlap_chunks, eng.overlap_first = pair, n, first
+            eng.pair_scan, eng.overlap_chunks, eng.overlap_first, eng.overlap_prep_ahead = pair, n, first, ahead
             eng.launches = {}
             out = eng.forward_stft(stft); eng.check_stack_errors()
             la = dict(eng.launches)
@@ -31,7 +32,7 @@ for pair in (False, True):
             for _ in range(8): eng.forward_stft(stft)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 8
             eng.check_stack_errors()
-            print(f"pair={int(pair)} overlap_chunks={n} first={first}: {'bit-identical' if ok else 'MISMATCH'}  {dt*1e3:.3f} ms per forward (B={B}, T={T}) launches {la}", flush=True)
+            print(f"pair={int(pair)} ahead={int(ahead)} overlap_chunks={n} first={first}: {'bit-identical' if ok else 'MISMATCH'}  {dt*1e3:.3f} ms per forward (B={B}, T={T}) launches {la}", flush=True)
 
 if os.environ.get("FRACS"):
     eng.pair_scan, eng.overlap_chunks, eng.overlap_first = True, 3, -1

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
 NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE, NORM_CUMLAPLACE = 0, 1, 2, 3
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
-ABI_VERSION = 13  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
+ABI_VERSION = 14  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -49,6 +49,18 @@ class CountTensor(ctypes.Structure):
     _fields_ = [("spikes_i8", _P), ("n_bytes", ctypes.c_ulonglong), ("count", _P)]
 
 
+class TrainSeqFwd(ctypes.Structure):  # SfsnTrainSeqFwd: one layer call of a multi-call training launch
+    _fields_ = [("z", _P), ("w_hh", _P), ("bias", _P), ("bn_w", _P), ("bn_b", _P), ("running_mean", _P), ("running_var", _P),
+                ("momentum", _F), ("eps", _F), ("R", _I), ("spikes", _P), ("u", _P), ("xhat", _P), ("f", _P), ("g", _P), ("invstd", _P),
+                ("scratch", _P)]
+
+
+class TrainSeqBwd(ctypes.Structure):  # SfsnTrainSeqBwd
+    _fields_ = [("w_hh", _P), ("dh_up", _P), ("u", _P), ("xhat", _P), ("f", _P), ("g", _P), ("invstd", _P), ("bn_w", _P), ("R", _I),
+                ("d_gates", _P), ("d_z", _P), ("d_bn_w", _P), ("d_bn_b", _P), ("scratch", _P)]
+
+
+TRAIN_MAX_CALLS = 8
 MAX_COUNT_TENSORS = 16
 HOP_MAX_LAYERS = 3
 HOP_MAX_GROUPS = 4
@@ -141,6 +153,14 @@ def lib() -> ctypes.CDLL:
     L.sfsn_gsn_train_step_fwd.argtypes = [_P] * 9 + [_F, _F, _I, _I, _I] + [_P] * 7 + [ctypes.c_uint, _P]
     L.sfsn_train_scratch_bytes.restype = ctypes.c_size_t
     L.sfsn_train_scratch_bytes.argtypes = [_I]
+    L.sfsn_train_seq_scratch_bytes.restype = ctypes.c_size_t
+    L.sfsn_train_seq_scratch_bytes.argtypes = [_I, _I]
+    L.sfsn_gsn_train_multi_check.restype = _I
+    L.sfsn_gsn_train_multi_check.argtypes = [ctypes.POINTER(_I), _I, _I, _I]
+    L.sfsn_gsn_train_seq_fwd_multi.restype = _I
+    L.sfsn_gsn_train_seq_fwd_multi.argtypes = [ctypes.POINTER(TrainSeqFwd), _I, _I, _I, _I, _P]
+    L.sfsn_gsn_train_seq_bwd_multi.restype = _I
+    L.sfsn_gsn_train_seq_bwd_multi.argtypes = [ctypes.POINTER(TrainSeqBwd), _I, _I, _I, _I, _P]
     L.sfsn_gsn_train_check.restype = _I
     L.sfsn_gsn_train_check.argtypes = [_I, _I, _I]
     L.sfsn_gsn_train_step_bwd.restype = _I
@@ -199,7 +219,8 @@ EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device
            "sfsn_w3_pack", "sfsn_w3_pack_bits", "sfsn_w3_unpack", "sfsn_gsn_layer_scan", "sfsn_gsn_layer_scan_fused", "sfsn_gsn_layer_scan_fused_x", "sfsn_stack_scratch_bytes", "sfsn_gsn_stack_scan",
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
            "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_stream_hop_resident", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft", "sfsn_gsn_train_step_fwd", "sfsn_gsn_train_step_bwd", "sfsn_train_scratch_bytes",
-           "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16", "sfsn_gsn_train_check", "sfsn_gsn_stack_scan_x")
+           "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16", "sfsn_gsn_train_check", "sfsn_gsn_stack_scan_x", "sfsn_train_seq_scratch_bytes", "sfsn_gsn_train_multi_check",
+           "sfsn_gsn_train_seq_fwd_multi", "sfsn_gsn_train_seq_bwd_multi")
 
 
 def check(rc: int, what: str = "") -> None:

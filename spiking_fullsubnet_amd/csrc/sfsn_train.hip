@@ -73,7 +73,7 @@ __device__ __forceinline__ bool tr_exchange(float* scratch, unsigned* /*counters
         for (unsigned spins = 0;; ++spins) {
             v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)(v >> 32) == epoch) break;
-            if (spins > 2000000u) {  // ~1 s: a launch whose blocks are not all resident must not hang the device
+            if (spins > 300000u) {  // ~0.3 s: a launch whose blocks are not all resident must not hang the device
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 good = 0;
                 break;
@@ -352,8 +352,9 @@ extern "C" int sfsn_gsn_train_check(int R, int H, int shared) {
     train_geometry(R, H, &RB, &rpb);
     if (RB > 16) return SFSN_EUNSUPPORTED;
     const int G = shared ? 1 : 2;
-    const size_t lds_f = ((size_t)G * TR_TILE * (H + 1) + (size_t)rpb * TR_TILE + (size_t)RB * TR_PART) * sizeof(float) + (size_t)rpb * H;
-    const size_t lds_b = ((size_t)rpb * TR_TILE + (size_t)RB * TR_PART + (size_t)G * H * (TR_TILE + rpb)) * sizeof(float);
+    // (the one-launch layer calls carry the membrane / its gradient and the packed new spikes in LDS on top of the step kernels' buffers)
+    const size_t lds_f = ((size_t)G * TR_TILE * (H + 4) + (size_t)(2 + G) * rpb * TR_TILE + (size_t)RB * TR_PART) * sizeof(float) + (size_t)rpb * H + (size_t)rpb * TR_TILE;
+    const size_t lds_b = ((size_t)3 * rpb * TR_TILE + (size_t)RB * TR_PART + (size_t)(G * H + 4) * (TR_TILE + rpb)) * sizeof(float);
     return (lds_f > 150 * 1024 || lds_b > 150 * 1024) ? SFSN_EUNSUPPORTED : SFSN_OK;
 }
 
@@ -415,40 +416,591 @@ extern "C" int sfsn_gsn_train_step_bwd(const float* dz_next, const float* w_hh, 
     return hip_ok_tr(hipGetLastError());
 }
 
-// ---- a whole layer call: the T step launches enqueued from here (the interpreter's share of a step launch was ~10 us of the
-// 15 it took at small batches).  Tensors as for the step entries with a leading [T]; zero initial state (`zero` = [R][H] zeros).
-extern "C" int sfsn_gsn_train_seq_fwd(const float* z, const float* w_hh, const float* bias, const float* bn_w, const float* bn_b,
-                                      float* running_mean, float* running_var, float momentum, float eps, int T, int R, int H,
-                                      int shared, const float* zero, float* spikes, float* u, float* xhat, float* f, float* g,
-                                      float* invstd, void* scratch, void* stream) {
-    if (T <= 0 || !zero) return SFSN_EINVAL;
-    const size_t RH = (size_t)R * H, RG = (size_t)R * (shared ? 1 : 2) * H;
-    for (int t = 0; t < T; ++t) {
-        const int rc = sfsn_gsn_train_step_fwd(z + t * RG, w_hh, bias, t ? spikes + (t - 1) * RH : zero, t ? u + (t - 1) * RH : zero, bn_w, bn_b,
-                                               running_mean, running_var, momentum, eps, R, H, shared, spikes + t * RH, u + t * RH,
-                                               xhat ? xhat + t * RH : nullptr, f + t * RH, g + t * RH, invstd ? invstd + (size_t)t * H : nullptr,
-                                               scratch, (unsigned)(t + 1), stream);
-        if (rc != SFSN_OK) return rc;
+// ---- a whole layer call in ONE launch (round 4) ---------------------------------------------------------------------------
+// The step launches above cost 15.6 us (forward) / 10.9 us (backward) for ~2 us of arithmetic: every step paid a launch ramp, a
+// reload of its W_hh tile into LDS and a host-side enqueue (16,000 launches per training step of baseline_m: the host could not
+// issue them faster than ~14 us each, so the three sub-band groups did not even overlap on streams of their own).  Here the
+// workgroups of a layer call stay resident for all T steps: the weight tile is loaded once, the carried membrane (forward) and
+// its gradient (backward) stay in LDS, and what a step needs from OTHER workgroups travels through the L2:
+//   * the BatchNorm partial sums between the row blocks of a neuron tile: the tagged granules of tr_exchange, epoch = step + 1;
+//   * forward: h_{t-1} of my rows for ALL neurons (each of the H / 16 tile workgroups of the row block wrote 16 of them): four
+//     spikes packed per 32-bit word, written through (sc1) into a two-slot buffer [t & 1][R][H / 4]; a per-row-block counter counts
+//     the tile workgroups that have published step t (their stores drained by vmcnt before the add); readers poll the counter
+//     (one thread), then read the words with sc1 loads.  Two slots suffice: a workgroup publishes h_{t+1} only after it has read
+//     h_t from every tile of its row block, which they published after reading h_{t-1};
+//   * backward: d_z of step t+1 of my rows (all G*H products): the API tensor itself, written with sc1 stores, same counter.
+// All workgroups of the launch must be resident (train_geometry keeps the grid under 220 blocks of 256 threads); every spin is
+// bounded (error word, the host raises).  Arithmetic and its order are the step kernels', value for value.
+__device__ __forceinline__ bool tr_wait_counter(const unsigned* cnt, unsigned want, unsigned* err) {
+    int good = 1;
+    if (threadIdx.x == 0) {
+        for (unsigned spins = 0;; ++spins) {
+            if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+            if (spins > 600000u) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return __syncthreads_and(good) != 0;
+}
+__device__ __forceinline__ void tr_publish(unsigned* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my write-through stores of this step have reached the coherent level
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+typedef int tr_v4i __attribute__((ext_vector_type(4)));
+typedef float tr_v4f __attribute__((ext_vector_type(4)));
+// n 16-byte pieces of coherent (sc1) global memory -> LDS, all threads of the workgroup, four loads per thread in flight
+// (rows of `ppr` pieces in the source, `dpr` >= ppr pieces apart in LDS)
+__device__ __forceinline__ void tr_copy16_sc1(void* lds_dst, const void* src, int n, int ppr, int dpr) {
+    const char* s8 = static_cast<const char*>(src);
+    tr_v4i* d = static_cast<tr_v4i*>(lds_dst);
+    const int pad = dpr - ppr;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * TR_THREADS) {
+        tr_v4i v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+        const int i1 = i0 + TR_THREADS, i2 = i0 + 2 * TR_THREADS, i3 = i0 + 3 * TR_THREADS;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v0) : "v"(s8 + (size_t)i0 * 16) : "memory");
+        if (i1 < n) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v1) : "v"(s8 + (size_t)i1 * 16) : "memory");
+        if (i2 < n) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v2) : "v"(s8 + (size_t)i2 * 16) : "memory");
+        if (i3 < n) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v3) : "v"(s8 + (size_t)i3 * 16) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)::"memory");
+        d[i0 + (i0 / ppr) * pad] = v0;
+        if (i1 < n) d[i1 + (i1 / ppr) * pad] = v1;
+        if (i2 < n) d[i2 + (i2 / ppr) * pad] = v2;
+        if (i3 < n) d[i3 + (i3 / ppr) * pad] = v3;
+    }
+}
+
+#ifdef SFSN_EXPERIMENTS
+#define TR_STAMP(k) do { if (x.prof && tile == 0 && rb == 0 && threadIdx.x == 0) { const long long n_ = (long long)wall_clock64(); x.prof[k] += n_ - tr_t0; tr_t0 = n_; } } while (0)
+#else
+#define TR_STAMP(k) do { } while (0)
+#endif
+struct TrainSeqExtra {
+    int T;
+    unsigned* hx;     // forward: [2][R][H / 4] packed spikes (write-through)
+    unsigned* rbcnt;  // [RB] publish counters of the row blocks
+    long long* prof;  // -DSFSN_EXPERIMENTS: per-phase wall-clock ticks of workgroup (0, 0) (null otherwise)
+    float* gran2;     // the partial-sum granules of the ODD steps (the even steps use p.scratch): a row block may write step s+1's
+                      // partials while a slower one has not read step s's yet -- without a launch boundary between the steps that
+                      // needs two slots (step s+2's are written only after every block's step s+1 partials were read, which they
+                      // wrote after reading all of step s)
+};
+
+// One launch serves up to TR_MAXG layer calls of the same (T, H, gate sharing) -- the sub-band groups of a model, which are independent
+// of one another: their workgroups sit side by side in ONE grid (workgroup -> (call, tile, row block) by a prefix table), so the
+// groups overlap without a second queue.  (Three launches on three streams did overlap -- until one of them was never dispatched:
+// reproducibly within a few hundred iterations a queued launch stayed at zero started workgroups behind finished ones,
+// scripts/dbg_train_hang.py.  One grid has no such dependence on how the runtime maps streams to hardware queues.)
+#define TR_MAXG 8
+struct TrainSeqFwdMulti {
+    TrainFwdParams p[TR_MAXG];
+    TrainSeqExtra x[TR_MAXG];
+    int wg_end[TR_MAXG];  // exclusive prefix end of each call's workgroups in the flat grid
+    int n;
+};
+struct TrainSeqBwdMulti {
+    TrainBwdParams p[TR_MAXG];
+    TrainSeqExtra x[TR_MAXG];
+    int wg_end[TR_MAXG];
+    int n;
+};
+
+__device__ __forceinline__ void train_seq_fwd_body(const TrainFwdParams& p, const TrainSeqExtra& x, const int tile, const int rb, const int tiles) {
+    extern __shared__ __attribute__((aligned(16))) char tr_smem[];
+    const int H = p.H, G = p.shared ? 1 : 2;
+    const int r_lo = rb * p.rpb, r_hi = (r_lo + p.rpb < p.R) ? r_lo + p.rpb : p.R, nr = r_hi - r_lo;
+    const int WLD = H + 4;                                                // (rows 16-byte aligned: the product reads 4 k per request)
+    float* wt = reinterpret_cast<float*>(tr_smem);                       // [G][16][WLD]
+    float* cbuf = wt + (size_t)G * TR_TILE * WLD;                         // [rpb][16] pre-normalisation membranes of my rows
+    float* cprev = cbuf + (size_t)p.rpb * TR_TILE;                        // [rpb][16] the carried membrane u_{t-1} (my rows, my neurons)
+    float* recb = cprev + (size_t)p.rpb * TR_TILE;                        // [rpb][G][16] the recurrent products of this step
+    float* parts = recb + (size_t)p.rpb * G * TR_TILE;                    // [RB][TR_PART]
+    unsigned* hb = reinterpret_cast<unsigned*>(parts + (size_t)p.RB * TR_PART);  // [rpb][H / 4] h_{t-1} of my rows, a byte per neuron
+    unsigned* sb = hb + (size_t)p.rpb * (H >> 2);                         // [rpb][4] my 16 new spikes per row, packed
+    __shared__ float red[TR_THREADS / TR_TILE][TR_TILE];
+    const int tid = threadIdx.x, j = tid & 15, rsub = tid >> 4;
+    const int wave = tid >> 6, lj = tid & 15, kq = (tid & 63) >> 4;
+    const int n0 = tile * TR_TILE, nj = n0 + j;
+    const int H4 = H >> 2;
+    unsigned* err = p.counters + tiles;
+    for (int i = tid; i < G * TR_TILE * H; i += TR_THREADS) {
+        const int gi = i / (TR_TILE * H), rem = i - gi * TR_TILE * H, jj = rem / H, k = rem - jj * H;
+        wt[(gi * TR_TILE + jj) * WLD + k] = p.w_hh[((size_t)gi * H + n0 + jj) * H + k];
+    }
+    if (tid == 0) __hip_atomic_fetch_add(x.rbcnt + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (diagnostics: workgroups started)
+    for (int i = tid; i < p.rpb * TR_TILE; i += TR_THREADS) cprev[i] = 0.f;
+    for (int i = tid; i < p.rpb * H4; i += TR_THREADS) hb[i] = 0u;
+    const float bf = p.bias[nj], bg = p.bias[H + nj];
+    const float gam = p.use_bn ? p.bn_w[nj] : 1.f, bet = p.use_bn ? p.bn_b[nj] : 0.f;
+    const bool stat_owner = rsub == 0 && rb == 0;
+    float rmean = (stat_owner && p.running_mean) ? p.running_mean[nj] : 0.f, rvar = (stat_owner && p.running_mean) ? p.running_var[nj] : 0.f;
+    const size_t RH = (size_t)p.R * H, RG = (size_t)p.R * G * H;
+    __syncthreads();
+    long long tr_t0 = (long long)wall_clock64();
+    (void)tr_t0;
+    for (int t = 0; t < x.T; ++t) {
+        if (t > 0) {  // h_{t-1} of my rows: every tile workgroup of my row block has published step t-1
+            if (!tr_wait_counter(x.rbcnt + rb, (unsigned)t * (unsigned)tiles, err)) return;
+            TR_STAMP(0);
+            const unsigned* src = x.hx + ((size_t)((t - 1) & 1) * p.R + r_lo) * H4;
+            tr_copy16_sc1(hb, src, (nr * H4) >> 2, H4 >> 2, H4 >> 2);  // (H / 4 words per row, H % 16 == 0: whole 16-byte pieces)
+            __syncthreads();
+            TR_STAMP(1);
+        }
+        const float* z = p.z + (size_t)t * RG;
+        float *o_f = p.f + (size_t)t * RH, *o_g = p.g + (size_t)t * RH, *o_u = p.u + (size_t)t * RH, *o_s = p.spikes + (size_t)t * RH;
+        float* o_x = p.xhat ? p.xhat + (size_t)t * RH : nullptr;
+        // the recurrent products of my rows x my 16 neurons on the matrix pipe (v_mfma_f32_16x16x4_f32: fp32 products, fp32
+        // accumulation; the scalar loop of the step kernel took 7 us per row and thread -- 22 of a step's 34 us at 48 rows per
+        // block).  A = h (0 / 1) of 16 rows, B = the weight rows of my neurons; k runs as (16 s + 4 kq + i): one packed word of h
+        // and one 16-byte piece of a weight row feed four instructions.  Wave w takes the row tiles w, w + 4, ...
+        for (int mt = wave; mt < (p.rpb >> 4); mt += TR_THREADS / 64) {
+            tr_v4f accf = {0.f, 0.f, 0.f, 0.f}, accg = {0.f, 0.f, 0.f, 0.f};
+            const unsigned* hrow = hb + (size_t)(mt * 16 + lj) * H4;
+            const float* wfr = wt + (size_t)lj * WLD;
+            const float* wgr = wt + (size_t)((G - 1) * TR_TILE + lj) * WLD;
+            for (int s4 = 0; s4 < (H >> 4); ++s4) {
+                const unsigned hw = hrow[4 * s4 + kq];
+                const tr_v4f wv = *reinterpret_cast<const tr_v4f*>(wfr + 16 * s4 + 4 * kq);
+                tr_v4f wgv = wv;
+                if (G == 2) wgv = *reinterpret_cast<const tr_v4f*>(wgr + 16 * s4 + 4 * kq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float hk = (float)((hw >> (8 * e)) & 1u);
+                    accf = __builtin_amdgcn_mfma_f32_16x16x4f32(hk, wv[e], accf, 0, 0, 0);
+                    if (G == 2) accg = __builtin_amdgcn_mfma_f32_16x16x4f32(hk, wgv[e], accg, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {  // D: lane (lj, kq) holds rows 4 kq + e of the tile, neuron lj
+                recb[(size_t)((mt * 16 + 4 * kq + e) * G) * TR_TILE + lj] = accf[e];
+                if (G == 2) recb[(size_t)((mt * 16 + 4 * kq + e) * G + 1) * TR_TILE + lj] = accg[e];
+            }
+        }
+        __syncthreads();
+        float sum = 0.f;
+        for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
+            const float rf = recb[(size_t)((r - r_lo) * G) * TR_TILE + j];
+            const float rg = recb[(size_t)((r - r_lo) * G + (G - 1)) * TR_TILE + j];
+            const float zf = z[(size_t)r * G * H + nj], zg = z[(size_t)r * G * H + (G - 1) * H + nj];
+            const float pre_f = (zf + bf) + rf;
+            const float pre_g = (zg + bg) + rg;
+            const float f = 1.0f / (1.0f + expf(-pre_f));
+            const float a = f * cprev[(r - r_lo) * TR_TILE + j];
+            const float b = (1.0f - f) * pre_g;
+            const float cy = a + b;
+            cbuf[(r - r_lo) * TR_TILE + j] = cy;
+            o_f[(size_t)r * H + nj] = f;
+            o_g[(size_t)r * H + nj] = pre_g;
+            sum += cy;
+        }
+        float mean = 0.f, invstd = 1.f, var = 0.f;
+        TR_STAMP(2);
+        if (p.use_bn) {
+            const float tot_b = reduce16(sum, red, rsub, j);
+            const float mean_b = nr > 0 ? tot_b / (float)nr : 0.f;
+            float sq = 0.f;
+            for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
+                const float d = cbuf[(r - r_lo) * TR_TILE + j] - mean_b;
+                sq = __builtin_fmaf(d, d, sq);
+            }
+            const float m2_b = reduce16(sq, red, rsub, j);
+            float m2 = m2_b;
+            mean = mean_b;
+            TR_STAMP(3);
+            if (p.RB > 1) {
+                if (!tr_exchange((t & 1) ? x.gran2 : p.scratch, p.counters, err, tile, rb, p.RB, (unsigned)(t + 1), mean_b, m2_b, (float)nr, rsub, j, parts)) return;
+                TR_STAMP(4);
+                float cnt = 0.f;
+                mean = 0.f; m2 = 0.f;
+                for (int b = 0; b < p.RB; ++b) {
+                    const float nb = parts[b * TR_PART], mb = parts[b * TR_PART + 2 + j], qb = parts[b * TR_PART + 18 + j];
+                    if (nb > 0.f) {
+                        const float tot = cnt + nb, delta = mb - mean;
+                        mean = mean + delta * (nb / tot);
+                        m2 = m2 + qb + delta * delta * (cnt * nb / tot);
+                        cnt = tot;
+                    }
+                }
+            }
+            var = m2 / (float)p.R;
+            invstd = 1.0f / sqrtf(var + p.eps);
+        } else {
+            __syncthreads();
+        }
+        for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
+            const float cy = cbuf[(r - r_lo) * TR_TILE + j];
+            float uu = cy;
+            if (p.use_bn) {
+                const float xh = (cy - mean) * invstd;
+                uu = xh * gam + bet;
+                o_x[(size_t)r * H + nj] = xh;
+            }
+            o_u[(size_t)r * H + nj] = uu;
+            const bool fire = uu >= 0.f;
+            o_s[(size_t)r * H + nj] = fire ? 1.f : 0.f;
+            cprev[(r - r_lo) * TR_TILE + j] = uu;
+            reinterpret_cast<unsigned char*>(sb)[(r - r_lo) * TR_TILE + j] = fire ? 1 : 0;
+        }
+        if (p.use_bn && stat_owner) {
+            p.invstd[(size_t)t * H + nj] = invstd;
+            if (p.running_mean) {
+                const float unb = p.R > 1 ? var * ((float)p.R / (float)(p.R - 1)) : var;
+                rmean = (1.0f - p.momentum) * rmean + p.momentum * mean;
+                rvar = (1.0f - p.momentum) * rvar + p.momentum * unb;
+            }
+        }
+        __syncthreads();
+        TR_STAMP(5);
+        if (t + 1 < x.T) {  // my 16 spikes of every row -> the slot of step t, write-through; then count me in
+            unsigned* dst = x.hx + ((size_t)(t & 1) * p.R + r_lo) * H4 + tile * 4;
+            for (int i = tid; i < nr * 4; i += TR_THREADS)
+                __hip_atomic_store(dst + (size_t)(i >> 2) * H4 + (i & 3), sb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tr_publish(x.rbcnt + rb);
+            TR_STAMP(6);
+        }
+    }
+    if (p.use_bn && stat_owner && p.running_mean) {
+        p.running_mean[nj] = rmean;
+        p.running_var[nj] = rvar;
+    }
+}
+
+// backward: steps t = T-1 ... 0 in one launch.  p.dh_up / u / xhat / f / g / invstd / d_gates / d_z point at the [T]-leading tensors;
+// c_prev of step t is u[t-1] (zero at t = 0); the carried membrane gradient stays in LDS.
+__global__ __launch_bounds__(TR_THREADS) void gsn_train_seq_fwd_kernel(const TrainSeqFwdMulti m) {
+    int g = 0;
+    while (g + 1 < m.n && (int)blockIdx.x >= m.wg_end[g]) ++g;
+    const int li = (int)blockIdx.x - (g ? m.wg_end[g - 1] : 0), tiles = m.p[g].H / TR_TILE;
+    train_seq_fwd_body(m.p[g], m.x[g], li % tiles, li / tiles, tiles);
+}
+
+__device__ __forceinline__ void train_seq_bwd_body(const TrainBwdParams& p, const TrainSeqExtra& x, const int tile, const int rb, const int tiles) {
+    extern __shared__ __attribute__((aligned(16))) char tr_smem[];
+    __shared__ float red[TR_THREADS / TR_TILE][TR_TILE];
+    const int H = p.H, G = p.shared ? 1 : 2, GH = G * p.H;
+    const int r_lo = rb * p.rpb, r_hi = (r_lo + p.rpb < p.R) ? r_lo + p.rpb : p.R, nr = r_hi - r_lo;
+    const int tid = threadIdx.x, j = tid & 15, rsub = tid >> 4;
+    const int nj = tile * TR_TILE + j;
+    float* dbuf = reinterpret_cast<float*>(tr_smem);   // [rpb][16] du of my rows
+    float* dcn = dbuf + (size_t)p.rpb * TR_TILE;        // [rpb][16] dL/dc carried from step t+1 (my rows, my neurons)
+    const int DLD = GH + 4;                             // (row stride of the two matrix operands in LDS: 16-byte aligned, off the bank period)
+    float* recb = dcn + (size_t)p.rpb * TR_TILE;        // [rpb][16] dL/dh_t through step t+1's recurrent product
+    float* parts = recb + (size_t)p.rpb * TR_TILE;      // [RB][TR_PART]
+    float* wcol = parts + (size_t)p.RB * TR_PART;       // [16][DLD]: the columns of W_hh that feed my 16 neurons of h_t, one row per neuron
+    float* dzb = wcol + (size_t)TR_TILE * DLD;          // [rpb][DLD]: d_z of step t+1, my rows
+    unsigned* err = p.counters + tiles;
+    const int wave = tid >> 6, lj = tid & 15, kq = (tid & 63) >> 4;
+    for (int i = tid; i < GH * TR_TILE; i += TR_THREADS) {
+        const int nn = i / TR_TILE, jj = i - nn * TR_TILE;
+        wcol[(size_t)jj * DLD + nn] = p.w_hh[(size_t)nn * H + tile * TR_TILE + jj];
+    }
+    for (int i = tid; i < p.rpb * DLD; i += TR_THREADS) dzb[i] = 0.f;
+    if (tid == 0) __hip_atomic_fetch_add(x.rbcnt + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (diagnostics: workgroups started)
+    for (int i = tid; i < p.rpb * TR_TILE; i += TR_THREADS) dcn[i] = 0.f;
+    const size_t RH = (size_t)p.R * H, RG = (size_t)p.R * GH;
+    float* dzs = p.shared ? p.d_z : p.d_gates;  // the gradient of the (shared or per-gate) products: [T][R][G*H]
+    const float gam = p.use_bn ? p.bn_w[nj] : 1.f;
+    float acc_w = 0.f, acc_b = 0.f;
+    const bool stat_owner = rsub == 0 && rb == 0;
+    if (p.use_bn && stat_owner) { acc_w = p.d_bn_w[nj]; acc_b = p.d_bn_b[nj]; }
+    __syncthreads();
+    long long tr_t0 = (long long)wall_clock64();
+    (void)tr_t0;
+    for (int t = x.T - 1; t >= 0; --t) {
+        const int s = x.T - 1 - t;
+        if (s > 0) {  // d_z of step t+1 of my rows: every tile workgroup of my row block has published it
+            if (!tr_wait_counter(x.rbcnt + rb, (unsigned)s * (unsigned)tiles, err)) return;
+            TR_STAMP(0);
+            const float* src = dzs + (size_t)(t + 1) * RG + (size_t)r_lo * GH;
+            tr_copy16_sc1(dzb, src, (nr * GH) >> 2, GH >> 2, DLD >> 2);
+            __syncthreads();
+            TR_STAMP(1);
+            // sum_n dz_{t+1}[r][n] W_hh[n][my neuron] on the matrix pipe (fp32 products and accumulation; 26 of the scalar step's 44 us)
+            for (int mt = wave; mt < (p.rpb >> 4); mt += TR_THREADS / 64) {
+                tr_v4f acc = {0.f, 0.f, 0.f, 0.f};
+                const float* dzr = dzb + (size_t)(mt * 16 + lj) * DLD;
+                const float* wr = wcol + (size_t)lj * DLD;
+                for (int s4 = 0; s4 < (GH >> 4); ++s4) {
+                    const tr_v4f av = *reinterpret_cast<const tr_v4f*>(dzr + 16 * s4 + 4 * kq);
+                    const tr_v4f bv = *reinterpret_cast<const tr_v4f*>(wr + 16 * s4 + 4 * kq);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) recb[(size_t)(mt * 16 + 4 * kq + e) * TR_TILE + lj] = acc[e];
+            }
+            __syncthreads();
+        }
+        const float *i_u = p.u + (size_t)t * RH, *i_f = p.f + (size_t)t * RH, *i_g = p.g + (size_t)t * RH, *i_up = p.dh_up + (size_t)t * RH;
+        const float* i_x = p.xhat ? p.xhat + (size_t)t * RH : nullptr;
+        const float* i_cp = t ? p.u + (size_t)(t - 1) * RH : nullptr;
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
+            const size_t o = (size_t)r * H + nj;
+            float dh = 0.f;
+            dh += i_up[o];
+            if (s > 0) dh += recb[(size_t)(r - r_lo) * TR_TILE + j];  // dL/dh_t through step t+1's recurrent product
+            const float uu = i_u[o];
+            const float tri = fmaxf(0.f, 1.0f - fabsf(uu));
+            float du = dh * tri;
+            if (s > 0) du += dcn[(r - r_lo) * TR_TILE + j];
+            dbuf[(r - r_lo) * TR_TILE + j] = du;
+            if (p.use_bn) {
+                s1 += du;
+                s2 = __builtin_fmaf(du, i_x[o], s2);
+            }
+        }
+        float k1 = 0.f, k2 = 0.f, scale = 1.f;
+        TR_STAMP(2);
+        if (p.use_bn) {
+            k1 = reduce16(s1, red, rsub, j);
+            k2 = reduce16(s2, red, rsub, j);
+            TR_STAMP(3);
+            if (p.RB > 1) {
+                if (!tr_exchange((s & 1) ? x.gran2 : p.scratch, p.counters, err, tile, rb, p.RB, (unsigned)(s + 1), k1, k2, (float)nr, rsub, j, parts)) return;
+                TR_STAMP(4);
+                k1 = 0.f; k2 = 0.f;
+                for (int b = 0; b < p.RB; ++b) {
+                    k1 += parts[b * TR_PART + 2 + j];
+                    k2 += parts[b * TR_PART + 18 + j];
+                }
+            }
+            scale = gam * p.invstd[(size_t)t * H + nj] / (float)p.R;
+            if (stat_owner) { acc_w += k2; acc_b += k1; }
+        } else {
+            __syncthreads();
+        }
+        float* o_dg = p.d_gates + (size_t)t * p.R * 2 * H;
+        float* o_dz = p.shared ? p.d_z + (size_t)t * RH : nullptr;
+        for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
+            const size_t o = (size_t)r * H + nj;
+            const float du = dbuf[(r - r_lo) * TR_TILE + j];
+            const float dcy = p.use_bn ? scale * ((float)p.R * du - k1 - i_x[o] * k2) : du;
+            const float f = i_f[o], g = i_g[o], cp = i_cp ? i_cp[o] : 0.f;
+            const float df = dcy * (cp - g);
+            const float dpf = df * f * (1.0f - f);
+            const float dpg = dcy * (1.0f - f);
+            dcn[(r - r_lo) * TR_TILE + j] = dcy * f;
+            // what the next step's workgroups read goes out write-through (the per-gate tensor when the products are not shared)
+            if (p.shared) {
+                o_dg[(size_t)r * 2 * H + nj] = dpf;
+                o_dg[(size_t)r * 2 * H + H + nj] = dpg;
+                __hip_atomic_store(reinterpret_cast<unsigned*>(o_dz + o), __float_as_uint(dpf + dpg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(reinterpret_cast<unsigned*>(o_dg + (size_t)r * 2 * H + nj), __float_as_uint(dpf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<unsigned*>(o_dg + (size_t)r * 2 * H + H + nj), __float_as_uint(dpg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        TR_STAMP(5);
+        if (t > 0) tr_publish(x.rbcnt + rb);
+        else __syncthreads();
+        TR_STAMP(6);
+    }
+    if (p.use_bn && stat_owner) { p.d_bn_w[nj] = acc_w; p.d_bn_b[nj] = acc_b; }
+}
+
+__global__ __launch_bounds__(TR_THREADS) void gsn_train_seq_bwd_kernel(const TrainSeqBwdMulti m) {
+    int g = 0;
+    while (g + 1 < m.n && (int)blockIdx.x >= m.wg_end[g]) ++g;
+    const int li = (int)blockIdx.x - (g ? m.wg_end[g - 1] : 0), tiles = m.p[g].H / TR_TILE;
+    train_seq_bwd_body(m.p[g], m.x[g], li % tiles, li / tiles, tiles);
+}
+
+// ---- a whole layer call: one launch for all T steps (the kernels above).  Tensors as for the step entries with a leading [T]; zero
+// initial state.  `scratch`: sfsn_train_seq_scratch_bytes(R, H) bytes, ZEROED by the caller before the call (the packed-spike
+// slots, the row blocks' publish counters, then the step entries' layout: granules, error word in the last four words).
+// -DSFSN_EXPERIMENTS and SFSN_TRAIN_PROF=1: where a step of workgroup (0, 0) spends its time (synchronises after every layer call)
+#ifdef SFSN_EXPERIMENTS
+#include <cstdio>
+#include <cstdlib>
+static long long* seq_prof_begin() {
+    static long long* buf = nullptr;
+    if (!getenv("SFSN_TRAIN_PROF")) return nullptr;
+    if (!buf && hipMalloc(&buf, 8 * sizeof(long long)) != hipSuccess) return nullptr;
+    (void)hipMemset(buf, 0, 8 * sizeof(long long));
+    return buf;
+}
+static void seq_prof_end(long long* buf, const char* what, int T, int R, int H, int RB, hipStream_t st) {
+    if (!buf) return;
+    long long h[8];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[train prof] %s T=%d R=%d H=%d RB=%d us/step: wait %.2f load %.2f product %.2f reduce %.2f exchange %.2f output %.2f publish %.2f\n", what, T, R, H, RB,
+            h[0] / 100.0 / T, h[1] / 100.0 / T, h[2] / 100.0 / T, h[3] / 100.0 / T, h[4] / 100.0 / T, h[5] / 100.0 / T, h[6] / 100.0 / T);
+}
+#else
+static long long* seq_prof_begin() { return nullptr; }
+static void seq_prof_end(long long*, const char*, int, int, int, int, hipStream_t) {}
+#endif
+static size_t seq_gran_bytes(int H) { return (size_t)(H / TR_TILE) * 16 * TR_PARTG * sizeof(unsigned long long); }
+static size_t seq_hx_bytes(int R, int H) { return (((size_t)2 * R * (H / 4) + 32) * sizeof(unsigned) + 15) & ~(size_t)15; }  // (+ [16] started, [17] finished workgroups)
+static size_t seq_head_bytes(int R, int H) { return seq_hx_bytes(R, H) + seq_gran_bytes(H); }  // [hx | rbcnt | odd-step granules]
+
+extern "C" size_t sfsn_train_seq_scratch_bytes(int R, int H) {
+    if (R <= 0 || H <= 0 || H % TR_TILE) return 0;
+    return seq_head_bytes(R, H) + sfsn_train_scratch_bytes(H);
+}
+
+static size_t seq_lds_fwd(int G, int H, int RB, int rpb) {
+    return ((size_t)G * TR_TILE * (H + 4) + (size_t)(2 + G) * rpb * TR_TILE + (size_t)RB * TR_PART) * sizeof(float) + (size_t)rpb * H + (size_t)rpb * TR_TILE;
+}
+static size_t seq_lds_bwd(int G, int H, int RB, int rpb) {
+    return ((size_t)3 * rpb * TR_TILE + (size_t)RB * TR_PART + (size_t)(G * H + 4) * (TR_TILE + rpb)) * sizeof(float);
+}
+
+// all workgroups of a launch must be resident together: blocks per compute unit at this LDS size x compute units
+static int seq_slots(const void* kern, size_t lds) {
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, TR_THREADS, lds) != hipSuccess) return -1;
+    return per * cus;
+}
+
+static int seq_multi_geometry(const int* R, int n, int H, int shared, int* wgs, size_t* lds_f, size_t* lds_b) {
+    if (!R || n <= 0 || n > TR_MAXG || H <= 0) return SFSN_EINVAL;
+    if (H % TR_TILE != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
+    const int G = shared ? 1 : 2, tiles = H / TR_TILE;
+    *wgs = 0; *lds_f = 0; *lds_b = 0;
+    for (int i = 0; i < n; ++i) {
+        if (R[i] <= 0) return SFSN_EINVAL;
+        int RB, rpb;
+        train_geometry(R[i], H, &RB, &rpb);
+        if (RB > 16) return SFSN_EUNSUPPORTED;
+        const size_t lf = seq_lds_fwd(G, H, RB, rpb), lb = seq_lds_bwd(G, H, RB, rpb);
+        if (lf > 150 * 1024 || lb > 150 * 1024) return SFSN_EUNSUPPORTED;
+        *lds_f = lf > *lds_f ? lf : *lds_f;
+        *lds_b = lb > *lds_b ? lb : *lds_b;
+        *wgs += tiles * RB;
     }
     return SFSN_OK;
 }
 
-// d_gates [T][R][2H], d_z [T][R][H] (shared) or NULL; dc_work [2][R][H] scratch for the carried membrane gradient
+// SFSN_OK when ONE launch per direction can hold the workgroups of all n layer calls (rows R[i], same H / gate sharing) resident
+// together; SFSN_EUNSUPPORTED otherwise (issue the calls one after the other, or in smaller sets).  Needs the device.
+extern "C" int sfsn_gsn_train_multi_check(const int* R, int n, int H, int shared) {
+    int wgs; size_t lf, lb;
+    const int rc = seq_multi_geometry(R, n, H, shared, &wgs, &lf, &lb);
+    if (rc != SFSN_OK) return rc;
+    const int sf = seq_slots(reinterpret_cast<const void*>(gsn_train_seq_fwd_kernel), lf), sb = seq_slots(reinterpret_cast<const void*>(gsn_train_seq_bwd_kernel), lb);
+    if (sf < 0 || sb < 0) return SFSN_EHIP;
+    return (wgs <= sf && wgs <= sb) ? SFSN_OK : SFSN_EUNSUPPORTED;
+}
+
+extern "C" int sfsn_gsn_train_seq_fwd_multi(const SfsnTrainSeqFwd* c, int n, int T, int H, int shared, void* stream) {
+    if (!c || n <= 0 || n > TR_MAXG || T <= 0 || H <= 0) return SFSN_EINVAL;
+    int Rs[TR_MAXG];
+    for (int i = 0; i < n; ++i) {
+        if (!c[i].z || !c[i].w_hh || !c[i].bias || !c[i].spikes || !c[i].u || !c[i].f || !c[i].g || !c[i].scratch) return SFSN_EINVAL;
+        if (c[i].bn_w && (!c[i].bn_b || !c[i].xhat || !c[i].invstd)) return SFSN_EINVAL;
+        if ((c[i].bn_w != nullptr) != (c[0].bn_w != nullptr)) return SFSN_EINVAL;
+        if ((c[i].running_mean == nullptr) != (c[i].running_var == nullptr)) return SFSN_EINVAL;
+        Rs[i] = c[i].R;
+    }
+    int wgs; size_t lds, lds_b;
+    int rc = seq_multi_geometry(Rs, n, H, shared, &wgs, &lds, &lds_b);
+    if (rc != SFSN_OK) return rc;
+    auto kern = gsn_train_seq_fwd_kernel;
+    const int slots = seq_slots(reinterpret_cast<const void*>(kern), lds);
+    if (slots < 0) return SFSN_EHIP;
+    if (wgs > slots) return SFSN_EUNSUPPORTED;
+    const int tiles = H / TR_TILE;
+    TrainSeqFwdMulti m;
+    m.n = n;
+    int end = 0;
+    for (int i = 0; i < n; ++i) {
+        TrainFwdParams& p = m.p[i];
+        TrainSeqExtra& x = m.x[i];
+        const int R = c[i].R;
+        train_geometry(R, H, &p.RB, &p.rpb);
+        char* base = static_cast<char*>(c[i].scratch);
+        float* step_scr = reinterpret_cast<float*>(base + seq_head_bytes(R, H));
+        p.z = c[i].z; p.w_hh = c[i].w_hh; p.bias = c[i].bias; p.h_prev = nullptr; p.c_prev = nullptr; p.bn_w = c[i].bn_w; p.bn_b = c[i].bn_b;
+        p.running_mean = c[i].running_mean; p.running_var = c[i].running_var; p.spikes = c[i].spikes; p.u = c[i].u; p.xhat = c[i].xhat;
+        p.f = c[i].f; p.g = c[i].g; p.invstd = c[i].invstd; p.momentum = c[i].momentum; p.eps = c[i].eps; p.R = R; p.H = H; p.shared = shared;
+        p.use_bn = c[i].bn_w != nullptr; p.epoch = 0; p.scratch = step_scr;
+        p.counters = reinterpret_cast<unsigned*>(step_scr + (size_t)tiles * 16 * TR_PARTG * 2);
+        x.T = T;
+        x.hx = reinterpret_cast<unsigned*>(base);
+        x.rbcnt = x.hx + (size_t)2 * R * (H / 4);
+        x.gran2 = reinterpret_cast<float*>(base + seq_hx_bytes(R, H));
+        x.prof = (n == 1) ? seq_prof_begin() : nullptr;
+        end += tiles * p.RB;
+        m.wg_end[i] = end;
+    }
+    hipLaunchKernelGGL(kern, dim3(end), dim3(TR_THREADS), lds, static_cast<hipStream_t>(stream), m);
+    if (n == 1) seq_prof_end(m.x[0].prof, "fwd", T, c[0].R, H, m.p[0].RB, static_cast<hipStream_t>(stream));
+    return hip_ok_tr(hipGetLastError());
+}
+
+extern "C" int sfsn_gsn_train_seq_bwd_multi(const SfsnTrainSeqBwd* c, int n, int T, int H, int shared, void* stream) {
+    if (!c || n <= 0 || n > TR_MAXG || T <= 0 || H <= 0) return SFSN_EINVAL;
+    int Rs[TR_MAXG];
+    for (int i = 0; i < n; ++i) {
+        if (!c[i].w_hh || !c[i].dh_up || !c[i].u || !c[i].f || !c[i].g || !c[i].d_gates || (shared && !c[i].d_z) || !c[i].scratch) return SFSN_EINVAL;
+        if (c[i].bn_w && (!c[i].xhat || !c[i].invstd || !c[i].d_bn_w || !c[i].d_bn_b)) return SFSN_EINVAL;
+        if ((c[i].bn_w != nullptr) != (c[0].bn_w != nullptr)) return SFSN_EINVAL;
+        Rs[i] = c[i].R;
+    }
+    int wgs; size_t lds_f, lds;
+    int rc = seq_multi_geometry(Rs, n, H, shared, &wgs, &lds_f, &lds);
+    if (rc != SFSN_OK) return rc;
+    auto kern = gsn_train_seq_bwd_kernel;
+    const int slots = seq_slots(reinterpret_cast<const void*>(kern), lds);
+    if (slots < 0) return SFSN_EHIP;
+    if (wgs > slots) return SFSN_EUNSUPPORTED;
+    const int tiles = H / TR_TILE;
+    TrainSeqBwdMulti m;
+    m.n = n;
+    int end = 0;
+    for (int i = 0; i < n; ++i) {
+        TrainBwdParams& p = m.p[i];
+        TrainSeqExtra& x = m.x[i];
+        const int R = c[i].R;
+        train_geometry(R, H, &p.RB, &p.rpb);
+        char* base = static_cast<char*>(c[i].scratch);
+        float* step_scr = reinterpret_cast<float*>(base + seq_head_bytes(R, H));
+        p.dz_next = nullptr; p.w_hh = c[i].w_hh; p.dh_up = c[i].dh_up; p.dh_rec = nullptr; p.dc_next = nullptr; p.u = c[i].u; p.xhat = c[i].xhat;
+        p.f = c[i].f; p.g = c[i].g; p.c_prev = nullptr; p.invstd = c[i].invstd; p.bn_w = c[i].bn_w; p.d_gates = c[i].d_gates; p.d_z = c[i].d_z;
+        p.dc_prev = nullptr; p.d_bn_w = c[i].d_bn_w; p.d_bn_b = c[i].d_bn_b;
+        p.R = R; p.H = H; p.shared = shared; p.use_bn = c[i].bn_w != nullptr; p.epoch = 0; p.scratch = step_scr;
+        p.counters = reinterpret_cast<unsigned*>(step_scr + (size_t)tiles * 16 * TR_PARTG * 2);
+        x.T = T;
+        x.hx = reinterpret_cast<unsigned*>(base);
+        x.rbcnt = x.hx + (size_t)2 * R * (H / 4);
+        x.gran2 = reinterpret_cast<float*>(base + seq_hx_bytes(R, H));
+        x.prof = (n == 1) ? seq_prof_begin() : nullptr;
+        end += tiles * p.RB;
+        m.wg_end[i] = end;
+    }
+    hipLaunchKernelGGL(kern, dim3(end), dim3(TR_THREADS), lds, static_cast<hipStream_t>(stream), m);
+    if (n == 1) seq_prof_end(m.x[0].prof, "bwd", T, c[0].R, H, m.p[0].RB, static_cast<hipStream_t>(stream));
+    return hip_ok_tr(hipGetLastError());
+}
+
+// one layer call (= the multi entries with n = 1, ABI-13 call shape)
+extern "C" int sfsn_gsn_train_seq_fwd(const float* z, const float* w_hh, const float* bias, const float* bn_w, const float* bn_b,
+                                      float* running_mean, float* running_var, float momentum, float eps, int T, int R, int H,
+                                      int shared, const float* /*zero: unused since ABI 14*/, float* spikes, float* u, float* xhat, float* f, float* g,
+                                      float* invstd, void* scratch, void* stream) {
+    SfsnTrainSeqFwd c;
+    c.z = z; c.w_hh = w_hh; c.bias = bias; c.bn_w = bn_w; c.bn_b = bn_b; c.running_mean = running_mean; c.running_var = running_var;
+    c.momentum = momentum; c.eps = eps; c.R = R; c.spikes = spikes; c.u = u; c.xhat = xhat; c.f = f; c.g = g; c.invstd = invstd; c.scratch = scratch;
+    return sfsn_gsn_train_seq_fwd_multi(&c, 1, T, H, shared, stream);
+}
+
+// d_gates [T][R][2H], d_z [T][R][H] (shared) or NULL; d_bn_w / d_bn_b are accumulated into (+=) as by the step entry
 extern "C" int sfsn_gsn_train_seq_bwd(const float* w_hh, const float* dh_up, const float* u, const float* xhat, const float* f,
                                       const float* g, const float* invstd, const float* bn_w, int T, int R, int H, int shared,
-                                      const float* zero, float* d_gates, float* d_z, float* dc_work, float* d_bn_w, float* d_bn_b,
-                                      void* scratch, void* stream) {
-    if (T <= 0 || !zero || !dc_work || !d_gates || (shared && !d_z)) return SFSN_EINVAL;
-    const size_t RH = (size_t)R * H, RG = (size_t)R * (shared ? 1 : 2) * H;
-    float* dzs = shared ? d_z : d_gates;  // the gradient of the (shared or per-gate) products: [T][R][G*H]
-    for (int t = T - 1; t >= 0; --t) {
-        const bool last = t == T - 1;
-        const int rc = sfsn_gsn_train_step_bwd(last ? nullptr : dzs + (t + 1) * RG, w_hh, dh_up + t * RH, nullptr,
-                                               last ? nullptr : dc_work + ((t + 1) & 1) * RH, u + t * RH, xhat ? xhat + t * RH : nullptr,
-                                               f + t * RH, g + t * RH, t ? u + (t - 1) * RH : zero, invstd ? invstd + (size_t)t * H : nullptr, bn_w,
-                                               R, H, shared, d_gates + (size_t)t * R * 2 * H, shared ? d_z + t * RH : nullptr,
-                                               dc_work + (t & 1) * RH, d_bn_w, d_bn_b, scratch, (unsigned)(T - t), stream);
-        if (rc != SFSN_OK) return rc;
-    }
-    return SFSN_OK;
+                                      const float* /*zero: unused since ABI 14*/, float* d_gates, float* d_z, float* /*dc_work: unused since ABI 14*/,
+                                      float* d_bn_w, float* d_bn_b, void* scratch, void* stream) {
+    SfsnTrainSeqBwd c;
+    c.w_hh = w_hh; c.dh_up = dh_up; c.u = u; c.xhat = xhat; c.f = f; c.g = g; c.invstd = invstd; c.bn_w = bn_w; c.R = R;
+    c.d_gates = d_gates; c.d_z = d_z; c.d_bn_w = d_bn_w; c.d_bn_b = d_bn_b; c.scratch = scratch;
+    return sfsn_gsn_train_seq_bwd_multi(&c, 1, T, H, shared, stream);
 }

@@ -253,6 +253,9 @@ class Engine:
         # hand-off wait expired raises HERE instead of at the next forward); False: non-blocking, see check_stack_errors()
         self.strict_errors = os.environ.get("SFSN_STRICT_ERRORS", "0") == "1"
         self._ov_streams = None
+        # overlapped schedule: the full-band model's features and layer-0 input products of ALL chunks go out at once on a stream
+        # of their own (nothing gates them), so its stack launches follow one another without the time-parallel kernels between them
+        self.overlap_prep_ahead = os.environ.get("SFSN_PREP_AHEAD", "1") != "0"
         self.stack_wide = True
         self._stack_scratch: List[torch.Tensor] = []
         self._stack_err_pending: List[tuple] = []  # (event, pinned copy of a launch's error word): polled at the next forward
@@ -814,7 +817,8 @@ class Engine:
         # ---------------- tensors
         x_fb = torch.empty((T, B, spec.fb_in), **f32)
         xs = [torch.empty((T, B * spec.units(g), spec.sb_input_size(g)), **f32) for g in range(ng)]
-        fb = self._alloc_stack([self.fb], [B], T, nt_max, want_layers, want_membrane, "fb")
+        prep_ahead = bool(overlap and self.overlap_prep_ahead)
+        fb = self._alloc_stack([self.fb], [B], T, T if prep_ahead else nt_max, want_layers, want_membrane, "fb")
         sb = self._alloc_stack(self.sb, [x.shape[1] for x in xs], T, nt_max, want_layers, want_membrane, "sb")
         enh = torch.empty((B, S, F, T), dtype=torch.complex64, device=dev)
         enh_mag = torch.empty((B, S, F, T), **f32)
@@ -854,6 +858,11 @@ class Engine:
             fork.record(main)
             sa.wait_event(fork)
             sb_.wait_event(fork)
+            if prep_ahead:
+                if ("aux", main.cuda_stream) not in self._ov_streams:
+                    self._ov_streams[("aux", main.cuda_stream)] = torch.cuda.Stream(device=dev)
+                aux_stream = self._ov_streams[("aux", main.cuda_stream)]
+                aux_stream.wait_event(fork)
         else:
             sstreams = gstreams = [main] * n_stage
             rpw_fb, rpw_sb = self.rows_per_wg
@@ -877,15 +886,37 @@ class Engine:
             use_stack, wide, rpw_stack = self._stack_choice(seqs, [x.shape[1] for x in xs_], want_membrane)
             if not pipeline and use_stack:
                 # all layers in one launch: features, layer 0's input term, the stack scan, the projection
-                for c, (t0, nt) in enumerate(bounds):
-                    if staged and gate_events is not None:
-                        gstreams[first].wait_event(gate_events[c])
-                    feat_fn(t0, nt, hG[first])
+                ahead = prep_ahead and gate_events is None and d["zin"][0][0].shape[0] >= T
+                def prep(t0, nt, dz, st):
+                    feat_fn(t0, nt, st)
                     xg = self._stack_x_groups(seqs, xs_, nt, wide, rpw_stack or self.stack_rows_per_wg[tag], want_membrane)
                     zr = [i for i in range(len(seqs)) if i not in xg]
                     if zr:
-                        self._stage_input(pick(seqs, zr), 0, pick(xs_, zr), pick(d["zin"][0], zr), t0, nt, hG[first], tag)
-                    self._stage_stack(seqs, d, t0, nt, hS[first], tag, wide, rpw_stack, xs_=xs_, xg=xg)
+                        self._stage_input(pick(seqs, zr), 0, pick(xs_, zr), pick(dz["zin"][0], zr), t0, nt, st, tag)
+                    return xg
+                if ahead:  # layer 0's input term has a buffer for the whole sequence: chunk c's rows are [t0, t0 + nt)
+                    exp = os.environ.get("SFSN_PREP_AHEAD_EXP", "0")
+                    views = [dict(d, zin=[[z[t0:t0 + nt] if (l_ == 0 or exp == "1") else z[:nt] for z in zl] for l_, zl in enumerate(d["zin"])])
+                             for t0, nt in bounds]
+                    if exp == "2":
+                        views = [dict(d, zin=[[z[(c_ % 2) * nt_max:(c_ % 2) * nt_max + nt] if l_ == 0 else z[:nt] for z in zl] for l_, zl in enumerate(d["zin"])])
+                                 for c_, (t0, nt) in enumerate(bounds)]
+                    h_aux, ready = self._handle(aux_stream), []
+                    for (t0, nt), dv in zip(bounds, views):
+                        xg = prep(t0, nt, dv, h_aux)
+                        ev = torch.cuda.Event()
+                        ev.record(aux_stream)
+                        ready.append((ev, xg))
+                for c, (t0, nt) in enumerate(bounds):
+                    if ahead:
+                        dv, (ev, xg) = views[c], ready[c]
+                        sstreams[first].wait_event(ev)
+                    else:
+                        dv = d
+                        if staged and gate_events is not None:
+                            gstreams[first].wait_event(gate_events[c])
+                        xg = prep(t0, nt, dv, hG[first])
+                    self._stage_stack(seqs, dv, t0, nt, hS[first], tag, wide, rpw_stack, xs_=xs_, xg=xg)
                     self._stage_proj(seqs, d["s8"][nl - 1], d["proj"], t0, nt, hG[first], tag)
                     if post_fn is not None:
                         post_fn(t0, nt, hG[first])
@@ -984,7 +1015,7 @@ class Engine:
         else:
             sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, fb_done if staged else None)
         if staged:
-            for s_ in {id(x): x for x in sstreams + gstreams}.values():
+            for s_ in {id(x): x for x in sstreams + gstreams + ([aux_stream] if prep_ahead else [])}.values():
                 link(s_, main)
 
         if want_counts and not want_layers:

@@ -33,13 +33,26 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+import os
+# the same layer of all sub-band groups in ONE launch per direction (SFSN_TRAIN_GROUPS_TOGETHER=0: one group after the other)
+GROUPS_TOGETHER = os.environ.get("SFSN_TRAIN_GROUPS_TOGETHER", "1") != "0"
+
 _EXCHANGE_FAILED = ("sfsn_gsn_train_step: the row blocks of a step did not all arrive (a launch's workgroups were not co-resident); "
                     "the outputs of that layer call are invalid")
+_debug_scratch = None  # scripts/dbg_train_hang.py sets a list: every layer call appends (what, R, H, T, scratch tensor)
 _pending: list = []  # (event, pinned copy of a forward call's error word): looked at, without blocking, by the next layer call
 
 
+def check_pending() -> None:
+    """Wait for every layer call issued so far and raise if one of them reported a failed row-block exchange (its outputs and
+    gradients are invalid; the gradients are NaN).  A training loop may call this before its optimiser step; without it the next
+    layer call raises."""
+    _poll_pending(block=True)
+
+
 def _poll_pending(block: bool = False) -> None:
-    """Raise if an earlier forward-only layer call (no backward followed it) reported a failed row-block exchange."""
+    """Raise if an earlier layer call reported a failed row-block exchange (a forward nobody followed with a backward, or a
+    backward: its gradients are NaN)."""
     keep = []
     for ev, pin in _pending:
         if block:
@@ -112,10 +125,13 @@ class GSNLayerTrainFn(torch.autograd.Function):
         a_bw, a_bb, a_rm, a_rv = _p(bw), _p(bb), _p(rmean), _p(rvar)
         mom, ep, sh = float(0.1 if momentum is None else momentum), float(eps), int(shared)
         fwd = L.sfsn_gsn_train_step_fwd
-        scr = torch.zeros((L.sfsn_train_scratch_bytes(H) // 4,), dtype=torch.int32, device=dev)  # partial sums / arrival counters of the row blocks
-        p_scr = P(scr.data_ptr())
         seq = not fold
-        if seq:  # the T step launches enqueued by the library (one call per layer; the interpreter's share of a step was ~10 us)
+        # zeroed per call: packed-spike slots and publish counters of the one-launch layer call, partial-sum granules, error word (last 4 words)
+        scr = torch.zeros(((L.sfsn_train_seq_scratch_bytes(R, H) if seq else L.sfsn_train_scratch_bytes(H)) // 4,), dtype=torch.int32, device=dev)
+        p_scr = P(scr.data_ptr())
+        if _debug_scratch is not None:
+            _debug_scratch.append(("fwd", R, H, T, scr))
+        if seq:  # ONE launch for the T steps of the layer (csrc/sfsn_train.hip: workgroups resident over the sequence)
             with torch.cuda.device(dev):
                 check(L.sfsn_gsn_train_seq_fwd(P(pz), P(pw), P(pb), a_bw, a_bb, a_rm, a_rv, mom, ep, T, R, H, sh, P(pzero), P(psp), P(pu),
                                                P(pxh) if pxh else None, P(pf), P(pg), P(pis) if pis else None, p_scr, st), "sfsn_gsn_train_seq_fwd")
@@ -178,15 +194,16 @@ class GSNLayerTrainFn(torch.autograd.Function):
         pdc = [dc_buf[0].data_ptr(), dc_buf[1].data_ptr()]
         sh = int(shared)
         bwd = L.sfsn_gsn_train_step_bwd
-        scr = torch.zeros((L.sfsn_train_scratch_bytes(H) // 4,), dtype=torch.int32, device=dev)
-        p_scr = P(scr.data_ptr())
-        dh_rec = dc = None
         seq = not fold
+        scr = torch.zeros(((L.sfsn_train_seq_scratch_bytes(R, H) if seq else L.sfsn_train_scratch_bytes(H)) // 4,), dtype=torch.int32, device=dev)
+        p_scr = P(scr.data_ptr())
+        if _debug_scratch is not None:
+            _debug_scratch.append(("bwd", R, H, T, scr))
+        dh_rec = dc = None
         if seq:
-            dcw = torch.empty((2, R, H), **f32)
             with torch.cuda.device(dev):
                 check(L.sfsn_gsn_train_seq_bwd(P(pw), P(pdy), P(pu), P(pxh) if bn_kernel else None, P(pf), P(pg), P(pis) if bn_kernel else None, a_bw,
-                                               T, R, H, sh, P(pzero), P(pdg), P(pdz) if shared else None, P(dcw.data_ptr()), a_dw, a_db, p_scr, st),
+                                               T, R, H, sh, None, P(pdg), P(pdz) if shared else None, None, a_dw, a_db, p_scr, st),
                       "sfsn_gsn_train_seq_bwd")
         with torch.cuda.device(dev):
             for t in (() if seq else range(T - 1, -1, -1)):
@@ -212,19 +229,219 @@ class GSNLayerTrainFn(torch.autograd.Function):
                              P(pdz + t * sRG) if shared else None, P(pdc[t & 1]), a_dw, a_db, p_scr, T - t, st)
                 if rc:
                     check(rc, "sfsn_gsn_train_step_bwd")
-        if int(scr[-4:].max().item()) != 0 or int(ctx.scr[-4:].max().item()) != 0:
-            raise RuntimeError(_EXCHANGE_FAILED)
+        # a failed row-block exchange (this call's or its forward's) must not yield gradients that look like numbers -- and this
+        # function must not block the host either: the autograd engine walks the graph on one thread, and the sub-band groups'
+        # layer calls run side by side on their own streams (forward_live) only as long as nobody waits here.  So: every returned
+        # gradient is poisoned with NaN ON THE DEVICE when either error word is set, and the words travel to pinned memory for the
+        # next layer call (or training.check_pending()) to raise on.
+        bad = (scr[-4:].max() + ctx.scr[-4:].max()) > 0
+        poison = torch.where(bad, torch.full((), float("nan"), **f32), torch.zeros((), **f32))
+        pin = torch.empty((4,), dtype=torch.int32, pin_memory=True)
+        pin.copy_(torch.maximum(scr[-4:], ctx.scr[-4:]), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        _pending.append((ev, pin))
         dz = (d_z if shared else d_gates).reshape(T * R, GH)
-        dx = torch.mm(dz, w_ih).view(T, R, I)
-        dw_ih = torch.mm(dz.t(), x.reshape(T * R, I))
+        dx = torch.mm(dz, w_ih).view(T, R, I).add_(poison)
+        dw_ih = torch.mm(dz.t(), x.reshape(T * R, I)).add_(poison)
         h_prev = torch.cat([zero.unsqueeze(0), spikes[:-1]], 0).reshape(T * R, H)
-        dw_hh = torch.mm(dz.t(), h_prev)
-        dbias = d_gates.reshape(T * R, 2 * H).sum(0)
+        dw_hh = torch.mm(dz.t(), h_prev).add_(poison)
+        dbias = d_gates.reshape(T * R, 2 * H).sum(0).add_(poison)
+        if bn_kernel:
+            d_bn_w.add_(poison)
+            d_bn_b.add_(poison)
         if not use_bn:
             d_bn_w = d_bn_b = None
         elif fold:
             d_bn_w = d_bn_b = None  # (eval-mode gradients of gamma / beta are not produced: parameters are frozen in eval use)
         return dx, dw_ih, dw_hh, dbias, d_bn_w, d_bn_b, None, None, None, None, None
+
+
+class GSNLayersTrainFn(torch.autograd.Function):
+    """The same layer of n independent sequence models in ONE launch per direction (sfsn_gsn_train_seq_fwd_multi / _bwd_multi): the
+    sub-band groups of a model do not depend on one another, and a training-mode layer call -- T dependent steps of a few hundred
+    small workgroups -- leaves most of the chip idle; side by side in one grid the three groups of baseline_m take the time of the
+    largest.  ``forward(ctx, meta, *flat)``: flat = n x (x [T, R_i, I_i], w_ih, w_hh, bias, bn_w, bn_b); meta = dict(shared, stats
+    [n x (running_mean, running_var, num_batches_tracked) or None], momentum [n], eps [n]).  Training-mode BatchNorm (per-step batch
+    statistics) or no BatchNorm; returns the n spike tensors [T, R_i, H]."""
+
+    @staticmethod
+    def forward(ctx, meta, *flat):
+        L = _lib.lib()
+        _poll_pending()
+        n = len(flat) // 6
+        shared = bool(meta["shared"])
+        xs = [flat[6 * i].contiguous().float() for i in range(n)]
+        if not all(x.is_cuda for x in xs):
+            raise RuntimeError("spiking_fullsubnet_amd has no CPU path: move the module and its input to a HIP device")
+        dev = xs[0].device
+        T = xs[0].shape[0]
+        GH, H = flat[2].shape
+        use_bn = flat[4] is not None
+        f32 = dict(dtype=torch.float32, device=dev)
+        calls = (_lib.TrainSeqFwd * n)()
+        keep, saved, geo = [], [], []
+        P = ctypes.c_void_p
+        for i in range(n):
+            x, w_ih, w_hh, bias, bn_w, bn_b = xs[i], *flat[6 * i + 1:6 * i + 6]
+            Ti, R, I = x.shape
+            assert Ti == T and tuple(w_hh.shape) == (GH, H) and (bn_w is not None) == use_bn
+            stats = meta["stats"][i]
+            if use_bn:
+                if R == 1:  # nn.BatchNorm1d in training mode (torch/nn/functional.py: _verify_batch_size)
+                    raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([{R}, {H}])")
+                if meta["momentum"][i] is None:
+                    raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative moving average) is not implemented by the HIP training step")
+                if stats is not None:
+                    for nm, t_ in (("running_mean", stats[0]), ("running_var", stats[1])):
+                        if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != dev or t_.numel() != H:
+                            raise TypeError(f"BatchNorm {nm} must be a contiguous float32 tensor of {H} elements on {dev}, got "
+                                            f"{t_.dtype} {tuple(t_.shape)} on {t_.device}")
+            w_ih_c, w_hh_c, bias_c = w_ih.detach().contiguous().float(), w_hh.detach().contiguous().float(), bias.detach().contiguous().float()
+            z = torch.mm(x.reshape(T * R, I), w_ih_c.t()).view(T, R, GH)
+            spikes, u = torch.empty((T, R, H), **f32), torch.empty((T, R, H), **f32)
+            fg, gg = torch.empty((T, R, H), **f32), torch.empty((T, R, H), **f32)
+            xhat = torch.empty((T, R, H), **f32) if use_bn else None
+            invstd = torch.empty((T, H), **f32) if use_bn else None
+            bw = bn_w.detach().contiguous().float() if use_bn else None
+            bb = bn_b.detach().contiguous().float() if use_bn else None
+            scr = torch.zeros((L.sfsn_train_seq_scratch_bytes(R, H) // 4,), dtype=torch.int32, device=dev)
+            c = calls[i]
+            c.z, c.w_hh, c.bias, c.bn_w, c.bn_b = z.data_ptr(), w_hh_c.data_ptr(), bias_c.data_ptr(), _dp(bw), _dp(bb)
+            c.running_mean = _dp(stats[0]) if (use_bn and stats is not None) else None
+            c.running_var = _dp(stats[1]) if (use_bn and stats is not None) else None
+            c.momentum, c.eps, c.R = float(0.1 if meta["momentum"][i] is None else meta["momentum"][i]), float(meta["eps"][i]), R
+            c.spikes, c.u, c.xhat, c.f, c.g, c.invstd, c.scratch = spikes.data_ptr(), u.data_ptr(), _dp(xhat), fg.data_ptr(), gg.data_ptr(), _dp(invstd), scr.data_ptr()
+            keep.append((z, scr))
+            zero = torch.zeros((1,), **f32)
+            saved += [x, w_ih_c, w_hh_c, spikes, u, fg, gg, xhat if use_bn else zero, invstd if use_bn else zero, bw if use_bn else zero]
+            geo.append((R, I))
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            check(L.sfsn_gsn_train_seq_fwd_multi(calls, n, T, H, int(shared), st), "sfsn_gsn_train_seq_fwd_multi")
+        errs = torch.stack([scr[-4:] for _, scr in keep]).max()
+        if not any(ctx.needs_input_grad):
+            if int(errs.item()) != 0:
+                raise RuntimeError(_EXCHANGE_FAILED)
+        else:
+            pin = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+            pin.copy_(errs.reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            _pending.append((ev, pin))
+        if use_bn:
+            for i in range(n):
+                stats = meta["stats"][i]
+                if stats is not None and stats[2] is not None:
+                    stats[2].add_(T)  # num_batches_tracked: one BatchNorm call per time step
+        ctx.save_for_backward(*saved)
+        ctx.fwd_err = errs
+        ctx.meta = (shared, use_bn, n, T, H, GH, geo)
+        outs = tuple(saved[10 * i + 3] for i in range(n))
+        return outs
+
+    @staticmethod
+    def backward(ctx, *dys):
+        shared, use_bn, n, T, H, GH, geo = ctx.meta
+        saved = ctx.saved_tensors
+        L = _lib.lib()
+        dev = saved[0].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        calls = (_lib.TrainSeqBwd * n)()
+        work = []
+        for i in range(n):
+            x, w_ih, w_hh, spikes, u, fg, gg, xhat, invstd, bw = saved[10 * i:10 * i + 10]
+            R, I = geo[i]
+            dy = dys[i]
+            dy = torch.zeros((T, R, H), **f32) if dy is None else dy.contiguous().float()
+            d_gates = torch.empty((T, R, 2 * H), **f32)
+            d_z = torch.empty((T, R, H), **f32) if shared else None
+            d_bn_w, d_bn_b = (torch.zeros((H,), **f32), torch.zeros((H,), **f32)) if use_bn else (None, None)
+            scr = torch.zeros((L.sfsn_train_seq_scratch_bytes(R, H) // 4,), dtype=torch.int32, device=dev)
+            c = calls[i]
+            c.w_hh, c.dh_up, c.u, c.f, c.g, c.R = w_hh.data_ptr(), dy.data_ptr(), u.data_ptr(), fg.data_ptr(), gg.data_ptr(), R
+            c.xhat, c.invstd, c.bn_w = (xhat.data_ptr(), invstd.data_ptr(), bw.data_ptr()) if use_bn else (None, None, None)
+            c.d_gates, c.d_z, c.d_bn_w, c.d_bn_b, c.scratch = d_gates.data_ptr(), _dp(d_z), _dp(d_bn_w), _dp(d_bn_b), scr.data_ptr()
+            work.append((dy, d_gates, d_z, d_bn_w, d_bn_b, scr))
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            check(L.sfsn_gsn_train_seq_bwd_multi(calls, n, T, H, int(shared), st), "sfsn_gsn_train_seq_bwd_multi")
+        # no host synchronisation here (see GSNLayerTrainFn.backward): NaN-poisoned gradients on a failed exchange, the error word to
+        # pinned memory for the next layer call / check_pending()
+        errs = torch.maximum(torch.stack([w[5][-4:] for w in work]).max(), ctx.fwd_err)
+        poison = torch.where(errs > 0, torch.full((), float("nan"), **f32), torch.zeros((), **f32))
+        pin = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+        pin.copy_(errs.reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        _pending.append((ev, pin))
+        grads = []
+        for i in range(n):
+            x, w_ih, w_hh, spikes, u, fg, gg, xhat, invstd, bw = saved[10 * i:10 * i + 10]
+            R, I = geo[i]
+            dy, d_gates, d_z, d_bn_w, d_bn_b, scr = work[i]
+            dz = (d_z if shared else d_gates).reshape(T * R, GH)
+            dx = torch.mm(dz, w_ih).view(T, R, I).add_(poison)
+            dw_ih = torch.mm(dz.t(), x.reshape(T * R, I)).add_(poison)
+            h_prev = torch.cat([torch.zeros((1, R, H), **f32), spikes[:-1]], 0).reshape(T * R, H)
+            dw_hh = torch.mm(dz.t(), h_prev).add_(poison)
+            dbias = d_gates.reshape(T * R, 2 * H).sum(0).add_(poison)
+            if use_bn:
+                d_bn_w.add_(poison)
+                d_bn_b.add_(poison)
+            grads += [dx, dw_ih, dw_hh, dbias, d_bn_w, d_bn_b]
+        return (None, *grads)
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+def _cell_args(cell):
+    bn = getattr(cell, "batchnorm", None) if cell.use_bn else None
+    stats, momentum, eps = None, 0.1, 1e-5
+    if bn is not None:
+        stats = (bn.running_mean, bn.running_var, bn.num_batches_tracked)
+        momentum, eps = bn.momentum, bn.eps  # (momentum None = cumulative moving average: rejected in training mode)
+    return bn, stats, momentum, eps
+
+
+def gsn_stacks(xs, stacks, training: bool):
+    """StackedGSU.forward of several independent stacks (the sub-band groups): layer l of all of them in one launch per direction when
+    the launch can hold their workgroups together (same depth / hidden size / gate sharing / BatchNorm use, training-mode statistics
+    or no BatchNorm); one stack after the other otherwise.  Returns a list of [x, S1, ..., SL] lists."""
+    n = len(stacks)
+    def same(fn):
+        return len({fn(st) for st in stacks}) == 1
+    ok = (GROUPS_TOGETHER and 1 < n <= _lib.TRAIN_MAX_CALLS and same(lambda st: len(st.layers))
+          and all(x.is_cuda and x.shape[0] == xs[0].shape[0] for x in xs))
+    if ok:
+        for l in range(len(stacks[0].layers)):
+            cells = [st.layers[l].cell for st in stacks]
+            ok = ok and len({(tuple(c.weight_hh.shape), bool(c.shared_weights), bool(c.use_bn)) for c in cells}) == 1
+            ok = ok and (not cells[0].use_bn or training)  # (eval-mode BatchNorm: the folded per-step path of GSNLayerTrainFn)
+    if ok:
+        L = _lib.lib()
+        H = stacks[0].layers[0].cell.weight_hh.shape[1]
+        Rs = (ctypes.c_int * n)(*[int(x.shape[1]) for x in xs])
+        with torch.cuda.device(xs[0].device):
+            ok = L.sfsn_gsn_train_multi_check(Rs, n, H, int(bool(stacks[0].layers[0].cell.shared_weights))) == _lib.SFSN_OK
+    if not ok:
+        return [gsn_stack(x, st, training) for x, st in zip(xs, stacks)]
+    outs = [[x] for x in xs]
+    cur = list(xs)
+    for l in range(len(stacks[0].layers)):
+        flat, stats, moms, epss = [], [], [], []
+        for i, st in enumerate(stacks):
+            cell = st.layers[l].cell
+            bn, stt, mom, eps = _cell_args(cell)
+            flat += [cur[i], cell.weight_ih, cell.weight_hh, cell.bias_ih, None if bn is None else bn.weight, None if bn is None else bn.bias]
+            stats.append(stt); moms.append(mom); epss.append(eps)
+        meta = dict(shared=bool(stacks[0].layers[l].cell.shared_weights), stats=stats, momentum=moms, eps=epss)
+        cur = list(GSNLayersTrainFn.apply(meta, *flat))
+        for i in range(n):
+            outs[i].append(cur[i])
+    return outs
 
 
 def gsn_stack(x: torch.Tensor, stack, training: bool) -> List[torch.Tensor]:
@@ -265,6 +482,34 @@ def sequence_model(seq, x_bft: torch.Tensor, training: bool):
     return seq.output_activate_function(y).permute(1, 2, 0), outs
 
 
+def sequence_models(seqs, xs_bft, training: bool):
+    """SequenceModel.forward of several independent models (the sub-band groups): their cell stacks go through gsn_stacks (layer l of
+    all of them in one launch per direction).  Returns [(y [R, P, T], all_layer_outputs), ...]."""
+    if any(seq.sequence_model_name == "LSTM" for seq in seqs) or len(seqs) < 2:
+        return [sequence_model(seq, x, training) for seq, x in zip(seqs, xs_bft)]
+    xs = []
+    for seq, x_bft in zip(seqs, xs_bft):
+        x = x_bft.permute(2, 0, 1)  # time-major
+        if seq.use_pre_layer_norm:
+            x = seq.pre_layer_norm(x)
+        xs.append(x.contiguous())
+    res = []
+    for seq, outs in zip(seqs, gsn_stacks(xs, [seq.sequence_model for seq in seqs], training)):
+        y = seq.proj(outs[-1])
+        res.append((seq.output_activate_function(y).permute(1, 2, 0), outs + [y]))
+    return res
+
+
+def _frozen_sequence_models(seqs, xs_bft, training: bool):
+    """The frozen SequenceModel.forward (model_low_freq.py:100-139) of several independent models, cell stacks through gsn_stacks."""
+    xs = [x_bft.permute(2, 0, 1).contiguous() for x_bft in xs_bft]  # [B, F, T] => [T, B, F]
+    res = []
+    for seq, outs in zip(seqs, gsn_stacks(xs, [seq.sequence_model for seq in seqs], training)):
+        y = seq.fc_output_layer(outs[-1])
+        res.append((y.permute(1, 2, 0), outs + [y]))
+    return res
+
+
 def _reflect(idx: torch.Tensor, nf: int) -> torch.Tensor:
     idx = torch.where(idx < 0, -idx, idx)
     return torch.where(idx > nf - 1, 2 * (nf - 1) - idx, idx)
@@ -291,18 +536,25 @@ def forward_live(model, wave: torch.Tensor):
     sb = model.sb_model
     cut = list(sb.freq_cutoffs)
     enh_groups, sb_all = [], []
-    for g, seq in enumerate(sb.sb_models):
-        lo, hi, c, n, d = cut[g], cut[g + 1], sb.center_freq_sizes[g], sb.neighbor_freq_sizes[g], sb.df_orders[g]
+    for g in range(len(sb.sb_models)):  # (every group's ValueError before any group's launches)
+        lo, hi, c = cut[g], cut[g + 1], sb.center_freq_sizes[g]
         if (hi - lo) % c != 0:
             raise ValueError(f"Number of frequency bins must be divisible by the center frequency.GOT: ctr_freq={c}, "
                              f"upper_cutoff_freq={hi}, lower_cutoff_freq={lo}")
+    xs_g = []
+    for g, seq in enumerate(sb.sb_models):
+        lo, hi, c, n = cut[g], cut[g + 1], sb.center_freq_sizes[g], sb.neighbor_freq_sizes[g]
         N = (hi - lo) // c
         k = torch.arange(N, device=dev)
         idx_noisy = _reflect(lo + k[:, None] * c - n + torch.arange(c + 2 * n, device=dev)[None, :], nf)   # [N, c + 2n]
         idx_fb = (lo + k[:, None] * c + torch.arange(c, device=dev)[None, :]) % P_fb                        # [N, c] (tiled full-band output)
         x = torch.cat([mag[:, idx_noisy], fb_out[:, idx_fb]], dim=2)                                         # [B, N, I, T]
-        I = x.shape[2]
-        y, outs = sequence_model(seq, x.reshape(B * N, I, T), training)                                      # [B N, P, T]
+        xs_g.append(x.reshape(B * N, x.shape[2], T))
+    ys_g = sequence_models(list(sb.sb_models), xs_g, training)                                               # [(y [B N, P, T], outs)]
+    for g, seq in enumerate(sb.sb_models):
+        lo, hi, c, n, d = cut[g], cut[g + 1], sb.center_freq_sizes[g], sb.neighbor_freq_sizes[g], sb.df_orders[g]
+        N = (hi - lo) // c
+        y, outs = ys_g[g]
         sb_all.append(outs)
         # projection channel p = ((ri * c + fci) * d + di) * S + si  ->  coefficient [B, di, si, n * c + fci, T] (re, im)
         coef = y.reshape(B, N, 2, c, d, S, T)
@@ -371,21 +623,29 @@ def forward_frozen(model, wave: torch.Tensor):
     sbm = model.sb_model
     cut = [0] + list(sbm.freq_cutoffs) + [nf]
     enh_groups, sb_all = [], []
+    for g in range(len(sbm.sb_models)):
+        lo, hi, c, cf = cut[g], cut[g + 1], sbm.sb_num_center_freqs[g], sbm.fb_num_center_freqs[g]
+        if (hi - lo) % c != 0 or (hi - lo) % cf != 0 or (hi - lo) // cf != (hi - lo) // c:
+            raise ValueError(f"Number of frequency bins must be divisible by the center frequency.GOT: ctr_freq={c}, "
+                             f"upper_cutoff_freq={hi}, lower_cutoff_freq={lo}")
+    xs_g = []
     for g, seq in enumerate(sbm.sb_models):
         lo, hi = cut[g], cut[g + 1]
         c, n = sbm.sb_num_center_freqs[g], sbm.sb_num_neighbor_freqs[g]
         cf, nfb = sbm.fb_num_center_freqs[g], sbm.fb_num_neighbor_freqs[g]
-        d = seq.df_order
-        if (hi - lo) % c != 0 or (hi - lo) % cf != 0 or (hi - lo) // cf != (hi - lo) // c:
-            raise ValueError(f"Number of frequency bins must be divisible by the center frequency.GOT: ctr_freq={c}, "
-                             f"upper_cutoff_freq={hi}, lower_cutoff_freq={lo}")
         N = (hi - lo) // c
         k = torch.arange(N, device=dev)
         idx_noisy = _reflect(lo + k[:, None] * c - n + torch.arange(c + 2 * n, device=dev)[None, :], nf)        # [N, c + 2n]
         idx_fb = _reflect(lo + k[:, None] * cf - nfb + torch.arange(cf + 2 * nfb, device=dev)[None, :], nf) % P_fb  # tiled full-band output
         x = laplace(torch.cat([mag[:, idx_noisy], fb_out[:, idx_fb]], dim=2))                                    # [B, N, I, T]
-        I = x.shape[2]
-        y, outs = _frozen_sequence_model(seq, x.reshape(B * N, I, T), training)                                  # [B N, P, T]
+        xs_g.append(x.reshape(B * N, x.shape[2], T))
+    ys_g = _frozen_sequence_models(list(sbm.sb_models), xs_g, training)                                          # [(y [B N, P, T], outs)]
+    for g, seq in enumerate(sbm.sb_models):
+        lo, hi = cut[g], cut[g + 1]
+        c = sbm.sb_num_center_freqs[g]
+        d = seq.df_order
+        N = (hi - lo) // c
+        y, outs = ys_g[g]
         sb_all.append(outs)
         coef = y.reshape(B, N, 2, c, d, T)   # channel p = (ri * c + fci) * d + di  (:262-268)
         cre = coef[:, :, 0].permute(0, 3, 1, 2, 4).reshape(B, d, N * c, T)
