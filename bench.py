@@ -515,7 +515,7 @@ def streaming_bench(args, model, dev, world, rank):
 def training_bench(args, model, dev, world, rank, rw, B, T):
     """a training step of the live baseline_m model -- forward in train() mode (BatchNorm on the batch statistics
     of every time step inside every cell, efficient_spiking_neuron.py:123,149-150) and backward through the triangle surrogate
-    (:94-101) -- on this package's differentiable path (training.py: one HIP launch per cell step and direction, library GEMMs for the
+    (:94-101) -- on this package's differentiable path (training.py: one HIP launch per layer and direction for all T steps, library GEMMs for the
     time-parallel products).  The recipe's batch is 64 clips (baseline_m.toml:72); the loss here is a stand-in of the same shape
     class (a mean over the enhanced waveform and magnitude).  Wall time per step, synchronised, no optimiser step (the optimiser,
     losses and trainer stay the reference's: out of scope)."""
@@ -540,6 +540,33 @@ def training_bench(args, model, dev, world, rank, rw, B, T):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     gn = float(torch.sqrt(sum((p_.grad.float() ** 2).sum() for p_ in model.parameters() if p_.grad is not None)))
+    # one more step (untimed) with HIP events around the layer-call launches: where the step's time is, per recurrent step
+    from spiking_fullsubnet_amd import training as _tr
+    _tr.launch_log = []
+    one()
+    torch.cuda.synchronize()
+    log, _tr.launch_log = _tr.launch_log, None
+    roof = None
+    if log:
+        per = {}
+        for kind, T_, shapes, e0, e1 in log:
+            d = per.setdefault(kind, dict(launches=0, ms=0.0, steps=0, flop=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["steps"] += T_
+            d["flop"] += sum(2.0 * T_ * R * H * GH for R, H, GH in shapes)  # the recurrent product of every layer call of the launch
+        tot_ms = sum(d["ms"] for d in per.values())
+        flop = sum(d["flop"] for d in per.values())
+        roof = {"bound": "latency (two grid-wide exchanges per recurrent step: BatchNorm partial sums, then the new spikes / d_z)",
+                "kernel": "gsn_train_seq_fwd_kernel / gsn_train_seq_bwd_kernel (one launch per layer and direction for all T steps; the sub-band groups share a grid)",
+                "layer_call_launches_ms": round(tot_ms, 2), "share_of_step": round(tot_ms / ms, 3),
+                "forward": {"launches": per.get("fwd", {}).get("launches"), "ms": round(per.get("fwd", {}).get("ms", 0.0), 2),
+                            "us_per_recurrent_step": round(1e3 * per["fwd"]["ms"] / per["fwd"]["steps"], 2) if "fwd" in per else None},
+                "backward": {"launches": per.get("bwd", {}).get("launches"), "ms": round(per.get("bwd", {}).get("ms", 0.0), 2),
+                             "us_per_recurrent_step": round(1e3 * per["bwd"]["ms"] / per["bwd"]["steps"], 2) if "bwd" in per else None},
+                "mfma": {"instruction": "v_mfma_f32_16x16x4_f32", "useful_TFLOPs": round(flop / (tot_ms * 1e-3) / 1e12, 2), "peak_TFLOPs": 157.3,
+                         "frac": round(flop / (tot_ms * 1e-3) / 157.3e12, 4),
+                         "note": "recurrent products only (h.W_hh^T forward, dz.W_hh backward); the time-parallel products are library GEMMs outside these launches"}}
     if rank == 0:
         _emit(json.dumps({
             "metric": "training step wall time (forward in train() mode + backward), live baseline_m", "value": round(ms, 2), "unit": "ms",
@@ -550,7 +577,8 @@ def training_bench(args, model, dev, world, rank, rw, B, T):
                        "grad_norm": gn, "optimizer_step": "not included (the reference's optimiser; out of scope)",
                        "cell_steps_per_training_step": 2 * 4 * T,
                        "note": "the same loop written as ATen operations per cell step (the reference's structure) takes 2.65 s at B=16 and "
-                               "2.8 s at B=64 (scripts/exp_train.py)"}}))
+                               "2.8 s at B=64 (scripts/exp_train.py); round 3 (one launch per cell step and direction): 315 ms at B=64"},
+            "roofline": roof}))
 
 
 def waveform_streaming_bench(args, model, dev, world, rank, B):

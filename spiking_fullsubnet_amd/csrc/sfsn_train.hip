@@ -22,6 +22,7 @@
 //     df = dc' (c_prev - pre_g) ; dc_prev = dc' f ; dpre_g = dc' (1 - f) ; dpre_f = df f (1 - f)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "sfsn.h"
 
@@ -323,11 +324,19 @@ __global__ __launch_bounds__(TR_THREADS) void gsn_train_step_bwd_kernel(const Tr
     }
 }
 
-// rows per workgroup: enough row blocks to put ~all compute units to work, at least 16 rows each; every block of a launch must be
-// resident (they wait for each other): the grid stays below ~220 blocks of 256 threads with < 40 KB of LDS
+// rows per workgroup: enough row blocks to put most compute units to work, at least 16 rows each; every block of a launch must be
+// resident (they wait for each other): a layer call stays below ~160 blocks of 256 threads
+static int train_wg_target() {
+#ifdef SFSN_EXPERIMENTS
+    static const int v = getenv("SFSN_TRAIN_WGS") ? atoi(getenv("SFSN_TRAIN_WGS")) : 160;
+    return v;
+#else
+    return 160;  // (220 / 160 / 110 / 70 measured at B = 64, three groups in one launch: 9.4 / 8.3 / 8.1 / 8.3 ms forward, 13.6 / 12.5 / 13.1 / 14.7 backward per 200 steps x 2 layers)
+#endif
+}
 static void train_geometry(int R, int H, int* RB, int* rpb) {
     const int tiles = H / TR_TILE;
-    int rb = 220 / tiles;
+    int rb = train_wg_target() / tiles;
     if (rb < 1) rb = 1;
     int per = (R + rb - 1) / rb;
     if (per < 16) per = 16;

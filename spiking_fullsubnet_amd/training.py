@@ -39,6 +39,7 @@ GROUPS_TOGETHER = os.environ.get("SFSN_TRAIN_GROUPS_TOGETHER", "1") != "0"
 
 _EXCHANGE_FAILED = ("sfsn_gsn_train_step: the row blocks of a step did not all arrive (a launch's workgroups were not co-resident); "
                     "the outputs of that layer call are invalid")
+launch_log = None  # bench.py --training sets a list: (direction, T, [(R, H, G*H) per layer call], start event, end event) per launch
 _debug_scratch = None  # scripts/dbg_train_hang.py sets a list: every layer call appends (what, R, H, T, scratch tensor)
 _pending: list = []  # (event, pinned copy of a forward call's error word): looked at, without blocking, by the next layer call
 
@@ -64,6 +65,24 @@ def _poll_pending(block: bool = False) -> None:
         else:
             keep.append((ev, pin))
     _pending[:] = keep
+
+
+class _Logged:
+    """HIP events around a layer-call launch when ``launch_log`` is a list (bench.py's per-step figures); nothing otherwise."""
+    def __init__(self, kind, T, shapes):
+        self.rec = (kind, T, shapes) if launch_log is not None else None
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            self.e1.record()
+            launch_log.append(self.rec + (self.e0, self.e1))
+        return False
 
 
 class GSNLayerTrainFn(torch.autograd.Function):
@@ -132,7 +151,7 @@ class GSNLayerTrainFn(torch.autograd.Function):
         if _debug_scratch is not None:
             _debug_scratch.append(("fwd", R, H, T, scr))
         if seq:  # ONE launch for the T steps of the layer (csrc/sfsn_train.hip: workgroups resident over the sequence)
-            with torch.cuda.device(dev):
+            with torch.cuda.device(dev), _Logged("fwd", T, [(R, H, GH)]):
                 check(L.sfsn_gsn_train_seq_fwd(P(pz), P(pw), P(pb), a_bw, a_bb, a_rm, a_rv, mom, ep, T, R, H, sh, P(pzero), P(psp), P(pu),
                                                P(pxh) if pxh else None, P(pf), P(pg), P(pis) if pis else None, p_scr, st), "sfsn_gsn_train_seq_fwd")
         with torch.cuda.device(dev):
@@ -201,7 +220,7 @@ class GSNLayerTrainFn(torch.autograd.Function):
             _debug_scratch.append(("bwd", R, H, T, scr))
         dh_rec = dc = None
         if seq:
-            with torch.cuda.device(dev):
+            with torch.cuda.device(dev), _Logged("bwd", T, [(R, H, GH)]):
                 check(L.sfsn_gsn_train_seq_bwd(P(pw), P(pdy), P(pu), P(pxh) if bn_kernel else None, P(pf), P(pg), P(pis) if bn_kernel else None, a_bw,
                                                T, R, H, sh, None, P(pdg), P(pdz) if shared else None, None, a_dw, a_db, p_scr, st),
                       "sfsn_gsn_train_seq_bwd")
@@ -317,7 +336,7 @@ class GSNLayersTrainFn(torch.autograd.Function):
             saved += [x, w_ih_c, w_hh_c, spikes, u, fg, gg, xhat if use_bn else zero, invstd if use_bn else zero, bw if use_bn else zero]
             geo.append((R, I))
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _Logged("fwd", T, [(R, H, GH) for R, _ in geo]):
             check(L.sfsn_gsn_train_seq_fwd_multi(calls, n, T, H, int(shared), st), "sfsn_gsn_train_seq_fwd_multi")
         errs = torch.stack([scr[-4:] for _, scr in keep]).max()
         if not any(ctx.needs_input_grad):
@@ -364,7 +383,7 @@ class GSNLayersTrainFn(torch.autograd.Function):
             c.d_gates, c.d_z, c.d_bn_w, c.d_bn_b, c.scratch = d_gates.data_ptr(), _dp(d_z), _dp(d_bn_w), _dp(d_bn_b), scr.data_ptr()
             work.append((dy, d_gates, d_z, d_bn_w, d_bn_b, scr))
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _Logged("bwd", T, [(R, H, GH) for R, _ in geo]):
             check(L.sfsn_gsn_train_seq_bwd_multi(calls, n, T, H, int(shared), st), "sfsn_gsn_train_seq_bwd_multi")
         # no host synchronisation here (see GSNLayerTrainFn.backward): NaN-poisoned gradients on a failed exchange, the error word to
         # pinned memory for the next layer call / check_pending()
