@@ -304,6 +304,10 @@ typedef struct sfsn_feature_group {
 int sfsn_features(const float* stft_ri /* [B][F][T][2] */, const float* fb_tbf /* [T][B][FB], NULL if unused */,
                   int B, int F, int T, int FB, float fdrc, const sfsn_feature_group* groups /* host */, int n_groups,
                   int t0, int nt /* frames [t0, t0+nt) are produced; tensors are indexed by absolute frame */, void* stream);
+/* The same launch with a side job: extra workgroups zero `zero_bytes` bytes at `zero_ptr` (both multiples of 16) -- the zero initial
+ * state of the forward's scans (MODEL:100-106) written by the first launch of the forward's chain instead of a fill launch of its own. */
+int sfsn_features_z(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc, const sfsn_feature_group* groups,
+                    int n_groups, int t0, int nt, float* zero_ptr, size_t zero_bytes, void* stream);
 
 /* Per-clip means for offline_laplace_norm (FROZEN:162-164: mean over all non-batch dims of the gathered,
  * un-normalised group tensor).  mu_out [n_groups][B].  Two launches: row sums of mag / fb, then the

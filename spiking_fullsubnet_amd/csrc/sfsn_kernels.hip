@@ -1251,9 +1251,22 @@ __device__ __forceinline__ void feat_chunk_rows(const FeatGroupDev& g, const flo
     }
 }
 
+// (zero_ptr, zero_n16): rows blockIdx.y >= B of the grid carry no feature tile -- they zero `zero_n16` 16-byte pieces at `zero_ptr`:
+// the zero initial state of a forward's scans (MODEL:100-106), written by the first launch of the forward's chain instead of by a
+// fill kernel of its own (round 3: 217 fill launches averaging 149 us each in the timed region, queued behind scan workgroups).
 __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ stft, const float* __restrict__ fb,
-                                                        const FeatParams p) {
+                                                        const FeatParams p, float* __restrict__ zero_ptr, const size_t zero_n16) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.y >= p.B) {
+        const size_t blk = (size_t)(blockIdx.y - p.B) * gridDim.x + blockIdx.x;
+        v4f* dst = reinterpret_cast<v4f*>(zero_ptr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const size_t k = (blk * 8 + i) * 256 + threadIdx.x;
+            if (k < zero_n16) dst[k] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
     const int nf = p.F - 1, T = p.T, B = p.B, FB = p.FB;
     float* magT = smem;                                         // [f_cnt][33]
     float* fbT = smem + (size_t)p.f_cnt * 33;                   // [32][FB]
@@ -2081,9 +2094,17 @@ static int fill_feat(FeatParams& p, const sfsn_feature_group* groups, int n_grou
     return SFSN_OK;
 }
 
+extern "C" int sfsn_features_z(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc,
+                               const sfsn_feature_group* groups, int n_groups, int t0, int nt, float* zero_ptr, size_t zero_bytes, void* stream);
 extern "C" int sfsn_features(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc,
                              const sfsn_feature_group* groups, int n_groups, int t0, int nt, void* stream) {
+    return sfsn_features_z(stft_ri, fb_tbf, B, F, T, FB, fdrc, groups, n_groups, t0, nt, nullptr, 0, stream);
+}
+
+extern "C" int sfsn_features_z(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc,
+                               const sfsn_feature_group* groups, int n_groups, int t0, int nt, float* zero_ptr, size_t zero_bytes, void* stream) {
     if (!stft_ri) return SFSN_EINVAL;
+    if ((zero_bytes != 0 && !zero_ptr) || (zero_bytes & 15) || (reinterpret_cast<uintptr_t>(zero_ptr) & 15)) return SFSN_EINVAL;
     FeatParams p;
     int rc = fill_feat(p, groups, n_groups, B, F, T, FB, fdrc, true, t0, nt);
     if (rc != SFSN_OK) return rc;
@@ -2097,7 +2118,11 @@ extern "C" int sfsn_features(const float* stft_ri, const float* fb_tbf, int B, i
                                 (int)lds) != hipSuccess)
             return SFSN_EHIP;
     }
-    hipLaunchKernelGGL(features_kernel, dim3((nt + FEAT_TT - 1) / FEAT_TT, B), dim3(256), lds, st, stft_ri, fb_tbf, p);
+    const unsigned gx = (unsigned)((nt + FEAT_TT - 1) / FEAT_TT);
+    const size_t n16 = zero_bytes / 16, zblocks = (n16 + 8 * 256 - 1) / (8 * 256);
+    const size_t zrows = (zblocks + gx - 1) / gx;
+    if ((size_t)B + zrows > 65535) return SFSN_EUNSUPPORTED;
+    hipLaunchKernelGGL(features_kernel, dim3(gx, (unsigned)(B + zrows)), dim3(256), lds, st, stft_ri, fb_tbf, p, zero_ptr, n16);
     return hip_ok(hipGetLastError());
 }
 

@@ -253,9 +253,12 @@ class Engine:
         # hand-off wait expired raises HERE instead of at the next forward); False: non-blocking, see check_stack_errors()
         self.strict_errors = os.environ.get("SFSN_STRICT_ERRORS", "0") == "1"
         self._ov_streams = None
-        # overlapped schedule: the full-band model's features and layer-0 input products of ALL chunks go out at once on a stream
-        # of their own (nothing gates them), so its stack launches follow one another without the time-parallel kernels between them
-        self.overlap_prep_ahead = os.environ.get("SFSN_PREP_AHEAD", "1") != "0"
+        # overlapped schedule, EXPERIMENT (off): the full-band model's features and layer-0 input products of ALL chunks go out at once
+        # on a stream of their own (nothing gates them), so its stack launches follow one another without the time-parallel kernels
+        # between them.  Bit-identical, but 2.97 instead of 2.80 ms per forward at B = 64, T = 1000: an input term produced a
+        # millisecond before it is read has left the 256 MB Infinity Cache (the sub-band kernels move > 1 GB in between), and the
+        # full-band scan -- two ring slots deep at H = 320 -- runs 1.9 instead of 1.6 us per frame from HBM (profiles/EXPERIMENTS.md)
+        self.overlap_prep_ahead = os.environ.get("SFSN_PREP_AHEAD", "0") != "0"
         self.stack_wide = True
         self._stack_scratch: List[torch.Tensor] = []
         self._stack_err_pending: List[tuple] = []  # (event, pinned copy of a launch's error word): polled at the next forward
@@ -584,8 +587,11 @@ class Engine:
                                         _ptr(seq.proj_b), ctypes.c_void_p(y.data_ptr() + t0 * R * seq.P * 4), nt * R, seq.H, seq.P, seq.P,
                                         st), "sfsn_spike_proj(proj)")
 
-    def _zero_states(self, Rs, H, nl):
-        flat = torch.zeros((2 * nl * sum(Rs) * H,), dtype=torch.float32, device=self.device)
+    def _zero_states(self, Rs, H, nl, flat=None):
+        """(h, c) state pairs of a stack as views of one flat buffer; ``flat`` given = a slice of the forward's state buffer, which the
+        forward's first feature launch zeroes (sfsn_features_z) -- otherwise a fill of its own."""
+        if flat is None:
+            flat = torch.zeros((2 * nl * sum(Rs) * H,), dtype=torch.float32, device=self.device)
         out, pos = [], 0
         for _ in range(nl):
             row = []
@@ -597,7 +603,7 @@ class Engine:
             out.append(row)
         return out
 
-    def _alloc_stack(self, seqs, Rs, T, nt_max, want_layers, want_membrane, tag):
+    def _alloc_stack(self, seqs, Rs, T, nt_max, want_layers, want_membrane, tag, state_flat=None):
         """Per-forward tensors of a stack of sequence models sharing (H, L): API outputs are fresh, scratch is cached."""
         dev, H, G, nl = self.device, seqs[0].H, seqs[0].cells[0].G, len(seqs[0].cells)
         HP = (H + 63) // 64 * 64
@@ -615,7 +621,7 @@ class Engine:
         f32 = dict(dtype=torch.float32, device=dev)
         return dict(
             zin=[[z[:nt_max] for z in zl] for zl in ws["zin"]], s8=[[b[:T] for b in bl] for bl in ws["s8"]],
-            states=self._zero_states(Rs, H, nl),  # zero init, modeling:100-106 (one fill kernel for all of them)
+            states=self._zero_states(Rs, H, nl, state_flat),  # zero init, modeling:100-106
             spk=[[torch.empty((T, R, H), **f32) if want_layers else None for R in Rs] for _ in range(nl)],
             mem=[[torch.empty((T, R, H), **f32) if want_membrane else None for R in Rs] for _ in range(nl)],
             proj=[torch.empty((T, R, seq.P), **f32) for seq, R in zip(seqs, Rs)])
@@ -818,8 +824,15 @@ class Engine:
         x_fb = torch.empty((T, B, spec.fb_in), **f32)
         xs = [torch.empty((T, B * spec.units(g), spec.sb_input_size(g)), **f32) for g in range(ng)]
         prep_ahead = bool(overlap and self.overlap_prep_ahead)
-        fb = self._alloc_stack([self.fb], [B], T, T if prep_ahead else nt_max, want_layers, want_membrane, "fb")
-        sb = self._alloc_stack(self.sb, [x.shape[1] for x in xs], T, nt_max, want_layers, want_membrane, "sb")
+        # the zero initial state of every scan of the forward: ONE buffer, zeroed by the forward's first feature launch (every scan
+        # depends on that launch through its input) -- no fill launch on the forward's chain
+        n_fb = 2 * nl_fb * B * self.fb.H
+        n_sb = 2 * nl_sb * sum(x.shape[1] for x in xs) * self.sb[0].H
+        fold = os.environ.get("SFSN_ZERO_FOLD", "1") != "0"  # (0: a fill launch of its own, for comparison)
+        state_flat = torch.empty((n_fb + n_sb,), **f32) if fold else torch.zeros((n_fb + n_sb,), **f32)
+        zero_job = [state_flat] if fold else []
+        fb = self._alloc_stack([self.fb], [B], T, T if prep_ahead else nt_max, want_layers, want_membrane, "fb", state_flat[:n_fb])
+        sb = self._alloc_stack(self.sb, [x.shape[1] for x in xs], T, nt_max, want_layers, want_membrane, "sb", state_flat[n_fb:])
         enh = torch.empty((B, S, F, T), dtype=torch.complex64, device=dev)
         enh_mag = torch.empty((B, S, F, T), **f32)
         enh_ri = torch.view_as_real(enh)
@@ -895,12 +908,7 @@ class Engine:
                         self._stage_input(pick(seqs, zr), 0, pick(xs_, zr), pick(dz["zin"][0], zr), t0, nt, st, tag)
                     return xg
                 if ahead:  # layer 0's input term has a buffer for the whole sequence: chunk c's rows are [t0, t0 + nt)
-                    exp = os.environ.get("SFSN_PREP_AHEAD_EXP", "0")
-                    views = [dict(d, zin=[[z[t0:t0 + nt] if (l_ == 0 or exp == "1") else z[:nt] for z in zl] for l_, zl in enumerate(d["zin"])])
-                             for t0, nt in bounds]
-                    if exp == "2":
-                        views = [dict(d, zin=[[z[(c_ % 2) * nt_max:(c_ % 2) * nt_max + nt] if l_ == 0 else z[:nt] for z in zl] for l_, zl in enumerate(d["zin"])])
-                                 for c_, (t0, nt) in enumerate(bounds)]
+                    views = [dict(d, zin=[[z[t0:t0 + nt] if l_ == 0 else z[:nt] for z in zl] for l_, zl in enumerate(d["zin"])]) for t0, nt in bounds]
                     h_aux, ready = self._handle(aux_stream), []
                     for (t0, nt), dv in zip(bounds, views):
                         xg = prep(t0, nt, dv, h_aux)
@@ -983,7 +991,9 @@ class Engine:
 
         def feat_fb(t0, nt, st):
             with self.timed("features:fb", st):
-                check(L.sfsn_features(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, t0, nt, st), "sfsn_features(fb)")
+                z = zero_job.pop() if zero_job else None  # (the first full-band feature launch of the forward carries the state zeroing)
+                check(L.sfsn_features_z(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, t0, nt, None if z is None else _ptr(z),
+                                        0 if z is None else z.numel() * 4, st), "sfsn_features(fb)")
                 if cum is not None:
                     cum_norm(x_fb, 0, t0, nt, st)
 
