@@ -262,6 +262,8 @@ class Engine:
         self.stack_wide = True
         self._stack_scratch: List[torch.Tensor] = []
         self._stack_err_pending: List[tuple] = []  # (event, pinned copy of a launch's error word): polled at the next forward
+        self._defer_err = None  # overlapped schedule: [(what, scratch)] of the running forward's stack launches (one copy per forward)
+        self._err_stream = None
 
     # ---------------------------------------------------------------------------------------------
     def _stream(self):
@@ -539,12 +541,19 @@ class Engine:
         # at without blocking at the next forward (and by check_stack_errors): a failed launch cannot go unnoticed for long
         if not torch.cuda.is_current_stream_capturing():
             stream = self._tstream(st)
+            what = f"{tag} rows={rows} frames={nt} wide={wide} rows_per_wg={rp} lag={self.stack_lag if lag is None else lag}"
+            if self._defer_err is not None:
+                # the overlapped schedule of a forward alone: the copy (a 4-byte blit + its completion) would sit between this launch
+                # and the projection that follows it on the same stream, ~10 us on the forward's chain per launch -- the forward
+                # collects its launches' words once, off the chain, when its streams have joined (_forward_stft)
+                self._defer_err.append((what, scratch))
+                return
             with torch.cuda.stream(stream):
                 pin = torch.empty((1,), dtype=torch.int32, pin_memory=True)
                 pin.copy_(scratch[:1], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(stream)
-            self._stack_err_pending.append((ev, pin, f"{tag} rows={rows} frames={nt} wide={wide} rows_per_wg={rp} lag={self.stack_lag if lag is None else lag}", scratch))
+            self._stack_err_pending.append((ev, pin, what, scratch))
 
     def _poll_stack_errors(self, block: bool = False) -> None:
         keep = []
@@ -566,7 +575,8 @@ class Engine:
         of a launch that gave up are not all zeroed by its last workgroup -- reset both, or every later launch on this scratch
         buffer would report the old failure (round-2 advisor finding)."""
         torch.cuda.synchronize(self.device)
-        scratch.zero_()
+        for sc in (scratch if isinstance(scratch, (list, tuple)) else [scratch]):
+            sc.zero_()
         torch.cuda.synchronize(self.device)
 
     def check_stack_errors(self) -> None:
@@ -754,6 +764,7 @@ class Engine:
         only its two layer pairs overlap.
         """
         spec, L = self.spec, self.lib
+        self._defer_err = None  # (a forward that raised half way must not leave the next one's error words uncollected)
         want_layers = want_layers or want_membrane  # membranes are a test output of the fp32-spike kernel variant
         if stft.device != self.device or stft.dtype != torch.complex64 or stft.dim() != 3:
             raise RuntimeError(f"expected a complex64 [B, F, T] tensor on {self.device}, got {stft.dtype} {tuple(stft.shape)} on {stft.device}")
@@ -865,6 +876,7 @@ class Engine:
             if main.cuda_stream not in self._ov_streams:  # a pair per calling stream: forwards in flight stay independent
                 self._ov_streams[main.cuda_stream] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
             sa, sb_ = self._ov_streams[main.cuda_stream]
+            self._defer_err = []
             sstreams = gstreams = [sa] * nl_fb + [sb_] * nl_sb
             rpw_fb, rpw_sb = self.rows_per_wg
             fork = torch.cuda.Event()
@@ -1027,6 +1039,27 @@ class Engine:
         if staged:
             for s_ in {id(x): x for x in sstreams + gstreams + ([aux_stream] if prep_ahead else [])}.values():
                 link(s_, main)
+        if self._defer_err:
+            # the error words of this forward's stack launches: one maximum, one copy to pinned memory, on a stream of its own behind
+            # the joined forward (nothing of the forward waits for it)
+            items, self._defer_err = self._defer_err, None
+            if self._err_stream is None:
+                self._err_stream = torch.cuda.Stream(device=dev)
+            es = self._err_stream
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            es.wait_event(ev0)
+            with torch.cuda.stream(es):
+                uniq = list({id(sc): sc for _, sc in items}.values())
+                word = torch.stack([sc[0] for sc in uniq]).max().reshape(1)
+                pin = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+                pin.copy_(word, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(es)
+            for sc in uniq:
+                sc.record_stream(es)
+            self._stack_err_pending.append((ev, pin, "; ".join(sorted({w for w, _ in items})), uniq))
+        self._defer_err = None
 
         if want_counts and not want_layers:
             # SynOPs without the fp32 spike tensors: count the int8 spikes, one launch for all layers
