@@ -35,9 +35,9 @@
 #endif
 #ifndef SFSN_S3_CWF
 // 1: the COMPUTE waves write the fp32 spikes themselves, one small store per wave and step (the 64-byte row segments of a tile; the
-// L2 merges them into lines) -- a round-4 experiment, OFF.  Why it was tried: a wave has at most 63 memory operations in flight and
-// a store takes 4-6 us to retire here, so an 8-row role whose stores all leave through one or two IO waves cannot go below
-// (stores per frame) x (retire time) / 63 per step: the publishing layer-1 role of a pair launch runs at 0.9 us per step on an
+// L2 merges them into lines) -- a round-4 experiment, OFF.  Why it was tried: ONE wave issues a 1 KiB store every 0.058 us
+// (17 KB/us, scripts/micro/store_retire.hip: idle chip or 208 workgroups alike, whatever the queue depth), so an 8-row role whose
+// nine stores per frame leave through one IO wave spends 0.52 us per step issuing them: the publishing layer-1 role of a pair launch runs at 0.9 us per step on an
 // idle chip whichever IO wave carries the seven fp32 stores of a frame (scripts/exp_stack_direct.py, ROWS=64), and the plain
 // 8-row scan (nine stores per frame through the storer) sits at 0.69.  With fourteen store queues the publishing role ran at
 // 0.63 -- but the compute-bound roles lost far more than that: one VMEM store per compute wave and step in front of the step
