@@ -28,6 +28,10 @@
 
 #define TR_THREADS 256
 #define TR_TILE 16
+#define TR_PF 4  // rows per thread whose step inputs are prefetched ahead of a wait (up to 64 rows per block; more rows: direct loads)
+__device__ __forceinline__ float tr_pick(const float (&a)[TR_PF], int i) {  // a[i] without a scratch-memory array (i < TR_PF)
+    return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3];
+}
 
 static inline int hip_ok_tr(hipError_t e) { return e == hipSuccess ? SFSN_OK : SFSN_EHIP; }
 
@@ -433,11 +437,13 @@ extern "C" int sfsn_gsn_train_step_bwd(const float* dz_next, const float* w_hh, 
 // its gradient (backward) stay in LDS, and what a step needs from OTHER workgroups travels through the L2:
 //   * the BatchNorm partial sums between the row blocks of a neuron tile: the tagged granules of tr_exchange, epoch = step + 1;
 //   * forward: h_{t-1} of my rows for ALL neurons (each of the H / 16 tile workgroups of the row block wrote 16 of them): four
-//     spikes packed per 32-bit word, written through (sc1) into a two-slot buffer [t & 1][R][H / 4]; a per-row-block counter counts
-//     the tile workgroups that have published step t (their stores drained by vmcnt before the add); readers poll the counter
-//     (one thread), then read the words with sc1 loads.  Two slots suffice: a workgroup publishes h_{t+1} only after it has read
-//     h_t from every tile of its row block, which they published after reading h_{t-1};
-//   * backward: d_z of step t+1 of my rows (all G*H products): the API tensor itself, written with sc1 stores, same counter.
+//     spikes + the step's epoch per 32-bit word, ONE write-through (sc1) store each, into a two-slot buffer [t & 1][R][H / 4];
+//     readers poll the words themselves (tr_read_tagged: data and "ready" arrive together -- the first form, words + a per-row-block
+//     counter behind a drained store queue, spent 5.9 of a 14.8 us step on publish / wait / read).  Two slots suffice: a
+//     workgroup publishes h_{t+1} only after it has read h_t from every tile of its row block, which they published after reading h_{t-1};
+//   * backward: d_z of step t+1 of my rows (all G*H products, fp32: no room for a tag): the API tensor itself, written with sc1
+//     stores; a per-row-block counter counts the tile workgroups that have published a step (their stores drained by vmcnt before
+//     the add); readers poll the counter (one thread), then read with sc1 loads.
 // All workgroups of the launch must be resident (train_geometry keeps the grid under 220 blocks of 256 threads); every spin is
 // bounded (error word, the host raises).  Arithmetic and its order are the step kernels', value for value.
 __device__ __forceinline__ bool tr_wait_counter(const unsigned* cnt, unsigned want, unsigned* err) {
@@ -463,24 +469,82 @@ __device__ __forceinline__ void tr_publish(unsigned* cnt) {
 typedef int tr_v4i __attribute__((ext_vector_type(4)));
 typedef float tr_v4f __attribute__((ext_vector_type(4)));
 // n 16-byte pieces of coherent (sc1) global memory -> LDS, all threads of the workgroup, four loads per thread in flight
+// Four coherent 16-byte loads and the wait for them in ONE asm block: the compiler must not touch the destination registers between a
+// load's issue and the s_waitcnt (with the wait as a statement of its own, tied to the registers by "+v", hipcc copied the
+// destinations BEFORE the wait -- a read of registers with a load outstanding, which the hardware does not interlock).
+__device__ __forceinline__ void tr_load4x16_sc1(tr_v4i& v0, tr_v4i& v1, tr_v4i& v2, tr_v4i& v3, const void* p0, const void* p1, const void* p2,
+                                                const void* p3) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\t"
+        "global_load_dwordx4 %1, %5, off sc1\n\t"
+        "global_load_dwordx4 %2, %6, off sc1\n\t"
+        "global_load_dwordx4 %3, %7, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+        : "memory");
+}
 // (rows of `ppr` pieces in the source, `dpr` >= ppr pieces apart in LDS)
 __device__ __forceinline__ void tr_copy16_sc1(void* lds_dst, const void* src, int n, int ppr, int dpr) {
     const char* s8 = static_cast<const char*>(src);
     tr_v4i* d = static_cast<tr_v4i*>(lds_dst);
     const int pad = dpr - ppr;
     for (int i0 = threadIdx.x; i0 < n; i0 += 4 * TR_THREADS) {
-        tr_v4i v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+        tr_v4i v0, v1, v2, v3;
         const int i1 = i0 + TR_THREADS, i2 = i0 + 2 * TR_THREADS, i3 = i0 + 3 * TR_THREADS;
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v0) : "v"(s8 + (size_t)i0 * 16) : "memory");
-        if (i1 < n) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v1) : "v"(s8 + (size_t)i1 * 16) : "memory");
-        if (i2 < n) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v2) : "v"(s8 + (size_t)i2 * 16) : "memory");
-        if (i3 < n) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v3) : "v"(s8 + (size_t)i3 * 16) : "memory");
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)::"memory");
+        // (pieces past the end: a harmless second read of this thread's first piece)
+        tr_load4x16_sc1(v0, v1, v2, v3, s8 + (size_t)i0 * 16, s8 + (size_t)(i1 < n ? i1 : i0) * 16, s8 + (size_t)(i2 < n ? i2 : i0) * 16,
+                        s8 + (size_t)(i3 < n ? i3 : i0) * 16);
         d[i0 + (i0 / ppr) * pad] = v0;
         if (i1 < n) d[i1 + (i1 / ppr) * pad] = v1;
         if (i2 < n) d[i2 + (i2 / ppr) * pad] = v2;
         if (i3 < n) d[i3 + (i3 / ppr) * pad] = v3;
     }
+}
+
+// Forward spike exchange, data-tagged: a 32-bit word carries four spikes (bits 0..3) and the step's epoch (bits 4..31), written by
+// ONE write-through store -- data and "ready" arrive together, as in tr_exchange: no drained store queue, no counter, no publish
+// barrier on the writer's side; the reader polls the words it needs (16-byte pieces = the 16 neurons of one tile for one row) until
+// all four carry the epoch it waits for, and unpacks them to the byte-per-neuron form the product reads.  n16 pieces, all threads.
+__device__ __forceinline__ unsigned tr_unpack4(unsigned w) { return (w & 1u) | ((w & 2u) << 7) | ((w & 4u) << 14) | ((w & 8u) << 21); }
+__device__ __forceinline__ bool tr_read_tagged(unsigned* lds_dst, const unsigned* src, int n16, unsigned epoch, unsigned* err) {
+    int good = 1;
+    for (int i0 = threadIdx.x; i0 < n16; i0 += 4 * TR_THREADS) {
+        tr_v4i v[4];
+        unsigned pend = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = tr_v4i{0, 0, 0, 0};
+            if (i0 + k * TR_THREADS < n16) pend |= 1u << k;
+        }
+        const unsigned* q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = src + 4 * (size_t)((pend & (1u << k)) ? i0 + k * TR_THREADS : i0);  // (absent pieces: my first one again)
+        for (unsigned spins = 0; pend; ++spins) {
+            tr_load4x16_sc1(v[0], v[1], v[2], v[3], q[0], q[1], q[2], q[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((pend & (1u << k)) && ((unsigned)v[k].x >> 4) == epoch && ((unsigned)v[k].y >> 4) == epoch && ((unsigned)v[k].z >> 4) == epoch &&
+                    ((unsigned)v[k].w >> 4) == epoch)
+                    pend &= ~(1u << k);
+            if (!pend) break;
+            if (spins > 600000u) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k * TR_THREADS < n16) {
+                tr_v4i o;
+                o.x = (int)tr_unpack4((unsigned)v[k].x); o.y = (int)tr_unpack4((unsigned)v[k].y);
+                o.z = (int)tr_unpack4((unsigned)v[k].z); o.w = (int)tr_unpack4((unsigned)v[k].w);
+                reinterpret_cast<tr_v4i*>(lds_dst)[i0 + k * TR_THREADS] = o;
+            }
+    }
+    return __syncthreads_and(good) != 0;
 }
 
 #ifdef SFSN_EXPERIMENTS
@@ -552,15 +616,21 @@ __device__ __forceinline__ void train_seq_fwd_body(const TrainFwdParams& p, cons
     long long tr_t0 = (long long)wall_clock64();
     (void)tr_t0;
     for (int t = 0; t < x.T; ++t) {
-        if (t > 0) {  // h_{t-1} of my rows: every tile workgroup of my row block has published step t-1
-            if (!tr_wait_counter(x.rbcnt + rb, (unsigned)t * (unsigned)tiles, err)) return;
-            TR_STAMP(0);
+        // this step's input terms of my (row, neuron) pairs do not depend on anybody: requested before the wait for h_{t-1}
+        const float* z = p.z + (size_t)t * RG;
+        float zfp[TR_PF], zgp[TR_PF];
+#pragma unroll
+        for (int i = 0; i < TR_PF; ++i) {
+            const int r = r_lo + rsub + i * (TR_THREADS / TR_TILE);
+            const int rc = r < r_hi ? r : r_lo;
+            zfp[i] = z[(size_t)rc * G * H + nj];
+            zgp[i] = z[(size_t)rc * G * H + (G - 1) * H + nj];
+        }
+        if (t > 0) {  // h_{t-1} of my rows, 16 neurons from each tile workgroup of my row block: tagged words of epoch t
             const unsigned* src = x.hx + ((size_t)((t - 1) & 1) * p.R + r_lo) * H4;
-            tr_copy16_sc1(hb, src, (nr * H4) >> 2, H4 >> 2, H4 >> 2);  // (H / 4 words per row, H % 16 == 0: whole 16-byte pieces)
-            __syncthreads();
+            if (!tr_read_tagged(hb, src, (nr * H4) >> 2, (unsigned)t, err)) return;  // (H / 4 words per row, H % 16 == 0: whole 16-byte pieces)
             TR_STAMP(1);
         }
-        const float* z = p.z + (size_t)t * RG;
         float *o_f = p.f + (size_t)t * RH, *o_g = p.g + (size_t)t * RH, *o_u = p.u + (size_t)t * RH, *o_s = p.spikes + (size_t)t * RH;
         float* o_x = p.xhat ? p.xhat + (size_t)t * RH : nullptr;
         // the recurrent products of my rows x my 16 neurons on the matrix pipe (v_mfma_f32_16x16x4_f32: fp32 products, fp32
@@ -592,10 +662,18 @@ __device__ __forceinline__ void train_seq_fwd_body(const TrainFwdParams& p, cons
         }
         __syncthreads();
         float sum = 0.f;
-        for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
+        int pi = 0;
+        for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE, ++pi) {
             const float rf = recb[(size_t)((r - r_lo) * G) * TR_TILE + j];
             const float rg = recb[(size_t)((r - r_lo) * G + (G - 1)) * TR_TILE + j];
-            const float zf = z[(size_t)r * G * H + nj], zg = z[(size_t)r * G * H + (G - 1) * H + nj];
+            float zf, zg;
+            if (pi < TR_PF) {
+                zf = tr_pick(zfp, pi);
+                zg = tr_pick(zgp, pi);
+            } else {
+                zf = z[(size_t)r * G * H + nj];
+                zg = z[(size_t)r * G * H + (G - 1) * H + nj];
+            }
             const float pre_f = (zf + bf) + rf;
             const float pre_g = (zg + bg) + rg;
             const float f = 1.0f / (1.0f + expf(-pre_f));
@@ -665,11 +743,15 @@ __device__ __forceinline__ void train_seq_fwd_body(const TrainFwdParams& p, cons
         }
         __syncthreads();
         TR_STAMP(5);
-        if (t + 1 < x.T) {  // my 16 spikes of every row -> the slot of step t, write-through; then count me in
+        if (t + 1 < x.T) {  // my 16 spikes of every row -> the slot of step t: four tagged words per row, write-through
             unsigned* dst = x.hx + ((size_t)(t & 1) * p.R + r_lo) * H4 + tile * 4;
-            for (int i = tid; i < nr * 4; i += TR_THREADS)
-                __hip_atomic_store(dst + (size_t)(i >> 2) * H4 + (i & 3), sb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tr_publish(x.rbcnt + rb);
+            const unsigned tag = (unsigned)(t + 1) << 4;
+            for (int i = tid; i < nr * 4; i += TR_THREADS) {
+                const unsigned w = sb[i];
+                __hip_atomic_store(dst + (size_t)(i >> 2) * H4 + (i & 3), tag | (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();  // (sb is rewritten by the next step's output loop)
             TR_STAMP(6);
         }
     }
@@ -722,6 +804,19 @@ __device__ __forceinline__ void train_seq_bwd_body(const TrainBwdParams& p, cons
     (void)tr_t0;
     for (int t = x.T - 1; t >= 0; --t) {
         const int s = x.T - 1 - t;
+        const float *i_u = p.u + (size_t)t * RH, *i_f = p.f + (size_t)t * RH, *i_g = p.g + (size_t)t * RH, *i_up = p.dh_up + (size_t)t * RH;
+        const float* i_x = p.xhat ? p.xhat + (size_t)t * RH : nullptr;
+        const float* i_cp = t ? p.u + (size_t)(t - 1) * RH : nullptr;
+        // this step's own inputs (forward-saved tensors, the upstream gradient) do not depend on anybody: requested before the wait
+        float upp[TR_PF], uup[TR_PF], xhp[TR_PF];
+#pragma unroll
+        for (int i = 0; i < TR_PF; ++i) {
+            const int r = r_lo + rsub + i * (TR_THREADS / TR_TILE);
+            const size_t o = (size_t)(r < r_hi ? r : r_lo) * H + nj;
+            upp[i] = i_up[o];
+            uup[i] = i_u[o];
+            xhp[i] = p.use_bn ? i_x[o] : 0.f;
+        }
         if (s > 0) {  // d_z of step t+1 of my rows: every tile workgroup of my row block has published it
             if (!tr_wait_counter(x.rbcnt + rb, (unsigned)s * (unsigned)tiles, err)) return;
             TR_STAMP(0);
@@ -745,24 +840,32 @@ __device__ __forceinline__ void train_seq_bwd_body(const TrainBwdParams& p, cons
             }
             __syncthreads();
         }
-        const float *i_u = p.u + (size_t)t * RH, *i_f = p.f + (size_t)t * RH, *i_g = p.g + (size_t)t * RH, *i_up = p.dh_up + (size_t)t * RH;
-        const float* i_x = p.xhat ? p.xhat + (size_t)t * RH : nullptr;
-        const float* i_cp = t ? p.u + (size_t)(t - 1) * RH : nullptr;
         float s1 = 0.f, s2 = 0.f;
-        for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
+        int pi = 0;
+        for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE, ++pi) {
             const size_t o = (size_t)r * H + nj;
             float dh = 0.f;
-            dh += i_up[o];
+            dh += pi < TR_PF ? tr_pick(upp, pi) : i_up[o];
             if (s > 0) dh += recb[(size_t)(r - r_lo) * TR_TILE + j];  // dL/dh_t through step t+1's recurrent product
-            const float uu = i_u[o];
+            const float uu = pi < TR_PF ? tr_pick(uup, pi) : i_u[o];
             const float tri = fmaxf(0.f, 1.0f - fabsf(uu));
             float du = dh * tri;
             if (s > 0) du += dcn[(r - r_lo) * TR_TILE + j];
             dbuf[(r - r_lo) * TR_TILE + j] = du;
             if (p.use_bn) {
                 s1 += du;
-                s2 = __builtin_fmaf(du, i_x[o], s2);
+                s2 = __builtin_fmaf(du, pi < TR_PF ? tr_pick(xhp, pi) : i_x[o], s2);
             }
+        }
+        // ... and what the last loop of the step reads (forget gate, cell-gate pre-activation, previous membrane): under the exchange
+        float fp[TR_PF], gp[TR_PF], cpp[TR_PF];
+#pragma unroll
+        for (int i = 0; i < TR_PF; ++i) {
+            const int r = r_lo + rsub + i * (TR_THREADS / TR_TILE);
+            const size_t o = (size_t)(r < r_hi ? r : r_lo) * H + nj;
+            fp[i] = i_f[o];
+            gp[i] = i_g[o];
+            cpp[i] = i_cp ? i_cp[o] : 0.f;
         }
         float k1 = 0.f, k2 = 0.f, scale = 1.f;
         TR_STAMP(2);
@@ -786,11 +889,14 @@ __device__ __forceinline__ void train_seq_bwd_body(const TrainBwdParams& p, cons
         }
         float* o_dg = p.d_gates + (size_t)t * p.R * 2 * H;
         float* o_dz = p.shared ? p.d_z + (size_t)t * RH : nullptr;
-        for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) {
+        pi = 0;
+        for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE, ++pi) {
             const size_t o = (size_t)r * H + nj;
             const float du = dbuf[(r - r_lo) * TR_TILE + j];
-            const float dcy = p.use_bn ? scale * ((float)p.R * du - k1 - i_x[o] * k2) : du;
-            const float f = i_f[o], g = i_g[o], cp = i_cp ? i_cp[o] : 0.f;
+            const float xh = p.use_bn ? (pi < TR_PF ? tr_pick(xhp, pi) : i_x[o]) : 0.f;
+            const float dcy = p.use_bn ? scale * ((float)p.R * du - k1 - xh * k2) : du;
+            const float f = pi < TR_PF ? tr_pick(fp, pi) : i_f[o], g = pi < TR_PF ? tr_pick(gp, pi) : i_g[o];
+            const float cp = pi < TR_PF ? tr_pick(cpp, pi) : (i_cp ? i_cp[o] : 0.f);
             const float df = dcy * (cp - g);
             const float dpf = df * f * (1.0f - f);
             const float dpg = dcy * (1.0f - f);

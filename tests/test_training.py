@@ -247,6 +247,58 @@ def test_training_layer_call_checks_before_it_launches():
     training._poll_pending(block=True)
 
 
+@pytest.mark.parametrize("shared,bn", [(True, True), (False, True), (True, False)])
+def test_layer_calls_of_several_groups_in_one_launch_equal_the_calls_one_by_one(shared, bn):
+    """training.gsn_stacks: layer l of several independent stacks in ONE launch per direction (sfsn_gsn_train_seq_fwd_multi / _bwd_multi:
+    the sub-band groups of a model share a grid) gives the bits of the same layer calls issued one after the other -- spikes, BatchNorm
+    buffers and every gradient -- for rows that need several row blocks per tile (R = 200) and rows that do not; and falls back to
+    single calls when the stacks do not match (different depth)."""
+    import copy
+    import spiking_fullsubnet_amd.modeling_spiking_fullsubnet as M
+    from spiking_fullsubnet_amd import training
+    torch.manual_seed(3)
+    T, H = 14, 48
+    dims = [(200, 10), (40, 22), (17, 30)]
+    stacks = [M.StackedGSU(I, H, 2, shared, bn).to(DEV).train() for _, I in dims]
+    for st in stacks:
+        for layer in st.layers:
+            if bn:
+                layer.cell.batchnorm.weight.data.uniform_(0.5, 1.5)
+                layer.cell.batchnorm.bias.data.uniform_(-0.3, 0.3)
+    twins = [copy.deepcopy(st) for st in stacks]
+    xs = [torch.randn(T, R, I, device=DEV) for R, I in dims]
+    cots = [torch.randn(T, R, H, device=DEV) for R, _ in dims]
+
+    def run(sts, together):
+        training.GROUPS_TOGETHER = together
+        try:
+            ins = [x.clone().requires_grad_(True) for x in xs]
+            outs = training.gsn_stacks(ins, sts, True)
+            loss = sum((o[-1] * c).sum() + 0.5 * (o[1] * c).sum() for o, c in zip(outs, cots))
+            loss.backward()
+            training.check_pending()
+        finally:
+            training.GROUPS_TOGETHER = True
+        return ins, outs
+    n0 = len(training._pending)
+    ins_a, outs_a = run(stacks, True)
+    ins_b, outs_b = run(twins, False)
+    for g in range(len(dims)):
+        for l in range(1, 3):
+            assert torch.equal(outs_a[g][l], outs_b[g][l]), (g, l)
+        assert torch.equal(ins_a[g].grad, ins_b[g].grad), g
+        for (na, pa), (nb, pb) in zip(stacks[g].named_parameters(), twins[g].named_parameters()):
+            assert na == nb and torch.equal(pa.grad, pb.grad), (g, na)
+        for (na, ba), (nb, bb) in zip(stacks[g].named_buffers(), twins[g].named_buffers()):
+            assert torch.equal(ba, bb), (g, na)
+    # stacks of different depth: no common launch, same results as the stacks alone
+    odd = [M.StackedGSU(10, H, 1, shared, bn).to(DEV).train(), M.StackedGSU(22, H, 2, shared, bn).to(DEV).train()]
+    odd2 = [copy.deepcopy(st) for st in odd]
+    a = training.gsn_stacks([xs[0], xs[1]], odd, True)
+    b = [training.gsn_stack(xs[0], odd2[0], True), training.gsn_stack(xs[1], odd2[1], True)]
+    assert all(torch.equal(u, v) for oa, ob in zip(a, b) for u, v in zip(oa[1:], ob[1:]))
+
+
 def test_lstm_and_output_activation_options_run_on_the_aten_path():
     """sequence_model="LSTM" (the reference's nn.LSTM ablation, modeling_spiking_fullsubnet.py:38-45,68-79) and an output activation:
     constructor options the inference kernels do not cover are served by the differentiable path, in eval mode too."""
