@@ -515,6 +515,7 @@ class Engine:
                     fin[l * ns + i].spikes_in = d["s8"][l - 1][i].data_ptr() + t0 * R * HP
                     fin[l * ns + i].w_ih, fin[l * ns + i].w_ih_dq = pk.data_ptr(), dq.data_ptr()
         nbytes = L.sfsn_stack_scratch_bytes(nl, ns, rows)
+        own_scratch = scratch is None
         if scratch is None:  # (a streaming session owns its own: its captured graph must not outlive a cache entry)
             def make():
                 # zero-filled on the stream the kernel is launched on: on the overlapped schedule that is a side stream which
@@ -542,7 +543,7 @@ class Engine:
         if not torch.cuda.is_current_stream_capturing():
             stream = self._tstream(st)
             what = f"{tag} rows={rows} frames={nt} wide={wide} rows_per_wg={rp} lag={self.stack_lag if lag is None else lag}"
-            if self._defer_err is not None:
+            if self._defer_err is not None and own_scratch:
                 # the overlapped schedule of a forward alone: the copy (a 4-byte blit + its completion) would sit between this launch
                 # and the projection that follows it on the same stream, ~10 us on the forward's chain per launch -- the forward
                 # collects its launches' words once, off the chain, when its streams have joined (_forward_stft)
