@@ -1237,6 +1237,43 @@ def test_fused_scan_entry_points_reject_what_they_do_not_cover(hip):
     torch.cuda.synchronize()
 
 
+def test_feature_launch_zeroes_the_scan_states_and_nothing_else(hip, monkeypatch):
+    """sfsn_features_z: extra workgroups of the feature launch write the zero initial state of the forward's scans (MODEL:100-106)
+    -- exactly the bytes asked for, the features themselves unchanged -- and the engine's forward gives the same bits with the
+    states zeroed that way as with a fill launch of its own (SFSN_ZERO_FOLD=0)."""
+    from spiking_fullsubnet_amd import _lib
+    from spiking_fullsubnet_amd._lib import FeatureGroup
+    B, F, T, I = 3, 33, 40, 32
+    rng = np.random.default_rng(5)
+    ri = _t(rng.standard_normal((B, F, T, 2)).astype(np.float32))
+    xa, xb = torch.empty((T, B, I), device=DEV), torch.empty((T, B, I), device=DEV)
+    for n16 in (0, 1, 100, 2048 * 3 + 5):
+        buf = torch.full((4 * n16 + 64,), 7.0, device=DEV)
+        for x, z in ((xa, None), (xb, buf)):
+            g = (FeatureGroup * 1)()
+            g[0].x, g[0].lo, g[0].n_units, g[0].ctr, g[0].nbr, g[0].ctr_fb, g[0].nbr_fb, g[0].norm, g[0].ln_eps = x.data_ptr(), 0, 1, I, 0, 0, 0, 0, 1e-5
+            rc = hip.sfsn_features_z(ri.data_ptr(), None, B, F, T, 0, 0.5, g, 1, 0, T, None if z is None else ctypes.c_void_p(z.data_ptr() + 64),
+                                     0 if z is None else 16 * n16, None)
+            assert rc == 0, rc
+        torch.cuda.synchronize()
+        assert torch.equal(xa, xb)
+        assert bool((buf[:16] == 7).all()) and bool((buf[16:16 + 4 * n16] == 0).all()) and bool((buf[16 + 4 * n16:] == 7).all()), n16
+    assert hip.sfsn_features_z(ri.data_ptr(), None, B, F, T, 0, 0.5, g, 1, 0, T, ctypes.c_void_p(buf.data_ptr() + 4), 16, None) == _lib.SFSN_EINVAL
+    assert hip.sfsn_features_z(ri.data_ptr(), None, B, F, T, 0, 0.5, g, 1, 0, T, ctypes.c_void_p(buf.data_ptr()), 24, None) == _lib.SFSN_EINVAL
+    import spiking_fullsubnet_amd as pkg
+    kw = rw.LIVE_TINY
+    model = pkg.SpikingFullSubNet(**kw)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rw.live_state_dict(kw, 3).items()}, strict=True)
+    model = model.eval().to(DEV)
+    stft = model._stft(_t(rw.synth_wave(3, 300, 9)))
+    a = model.engine().forward_stft(stft)
+    monkeypatch.setenv("SFSN_ZERO_FOLD", "0")
+    b = model.engine().forward_stft(stft)
+    assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(b["enh_stft"]))
+    assert all(torch.equal(u, v) for u, v in zip(a["fb_all"] + sum(a["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])))
+    model.engine().check_stack_errors()
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (one rank per GPU; with
     SFSN_BENCH_BACKEND=gloo the two ranks share this box's GPU -- a plumbing check of the N > 1 path): one JSON line, n_gpus 2,
