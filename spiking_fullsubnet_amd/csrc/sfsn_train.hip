@@ -338,13 +338,20 @@ static int train_wg_target() {
     return 160;  // (220 / 160 / 110 / 70 measured at B = 64, three groups in one launch: 9.4 / 8.3 / 8.1 / 8.3 ms forward, 13.6 / 12.5 / 13.1 / 14.7 backward per 200 steps x 2 layers)
 #endif
 }
-static void train_geometry(int R, int H, int* RB, int* rpb) {
+static void train_geometry(int R, int H, int G, int* RB, int* rpb) {
     const int tiles = H / TR_TILE;
     int rb = train_wg_target() / tiles;
     if (rb < 1) rb = 1;
-    int per = (R + rb - 1) / rb;
-    if (per < 16) per = 16;
-    per = (per + 15) & ~15;
+    int per = 16;
+    for (;; ++rb) {
+        per = (R + rb - 1) / rb;
+        if (per < 16) per = 16;
+        per = (per + 15) & ~15;
+        // many rows: more row blocks (up to the 16 the exchange buffers hold) before the backward launch's LDS -- W_hh columns and the
+        // d_z rows of a block, (G H + 4) x (16 + rows) floats -- would not fit
+        const size_t lds_b = ((size_t)3 * per * TR_TILE + (size_t)16 * TR_PART + (size_t)(G * H + 4) * (TR_TILE + per)) * sizeof(float);
+        if (lds_b <= 150 * 1024 || rb >= 16) break;
+    }
     *rpb = per;
     *RB = (R + per - 1) / per;
 }
@@ -362,9 +369,9 @@ extern "C" int sfsn_gsn_train_check(int R, int H, int shared) {
     if (R <= 0 || H <= 0) return SFSN_EINVAL;
     if (H % TR_TILE != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     int RB, rpb;
-    train_geometry(R, H, &RB, &rpb);
-    if (RB > 16) return SFSN_EUNSUPPORTED;
     const int G = shared ? 1 : 2;
+    train_geometry(R, H, G, &RB, &rpb);
+    if (RB > 16) return SFSN_EUNSUPPORTED;
     // (the one-launch layer calls carry the membrane / its gradient and the packed new spikes in LDS on top of the step kernels' buffers)
     const size_t lds_f = ((size_t)G * TR_TILE * (H + 4) + (size_t)(2 + G) * rpb * TR_TILE + (size_t)RB * TR_PART) * sizeof(float) + (size_t)rpb * H + (size_t)rpb * TR_TILE;
     const size_t lds_b = ((size_t)3 * rpb * TR_TILE + (size_t)RB * TR_PART + (size_t)(G * H + 4) * (TR_TILE + rpb)) * sizeof(float);
@@ -382,7 +389,7 @@ extern "C" int sfsn_gsn_train_step_fwd(const float* z, const float* w_hh, const 
     if ((running_mean == nullptr) != (running_var == nullptr)) return SFSN_EINVAL;
     const int G = shared ? 1 : 2, tiles = H / TR_TILE;
     TrainFwdParams p;
-    train_geometry(R, H, &p.RB, &p.rpb);
+    train_geometry(R, H, shared ? 1 : 2, &p.RB, &p.rpb);
     if (p.RB > 16) return SFSN_EUNSUPPORTED;  // (more than 16 x 220 / tiles x ... rows per layer and step)
     if (p.RB > 1 && use_bn && (!scratch || epoch == 0)) return SFSN_EINVAL;
     const size_t lds = ((size_t)G * TR_TILE * (H + 1) + (size_t)p.rpb * TR_TILE + (size_t)p.RB * TR_PART) * sizeof(float) + (size_t)p.rpb * H;
@@ -411,7 +418,7 @@ extern "C" int sfsn_gsn_train_step_bwd(const float* dz_next, const float* w_hh, 
     if (dz_next && !w_hh) return SFSN_EINVAL;
     const int tiles = H / TR_TILE;
     TrainBwdParams p;
-    train_geometry(R, H, &p.RB, &p.rpb);
+    train_geometry(R, H, shared ? 1 : 2, &p.RB, &p.rpb);
     if (p.RB > 16) return SFSN_EUNSUPPORTED;
     if (p.RB > 1 && use_bn && (!scratch || epoch == 0)) return SFSN_EINVAL;
     const size_t lds = ((size_t)p.rpb * TR_TILE + (size_t)p.RB * TR_PART + (dz_next ? (size_t)(shared ? 1 : 2) * H * (TR_TILE + p.rpb) : 0)) * sizeof(float);
@@ -985,7 +992,7 @@ static int seq_multi_geometry(const int* R, int n, int H, int shared, int* wgs, 
     for (int i = 0; i < n; ++i) {
         if (R[i] <= 0) return SFSN_EINVAL;
         int RB, rpb;
-        train_geometry(R[i], H, &RB, &rpb);
+        train_geometry(R[i], H, G, &RB, &rpb);
         if (RB > 16) return SFSN_EUNSUPPORTED;
         const size_t lf = seq_lds_fwd(G, H, RB, rpb), lb = seq_lds_bwd(G, H, RB, rpb);
         if (lf > 150 * 1024 || lb > 150 * 1024) return SFSN_EUNSUPPORTED;
@@ -1032,7 +1039,7 @@ extern "C" int sfsn_gsn_train_seq_fwd_multi(const SfsnTrainSeqFwd* c, int n, int
         TrainFwdParams& p = m.p[i];
         TrainSeqExtra& x = m.x[i];
         const int R = c[i].R;
-        train_geometry(R, H, &p.RB, &p.rpb);
+        train_geometry(R, H, shared ? 1 : 2, &p.RB, &p.rpb);
         char* base = static_cast<char*>(c[i].scratch);
         float* step_scr = reinterpret_cast<float*>(base + seq_head_bytes(R, H));
         p.z = c[i].z; p.w_hh = c[i].w_hh; p.bias = c[i].bias; p.h_prev = nullptr; p.c_prev = nullptr; p.bn_w = c[i].bn_w; p.bn_b = c[i].bn_b;
@@ -1077,7 +1084,7 @@ extern "C" int sfsn_gsn_train_seq_bwd_multi(const SfsnTrainSeqBwd* c, int n, int
         TrainBwdParams& p = m.p[i];
         TrainSeqExtra& x = m.x[i];
         const int R = c[i].R;
-        train_geometry(R, H, &p.RB, &p.rpb);
+        train_geometry(R, H, shared ? 1 : 2, &p.RB, &p.rpb);
         char* base = static_cast<char*>(c[i].scratch);
         float* step_scr = reinterpret_cast<float*>(base + seq_head_bytes(R, H));
         p.dz_next = nullptr; p.w_hh = c[i].w_hh; p.dh_up = c[i].dh_up; p.dh_rec = nullptr; p.dc_next = nullptr; p.u = c[i].u; p.xhat = c[i].xhat;

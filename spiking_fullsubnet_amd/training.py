@@ -20,6 +20,7 @@ package this has no CPU path (a CPU module raises).
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List
 
 import torch
@@ -33,7 +34,9 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-import os
+# debugging / cross-checks: True = round 3's launch per time step (sfsn_gsn_train_step_fwd / _bwd, scalar products) instead of one launch
+# per layer and direction (scripts/exp_train_shapes.py compares the two over odd shapes)
+STEP_LAUNCHES = os.environ.get("SFSN_TRAIN_STEP_LAUNCHES", "0") != "0"
 # the same layer of all sub-band groups in ONE launch per direction (SFSN_TRAIN_GROUPS_TOGETHER=0: one group after the other)
 GROUPS_TOGETHER = os.environ.get("SFSN_TRAIN_GROUPS_TOGETHER", "1") != "0"
 
@@ -144,7 +147,7 @@ class GSNLayerTrainFn(torch.autograd.Function):
         a_bw, a_bb, a_rm, a_rv = _p(bw), _p(bb), _p(rmean), _p(rvar)
         mom, ep, sh = float(0.1 if momentum is None else momentum), float(eps), int(shared)
         fwd = L.sfsn_gsn_train_step_fwd
-        seq = not fold
+        seq = not fold and not STEP_LAUNCHES
         # zeroed per call: packed-spike slots and publish counters of the one-launch layer call, partial-sum granules, error word (last 4 words)
         scr = torch.zeros(((L.sfsn_train_seq_scratch_bytes(R, H) if seq else L.sfsn_train_scratch_bytes(H)) // 4,), dtype=torch.int32, device=dev)
         p_scr = P(scr.data_ptr())
@@ -165,7 +168,7 @@ class GSNLayerTrainFn(torch.autograd.Function):
                     u[t].mul_(alpha).add_(beta)
                     spikes[t].copy_((u[t] >= 0).float())
         ctx.scr = scr  # (its error word is read in backward: no synchronisation there until the gradients are assembled)
-        if seq:
+        if not fold:
             if not any(ctx.needs_input_grad):
                 # nothing will call backward() (BatchNorm recalibration, validation with the module left in train()): an exchange that
                 # timed out leaves spikes / u / running statistics unwritten -- find out before handing them out
@@ -213,7 +216,7 @@ class GSNLayerTrainFn(torch.autograd.Function):
         pdc = [dc_buf[0].data_ptr(), dc_buf[1].data_ptr()]
         sh = int(shared)
         bwd = L.sfsn_gsn_train_step_bwd
-        seq = not fold
+        seq = not fold and not STEP_LAUNCHES
         scr = torch.zeros(((L.sfsn_train_seq_scratch_bytes(R, H) if seq else L.sfsn_train_scratch_bytes(H)) // 4,), dtype=torch.int32, device=dev)
         p_scr = P(scr.data_ptr())
         if _debug_scratch is not None:
@@ -432,7 +435,7 @@ def gsn_stacks(xs, stacks, training: bool):
     n = len(stacks)
     def same(fn):
         return len({fn(st) for st in stacks}) == 1
-    ok = (GROUPS_TOGETHER and 1 < n <= _lib.TRAIN_MAX_CALLS and same(lambda st: len(st.layers))
+    ok = (GROUPS_TOGETHER and not STEP_LAUNCHES and 1 < n <= _lib.TRAIN_MAX_CALLS and same(lambda st: len(st.layers))
           and all(x.is_cuda and x.shape[0] == xs[0].shape[0] for x in xs))
     if ok:
         for l in range(len(stacks[0].layers)):
