@@ -276,7 +276,8 @@ __global__ __launch_bounds__(1024) void pair_l2_kernel(const PArgs p) {
                     if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(st[3])); __builtin_amdgcn_sched_barrier(0); }
                     if constexpr (MODE == 1) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (SPLIT) in_mfma(t2 + 2, 2 * par, 2 * par + 2);
+                        if constexpr (SPLIT == 2) in_mfma(t2 + 2, 0, KS);  // (model of a 16-row role: the whole input product EVERY step)
+                        else if constexpr (SPLIT) in_mfma(t2 + 2, 2 * par, 2 * par + 2);
                         else if (par == 0) in_mfma(t2 + 2, 0, KS);
                     }
                     if constexpr (MODE == 4 || MODE == 5) {
@@ -396,6 +397,8 @@ int main(int argc, char** argv) {
     printf("== 8-row IO-wave scan step; +12 input-product MFMAs per tile and two steps (W_ih planes 0-1 in LDS, plane 2 in registers) ==\n");
     RUN(0, 1, 0, 1);
     RUN(1, 1, 0, 1); RUN(4, 1, 0, 1); RUN(5, 1, 0, 1); RUN(5, 1, 1, 1); RUN(6, 1, 0, 1); RUN(7, 1, 0, 1); RUN(8, 1, 0, 1); RUN(9, 1, 0, 1); RUN(10, 1, 0, 1); RUN(11, 1, 0, 1);
+    printf("== model of a 16-row fused role: all 12 input-product MFMAs behind the epilogue EVERY step; epilogue once / twice (4 values per lane) ==\n");
+    RUN(1, 2, 0, 1); RUN(1, 2, 0, 2); RUN(0, 1, 0, 2);
     printf("== per-wave timeline of the last step ==\n");
     RUNS(7, 1, 0, 1); RUNS(8, 1, 0, 1); RUNS(9, 1, 0, 1); RUNS(5, 1, 1, 1); RUNS(10, 1, 0, 1);
     return 0;
