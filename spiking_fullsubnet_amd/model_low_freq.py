@@ -106,7 +106,7 @@ class Separator(_EngineMixin, nn.Module):
 
     def forward(self, noisy_y):
         """model_low_freq.py:561-618.  In training mode, or when gradients can flow into the input, the differentiable path of
-        training.py (``forward_frozen``: ATen front / back end, HIP training-step kernels for the cell loop); else the kernels."""
+        training.py (``forward_frozen``: ATen front / back end, HIP training kernels for the cell loop); else the kernels."""
         if self._wants_autograd(noisy_y):
             from . import training
             return training.forward_frozen(self, noisy_y)

@@ -10,7 +10,7 @@ same ``forward(input[B, samples])`` return tuple (:415-474).  A recipe switches 
 The sub-modules below are parameter containers that mirror the reference's module tree; in ``eval()`` mode all arithmetic
 between ``stft`` and ``istft`` runs in the gfx950 inference kernels of ``libsfsn_hip.so`` via ``Engine`` (no autograd graph).
 In ``train()`` mode -- or when gradients can flow into the input -- ``forward()`` takes the differentiable path of ``training.py``:
-the cell loop with per-step batch-statistics BatchNorm and the triangle surrogate's backward on the HIP training-step kernels
+the cell loop with per-step batch-statistics BatchNorm and the triangle surrogate's backward on the HIP training kernels
 (``csrc/sfsn_train.hip``), everything time-parallel as ATen operations.
 """
 from __future__ import annotations

@@ -5,10 +5,12 @@ What the recipes' training step needs (recipes/intel_ndns/spiking_fullsubnet/tra
 
 * the recurrent cell loop with ``nn.BatchNorm1d`` in TRAINING mode inside the cell -- every time step normalises with that step's
   batch statistics and updates the running statistics (efficient_spiking_neuron.py:123,149-150) -- and its backward pass through the
-  triangle surrogate of the spike (:94-101): ``GSNLayerTrainFn``, a ``torch.autograd.Function`` whose time steps are the HIP kernels
-  ``sfsn_gsn_train_step_fwd`` / ``sfsn_gsn_train_step_bwd`` (csrc/sfsn_train.hip: one launch per step, a workgroup owns 16 neurons
-  for all rows and reduces over the rows in LDS); the time-parallel products around them (input product, weight gradients, input
-  gradient) and the one sequential product of the backward pass (dh_{t-1} = dz_t . W_hh) are library GEMMs (``torch.mm``);
+  triangle surrogate of the spike (:94-101): ``GSNLayerTrainFn`` / ``GSNLayersTrainFn``, ``torch.autograd.Function``s whose whole time
+  loop is ONE HIP launch per direction (``sfsn_gsn_train_seq_fwd`` / ``_bwd``, csrc/sfsn_train.hip: the workgroups of a layer call --
+  16 neurons x a block of rows each -- stay resident for all T steps, recurrent products on the fp32 matrix pipe, carried state in
+  LDS, what a step needs from other workgroups exchanged through the L2; layer l of all sub-band groups in one grid,
+  ``_multi``); the time-parallel products around them (input product, weight gradients, input gradient) are library GEMMs
+  (``torch.mm``);
 * everything between ``stft`` and ``istft`` that is time-parallel (band selection, reflect-gathered sub-band features, LayerNorm,
   projections, deep filter) as differentiable ATen operations on index tensors built once per module -- the kernels of the
   inference engine have no backward.
@@ -615,7 +617,7 @@ def forward_frozen(model, wave: torch.Tensor):
     operations, for a module in training mode or an input that requires grad: the utterance-level ``offline_laplace_norm`` (:147-169:
     x / (mean over every non-batch dimension + EPSILON)) on the full-band input (:578) and on every group's concatenated sub-band
     input (:475), reflect-unfolded noisy AND full-band features (:350-431: the tiled full-band output has its own centre / neighbour
-    sizes), the cell loop on the HIP training-step kernels (GSNLayerTrainFn), deep filtering and reconstruction as in forward_live."""
+    sizes), the cell loop on the HIP training kernels (GSNLayerTrainFn / GSNLayersTrainFn), deep filtering and reconstruction as in forward_live."""
     ndim = wave.dim()
     assert ndim in (2, 3), "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
     if ndim == 3:
