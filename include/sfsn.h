@@ -288,14 +288,15 @@ int sfsn_spike_proj(const int8_t* s, const int8_t* w_packed, const float* w_dq, 
 #define SFSN_NORM_NONE 0
 #define SFSN_NORM_LAYERNORM 1 /* (x - mean) * rstd * ln_w + ln_b over the I features, eps inside the sqrt       */
 #define SFSN_NORM_LAPLACE 2   /* x / (mu[b] + 2.220446049250313e-16), mu from sfsn_laplace_means                 */
+#define SFSN_NORM_GAUSSIAN 4   /* (x - mu[b]) / (sd[b] + 2.220446049250313e-16), mu / sd from sfsn_gaussian_stats; sd is passed in ln_w */
 #define SFSN_NORM_CUMLAPLACE 3 /* sfsn_stream_hop only: x / (running mean of the row + eps), state carried per row -- the offline
                                   path runs sfsn_features with SFSN_NORM_NONE and then sfsn_cum_laplace_norm             */
 
 typedef struct sfsn_feature_group {
     float* x;           /* out [T][B*n_units][I]                                                             */
-    const float* ln_w;  /* [I] (LAYERNORM)                                                                    */
+    const float* ln_w;  /* [I] (LAYERNORM); GAUSSIAN: [B] the clips' standard deviations                      */
     const float* ln_b;  /* [I] (LAYERNORM)                                                                    */
-    const float* mu;    /* [B] (LAPLACE)                                                                      */
+    const float* mu;    /* [B] (LAPLACE, GAUSSIAN)                                                            */
     int lo, n_units, ctr, nbr, ctr_fb, nbr_fb;
     int norm;           /* SFSN_NORM_*                                                                        */
     float ln_eps;
@@ -313,8 +314,14 @@ int sfsn_features_z(const float* stft_ri, const float* fb_tbf, int B, int F, int
  * un-normalised group tensor).  mu_out [n_groups][B].  Two launches: row sums of mag / fb, then the
  * weighted combination; `scratch` needs B*(F-1+FB) floats. */
 int sfsn_laplace_means(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc,
-                       const sfsn_feature_group* groups /* host; only geometry fields are read */, int n_groups,
+                       const sfsn_feature_group* groups /* host, only geometry fields are read */, int n_groups,
                        float* mu_out, float* scratch, void* stream);
+/* Per-clip mean and UNBIASED standard deviation for offline_gaussian_norm (FROZEN:205-218: torch.mean / torch.std over all non-batch
+ * dims of the gathered, un-normalised group tensor).  mu_out, sd_out [n_groups][B].  `scratch`: 5 * B * (F - 1 + FB) + 2 floats,
+ * 8-byte aligned.  T >= 2. */
+int sfsn_gaussian_stats(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc,
+                        const sfsn_feature_group* groups /* host, only geometry fields are read */, int n_groups, float* mu_out,
+                        float* sd_out, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Deep-filter epilogue -- replaces the output re-index of SubBandSequenceModel.forward (MODEL:160-167,

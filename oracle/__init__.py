@@ -144,6 +144,14 @@ class Oracle:
         self._fn("laplace_norm", [_P, _I, _I, _I, _I, _P])(_ptr(x), T, B, BN // B, I, _ptr(mu))
         return x, mu
 
+    def gaussian_norm(self, x, B):
+        """x [T, B*N, I] -> (x - mean) / (std + eps) per clip (offline_gaussian_norm), mu [B]."""
+        x = self.arr(x).copy()
+        T, BN, I = x.shape
+        mu = np.empty((B,), self.dtype)
+        self._fn("gaussian_norm", [_P, _I, _I, _I, _I, _P, _P])(_ptr(x), T, B, BN // B, I, _ptr(mu), None)
+        return x, mu
+
     def cum_laplace_norm(self, x):
         """x [T, R, I] -> copy with every row divided by the running mean of what it has seen so far."""
         x = self.arr(x).copy()

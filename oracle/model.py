@@ -36,8 +36,8 @@ def spec_from_frozen_kwargs(kw: dict) -> dict:
     """Normalise ``Separator(**kw)`` (model_low_freq.py:486-509); interior cut points -> full cutoffs (:446-456)."""
     if kw["sequence_model"] != "GSU":
         raise NotImplementedError(f"Not implemented {kw['sequence_model']}")
-    if kw["norm_type"] not in ("offline_laplace_norm", "cumulative_laplace_norm"):
-        raise NotImplementedError("oracle restates offline_laplace_norm (the zoo checkpoints' setting) and cumulative_laplace_norm")
+    if kw["norm_type"] not in ("offline_laplace_norm", "cumulative_laplace_norm", "offline_gaussian_norm"):
+        raise NotImplementedError("oracle restates offline_laplace_norm (the zoo checkpoints' setting), offline_gaussian_norm and cumulative_laplace_norm")
     return dict(
         front="frozen", n_fft=kw["n_fft"], fdrc=kw["fdrc"], fb_in=kw["fb_freqs"], fb_hidden=kw["fb_hidden_size"],
         fb_layers=2, fb_proj=kw["fb_freqs"], sb_hidden=kw["sb_hidden_size"], sb_layers=2,
@@ -45,7 +45,8 @@ def spec_from_frozen_kwargs(kw: dict) -> dict:
         nbr=list(kw["sb_num_neighbor_freqs"]), ctr_fb=list(kw["fb_num_center_freqs"]),
         nbr_fb=list(kw["fb_num_neighbor_freqs"]), df=list(kw["sb_df_orders"]), num_spks=1,
         shared=kw.get("shared_weights", False), bn=kw.get("bn", False), ln_fb=False, ln_sb=False,
-        laplace=kw["norm_type"] == "offline_laplace_norm", cum_laplace=kw["norm_type"] == "cumulative_laplace_norm",
+        laplace=kw["norm_type"] == "offline_laplace_norm", gaussian=kw["norm_type"] == "offline_gaussian_norm",
+        cum_laplace=kw["norm_type"] == "cumulative_laplace_norm",
         proj_name="fc_output_layer",
     )
 
@@ -93,6 +94,8 @@ def forward_from_stft(spec: dict, sd: dict, stft, precision: str = "f32", want_m
     x_fb = o.gather_fullband(mag, spec["fb_in"])
     if spec["laplace"]:
         x_fb, res["mu_fb"] = o.laplace_norm(x_fb, B)
+    elif spec.get("gaussian"):
+        x_fb, res["mu_fb"] = o.gaussian_norm(x_fb, B)
     elif spec.get("cum_laplace"):
         x_fb = o.cum_laplace_norm(x_fb)
     fb_proj, fb_all, fb_mem = _sequence_model(o, x_fb, sd, "fb_model.", spec, spec["fb_layers"], spec["ln_fb"], want_membrane)
@@ -105,6 +108,8 @@ def forward_from_stft(spec: dict, sd: dict, stft, precision: str = "f32", want_m
         x = o.gather_group(mag, fb_proj, cut[g], cut[g + 1], spec["ctr"][g], spec["nbr"][g], spec["ctr_fb"][g], spec["nbr_fb"][g])
         if spec["laplace"]:
             x, _ = o.laplace_norm(x, B)
+        elif spec.get("gaussian"):
+            x, _ = o.gaussian_norm(x, B)
         elif spec.get("cum_laplace"):
             x = o.cum_laplace_norm(x)
         proj, outs, mems = _sequence_model(o, x, sd, f"sb_model.sb_models.{g}.", spec, spec["sb_layers"], spec["ln_sb"], want_membrane)

@@ -292,6 +292,34 @@ void ORA(laplace_norm)(real* x, int T, int B, int N, int I, real* mu_out) {
     }
 }
 
+/* offline_gaussian_norm (FROZEN:205-218): (x - mean) / (std + EPSILON) with torch.mean / torch.std (the UNBIASED estimate) over all
+ * non-batch dims, one pair per batch item; two passes in double.  Layout and in-place convention as laplace_norm; mu_out / sd_out
+ * [B] nullable. */
+void ORA(gaussian_norm)(real* x, int T, int B, int N, int I, real* mu_out, real* sd_out) {
+    for (int b = 0; b < B; ++b) {
+        double s = 0;
+        const double n = (double)T * N * I;
+        for (int t = 0; t < T; ++t) {
+            const real* p = x + ((size_t)t * B * N + (size_t)b * N) * I;
+            for (int i = 0; i < N * I; ++i) s += p[i];
+        }
+        const double m = s / n;
+        double q = 0;
+        for (int t = 0; t < T; ++t) {
+            const real* p = x + ((size_t)t * B * N + (size_t)b * N) * I;
+            for (int i = 0; i < N * I; ++i) q += ((double)p[i] - m) * ((double)p[i] - m);
+        }
+        const real mu = (real)m, sd = (real)sqrt(q / (n - 1.0));
+        const real den = sd + (real)2.220446049250313e-16;
+        if (mu_out) mu_out[b] = mu;
+        if (sd_out) sd_out[b] = sd;
+        for (int t = 0; t < T; ++t) {
+            real* p = x + ((size_t)t * B * N + (size_t)b * N) * I;
+            for (int i = 0; i < N * I; ++i) p[i] = (p[i] - mu) / den;
+        }
+    }
+}
+
 /* cumulative_laplace_norm (FROZEN:172-202; the form that accepts the 5-D sub-band tensor:
  * recipes/intel_ndns/spiking_fullsubnet_freeze_phase/model_low_freq_count_time.py:182-204 -- FROZEN's own
  * version unpacks four dimensions and raises on the sub-band input): every row (clip x unit) is divided, frame by

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
-NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE, NORM_CUMLAPLACE = 0, 1, 2, 3
+NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE, NORM_CUMLAPLACE, NORM_GAUSSIAN = 0, 1, 2, 3, 4
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
 ABI_VERSION = 14  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
@@ -191,6 +191,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_features_z.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _I, _I, _P, ctypes.c_size_t, _P]
     L.sfsn_laplace_means.restype = _I
     L.sfsn_laplace_means.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _P, _P, _P]
+    L.sfsn_gaussian_stats.restype = _I
+    L.sfsn_gaussian_stats.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _P, _P, _P, _P]
     L.sfsn_deepfilter.restype = _I
     L.sfsn_deepfilter.argtypes = [_P, _I, _I, _I, _I, ctypes.POINTER(DfGroup), _I, _P, _P, _I, _I, _P]
     L.sfsn_hist_shift.restype = _I
@@ -222,7 +224,7 @@ EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
            "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_stream_hop_resident", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft", "sfsn_gsn_train_step_fwd", "sfsn_gsn_train_step_bwd", "sfsn_train_scratch_bytes",
            "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16", "sfsn_gsn_train_check", "sfsn_gsn_stack_scan_x", "sfsn_train_seq_scratch_bytes", "sfsn_gsn_train_multi_check",
-           "sfsn_gsn_train_seq_fwd_multi", "sfsn_gsn_train_seq_bwd_multi", "sfsn_features_z")
+           "sfsn_gsn_train_seq_fwd_multi", "sfsn_gsn_train_seq_bwd_multi", "sfsn_features_z", "sfsn_gaussian_stats")
 
 
 def check(rc: int, what: str = "") -> None:

@@ -1206,6 +1206,9 @@ __device__ __forceinline__ void feat_chunk_rows(const FeatGroupDev& g, const flo
     }
     const float inv_I = 1.0f / (float)g.I;
     const float lap_den = NORM == SFSN_NORM_LAPLACE ? g.mu[b] + 2.220446049250313e-16f : 1.0f;
+    // offline_gaussian_norm (FROZEN:205-218): (x - mean) / (std + EPSILON), one (mean, unbiased std) per clip (g.mu, g.ln_w = std [B])
+    const float gau_mu = NORM == SFSN_NORM_GAUSSIAN ? g.mu[b] : 0.0f;
+    const float gau_den = NORM == SFSN_NORM_GAUSSIAN ? g.ln_w[b] + 2.220446049250313e-16f : 1.0f;
     const int seg = nk * g.I;
     for (int tt = wave; tt < FEAT_TT; tt += 4) {
         const int t = t0 + tt;
@@ -1237,6 +1240,9 @@ __device__ __forceinline__ void feat_chunk_rows(const FeatGroupDev& g, const flo
             } else if constexpr (NORM == SFSN_NORM_LAPLACE) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u) y[u] = v[u] / lap_den;
+            } else if constexpr (NORM == SFSN_NORM_GAUSSIAN) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) y[u] = (v[u] - gau_mu) / gau_den;
             } else {
 #pragma unroll
                 for (int u = 0; u < NU; ++u) y[u] = v[u];
@@ -1336,6 +1342,7 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
     do {                                                                                                                           \
         if (g.norm == SFSN_NORM_LAYERNORM) feat_chunk_rows<NU_, SFSN_NORM_LAYERNORM>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave); \
         else if (g.norm == SFSN_NORM_LAPLACE) feat_chunk_rows<NU_, SFSN_NORM_LAPLACE>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave); \
+        else if (g.norm == SFSN_NORM_GAUSSIAN) feat_chunk_rows<NU_, SFSN_NORM_GAUSSIAN>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave); \
         else feat_chunk_rows<NU_, SFSN_NORM_NONE>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave);               \
     } while (0)
             if (g.I <= 64) FEAT_ROWS(1);
@@ -1423,25 +1430,63 @@ __global__ __launch_bounds__(256) void spike_count_kernel(const CountParams p) {
 
 // ---- Laplace means -----------------------------------------------------------------------------------
 // rs[b][f] = sum_t mag[b][f][t] (f < nf), then rs[b][nf + f'] = sum_t fb[t][b][f'].  One wave per row.
+// (rs2 non-null: also the row sums of squares, as doubles -- offline_gaussian_norm's second moment)
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ stft, const float* __restrict__ fb,
-                                                      float* __restrict__ rs, int B, int F, int T, int FB, float fdrc) {
+                                                      float* __restrict__ rs, double* __restrict__ rs2, int B, int F, int T, int FB, float fdrc) {
     const int nf = F - 1, per_b = nf + FB;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (wid >= B * per_b) return;
     const int b = wid / per_b, f = wid - b * per_b;
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0;
     if (f < nf) {
         const float* src = stft + ((size_t)b * F + f) * T * 2;
         for (int t = lane; t < T; t += 64) {
             const float2 c = *reinterpret_cast<const float2*>(src + 2 * (size_t)t);
-            acc += (double)compress_mag(c.x, c.y, fdrc);
+            const double m = (double)compress_mag(c.x, c.y, fdrc);
+            acc += m;
+            acc2 += m * m;
         }
     } else if (fb) {
-        for (int t = lane; t < T; t += 64) acc += (double)fb[((size_t)t * B + b) * FB + (f - nf)];
+        for (int t = lane; t < T; t += 64) {
+            const double m = (double)fb[((size_t)t * B + b) * FB + (f - nf)];
+            acc += m;
+            acc2 += m * m;
+        }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) rs[wid] = (float)acc;
+    for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); acc2 += __shfl_xor(acc2, o); }
+    if (lane == 0) {
+        rs[wid] = (float)acc;
+        if (rs2) { rs2[wid] = acc2; reinterpret_cast<double*>(rs2 + (size_t)B * per_b)[wid] = acc; }  // (second half: the sums unrounded)
+    }
+}
+
+// offline_gaussian_norm's statistics per (group, clip) over the gathered index multiset: mean and UNBIASED standard deviation
+// (torch.std) from the sums and the sums of squares of the rows, combined in double.  One wave per (g, b).
+__global__ __launch_bounds__(64) void gaussian_stats_kernel(const double* __restrict__ rs2, const FeatParams p, float* __restrict__ mu,
+                                                             float* __restrict__ sd) {
+    const int gi = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const FeatGroupDev g = p.g[gi];
+    const int nf = p.F - 1, per_b = nf + p.FB;
+    const double* r2 = rs2 + (size_t)b * per_b;
+    const double* r1 = rs2 + (size_t)p.B * per_b + (size_t)b * per_b;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < g.N; ++k)
+        for (int j = lane; j < g.I; j += 64) {
+            const int idx = j < g.I1 ? reflect_bin(g.lo + k * g.ctr - g.nbr + j, nf)
+                                     : nf + (reflect_bin(g.lo + k * g.ctr_fb - g.nbr_fb + (j - g.I1), nf) % p.FB);
+            s1 += r1[idx];
+            s2 += r2[idx];
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) {
+        const double n = (double)p.T * g.N * g.I, m = s1 / n;
+        double var = (s2 - n * m * m) / (n - 1.0);
+        if (var < 0.0) var = 0.0;
+        mu[(size_t)gi * p.B + b] = (float)m;
+        sd[(size_t)gi * p.B + b] = (float)sqrt(var);
+    }
 }
 
 // mu[g][b] = (sum over the gathered index multiset of row sums) / (T * N * I).  One wave per (g, b).
@@ -2071,7 +2116,8 @@ static int fill_feat(FeatParams& p, const sfsn_feature_group* groups, int n_grou
         const int I1 = g.ctr + 2 * g.nbr, I2 = g.ctr_fb > 0 ? g.ctr_fb + 2 * g.nbr_fb : 0;
         if (I1 + I2 > 256) return SFSN_EUNSUPPORTED;
         if (g.lo + g.n_units * g.ctr > nf || g.nbr >= nf || (I2 && (FB <= 0 || g.nbr_fb >= nf))) return SFSN_EINVAL;
-        if (need_x && (!g.x || (g.norm == SFSN_NORM_LAYERNORM && (!g.ln_w || !g.ln_b)) || (g.norm == SFSN_NORM_LAPLACE && !g.mu)))
+        if (need_x && (!g.x || (g.norm == SFSN_NORM_LAYERNORM && (!g.ln_w || !g.ln_b)) || (g.norm == SFSN_NORM_LAPLACE && !g.mu) ||
+                       (g.norm == SFSN_NORM_GAUSSIAN && (!g.mu || !g.ln_w))))
             return SFSN_EINVAL;
         FeatGroupDev& d = p.g[i];
         d.x = g.x; d.ln_w = g.ln_w; d.ln_b = g.ln_b; d.mu = g.mu; d.lo = g.lo; d.N = g.n_units; d.ctr = g.ctr; d.nbr = g.nbr;
@@ -2134,8 +2180,26 @@ extern "C" int sfsn_laplace_means(const float* stft_ri, const float* fb_tbf, int
     if (rc != SFSN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int rows = B * (F - 1 + FB);
-    hipLaunchKernelGGL(rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, stft_ri, fb_tbf, scratch, B, F, T, FB, fdrc);
+    hipLaunchKernelGGL(rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, stft_ri, fb_tbf, scratch, static_cast<double*>(nullptr), B, F, T, FB, fdrc);
     hipLaunchKernelGGL(laplace_mu_kernel, dim3(n_groups, B), dim3(64), 0, st, scratch, p, mu_out);
+    return hip_ok(hipGetLastError());
+}
+
+// Per-clip mean and unbiased standard deviation for offline_gaussian_norm (FROZEN:205-218) of the gathered, un-normalised group
+// tensor: mu_out, sd_out [n_groups][B].  `scratch`: 5 * B * (F - 1 + FB) floats (row sums as floats, then sums of squares and
+// sums as doubles), 8-byte aligned.
+extern "C" int sfsn_gaussian_stats(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc,
+                                   const sfsn_feature_group* groups, int n_groups, float* mu_out, float* sd_out, float* scratch, void* stream) {
+    if (!stft_ri || !mu_out || !sd_out || !scratch || (reinterpret_cast<uintptr_t>(scratch) & 7u)) return SFSN_EINVAL;
+    if (T < 2) return SFSN_EINVAL;  // (the unbiased estimate needs two values; every group tensor of a clip has >= T of them)
+    FeatParams p;
+    int rc = fill_feat(p, groups, n_groups, B, F, T, FB, fdrc, false);
+    if (rc != SFSN_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rows = B * (F - 1 + FB);
+    double* rs2 = reinterpret_cast<double*>(scratch + (size_t)((rows + 1) & ~1));
+    hipLaunchKernelGGL(rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, stft_ri, fb_tbf, scratch, rs2, B, F, T, FB, fdrc);
+    hipLaunchKernelGGL(gaussian_stats_kernel, dim3(n_groups, B), dim3(64), 0, st, rs2, p, mu_out, sd_out);
     return hip_ok(hipGetLastError());
 }
 

@@ -45,7 +45,8 @@ class PathSpec:
     bn: bool = False
     ln_fb: bool = True
     ln_sb: bool = True
-    laplace: bool = False
+    laplace: bool = False         # frozen front-end with an utterance-level (offline, non-causal) norm: offline_laplace_norm, or ...
+    gaussian: bool = False        # ... offline_gaussian_norm (set together with `laplace`: same schedule, other statistics)
     cum_laplace: bool = False     # frozen front-end with cumulative_laplace_norm (causal: every row by its own running mean)
     proj_name: str = "proj"
 
@@ -637,13 +638,15 @@ class Engine:
             mem=[[torch.empty((T, R, H), **f32) if want_membrane else None for R in Rs] for _ in range(nl)],
             proj=[torch.empty((T, R, seq.P), **f32) for seq, R in zip(seqs, Rs)])
 
-    def _feature_groups(self, which: str, xs, mu):
+    def _feature_groups(self, which: str, xs, mu, sd=None):
         spec = self.spec
         if which == "fb":
             g = FeatureGroup()
             g.x, g.lo, g.n_units, g.ctr, g.nbr, g.ctr_fb, g.nbr_fb = _ptr(xs[0]), 0, 1, spec.fb_in, 0, 0, 0
             g.ln_eps = 1e-5
-            if spec.laplace:
+            if spec.laplace and spec.gaussian:
+                g.norm, g.mu, g.ln_w = _lib.NORM_GAUSSIAN, _ptr(mu), _ptr(sd)  # (the clips' standard deviations travel in ln_w)
+            elif spec.laplace:
                 g.norm, g.mu = _lib.NORM_LAPLACE, _ptr(mu)
             elif spec.ln_fb:
                 g.norm, g.ln_w, g.ln_b = _lib.NORM_LAYERNORM, _ptr(self.fb.ln_w), _ptr(self.fb.ln_b)
@@ -659,8 +662,10 @@ class Engine:
             g.lo, g.n_units, g.ctr, g.nbr = spec.cutoffs[i], spec.units(i), spec.ctr[i], spec.nbr[i]
             g.ctr_fb, g.nbr_fb, g.ln_eps = spec.ctr_fb[i], spec.nbr_fb[i], 1e-5
             if spec.laplace:
-                g.norm = _lib.NORM_LAPLACE
+                g.norm = _lib.NORM_GAUSSIAN if spec.gaussian else _lib.NORM_LAPLACE
                 g.mu = ctypes.c_void_p(mu.data_ptr() + i * mu.shape[1] * 4) if mu is not None else None
+                if spec.gaussian:
+                    g.ln_w = ctypes.c_void_p(sd.data_ptr() + i * sd.shape[1] * 4) if sd is not None else None
             elif spec.ln_sb:
                 g.norm, g.ln_w, g.ln_b = _lib.NORM_LAYERNORM, _ptr(self.sb[i].ln_w), _ptr(self.sb[i].ln_b)
             else:
@@ -851,12 +856,14 @@ class Engine:
         dfg = (DfGroup * ng)()
         for g in range(ng):
             dfg[g].proj, dfg[g].n_units, dfg[g].fc, dfg[g].df = _ptr(sb["proj"][g]), spec.units(g), spec.ctr[g], spec.df[g]
-        mu_fb = mu_sb = scratch = None
+        mu_fb = mu_sb = sd_fb = sd_sb = scratch = None
         if spec.laplace:
             mu_fb, mu_sb = torch.empty((1, B), **f32), torch.empty((ng, B), **f32)
-            scratch = torch.empty((B * (F - 1 + spec.fb_proj),), **f32)
-        fg_fb = self._feature_groups("fb", [x_fb], mu_fb)
-        fg_sb = self._feature_groups("sb", xs, mu_sb)
+            if spec.gaussian:
+                sd_fb, sd_sb = torch.empty((1, B), **f32), torch.empty((ng, B), **f32)
+            scratch = torch.empty(((5 if spec.gaussian else 1) * B * (F - 1 + spec.fb_proj) + 2,), **f32)
+        fg_fb = self._feature_groups("fb", [x_fb], mu_fb, sd_fb)
+        fg_sb = self._feature_groups("sb", xs, mu_sb, sd_sb)
         fb_proj = fb["proj"][0]
 
         # ---------------- streams: sequential = the current stream; pipelined = per stage one scan stream (own CUs) and one
@@ -1021,15 +1028,22 @@ class Engine:
             with self.timed("deepfilter", st):
                 check(L.sfsn_deepfilter(_ptr(ri), B, F, T, S, dfg, ng, _ptr(enh_ri), _ptr(enh_mag), t0, nt, st), "sfsn_deepfilter")
 
-        if spec.laplace:
+        if spec.laplace and spec.gaussian:
+            check(L.sfsn_gaussian_stats(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, _ptr(mu_fb), _ptr(sd_fb), _ptr(scratch), hG[0]),
+                  "sfsn_gaussian_stats(fb)")
+        elif spec.laplace:
             check(L.sfsn_laplace_means(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, _ptr(mu_fb), _ptr(scratch), hG[0]), "sfsn_laplace_means(fb)")
         fb_done = run_model([self.fb], fb, [x_fb], 0, feat_fb, "fb", rpw_fb, None, None)
         if spec.laplace:
             # the utterance-level Laplace mean of the sub-band input needs the whole full-band output: no chunk overlap fb -> sb
             if pipeline:
                 gstreams[nl_fb].wait_event(fb_done[-1])
-            check(L.sfsn_laplace_means(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, fg_sb, ng, _ptr(mu_sb), _ptr(scratch),
-                                       hG[nl_fb]), "sfsn_laplace_means(sb)")
+            if spec.gaussian:
+                check(L.sfsn_gaussian_stats(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, fg_sb, ng, _ptr(mu_sb), _ptr(sd_sb),
+                                            _ptr(scratch), hG[nl_fb]), "sfsn_gaussian_stats(sb)")
+            else:
+                check(L.sfsn_laplace_means(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, fg_sb, ng, _ptr(mu_sb), _ptr(scratch),
+                                           hG[nl_fb]), "sfsn_laplace_means(sb)")
             sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, None)
         elif pipeline and self.pipeline_two_phase:
             # full-band model first (its two layers overlapped), then the sub-band models (their two layers overlapped)

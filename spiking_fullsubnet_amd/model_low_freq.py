@@ -6,7 +6,8 @@ Same constructor keywords (:486-509), same state-dict names (``fc_output_layer``
 ``pre_layer_norm``; the zoo checkpoints load with ``strict=True``), same ``forward`` return tuple (:618).
 A frozen-recipe TOML switches over with ``[model_g] path = "spiking_fullsubnet_amd.model_low_freq.Separator"``.
 
-Input normalisation: the utterance-level ``offline_laplace_norm`` (:147-169, the setting of all zoo checkpoints) or the causal
+Input normalisation: the utterance-level ``offline_laplace_norm`` (:147-169, the setting of all zoo checkpoints) or
+``offline_gaussian_norm`` (:205-218: (x - mean) / (std + eps) per clip, no recipe uses it), or the causal
 ``cumulative_laplace_norm`` of ``baseline_m_cumulative_laplace_norm.toml`` -- in the reference that one raises on the 5-D sub-band
 tensor (:172-202 unpacks four dimensions); it is built here in the form of ``model_low_freq_count_time.py:182-204`` (every row by its
 own running mean), which also makes this front-end streamable (``streaming()``).
@@ -68,10 +69,9 @@ class Separator(_EngineMixin, nn.Module):
                  sb_num_neighbor_freqs, fb_num_center_freqs, fb_num_neighbor_freqs, fb_hidden_size, sb_hidden_size, sb_df_orders,
                  sequence_model, fb_output_activate_function, sb_output_activate_function, norm_type, shared_weights=False, bn=False):
         super().__init__()
-        if norm_type not in ("offline_laplace_norm", "cumulative_laplace_norm"):
-            # (the reference: model_low_freq.py:216-231 norm_wrapper; offline_gaussian_norm is used by no recipe)
-            raise NotImplementedError(f"norm_type={norm_type!r}: offline_laplace_norm (all zoo checkpoints) and cumulative_laplace_norm "
-                                      "(recipes/.../baseline_m_cumulative_laplace_norm.toml) are built")
+        if norm_type not in ("offline_laplace_norm", "cumulative_laplace_norm", "offline_gaussian_norm"):
+            # (the reference: model_low_freq.py:216-231 norm_wrapper raises NotImplementedError for anything else, with this message)
+            raise NotImplementedError("You must set up a type of Norm. e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")
         self.n_fft, self.hop_length, self.win_length, self.fdrc = n_fft, hop_length, win_length, fdrc
         self.freq_cutoffs, self.sb_df_orders = freq_cutoffs, sb_df_orders
         self.num_repeats, self.fb_freqs = num_freqs // fb_freqs, fb_freqs
@@ -91,7 +91,8 @@ class Separator(_EngineMixin, nn.Module):
             sb_hidden=sb_hidden_size, sb_layers=2, cutoffs=[0] + list(freq_cutoffs) + [num_freqs], ctr=list(sb_num_center_freqs),
             nbr=list(sb_num_neighbor_freqs), ctr_fb=list(fb_num_center_freqs), nbr_fb=list(fb_num_neighbor_freqs),
             df=list(sb_df_orders), num_spks=1, shared=shared_weights, bn=bn, ln_fb=False, ln_sb=False,
-            laplace=norm_type == "offline_laplace_norm", cum_laplace=norm_type == "cumulative_laplace_norm", proj_name="fc_output_layer")
+            laplace=norm_type in ("offline_laplace_norm", "offline_gaussian_norm"), gaussian=norm_type == "offline_gaussian_norm",
+            cum_laplace=norm_type == "cumulative_laplace_norm", proj_name="fc_output_layer")
 
     def _spec(self) -> PathSpec:
         return self._path_spec

@@ -639,7 +639,10 @@ def forward_frozen(model, wave: torch.Tensor):
     training = model.training
 
     def laplace(x):  # one scalar per batch item over everything else (non-causal)
-        mu = x.mean(dim=tuple(range(1, x.dim())), keepdim=True)
+        dims = tuple(range(1, x.dim()))
+        mu = x.mean(dim=dims, keepdim=True)
+        if spec.gaussian:  # offline_gaussian_norm (:205-218): torch.std = the unbiased estimate
+            return (x - mu) / (x.std(dim=dims, keepdim=True) + _LAPLACE_EPS)
         return x / (mu + _LAPLACE_EPS)
     fb_in = model.fb_freqs
     fb_out, fb_all = _frozen_sequence_model(model.fb_model, laplace(mag[:, :fb_in]), training)   # [B, P, T]

@@ -419,6 +419,9 @@ def main():
         finally:
             builtins.print = _print
         print("frozen_tiny_cum.npz frozen_m_cum.npz")
+    if not only or "frozen_gauss" in only:
+        # offline_gaussian_norm (model_low_freq.py:205-218: (x - mean) / (std + eps) per clip, torch.std = unbiased): no recipe uses it
+        frozen_case("frozen_tiny_gauss.npz", dict(rw.FROZEN_TINY, norm_type="offline_gaussian_norm"), rw.frozen_state_dict(rw.FROZEN_TINY, 37), 3, 40, True, False)
     if not only or "frozen_l" in only:
         # baseline_l sizes: four sub-band groups (16 + 24 + 2 + 1 units), sub-band hidden size 256
         frozen_case("frozen_l.npz", rw.FROZEN_L, rw.frozen_state_dict(rw.FROZEN_L, 33), 1, 24, False, False)

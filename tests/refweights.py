@@ -102,6 +102,7 @@ FROZEN_L = dict(FROZEN_S, fb_hidden_size=320, sb_hidden_size=256, freq_cutoffs=[
 FROZEN_XL = dict(FROZEN_M, shared_weights=False)  # .../spiking_fullsubnet_freeze_phase/baseline_xl.toml: separate gate weights
 
 FROZEN_TINY = dict(FROZEN_S, fb_hidden_size=48, sb_hidden_size=32, sb_df_orders=[2, 1, 3])
+FROZEN_TINY_GAUSS = dict(FROZEN_TINY, norm_type="offline_gaussian_norm")  # model_low_freq.py:205-218 (no recipe uses it)
 FROZEN_TINY_CUM = dict(FROZEN_TINY, norm_type="cumulative_laplace_norm")  # recipes/.../baseline_m_cumulative_laplace_norm.toml's norm
 
 

@@ -362,7 +362,7 @@ MODEL_CASES = [
     ("live_tiny_unshared.npz", "live", rw.LIVE_TINY_UNSHARED, 13), ("live_m.npz", "live", rw.LIVE_M, 21),
     ("frozen_tiny.npz", "frozen", rw.FROZEN_TINY, 31), ("frozen_s_zoo.npz", "frozen", rw.FROZEN_S, None),
     ("frozen_m_zoo.npz", "frozen", rw.FROZEN_M, None), ("frozen_l.npz", "frozen", rw.FROZEN_L, 33),
-    ("frozen_tiny_cum.npz", "frozen", rw.FROZEN_TINY_CUM, 35), ("frozen_m_cum.npz", "frozen", rw.FROZEN_M_CUM, 36),
+    ("frozen_tiny_gauss.npz", "frozen", rw.FROZEN_TINY_GAUSS, 37), ("frozen_tiny_cum.npz", "frozen", rw.FROZEN_TINY_CUM, 35), ("frozen_m_cum.npz", "frozen", rw.FROZEN_M_CUM, 36),
     ("frozen_xl.npz", "frozen", rw.FROZEN_XL, 34),
     # round 3: BASELINE configs[0] as written (trained baseline_s, ONE 4 s clip = 501 frames; weights: frozen_s_zoo.npz) and the
     # bench's sizes on two clips x 200 frames of amplitude-modulated noise (SURVEY 8d's second input distribution)

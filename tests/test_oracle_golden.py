@@ -71,7 +71,7 @@ CASES = [
     ("frozen_tiny.npz", "frozen", rw.FROZEN_TINY, 31),
     ("frozen_s_zoo.npz", "frozen", rw.FROZEN_S, None), ("frozen_m_zoo.npz", "frozen", rw.FROZEN_M, None),
     ("frozen_l.npz", "frozen", rw.FROZEN_L, 33), ("frozen_xl.npz", "frozen", rw.FROZEN_XL, 34),
-    ("frozen_tiny_cum.npz", "frozen", rw.FROZEN_TINY_CUM, 35), ("frozen_m_cum.npz", "frozen", rw.FROZEN_M_CUM, 36),
+    ("frozen_tiny_gauss.npz", "frozen", rw.FROZEN_TINY_GAUSS, 37), ("frozen_tiny_cum.npz", "frozen", rw.FROZEN_TINY_CUM, 35), ("frozen_m_cum.npz", "frozen", rw.FROZEN_M_CUM, 36),
     # round 3: BASELINE configs[0] as written (trained baseline_s, ONE 4 s clip = 501 frames; weights: frozen_s_zoo.npz) and the
     # bench's sizes on two clips x 200 frames of amplitude-modulated noise (SURVEY 8d's second input distribution)
     ("frozen_s_zoo_4s.npz", "frozen", rw.FROZEN_S, "frozen_s_zoo.npz"), ("live_m_am.npz", "live", rw.LIVE_M, 21),

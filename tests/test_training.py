@@ -213,6 +213,30 @@ def test_frozen_separator_training_step_matches_the_reference():
     assert y[0].shape == outs[0].shape and torch.isfinite(y[0]).all()
 
 
+def test_gaussian_norm_on_the_differentiable_path_equals_the_kernel_path():
+    """offline_gaussian_norm (model_low_freq.py:205-218) has two implementations: statistics + feature kernels for inference
+    (pinned on the reference-made fixture frozen_tiny_gauss.npz in test_hip_parity) and ATen ops on the differentiable path.  Same
+    module, eval mode, both ways: the normalised inputs of every sequence model agree to float rounding; a training step runs."""
+    import spiking_fullsubnet_amd as pkg
+    kw = rw.FROZEN_TINY_GAUSS
+    m = pkg.Separator(**kw)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rw.frozen_state_dict(rw.FROZEN_TINY, 37).items()}, strict=True)
+    m = m.to(DEV).eval()
+    wave = _t(rw.synth_wave(3, 30, 4))
+    with torch.no_grad():
+        a = m(wave)
+    m.autograd_in_eval = True
+    b = m(wave.clone().requires_grad_(True))
+    _close(b[2][0].detach().cpu().numpy(), a[2][0].cpu().numpy(), "full-band input", rtol=1e-5, atol_frac=1e-6)
+    _close(b[3][0][0].detach().cpu().numpy(), a[3][0][0].cpu().numpy(), "sub-band input of group 0", rtol=2e-5, atol_frac=2e-6)
+    m.train()
+    outs = m(wave)
+    (outs[0].pow(2).mean() + outs[1].mean()).backward()
+    from spiking_fullsubnet_amd import training
+    training.check_pending()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
 def test_training_layer_call_checks_before_it_launches():
     """Round-3 advisor findings: (a) both step kernels' geometry is validated before the first forward launch (the backward step
     needs more LDS than the forward one: R = 2048 at H = 224 used to pass forward and fail in backward()); (b) BatchNorm running
