@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 14 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 15 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -445,6 +445,8 @@ typedef struct sfsn_hop_desc {
                                       stream synchronisation (the caller spins on the words)                               */
     int frames_before;             /* frames this state has seen since it was zeroed (the caller adds `hop` after every launch):
                                       SFSN_NORM_CUMLAPLACE's denominator                                             */
+    int unshared;                  /* non-zero: separate forget / cell gate weights (shared_weights = False, NEURON:137-139): every
+                                      layer's w_hh / w_ih images and dq vectors cover 2H rows, forget rows first (ABI 15)      */
 } sfsn_hop_desc;
 
 size_t sfsn_hop_scratch_bytes(const sfsn_hop_desc* desc /* host */);

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
 NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE, NORM_CUMLAPLACE, NORM_GAUSSIAN = 0, 1, 2, 3, 4
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
-ABI_VERSION = 14  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
+ABI_VERSION = 15  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -80,7 +80,7 @@ class HopDesc(ctypes.Structure):
     _fields_ = [("fb", HopSeq), ("sb", HopSeq * HOP_MAX_GROUPS), ("n_groups", _I), ("B", _I), ("F", _I), ("S", _I), ("hop", _I),
                 ("D", _I), ("fdrc", _F), ("inp_ri", _P), ("hist_ri", _P), ("enh_ri", _P), ("enh_mag", _P),
                 ("scratch", _P), ("scratch_bytes", ctypes.c_size_t), ("launch_index", ctypes.c_uint), ("wave_in", _P), ("wave_state", _P),
-                ("ola_state", _P), ("wave_out", _P), ("window", _P), ("spec_g", _P), ("enh_g", _P), ("frame_index", _I), ("done", _P), ("frames_before", _I)]
+                ("ola_state", _P), ("wave_out", _P), ("window", _P), ("spec_g", _P), ("enh_g", _P), ("frame_index", _I), ("done", _P), ("frames_before", _I), ("unshared", _I)]
 
 
 def _sources():

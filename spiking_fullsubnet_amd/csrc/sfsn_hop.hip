@@ -88,6 +88,7 @@ struct HopParams {
     unsigned stage_of_block[HOP_MAX_BLOCKS / 4];  // one byte per workgroup: a single scalar load finds the role
     int nseq, nstage, nblocks;
     int B, F, S, hop, D, FB, fcov;
+    int G;  // 1: the forget and the cell gate share their weights (one product serves both); 2: separate weights, 2H rows per image
     float fdrc;
     unsigned launch;  // launches made on this state since it was zeroed: tag and state parity
     int frames_before;  // frames the state has seen since it was zeroed (SFSN_NORM_CUMLAPLACE's denominator)
@@ -215,7 +216,12 @@ __device__ __forceinline__ float2 hop_in_bin(const HopParams& p, int b, int f, i
 //      [fbw: the full-band projection's weight fragments, 3 x PT x KS KB (gated layer 0 only)].
 // ---------------------------------------------------------------------------------------------------------------------
 // ONE: hop == 1 (the configuration that matters): no frame loop, so nothing stays live across it.
-template <bool L0, bool ONE>
+// G = 2 (separate forget / cell gate weights, baseline_xl): a wave takes the two gates of its tile ONE AFTER THE OTHER through the same
+// weight registers -- both gates' fragments at once would be 240 registers of weights beside everything else.  The second gate's
+// recurrent weights are requested when the first gate's matrix instructions have been issued, its input weights when the
+// recurrent half is done: both arrive while the wave waits for the stage upstream.  Same products, same two roundings per gate and
+// the same cell as scan_body's G = 2 epilogue: bit-identical to the offline kernels.
+template <bool L0, bool ONE, int G>
 __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStep& hs, const HopStageDev& sd, const HopSeqDev& sq, char* smem) {
     const int l = sd.layer;
     const HopLayerDev& L = sq.layer[l];
@@ -275,7 +281,7 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStep
 #pragma unroll
         for (int ks = 0; ks < HOP_KS_MAX; ++ks) {
             Whh[d][ks] = v4i{0, 0, 0, 0};
-            if (ks < KS) Whh[d][ks] = *reinterpret_cast<const v4i*>(L.w_hh + ((((size_t)d * NT + tile) * KS + ks) * 64 + lane) * 16);
+            if (ks < KS) Whh[d][ks] = *reinterpret_cast<const v4i*>(L.w_hh + ((((size_t)d * (G * NT) + tile) * KS + ks) * 64 + lane) * 16);
         }
     v4f c = *reinterpret_cast<const v4f*>(L.c + (size_t)rowc * H + cc);
     const v4f dq = *reinterpret_cast<const v4f*>(L.w_hh_dq + cc);
@@ -294,7 +300,7 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStep
 #pragma unroll
         for (int ks = 0; ks < HOP_KS_MAX; ++ks) {
             Wih[d][ks] = v4i{0, 0, 0, 0};
-            if (!L0 && ks < KS) Wih[d][ks] = *reinterpret_cast<const v4i*>(L.w_ih + ((((size_t)d * NT + tile) * KS + ks) * 64 + lane) * 16);
+            if (!L0 && ks < KS) Wih[d][ks] = *reinterpret_cast<const v4i*>(L.w_ih + ((((size_t)d * (G * NT) + tile) * KS + ks) * 64 + lane) * 16);
         }
     if (L0 && fbp) {
         fdq = *reinterpret_cast<const v4f*>(fbq.w_p_dq + fcol);
@@ -312,6 +318,11 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStep
     v4f db;
 #pragma unroll
     for (int r = 0; r < 4; ++r) db[r] = bg[r] - bf[r];
+    v4f dqg = {0.0f, 0.0f, 0.0f, 0.0f}, dqig = {0.0f, 0.0f, 0.0f, 0.0f};  // G = 2: the cell gate's dequantisation scales
+    if constexpr (G == 2) {
+        dqg = *reinterpret_cast<const v4f*>(L.w_hh_dq + H + cc);
+        if (!L0) dqig = *reinterpret_cast<const v4f*>(L.w_ih_dq + H + cc);
+    }
     float lw[HOP_NU_MAX], lb[HOP_NU_MAX];
 #pragma unroll
     for (int u = 0; u < HOP_NU_MAX; ++u) {
@@ -339,6 +350,7 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStep
     for (int t = 0; t < hop; ++t) {
         // ---- recurrent half: needs frame t-1 of my own layer only
         v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+        v4i g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0}, g2 = {0, 0, 0, 0};  // G = 2: the cell gate's recurrent sums
         {
             v4i b[HOP_KS_MAX];
             if (t == 0) {
@@ -354,10 +366,31 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStep
                     a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[1][ks], b[ks], a1, 0, 0, 0);
                     a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[2][ks], b[ks], a2, 0, 0, 0);
                 }
+            if constexpr (G == 2) {  // the cell gate's recurrent product through the same registers (tile NT + tile of the image)
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int ks = 0; ks < HOP_KS_MAX; ++ks)
+                        if (ks < KS) Whh[d][ks] = *reinterpret_cast<const v4i*>(L.w_hh + ((((size_t)d * (G * NT) + NT + tile) * KS + ks) * 64 + lane) * 16);
+#pragma unroll
+                for (int ks = 0; ks < HOP_KS_MAX; ++ks)
+                    if (ks < KS) {
+                        g0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[0][ks], b[ks], g0, 0, 0, 0);
+                        g1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[1][ks], b[ks], g1, 0, 0, 0);
+                        g2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[2][ks], b[ks], g2, 0, 0, 0);
+                    }
+                if (!ONE) {  // (more frames follow in this launch: the forget gate's weights back for the next one)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+#pragma unroll
+                        for (int ks = 0; ks < HOP_KS_MAX; ++ks)
+                            if (ks < KS) Whh[d][ks] = *reinterpret_cast<const v4i*>(L.w_hh + ((((size_t)d * (G * NT) + tile) * KS + ks) * 64 + lane) * 16);
+                }
+            }
         }
         if (t == 0) HOP_STAMP(2);
         // ---- input half
-        v4f z;
+        v4f z, zg = {0.0f, 0.0f, 0.0f, 0.0f};
         if constexpr (L0) {
             // features of my rows (wave w: rows w and w + 8): the magnitude part needs the new frame only -- requested before
             // the wait for the full-band model
@@ -479,6 +512,20 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStep
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + bf[r];
+            if constexpr (G == 2) {  // the cell gate's rows of W_ih (fragment tile NT + tile), same operand, same association
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int cch = 0; cch < HOP_KC_MAX; ++cch)
+                    if (cch < KC) {
+                        const v4f wg = *reinterpret_cast<const v4f*>(L.w_ih_f32 + ((((size_t)(NT + tile) * KC + cch) * 64 + lane) * 4));
+                        const v4f bx = *reinterpret_cast<const v4f*>(xrow + xr * KPX + cch * 16 + q * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[cch & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg[e], bx[e], acc[cch & 3], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zg[r] = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + bg[r];
+            }
         } else {
             v4i b[HOP_KS_MAX];
             ok = hop_gather(sq.layer[l - 1].spikes + (size_t)t * R * HP, rt, R, KS, H, tagw, hbB, b, ok, p.cnt, wave, lane);
@@ -493,13 +540,28 @@ __device__ __forceinline__ void hop_layer_role(const HopParams& p, const HopStep
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] = recombine3(i0[r], i1[r], i2[r]) * dqi[r] + bf[r];  // sfsn_spike_proj's epilogue
+            if constexpr (G == 2) {
+                v4i j0 = {0, 0, 0, 0}, j1 = {0, 0, 0, 0}, j2 = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < HOP_KS_MAX; ++ks)
+                    if (ks < KS) {
+                        const v4i w0 = *reinterpret_cast<const v4i*>(L.w_ih + ((((size_t)0 * (G * NT) + NT + tile) * KS + ks) * 64 + lane) * 16);
+                        const v4i w1 = *reinterpret_cast<const v4i*>(L.w_ih + ((((size_t)1 * (G * NT) + NT + tile) * KS + ks) * 64 + lane) * 16);
+                        const v4i w2 = *reinterpret_cast<const v4i*>(L.w_ih + ((((size_t)2 * (G * NT) + NT + tile) * KS + ks) * 64 + lane) * 16);
+                        j0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, b[ks], j0, 0, 0, 0);
+                        j1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, b[ks], j1, 0, 0, 0);
+                        j2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, b[ks], j2, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zg[r] = recombine3(j0[r], j1[r], j2[r]) * dqig[r] + bg[r];
+            }
         }
-        // ---- cell (scan_body's epilogue, shared gates)
+        // ---- cell (scan_body's epilogue; G = 2: the cell gate has its own products)
         pk = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float pre_f = __builtin_fmaf(recombine3(a0[r], a1[r], a2[r]), dq[r], z[r]);
-            const float pre_g = pre_f + db[r];
+            const float pre_g = G == 2 ? __builtin_fmaf(recombine3(g0[r], g1[r], g2[r]), dqg[r], zg[r]) : pre_f + db[r];
             const float f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre_f * -1.44269504088896341f));
             const float m = __builtin_fmaf(f, c[r] - pre_g, pre_g);
             const float y = __builtin_fmaf(m, alpha[r], beta[r]);
@@ -826,12 +888,12 @@ __device__ __forceinline__ void hop_istft_role(const HopParams& p, const HopStep
 }
 
 // one hop of one workgroup: the role its block index selects
-template <bool ONE>
+template <bool ONE, int G>
 __device__ __forceinline__ void hop_dispatch(const HopParams& p, const HopStep& hs, char* smem) {
     if ((int)blockIdx.x < p.st[0].nwg) {
         // layer 0 of the full-band model is the head of the frame's critical path: its descriptors sit at fixed kernarg
         // offsets, so every scalar load is issued at once instead of table -> stage -> sequence
-        hop_layer_role<true, ONE>(p, hs, p.st[0], p.seq[0], smem);
+        hop_layer_role<true, ONE, G>(p, hs, p.st[0], p.seq[0], smem);
         return;
     }
     const int si = (int)((p.stage_of_block[blockIdx.x >> 2] >> (8 * (blockIdx.x & 3))) & 0xffu);
@@ -839,9 +901,9 @@ __device__ __forceinline__ void hop_dispatch(const HopParams& p, const HopStep& 
     const HopSeqDev& sq = p.seq[sd.seq];
     if (sd.layer >= 0) {
         if (sd.layer == 0)
-            hop_layer_role<true, ONE>(p, hs, sd, sq, smem);
+            hop_layer_role<true, ONE, G>(p, hs, sd, sq, smem);
         else
-            hop_layer_role<false, ONE>(p, hs, sd, sq, smem);
+            hop_layer_role<false, ONE, G>(p, hs, sd, sq, smem);
     } else if (sd.layer == -1) {
         hop_proj_role<ONE>(p, hs, sd, sq, smem);
     } else if (ONE && sd.layer == -2) {
@@ -851,14 +913,16 @@ __device__ __forceinline__ void hop_dispatch(const HopParams& p, const HopStep& 
     }
 }
 
-template <bool ONE>
+// (G = 2, separate gate weights, is a kernel of its own: the shared-weights kernels keep their register allocation -- 252 registers,
+//  no spills for the one-frame hop)
+template <bool ONE, int G>
 __global__ __launch_bounds__(HOP_THREADS) void stream_hop_kernel(const HopParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     HOP_STAMP(0);
     HopStep hs;
     hs.launch = p.launch; hs.frame_index = p.frame_index; hs.frames_before = p.frames_before;
-    hop_dispatch<ONE>(p, hs, smem);
+    hop_dispatch<ONE, G>(p, hs, smem);
     HOP_STAMP(7);
 }
 
@@ -870,6 +934,7 @@ __global__ __launch_bounds__(HOP_THREADS) void stream_hop_kernel(const HopParams
 // its memory, and only then may it ring the next hop (every consumer of hop k has read its inputs by then: the last stage
 // depends on all of them).  Bounded: a doorbell that stays silent for `idle_polls` polls ends the kernel (it must never outlive
 // its host thread), as does a hand-off wait that expires inside a hop.  Waveform mode, one-frame hops.
+template <int G>
 __global__ __launch_bounds__(HOP_THREADS) void stream_hop_resident_kernel(const HopParams p, unsigned* doorbell, unsigned idle_ticks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* fin = p.cnt + 2;  // workgroups that have finished (and released) a hop, counted up over the hops
@@ -909,7 +974,7 @@ __global__ __launch_bounds__(HOP_THREADS) void stream_hop_resident_kernel(const 
 #endif
         HopStep hs;
         hs.launch = p.launch + k; hs.frame_index = p.frame_index + (int)k; hs.frames_before = p.frames_before + (int)k * p.hop;
-        hop_dispatch<true>(p, hs, smem);
+        hop_dispatch<true, G>(p, hs, smem);
 #ifdef SFSN_HOP_STAMPS
         HOP_STAMP(7);
 #endif
@@ -973,6 +1038,7 @@ static int hop_plan(HopParams& p, size_t& lds, const sfsn_hop_desc* d) {
     }
     memset(&p, 0, sizeof(p));
     p.B = d->B; p.F = d->F; p.S = d->S; p.hop = d->hop; p.D = d->D; p.FB = d->fb.P; p.fdrc = d->fdrc;
+    p.G = d->unshared ? 2 : 1;
     p.inp = d->inp_ri; p.hist = d->hist_ri; p.enh = d->enh_ri; p.mag = d->enh_mag;
     if (wave) {
         p.wave_in = d->wave_in; p.wave_state = d->wave_state; p.ola_state = d->ola_state; p.wave_out = d->wave_out;
@@ -1094,16 +1160,20 @@ extern "C" int sfsn_stream_hop(const sfsn_hop_desc* desc, void* stream) {
     if (hipGetDevice(&dev) != hipSuccess) return SFSN_EHIP;
     static int lds_set[2][64];
     const int one = local.hop == 1 ? 1 : 0;
-    const void* kern = one ? reinterpret_cast<const void*>(stream_hop_kernel<true>) : reinterpret_cast<const void*>(stream_hop_kernel<false>);
+    const bool g2 = local.G == 2;
+    const void* kern = one ? (g2 ? reinterpret_cast<const void*>(stream_hop_kernel<true, 2>) : reinterpret_cast<const void*>(stream_hop_kernel<true, 1>))
+                           : (g2 ? reinterpret_cast<const void*>(stream_hop_kernel<false, 2>) : reinterpret_cast<const void*>(stream_hop_kernel<false, 1>));
     if (lds > 64 * 1024 && dev < 64 && !lds_set[one][dev]) {
         if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SFSN_EHIP;
         lds_set[one][dev] = 1;
     }
     if (lds > 160 * 1024) return SFSN_EUNSUPPORTED;
     if (one)
-        hipLaunchKernelGGL(stream_hop_kernel<true>, dim3(local.nblocks), dim3(HOP_THREADS), lds, static_cast<hipStream_t>(stream), local);
+        if (g2) hipLaunchKernelGGL((stream_hop_kernel<true, 2>), dim3(local.nblocks), dim3(HOP_THREADS), lds, static_cast<hipStream_t>(stream), local);
+        else hipLaunchKernelGGL((stream_hop_kernel<true, 1>), dim3(local.nblocks), dim3(HOP_THREADS), lds, static_cast<hipStream_t>(stream), local);
     else
-        hipLaunchKernelGGL(stream_hop_kernel<false>, dim3(local.nblocks), dim3(HOP_THREADS), lds, static_cast<hipStream_t>(stream), local);
+        if (g2) hipLaunchKernelGGL((stream_hop_kernel<false, 2>), dim3(local.nblocks), dim3(HOP_THREADS), lds, static_cast<hipStream_t>(stream), local);
+        else hipLaunchKernelGGL((stream_hop_kernel<false, 1>), dim3(local.nblocks), dim3(HOP_THREADS), lds, static_cast<hipStream_t>(stream), local);
     return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;
 }
 
@@ -1121,11 +1191,13 @@ extern "C" int sfsn_stream_hop_resident(const sfsn_hop_desc* desc, void* doorbel
     const int fit = hop_fits_device(local.nblocks);
     if (fit != SFSN_OK) return fit;
     if (lds > 160 * 1024) return SFSN_EUNSUPPORTED;
-    const void* kern = reinterpret_cast<const void*>(stream_hop_resident_kernel);
+    const bool g2 = local.G == 2;
+    const void* kern = g2 ? reinterpret_cast<const void*>(stream_hop_resident_kernel<2>) : reinterpret_cast<const void*>(stream_hop_resident_kernel<1>);
     if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SFSN_EHIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(local.cnt + 1, 0, 2 * sizeof(unsigned), st) != hipSuccess) return SFSN_EHIP;  // (word 2: the hop-finished count)
     const unsigned polls = (idle_ms > 30000u ? 30000u : idle_ms) * 100000u;  // ticks of the 100 MHz wall clock
-    hipLaunchKernelGGL(stream_hop_resident_kernel, dim3(local.nblocks), dim3(HOP_THREADS), lds, st, local, static_cast<unsigned*>(doorbell), polls);
+    if (g2) hipLaunchKernelGGL(stream_hop_resident_kernel<2>, dim3(local.nblocks), dim3(HOP_THREADS), lds, st, local, static_cast<unsigned*>(doorbell), polls);
+    else hipLaunchKernelGGL(stream_hop_resident_kernel<1>, dim3(local.nblocks), dim3(HOP_THREADS), lds, st, local, static_cast<unsigned*>(doorbell), polls);
     return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;
 }

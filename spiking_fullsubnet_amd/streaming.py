@@ -8,7 +8,7 @@ session therefore keeps, on the device: the (h, c) state of every layer and ``ma
 each ``step`` runs exactly the kernels of the offline forward on ``hop`` new frames.  Outputs are bit-identical to the
 offline forward on the concatenated input (tested).
 
-Two ways to run a hop.  ``one_launch`` (default where the library covers the model: shared gate weights, at most
+Two ways to run a hop.  ``one_launch`` (default where the library covers the model: shared or separate gate weights, at most
 3 layers / 4 groups): ``sfsn_stream_hop`` -- the whole frame in ONE launch of a few dozen small workgroups whose waves hand
 the frame from stage to stage through L2 (csrc/sfsn_hop.hip); its state is its own (double-buffered int8 spikes, membranes,
 history).  Otherwise the ~15 launches of the offline kernels, captured once into a HIP graph and replayed per hop: at
@@ -131,7 +131,7 @@ class StreamingSession:
         has its own state, all parts share the weights and write into the same output tensors."""
         eng, spec, L = self.eng, self.eng.spec, self.eng.lib
         B, F, S, hop, D, ng, dev = self.B, self.F, spec.num_spks, self.hop, self.D, spec.n_groups, self.dev
-        if not spec.shared or ng > HOP_MAX_GROUPS or max(spec.fb_layers, spec.sb_layers) > HOP_MAX_LAYERS or D + hop > 32:
+        if ng > HOP_MAX_GROUPS or max(spec.fb_layers, spec.sb_layers) > HOP_MAX_LAYERS or D + hop > 32:
             return None
 
         # Arenas instead of ~80 separately allocated tensors: the weights a launch reads (2.9 MB at baseline_m) and the state it
@@ -179,9 +179,17 @@ class StreamingSession:
                         w0 = cell.w_ih_f32
                         kc = (w0.shape[1] + 15) // 16
                         w0 = torch.nn.functional.pad(w0, (0, kc * 16 - w0.shape[1]))
-                        e["ih"] = (wpool.put(w0.view(seq.H // 16, 16, kc, 4, 4).permute(0, 2, 3, 1, 4).contiguous()),)
-                    else:
+                        # (separate gate weights: 2H rows, the forget gate's tiles first -- tile NT + j is the cell gate's tile j)
+                        e["ih"] = (wpool.put(w0.view(w0.shape[0] // 16, 16, kc, 4, 4).permute(0, 2, 3, 1, 4).contiguous()),)
+                    elif len(cell.w_ih_q) == 1:
                         e["ih"] = (wpool.put(cell.w_ih_q[0][0]), wpool.put(cell.w_ih_q[0][1]))
+                    else:
+                        # separate gate weights: the engine packs each gate's [H, H] on its own ([3][NT][KS] KiB images); the hop reads ONE
+                        # image of 2H rows, [3][2 NT][KS] with the forget gate's tiles first, and one dq vector [2H]
+                        nt_ = seq.H // 16
+                        pk = torch.cat([q_[0].reshape(3, nt_, -1) for q_ in cell.w_ih_q], dim=1).contiguous()
+                        dq = torch.cat([q_[1][:seq.H] for q_ in cell.w_ih_q]).contiguous()
+                        e["ih"] = (wpool.put(pk.reshape(-1)), wpool.put(dq))
                     e["c"] = (wpool.put(cell.bias), wpool.put(cell.alpha), wpool.put(cell.beta))
                     d["layers"].append(e)
                 w.append(d)
@@ -223,6 +231,7 @@ class StreamingSession:
                     c, spk = spool.zeros((R, seq.H), torch.float32), spool.zeros((hop, R, HP), torch.int8)
                     o.h[0], o.h[1], o.c, o.spikes = (a, a, a, a) if a else (ptr(h0), ptr(h1), ptr(c), ptr(spk))
             desc.n_groups, desc.B, desc.F, desc.S, desc.hop, desc.D, desc.fdrc = ng, nb, F, S, hop, D, spec.fdrc
+            desc.unshared = 0 if spec.shared else 1
             st = dict(hist=spool.zeros((nb, F, max(D, 1), 2), torch.float32))
             if self.waveform:
                 st.update(state=spool.zeros((nb, 512), torch.float32), ola=spool.zeros((nb, S, 512), torch.float32),

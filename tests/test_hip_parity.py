@@ -675,6 +675,7 @@ def test_forwards_in_flight_on_separate_streams_are_independent():
 @pytest.mark.parametrize("one_launch", ["auto", False])
 @pytest.mark.parametrize("kw,seed,B,hop,graph", [(rw.LIVE_TINY, 11, 2, 1, True), (rw.LIVE_M, 5, 1, 1, True), (rw.LIVE_M, 5, 3, 4, True),
                                                   (rw.LIVE_TINY_2SPK, 12, 2, 3, False), (rw.LIVE_TINY_UNSHARED, 7, 1, 1, True),
+                                                  (rw.LIVE_TINY_UNSHARED, 7, 3, 3, True), (dict(rw.LIVE_M, shared_weights=False), 8, 2, 1, True),
                                                   (rw.LIVE_M, 5, 37, 1, True),
                                                   (dict(rw.LIVE_TINY, use_pre_layer_norm_fb=False, use_pre_layer_norm_sb=False, bn=False), 13, 2, 1, True),
                                                   (dict(rw.LIVE_TINY, df_orders=[1, 1, 1]), 14, 3, 2, True)])
@@ -693,7 +694,7 @@ def test_streaming_session_equals_offline_forward(kw, seed, B, hop, graph, one_l
     sess = model.streaming(batch=B, hop=hop, graph=graph, rows_per_wg=None if seed != 12 else (0, 0),  # default / unfused geometry
                            one_launch=one_launch)
     if one_launch == "auto":
-        assert (sess._hop is not None) == bool(kw["shared_weights"])  # every shared-weight recipe takes the one-launch path
+        assert sess._hop is not None  # every recipe's sizes take the one-launch path (separate gate weights since round 4)
     else:
         assert sess._hop is None
     for rep in range(2):
@@ -712,6 +713,7 @@ def test_streaming_session_equals_offline_forward(kw, seed, B, hop, graph, one_l
 
 
 @pytest.mark.parametrize("kw,seed,B", [(rw.LIVE_TINY, 11, 2), (rw.LIVE_M, 5, 1), (rw.LIVE_TINY_2SPK, 12, 3), (rw.LIVE_M, 5, 17), (rw.LIVE_M, 5, 35),
+                                       (rw.LIVE_TINY_UNSHARED, 7, 2),
                                        (dict(rw.LIVE_TINY, df_orders=[1, 1, 1], use_pre_layer_norm_sb=False), 15, 1),
                                        (dict(rw.LIVE_M, df_orders=[1, 1, 1]), 16, 2)])  # recipes/intel_ndns/.../baseline_m_no_df.toml
 def test_waveform_streaming_equals_offline_forward(kw, seed, B):
@@ -847,7 +849,11 @@ def test_waveform_streaming_resident_launch(kw, seed, B):
 TINY_CUM = dict(rw.FROZEN_TINY_CUM, sb_df_orders=[3, 2, 1])  # (the fixture's orders [2, 1, 3] give the last group 384 projections: one launch covers 256)
 
 
-@pytest.mark.parametrize("kw,seed,B,hop", [(TINY_CUM, 35, 3, 1), (rw.FROZEN_M_CUM, 36, 2, 1), (TINY_CUM, 35, 2, 3)])
+XL_CUM = dict(rw.FROZEN_XL, norm_type="cumulative_laplace_norm")  # recipes/.../spiking_fullsubnet_freeze_phase/baseline_xl.toml as written
+
+
+@pytest.mark.parametrize("kw,seed,B,hop", [(TINY_CUM, 35, 3, 1), (rw.FROZEN_M_CUM, 36, 2, 1), (TINY_CUM, 35, 2, 3), (XL_CUM, 34, 2, 1),
+                                           (dict(TINY_CUM, shared_weights=False), 38, 3, 2)])
 def test_frozen_front_end_with_cumulative_norm_streams(kw, seed, B, hop):
     """cumulative_laplace_norm makes the frozen (model_zoo-architecture) front-end causal: the one-launch streaming session --
     on spectra and on waveforms -- reproduces the offline forward bit for bit (running sums carried per row)."""
@@ -925,8 +931,11 @@ def test_stream_hop_argument_checks_and_fallback():
     desc.hop = good[2]
     assert L.sfsn_hop_scratch_bytes(ctypes.byref(desc)) == good[1]
     unshared = build_module("live", rw.LIVE_TINY_UNSHARED, rw.live_state_dict(rw.LIVE_TINY_UNSHARED, 7))
-    with pytest.raises(NotImplementedError):
-        unshared.streaming(batch=1, hop=1, one_launch=True)
+    assert unshared.streaming(batch=1, hop=1, one_launch=True)._hop is not None  # (separate gate weights: covered since round 4)
+    deep = build_module("live", dict(rw.LIVE_TINY, sb_num_layers=4), rw.live_state_dict(dict(rw.LIVE_TINY, sb_num_layers=4), 7))
+    with pytest.raises(NotImplementedError):  # more layers than the launch has stages for: one_launch=True insists, "auto" falls back
+        deep.streaming(batch=1, hop=1, one_launch=True)
+    assert deep.streaming(batch=1, hop=1)._hop is None
     mid = build_module("live", rw.LIVE_M, rw.live_state_dict(rw.LIVE_M, 5))
     # more workgroups than compute units in one launch: the batch is cut into equal parts, one launch each
     assert len(mid.streaming(batch=16, hop=1)._hop["parts"]) == 1 and len(mid.streaming(batch=64, hop=1)._hop["parts"]) == 2
