@@ -373,13 +373,15 @@ int sfsn_cum_laplace_norm(float* x /* [T][R][I] */, int T, int R, int I, float* 
  * Arithmetic is that of sfsn_features / sfsn_spike_proj / sfsn_gsn_layer_scan / sfsn_deepfilter expression by expression;
  * the real-valued input product is sfsn_input_proj_f32's fp32-MFMA form with four accumulators.
  *
- * Shared gate weights, LayerNorm / cumulative Laplace / no normalisation, H % 16 == 0, H <= 320, I <= 192, P <= 256 (full-band P <= 128), at most
+ * Shared or separate gate weights (sfsn_hop_desc.unshared), LayerNorm / cumulative Laplace / no normalisation, H % 16 == 0, H <= 320, I <= 192, P <= 256 (full-band P <= 128), at most
  * SFSN_HOP_MAX_LAYERS layers and SFSN_HOP_MAX_GROUPS groups, D + hop <= 32, and few enough rows that every wave tile gets
  * its own compute unit (SFSN_EUNSUPPORTED otherwise: the caller then runs the per-kernel sequence).
  * ---------------------------------------------------------------------------------------------------- */
 #define SFSN_HOP_MAX_LAYERS 3
 #define SFSN_HOP_MAX_GROUPS 4
 typedef struct sfsn_hop_layer {
+    /* (desc.unshared: every image below covers the 2H rows of both gates, the forget gate's H rows first: [2H/16] fragment tiles,
+     *  sfsn_w3_pack(W [2H][.]) and dq vectors of 2H entries) */
     const float* w_ih_frag; /* layer 0: fp32 W_ih [H][I] in MFMA fragment order [H/16][KC][64][4], KC = ceil(I/16):
                                element ((tile*KC + c)*64 + 16*q + n)*4 + e = W_ih[16*tile + n][16*c + 4*q + e], zero where
                                the column index is >= I (NULL for layers >= 1)                                      */

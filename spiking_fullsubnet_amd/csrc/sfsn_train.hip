@@ -977,10 +977,19 @@ static size_t seq_lds_bwd(int G, int H, int RB, int rpb) {
 
 // all workgroups of a launch must be resident together: blocks per compute unit at this LDS size x compute units
 static int seq_slots(const void* kern, size_t lds) {
+    // (asked before every launch: the last few answers are remembered per (device, kernel, LDS size) -- the occupancy query costs tens of
+    //  microseconds, a training step makes sixteen launches)
+    struct Memo { int dev; const void* kern; size_t lds; int slots; };
+    static thread_local Memo memo[8];
+    static thread_local int n_memo = 0;
     int dev = 0, cus = 0, per = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
     if (lds > 64 * 1024 && hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    for (int i = 0; i < n_memo; ++i)
+        if (memo[i].dev == dev && memo[i].kern == kern && memo[i].lds == lds) return memo[i].slots;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, TR_THREADS, lds) != hipSuccess) return -1;
+    memo[n_memo < 8 ? n_memo++ : 7] = Memo{dev, kern, lds, per * cus};
     return per * cus;
 }
 
