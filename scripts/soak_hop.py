@@ -9,7 +9,8 @@ from test_hip_parity import build_module
 DEV = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-model = build_module("live", rw.LIVE_M, rw.live_state_dict(rw.LIVE_M, 5))
+kw = dict(rw.LIVE_M, shared_weights=False) if os.environ.get("UNSHARED") else rw.LIVE_M  # UNSHARED=1: separate gate weights (the G = 2 hop kernels)
+model = build_module("live", kw, rw.live_state_dict(kw, 5))
 a, b = model.streaming(batch=B, one_launch=True), model.streaming(batch=B, one_launch=False)
 g = torch.Generator(device="cpu").manual_seed(1)
 pool = torch.view_as_complex((0.05 * torch.randn((64, B, 257, 1, 2), generator=g)).to(DEV))
