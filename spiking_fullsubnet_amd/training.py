@@ -268,8 +268,8 @@ class GSNLayerTrainFn(torch.autograd.Function):
         dz = (d_z if shared else d_gates).reshape(T * R, GH)
         dx = torch.mm(dz, w_ih).view(T, R, I).add_(poison)
         dw_ih = torch.mm(dz.t(), x.reshape(T * R, I)).add_(poison)
-        h_prev = torch.cat([zero.unsqueeze(0), spikes[:-1]], 0).reshape(T * R, H)
-        dw_hh = torch.mm(dz.t(), h_prev).add_(poison)
+        # dL/dW_hh = sum_t dz_t^T h_{t-1}: h_{-1} = 0, so steps 1 .. T-1 against spikes 0 .. T-2 (views: no shifted copy of the spikes)
+        dw_hh = (torch.mm(dz[R:].t(), spikes[:-1].reshape((T - 1) * R, H)) if T > 1 else torch.zeros((GH, H), **f32)).add_(poison)
         dbias = d_gates.reshape(T * R, 2 * H).sum(0).add_(poison)
         if bn_kernel:
             d_bn_w.add_(poison)
@@ -407,8 +407,7 @@ class GSNLayersTrainFn(torch.autograd.Function):
             dz = (d_z if shared else d_gates).reshape(T * R, GH)
             dx = torch.mm(dz, w_ih).view(T, R, I).add_(poison)
             dw_ih = torch.mm(dz.t(), x.reshape(T * R, I)).add_(poison)
-            h_prev = torch.cat([torch.zeros((1, R, H), **f32), spikes[:-1]], 0).reshape(T * R, H)
-            dw_hh = torch.mm(dz.t(), h_prev).add_(poison)
+            dw_hh = (torch.mm(dz[R:].t(), spikes[:-1].reshape((T - 1) * R, H)) if T > 1 else torch.zeros((GH, H), **f32)).add_(poison)
             dbias = d_gates.reshape(T * R, 2 * H).sum(0).add_(poison)
             if use_bn:
                 d_bn_w.add_(poison)
