@@ -420,3 +420,17 @@ def test_training_entry_points_check_their_arguments_without_a_gpu():
     assert L.sfsn_gsn_train_seq_fwd(one, one, one, None, None, None, None, 0.1, 1e-5, 0, 4, 32, 1, one, one, one, None, one, one, None, None, None) == _lib.SFSN_EINVAL
     assert L.sfsn_gsn_train_seq_fwd(one, one, one, None, None, None, None, 0.1, 1e-5, 5, 4, 32, 1, None, one, one, None, one, one, None, None, None) == _lib.SFSN_EINVAL
     assert L.sfsn_gsn_train_seq_bwd(one, one, one, None, one, one, None, None, 5, 4, 32, 1, one, one, None, one, None, None, None, None) == _lib.SFSN_EINVAL
+    # round 4: the one-launch layer calls (scratch sizing, several calls per launch), the feature launch's zero job, the Gaussian statistics
+    assert L.sfsn_train_seq_scratch_bytes(0, 32) == 0 and L.sfsn_train_seq_scratch_bytes(8, 24) == 0
+    assert L.sfsn_train_seq_scratch_bytes(512, 224) >= 2 * 512 * 56 * 4 + L.sfsn_train_scratch_bytes(224)
+    calls = (_lib.TrainSeqFwd * 2)()
+    assert L.sfsn_gsn_train_seq_fwd_multi(calls, 2, 5, 32, 1, None) == _lib.SFSN_EINVAL      # (empty descriptors: missing tensors)
+    assert L.sfsn_gsn_train_seq_fwd_multi(calls, 9, 5, 32, 1, None) == _lib.SFSN_EINVAL      # more calls than a launch holds
+    assert L.sfsn_gsn_train_seq_bwd_multi((_lib.TrainSeqBwd * 1)(), 1, 0, 32, 1, None) == _lib.SFSN_EINVAL
+    Rs = (ctypes.c_int * 2)(8, 0)
+    assert L.sfsn_gsn_train_multi_check(Rs, 2, 32, 1) == _lib.SFSN_EINVAL and L.sfsn_gsn_train_multi_check(Rs, 1, 24, 1) == _lib.SFSN_EUNSUPPORTED
+    g = (_lib.FeatureGroup * 1)()
+    assert L.sfsn_features_z(one, None, 1, 33, 8, 0, 0.5, g, 1, 0, 8, ctypes.c_void_p(64), 24, None) == _lib.SFSN_EINVAL    # not whole 16-byte pieces
+    assert L.sfsn_features_z(one, None, 1, 33, 8, 0, 0.5, g, 1, 0, 8, None, 16, None) == _lib.SFSN_EINVAL                   # bytes without a buffer
+    assert L.sfsn_gaussian_stats(one, None, 1, 33, 1, 0, 0.5, g, 1, one, one, one, None) == _lib.SFSN_EINVAL                # one frame: no unbiased estimate
+    assert L.sfsn_gaussian_stats(one, None, 1, 33, 8, 0, 0.5, g, 1, one, None, one, None) == _lib.SFSN_EINVAL
