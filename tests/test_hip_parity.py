@@ -816,7 +816,7 @@ def test_streaming_hops_beside_a_saturated_chip_are_right_or_loud():
     assert torch.equal(torch.view_as_real(torch.cat(outs, -1)), torch.view_as_real(off["enh_stft"]))
 
 
-@pytest.mark.parametrize("kw,seed,B", [(rw.LIVE_M, 5, 1), (rw.LIVE_TINY_2SPK, 12, 3)])
+@pytest.mark.parametrize("kw,seed,B", [(rw.LIVE_M, 5, 1), (rw.LIVE_TINY_2SPK, 12, 3), (rw.LIVE_TINY_UNSHARED, 7, 2)])
 def test_waveform_streaming_resident_launch(kw, seed, B):
     """resident=True: ONE launch serves hop after hop, rung through a doorbell word in pinned host memory
     (sfsn_stream_hop_resident).  Same samples as the offline forward, bit for bit -- across a doorbell left silent until the
