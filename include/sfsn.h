@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 15 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 16 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -116,6 +116,10 @@ typedef struct sfsn_scan_segment {
     int8_t* spikes_i8;     /* [T][R][pad64(H)] out, REQUIRED (B operand of the next sfsn_spike_proj)         */
     float* membrane;       /* [T][R][H] out, nullable  (post-BN membrane; parity tests only; needs spikes_f32)*/
     int R;                 /* rows in this segment (> 0)                                                      */
+    unsigned long long* spike_count; /* nullable, 8-byte aligned (ABI 16).  When spikes_f32 is NULL the launch ADDS the number
+                            * of spikes it wrote for this segment (rows < R, neurons < H, its T frames) -- the reduction
+                            * audiozen/metric.py:303-340 takes of an all_layer_outputs entry, formed inside the scan:
+                            * zero it once per forward, chunked calls accumulate.  Ignored when spikes_f32 is given. */
 } sfsn_scan_segment;
 
 int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs /* host array */, int n_segs, int T, int H, int shared,
@@ -147,6 +151,10 @@ int sfsn_gsn_layer_scan_w16(const sfsn_scan_segment* segs /* host */, int n_segs
 size_t sfsn_train_scratch_bytes(int H);
 /* SFSN_OK when BOTH step kernels take this geometry (their LDS needs differ): call once per layer before the first forward step. */
 int sfsn_gsn_train_check(int R, int H, int shared);
+/* The same question for the per-step launches alone (their own, smaller LDS needs; with several row blocks per neuron tile also that
+ * a step launch can hold its workgroups resident: needs the device then).  training.py asks it before it falls back from the one-launch
+ * layer call (sfsn_gsn_train_multi_check said SFSN_EUNSUPPORTED) to a launch per step, and for the eval-mode-BatchNorm path.  ABI 16. */
+int sfsn_gsn_train_step_check(int R, int H, int shared);
 int sfsn_gsn_train_step_fwd(const float* z, const float* w_hh, const float* bias, const float* h_prev, const float* c_prev,
                             const float* bn_w, const float* bn_b, float* running_mean, float* running_var, float momentum, float eps,
                             int R, int H, int shared, float* spikes, float* u, float* xhat, float* f, float* g, float* invstd,

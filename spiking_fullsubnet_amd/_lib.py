@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
 NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE, NORM_CUMLAPLACE, NORM_GAUSSIAN = 0, 1, 2, 3, 4
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
-ABI_VERSION = 15  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
+ABI_VERSION = 16  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -25,7 +25,8 @@ _F = ctypes.c_float
 
 class ScanSegment(ctypes.Structure):
     _fields_ = [("zin", _P), ("w_hh", _P), ("w_dq", _P), ("bias", _P), ("bn_alpha", _P), ("bn_beta", _P),
-                ("h_state", _P), ("c_state", _P), ("spikes_f32", _P), ("spikes_i8", _P), ("membrane", _P), ("R", _I)]
+                ("h_state", _P), ("c_state", _P), ("spikes_f32", _P), ("spikes_i8", _P), ("membrane", _P), ("R", _I),
+                ("spike_count", _P)]
 
 
 class FusedInput(ctypes.Structure):
@@ -163,6 +164,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_gsn_train_seq_bwd_multi.argtypes = [ctypes.POINTER(TrainSeqBwd), _I, _I, _I, _I, _P]
     L.sfsn_gsn_train_check.restype = _I
     L.sfsn_gsn_train_check.argtypes = [_I, _I, _I]
+    L.sfsn_gsn_train_step_check.restype = _I
+    L.sfsn_gsn_train_step_check.argtypes = [_I, _I, _I]
     L.sfsn_gsn_train_step_bwd.restype = _I
     L.sfsn_gsn_train_step_bwd.argtypes = [_P] * 12 + [_I, _I, _I] + [_P] * 6 + [ctypes.c_uint, _P]
     L.sfsn_gsn_train_seq_fwd.restype = _I  # z, w_hh, bias, bn_w, bn_b, running_mean, running_var | momentum, eps | T, R, H, shared | zero, 6 outputs, scratch, stream
@@ -224,7 +227,7 @@ EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
            "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_stream_hop_resident", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft", "sfsn_gsn_train_step_fwd", "sfsn_gsn_train_step_bwd", "sfsn_train_scratch_bytes",
            "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16", "sfsn_gsn_train_check", "sfsn_gsn_stack_scan_x", "sfsn_train_seq_scratch_bytes", "sfsn_gsn_train_multi_check",
-           "sfsn_gsn_train_seq_fwd_multi", "sfsn_gsn_train_seq_bwd_multi", "sfsn_features_z", "sfsn_gaussian_stats")
+           "sfsn_gsn_train_seq_fwd_multi", "sfsn_gsn_train_seq_bwd_multi", "sfsn_features_z", "sfsn_gaussian_stats", "sfsn_gsn_train_step_check")
 
 
 def check(rc: int, what: str = "") -> None:

@@ -63,10 +63,10 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
     const int n_hi = NT - NW * (TPW - 1);  // waves [0, n_hi) own TPW tiles, the others TPW-1
     if (wave < n_hi)
         scan_body<G, KS, NW, TPW, OUT, LP, TPW>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state, smem, T,
-                                            H, NT, R, row0, rowc, n, q, tid, wave, rpw);
+                                            H, NT, R, row0, rowc, n, q, tid, wave, rpw, nullptr, nullptr, sg.count);
     else
         scan_body<G, KS, NW, TPW, OUT, LP, TPW - 1>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state,
-                                                smem, T, H, NT, R, row0, rowc, n, q, tid, wave, rpw);
+                                                smem, T, H, NT, R, row0, rowc, n, q, tid, wave, rpw, nullptr, nullptr, sg.count);
 }
 
 
@@ -82,6 +82,8 @@ __global__ __launch_bounds__(1024) void gsn_scan3_kernel(const ScanParams p) {
     rl.zin = sg.zin; rl.w_hh = sg.w_hh; rl.w_dq = sg.w_dq; rl.bias = sg.bias; rl.bn_alpha = sg.bn_alpha; rl.bn_beta = sg.bn_beta;
     rl.h_state = sg.h_state; rl.c_state = sg.c_state; rl.spikes_f32 = sg.spikes_f32; rl.spikes_i8 = sg.spikes_i8;
     rl.R = sg.R; rl.row0 = ((int)blockIdx.x - sg.tile0) * RPW;
+    rl.count = sg.count;
+    rl.lsplit = p.lsplit;
     StackLink lk;
     lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = nullptr; lk.lag = 0; lk.dbg = nullptr;
     scan3_role<KS, RPW, OUT, 0, D0>(rl, lk, scan_smem, p.T, p.H, p.NT);
@@ -220,6 +222,7 @@ __device__ __forceinline__ void fused_body(const ScanSegDev& sg, char* smem, int
     for (int t = 1; t < T; ++t) step(t, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (T > 0) fl.template run<OUT>(hbuf + (T & 1) * 16 * LDH, sg.spikes_f32, sg.spikes_i8, T - 1, R, H);
+    fl.template finish<OUT>(sg.count);
     const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
 #pragma unroll
     for (int i = 0; i < NTL; ++i) {
@@ -335,6 +338,7 @@ __global__ __launch_bounds__(512) void gsn_scan_stream_kernel(const ScanParams p
     }
     __syncthreads();
     const size_t plane = (size_t)G * NT * KS * 1024;
+    unsigned cnt = 0;  // spikes stored by this lane (launches without an fp32 spike tensor: sg.count)
     for (int t = 0; t < T; ++t) {
         const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
         int8_t* hn = hbuf + ((t & 1) ^ 1) * 16 * LDH;
@@ -378,6 +382,7 @@ __global__ __launch_bounds__(512) void gsn_scan_stream_kernel(const ScanParams p
             *reinterpret_cast<unsigned*>(hn + n * LDH + cc) = pk;
             if (row0 + n < R) {  // rows past R are computed (clamped duplicates) but not stored
                 *reinterpret_cast<unsigned*>(sg.spikes_i8 + ((size_t)t * R + rowc) * HP + cc) = pk;
+                cnt += (unsigned)__builtin_popcount(pk);
                 if (sg.spikes_f32) {
                     const v4f sp = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)(pk >> 24)};
                     *reinterpret_cast<v4f*>(sg.spikes_f32 + ((size_t)t * R + rowc) * H + cc) = sp;
@@ -398,6 +403,7 @@ __global__ __launch_bounds__(512) void gsn_scan_stream_kernel(const ScanParams p
         const v4f h = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)((pk >> 24) & 1u)};
         *reinterpret_cast<v4f*>(sg.h_state + (size_t)rowc * H + cc) = h;
     }
+    if (!sg.spikes_f32) wave_count_add(sg.count, cnt);
 }
 
 // =====================================================================================================
@@ -1102,6 +1108,7 @@ __device__ __forceinline__ void fusedx_body(const ScanSegDev& sg, char* smem, in
     for (int t = 1; t < T; ++t) step(t, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (T > 0) fl.template run<OUT>(hbuf + (T & 1) * 16 * LDH, sg.spikes_f32, sg.spikes_i8, T - 1, R, H);
+    fl.template finish<OUT>(sg.count);
     const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
 #pragma unroll
     for (int i = 0; i < NTL; ++i) {
@@ -1814,6 +1821,7 @@ static int layer_scan_impl(const sfsn_scan_segment* segs, int n_segs, int T, int
     if (H % 16 != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     ScanParams p;
     p.w16 = w16;
+    p.lsplit = sfsn_s3_lsplit_host();
     // rows per workgroup: as few as it takes to spread the launch over ~all 256 CUs (see the kernel comment)
     int rows_total = 0;
     for (int i = 0; i < n_segs; ++i) rows_total += segs[i].R > 0 ? segs[i].R : 0;
@@ -1847,7 +1855,7 @@ static int layer_scan_impl(const sfsn_scan_segment* segs, int n_segs, int T, int
             return SFSN_EINVAL;
         ScanSegDev& d = p.seg[i];
         d.zin = s.zin; d.w_hh = s.w_hh; d.w_dq = s.w_dq; d.bias = s.bias; d.bn_alpha = s.bn_alpha; d.bn_beta = s.bn_beta;
-        d.h_state = s.h_state; d.c_state = s.c_state; d.spikes_f32 = s.spikes_f32; d.spikes_i8 = s.spikes_i8;
+        d.h_state = s.h_state; d.c_state = s.c_state; d.spikes_f32 = s.spikes_f32; d.spikes_i8 = s.spikes_i8; d.count = s.spike_count;
         d.membrane = s.membrane; d.R = s.R; d.tile0 = tiles;
         tiles += (s.R + rpw - 1) / rpw;
     }
@@ -1907,6 +1915,7 @@ extern "C" int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs, const sf
     ScanParams p;
     p.rpw = 16;
     p.w16 = 0;
+    p.lsplit = sfsn_s3_lsplit_host();
     int tiles = 0;
     const int out = 2 | (segs[0].spikes_f32 ? 1 : 0);
     for (int i = 0; i < n_segs; ++i) {
@@ -1920,7 +1929,7 @@ extern "C" int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs, const sf
             return SFSN_EINVAL;
         ScanSegDev& d = p.seg[i];
         d.zin = nullptr; d.w_hh = s.w_hh; d.w_dq = s.w_dq; d.bias = s.bias; d.bn_alpha = s.bn_alpha; d.bn_beta = s.bn_beta;
-        d.h_state = s.h_state; d.c_state = s.c_state; d.spikes_f32 = s.spikes_f32; d.spikes_i8 = s.spikes_i8;
+        d.h_state = s.h_state; d.c_state = s.c_state; d.spikes_f32 = s.spikes_f32; d.spikes_i8 = s.spikes_i8; d.count = s.spike_count;
         d.membrane = nullptr; d.R = s.R; d.tile0 = tiles;
         d.spikes_in = fin[i].spikes_in; d.w_ih = fin[i].w_ih; d.w_ih_dq = fin[i].w_ih_dq;
         tiles += (s.R + 15) / 16;
@@ -1950,6 +1959,7 @@ extern "C" int sfsn_gsn_layer_scan_fused_x(const sfsn_scan_segment* segs, const 
     ScanParams p;
     p.rpw = 16;
     p.w16 = 0;
+    p.lsplit = sfsn_s3_lsplit_host();
     int tiles = 0, imax = 0;
     const int out = 2 | (segs[0].spikes_f32 ? 1 : 0);
     for (int i = 0; i < n_segs; ++i) {
@@ -1964,7 +1974,7 @@ extern "C" int sfsn_gsn_layer_scan_fused_x(const sfsn_scan_segment* segs, const 
             return SFSN_EINVAL;
         ScanSegDev& d = p.seg[i];
         d.zin = nullptr; d.w_hh = s.w_hh; d.w_dq = s.w_dq; d.bias = s.bias; d.bn_alpha = s.bn_alpha; d.bn_beta = s.bn_beta;
-        d.h_state = s.h_state; d.c_state = s.c_state; d.spikes_f32 = s.spikes_f32; d.spikes_i8 = s.spikes_i8;
+        d.h_state = s.h_state; d.c_state = s.c_state; d.spikes_f32 = s.spikes_f32; d.spikes_i8 = s.spikes_i8; d.count = s.spike_count;
         d.membrane = nullptr; d.R = s.R; d.tile0 = tiles;
         d.spikes_in = nullptr; d.w_ih = nullptr; d.w_ih_dq = nullptr;
         d.x_in = fin[i].x; d.w_ih_f32 = fin[i].w_ih; d.I = fin[i].I;

@@ -44,9 +44,36 @@
 // barrier cost them 0.1-0.2 us per step, at the top of the next step (under the LDS wait) 0.5-0.9 us (4-row scan 0.55 -> 1.4).
 #define SFSN_S3_CWF 0
 #endif
+#ifndef SFSN_S3_LSPLIT
+// Round 5: at 8 rows per workgroup a frame's fp32 spikes are SEVEN 1 KiB stores and its int8 rows two; one wave issues a VMEM store
+// every ~140 clk and an LDS-DMA piece every ~60 (scripts/micro/store_retire.hip, MI355X_MICROARCH.md), so whichever IO wave carried all
+// of them was the role's step: the plain role's storer 9 x 140 = 1260 clk (0.69 us per step measured against 0.61 without the fp32
+// tensor), the publishing role's loader 7 x 60 + 7 x 140 = 1400 clk (0.9 us measured on an idle chip).  The loader wave takes the first
+// SFSN_S3_LSPLIT store instructions of a frame's fp32 block and the storer wave the rest: 7 x 60 + 3 x 140 = 840 against (4 + 2) x 140 =
+// 840 clk -- neither IO wave is the step any more.  (Scan3Role::lsplit overrides it at run time for A/B runs: SFSN_S3_LSPLIT in the
+// environment of the host library.)
+#define SFSN_S3_LSPLIT 3
+#endif
 #ifndef SFSN_S3_PFMAX
 #define SFSN_S3_PFMAX 8   // frames of a publishing storer's stores that may be in flight (24 measured the same: the limit is elsewhere)
 #endif
+// the host's value of the split (the environment variable of the same name overrides the built-in default: A/B runs)
+inline int sfsn_s3_lsplit_host() {
+    static const int v = [] {
+        const char* e = getenv("SFSN_S3_LSPLIT");
+        const int x = e ? atoi(e) : SFSN_S3_LSPLIT;
+        return x < 0 ? 0 : (x > 16 ? 16 : x);
+    }();
+    return v;
+}
+inline int sfsn_s3x_lsplit_host() {  // the FUSEDX3 role's own value (its loader wave also converts the features: less room)
+    static const int v = [] {
+        const char* e = getenv("SFSN_S3X_LSPLIT");
+        const int x = e ? atoi(e) : sfsn_s3_lsplit_host();
+        return x < 0 ? 0 : (x > 16 ? 16 : x);
+    }();
+    return v;
+}
 template <int KS, int RPW, int FLG = 0>
 struct Scan3Cfg {
     static constexpr int HP = KS * 64, LDH = HP + 32;
@@ -57,7 +84,9 @@ struct Scan3Cfg {
     __host__ __device__ static constexpr int slot_bytes(int NT) { return pieces(NT) * 1024; }
     static constexpr int MAXP = (RPW * 14 * 4 + 63) / 64;  // pieces at NT = 14
     static constexpr bool GATED = (FLG & 1) != 0, PUB = (FLG & 2) != 0;
-    static constexpr int DWANT = (PUB && SFSN_S3_LSF) ? 6 : ((GATED || PUB) ? 9 : 4);
+    // (8 rows: the loader wave also carries a share of the fp32 spike stores -- SFSN_S3_LSPLIT below -- and needs the deeper ring for
+    //  the same reason as the publishing role's)
+    static constexpr int DWANT = (PUB && SFSN_S3_LSF) ? 6 : ((GATED || PUB) ? 9 : (RPW == 8 ? 6 : 4));
     static constexpr int DFIT = 65536 / (MAXP * 1024);       // LDS-DMA destinations stay below 64 KiB
     static constexpr int D = DWANT < DFIT ? DWANT : DFIT;    // input-term ring depth (frames)
     __host__ __device__ static constexpr int hbuf_off(int NT) { return D * slot_bytes(NT); }
@@ -127,16 +156,19 @@ struct S3FlushF {
     int lf[MAXF];
     unsigned okf;
     int nsf;  // store instructions per frame with at least one live lane (wave-uniform)
-    __device__ __forceinline__ void init(int lane, int row0, int R, int H) {
+    // store instructions [k_lo, k_hi) of the frame's block are mine (the loader and the storer wave share a frame's stores)
+    __device__ __forceinline__ void init(int lane, int row0, int R, int H, int k_lo = 0, int k_hi = MAXF) {
         const int q4 = H / 4;
         const int rows_live = (R - row0 < RPW) ? R - row0 : RPW;
-        nsf = (rows_live * q4 + 63) / 64;
+        const int nall = (rows_live * q4 + 63) / 64;
+        const int hi = k_hi < nall ? k_hi : nall, lo = k_lo < hi ? k_lo : hi;
+        nsf = hi - lo;
         okf = 0;
 #pragma unroll
         for (int k = 0; k < MAXF; ++k) {
             const int u = 64 * k + lane, rr = u / q4, c4 = u - rr * q4;
             lf[k] = rr * LDH + c4 * 4;
-            if (u < RPW * q4 && row0 + rr < R) okf |= 1u << k;
+            if (k >= lo && k < hi && u < RPW * q4 && row0 + rr < R) okf |= 1u << k;
         }
     }
     __device__ __forceinline__ void run(const int8_t* hsrc, float* pf /* block base of the frame */, int lane) const {
@@ -163,6 +195,8 @@ struct Scan3Role {
     float* spikes_f32;
     int8_t* spikes_i8;
     int R, row0;
+    unsigned long long* count = nullptr;  // nullable: a role without fp32 spikes adds the number of spikes it wrote (ScanSegDev::count)
+    int lsplit = SFSN_S3_LSPLIT;          // 8-row roles: fp32 store instructions per frame issued by the loader wave (the storer takes the rest)
 };
 
 // FLG bit 0: the input term is written by other workgroups of this launch (gated on lk.in, sc1 loads); bit 1: the int8 spikes
@@ -178,7 +212,11 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
 #define SFSN_S3_LSF 0
 #endif
     constexpr bool CWF = SFSN_S3_CWF && (OUT & 1);  // the compute waves write the fp32 spikes (see SFSN_S3_CWF)
-    constexpr bool LSF = !CWF && SFSN_S3_LSF && PUB && (OUT & 1);  // the loader wave also writes the fp32 spikes (round 3; see Scan3Cfg)
+    // the loader wave writes fp32 spikes too: ALL of them in a publishing role at 4 / 16 rows (round 3; see Scan3Cfg), its share of
+    // every frame at 8 rows (SFSN_S3_LSPLIT)
+    constexpr bool LSPLIT = RPW == 8 && !CWF && (OUT & 1);
+    constexpr bool LSF = !CWF && (OUT & 1) && ((SFSN_S3_LSF && PUB) || LSPLIT);
+    const int ltake = LSPLIT ? rl.lsplit : 64;  // store instructions per frame the loader takes (64 = all)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
@@ -332,7 +370,7 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
         int avail = GATED ? 0 : T;
         int failed = 0;
         S3FlushF<RPW, LDH> ff;
-        if constexpr (LSF) ff.init(lane, row0, R, H);
+        if constexpr (LSF) ff.init(lane, row0, R, H, 0, ltake);
         // operations issued after the DMAs of a frame and before the wait D-2 steps later: D-2 steps of DMAs (and stores)
         // plus the stores of the issuing step itself; the counter has 6 bits (a smaller allowance is only stricter)
         int allow = (D - 2) * np;
@@ -381,11 +419,12 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
         // ================================================= storer wave =================================================
         constexpr int MAX8 = (RPW * KS * 4 + 63) / 64;
         constexpr int nu8 = RPW * (HP / 16), ns8 = (nu8 + 63) / 64;
-        constexpr bool F32 = (OUT & 1) && !LSF && !CWF;  // (else the loader wave or the compute waves write the fp32 spikes)
+        constexpr bool F32 = (OUT & 1) && (!LSF || LSPLIT) && !CWF;  // (what the loader wave / the compute waves do not write)
         S3FlushF<RPW, LDH> ff;
-        if constexpr (F32) ff.init(lane, row0, R, H);
+        if constexpr (F32) ff.init(lane, row0, R, H, LSPLIT ? ltake : 0);
         int l8[MAX8];
         unsigned ok8 = 0;
+        unsigned cnt = 0;  // spikes flushed by this lane (roles without an fp32 spike tensor: rl.count)
 #pragma unroll
         for (int k = 0; k < MAX8; ++k) {
             const int u = 64 * k + lane, rr = u / (HP / 16), c16 = u - rr * (HP / 16);
@@ -404,6 +443,7 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
                         const v4i d = *reinterpret_cast<const v4i*>(hsrc + l8[k]);
                         if (PUB && !(exp_flags & 8)) store16_sc1(p8, (unsigned)((64 * k + lane) * 16), d);  // (bit 3: timing experiment, plain)
                         else *reinterpret_cast<v4i*>(p8 + (size_t)(64 * k + lane) * 16) = d;
+                        if constexpr (!(OUT & 1)) cnt += popc16(d);  // (live rows only; the pad columns of the state buffer hold zeros)
                     }
                 }
             }
@@ -445,6 +485,7 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) stack_publish(lk, T);  // (also after an expired spin: consumers must not wait for us)
         }
+        if constexpr (!(OUT & 1)) wave_count_add(rl.count, cnt);
         return;
     }
 

@@ -59,6 +59,7 @@ struct Scan3iRole {
     float* spikes_f32;
     int8_t* spikes_i8;
     int R, row0;
+    unsigned long long* count = nullptr;  // (as Scan3Role::count)
 };
 
 // TL = 1: H mod 64 is in (0, 32]: the last k-step of the RECURRENT product is ONE 16x16x32 matrix instruction whose 8-byte fragments
@@ -377,6 +378,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
         if constexpr (F32) ff.init(lane, row0, R, H);
         int l8[MAX8];
         unsigned ok8 = 0;
+        unsigned cnt = 0;  // (as scan3_role's storer)
 #pragma unroll
         for (int k = 0; k < MAX8; ++k) {
             const int u = 64 * k + lane, rr = u / (HP / 16), c16 = u - rr * (HP / 16);
@@ -395,6 +397,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
                         const v4i d = *reinterpret_cast<const v4i*>(hsrc + l8[k]);
                         if (PUB) store16_sc1(p8, (unsigned)((64 * k + lane) * 16), d);
                         else *reinterpret_cast<v4i*>(p8 + (size_t)(64 * k + lane) * 16) = d;
+                        if constexpr (!(OUT & 1)) cnt += popc16(d);
                     }
                 }
             }
@@ -430,6 +433,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) stack_publish(lk, T);  // (also after an expired spin: consumers must not wait for us)
         }
+        if constexpr (!(OUT & 1)) wave_count_add(rl.count, cnt);
         return;
     }
 

@@ -51,6 +51,8 @@ struct Scan3xRole {
     float* spikes_f32;
     int8_t* spikes_i8;
     int R, row0;
+    unsigned long long* count = nullptr;  // (as Scan3Role::count)
+    int lsplit = SFSN_S3_LSPLIT;          // fp32 store instructions per frame issued by the loader wave (see SFSN_S3_LSPLIT)
 };
 
 // KSB: 32-wide k-chunks of the input product (2: 32 < I <= 64, 1: I <= 32) -- compile time, so that a step is straight-line code (a
@@ -283,6 +285,13 @@ __device__ __forceinline__ void scan3x_role(const Scan3xRole& rl, const StackLin
         }
         const size_t frame = (size_t)R * I;
         const float* xbase = rl.x + (size_t)row0 * I;
+        // my share of a frame's fp32 spike stores (round 5, SFSN_S3_LSPLIT: nine 1 KiB stores per frame through the storer wave alone
+        // were 1260 clk of store issue per step)
+        S3FlushF<RPW, LDH> ffl;
+        if constexpr (OUT & 1) ffl.init(lane, row0, R, H, 0, rl.lsplit);
+        const int lst = (OUT & 1) ? ffl.nsf : 0;
+        int allow = (A - 4) * (NPX + lst) + lst;  // behind the DMA of frame t + 4: the DMAs and stores of the steps since, and this step's stores
+        if (allow > 62) allow = 62;
         auto issue = [&](int slot, int td) __attribute__((always_inline)) {
 #pragma unroll
             for (int p = 0; p < NPX; ++p)
@@ -317,10 +326,11 @@ __device__ __forceinline__ void scan3x_role(const Scan3xRole& rl, const StackLin
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             issue((t + A) % DX, (t + A < T) ? t + A : T - 1);
+            if constexpr (OUT & 1) if (t > 0) ffl.run(hbuf + (t & 1) * 16 * LDH, rl.spikes_f32 + ((size_t)(t - 1) * R + row0) * H, lane);
             // frames t + 5, t + 6 may stay in flight: frame t + 4 has landed -> convert it (its planes are read from step t + 1 or
             // t + 2 on; the slot it overwrites held frame t - 2, dead for two barriers -- also at step 0 / 1, where a compute wave may
             // still be reading frames 0, 1 for the product it forms before the loop)
-            wait_vmcnt_n((A - 4) * NPX);
+            wait_vmcnt_n(allow);
 #ifndef SFSN_X3_NOCONVERT  // (timing experiment: wrong results)
             convert(t + 4);
 #endif
@@ -328,18 +338,20 @@ __device__ __forceinline__ void scan3x_role(const Scan3xRole& rl, const StackLin
             __builtin_amdgcn_s_barrier();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (OUT & 1) if (T > 0) ffl.run(hbuf + (T & 1) * 16 * LDH, rl.spikes_f32 + ((size_t)(T - 1) * R + row0) * H, lane);
         return;
     }
 
     if (wave == NT + 1) {
-        // ================================================= storer wave: every store of the role =================================================
+        // ================================================= storer wave: every store of the role but the loader's share =================================================
         constexpr int MAX8 = (RPW * KS * 4 + 63) / 64;
         constexpr int nu8 = RPW * (HP / 16), ns8 = (nu8 + 63) / 64;
         constexpr bool F32 = (OUT & 1) != 0;
         S3FlushF<RPW, LDH> ff;
-        if constexpr (F32) ff.init(lane, row0, R, H);
+        if constexpr (F32) ff.init(lane, row0, R, H, rl.lsplit);
         int l8[MAX8];
         unsigned ok8 = 0;
+        unsigned cnt = 0;  // (as scan3_role's storer)
 #pragma unroll
         for (int k = 0; k < MAX8; ++k) {
             const int u = 64 * k + lane, rr = u / (HP / 16), c16 = u - rr * (HP / 16);
@@ -355,6 +367,7 @@ __device__ __forceinline__ void scan3x_role(const Scan3xRole& rl, const StackLin
                         const v4i d = *reinterpret_cast<const v4i*>(hsrc + l8[k]);
                         if (PUB) store16_sc1(p8, (unsigned)((64 * k + lane) * 16), d);
                         else *reinterpret_cast<v4i*>(p8 + (size_t)(64 * k + lane) * 16) = d;
+                        if constexpr (!(OUT & 1)) cnt += popc16(d);
                     }
                 }
             }
@@ -382,6 +395,7 @@ __device__ __forceinline__ void scan3x_role(const Scan3xRole& rl, const StackLin
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) stack_publish(lk, T);
         }
+        if constexpr (!(OUT & 1)) wave_count_add(rl.count, cnt);
         return;
     }
 

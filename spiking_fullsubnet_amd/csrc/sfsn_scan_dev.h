@@ -38,6 +38,9 @@ struct ScanSegDev {
     const float* x_in;
     const float* w_ih_f32;
     int I;
+    // nullable: a launch that writes NO fp32 spikes adds the number of spikes it wrote (rows < R, its T frames) -- SynOPs / NeuronOPs
+    // without the [T][R][H] tensors and without a counting pass over the int8 copies (the reduction inside the scan)
+    unsigned long long* count;
 };
 
 struct ScanParams {
@@ -45,7 +48,26 @@ struct ScanParams {
     int nseg, T, H, NT;  // NT = H / 16 output tiles per gate
     int rpw;             // rows per workgroup (16, 8 or 4): fewer rows per CU = less HBM traffic per CU per step
     int w16;             // 1: 16-bit weights, digit plane 0 is zero (sfsn_gsn_layer_scan_w16): the scan3 kernels skip it
+    int lsplit;          // 8-row IO-wave scans: fp32 store instructions per frame issued by the loader wave (SFSN_S3_LSPLIT)
 };
+
+// Wave-wide sum of a per-lane counter (DPP row shifts / broadcasts, as sfsn_feat_dev.h's wave_sum), then ONE 64-bit atomic per wave:
+// the exit of a scan workgroup that counted the spikes it flushed (a launch that writes no fp32 spike tensor, ScanSegDev::count).
+__device__ __forceinline__ void wave_count_add(unsigned long long* dst, unsigned cnt) {
+    if (dst == nullptr) return;  // (wave-uniform)
+    int v = (int)cnt;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8  -> lane 15 of a row = row sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2, 3 -> lane 63 = total
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane(v, 63);
+    if (total != 0 && (threadIdx.x & 63) == 0) atomicAdd(dst, (unsigned long long)total);
+}
+__device__ __forceinline__ unsigned popc16(const v4i d) {  // spikes in 16 bytes of 0 / 1
+    return __builtin_popcount((unsigned)d.x) + __builtin_popcount((unsigned)d.y) + __builtin_popcount((unsigned)d.z) + __builtin_popcount((unsigned)d.w);
+}
 
 __device__ __forceinline__ float recombine3(int a0, int a1, int a2) {
     // exact value (a2*65536 + a1*256 + a0) rounded ONCE to fp32: |a1*256 + a0| < 2^24 is exact as a float,
@@ -222,16 +244,23 @@ struct ScanFlush {
     // lane (4-byte sc1 stores are one fabric write each), threads [0, rpw * HP/16) take one chunk each
     int o8_lds, nact8;
     unsigned o8_glb;
+    // spike counting (launches without an fp32 spike tensor, ScanSegDev::count): bit k of `real` = my chunk slot k is the ONE writer of
+    // its four bytes (not a pad column's or a past-R row's duplicate), bit 31 = the same for my 16-byte write-through chunk; `cnt` =
+    // spikes I have flushed so far.  Dead code (and no registers) in the instantiations that write fp32 spikes.
+    unsigned real, cnt;
     __device__ __forceinline__ void init(int tid, int row0, int R, int H, int nthreads, int rpw) {
         const int chunks = rpw * (C::HP / 4);  // multiple of 64: a wave is active or idle as a whole in every slot
         const int tid0 = __builtin_amdgcn_readfirstlane(tid & ~63);
         nact = 0;
+        real = 0;
+        cnt = 0;
 #pragma unroll
         for (int k = 0; k < C::FL; ++k) {
             if (tid0 + k * nthreads < chunks) nact = k + 1;
             const int c = (tid + k * nthreads) % chunks;
             const int rr = c / (C::HP / 4);
             int j4 = (c - rr * (C::HP / 4)) * 4;
+            if (tid + k * nthreads < chunks && j4 <= H - 4 && row0 + rr < R) real |= 1u << k;
             if (j4 > H - 4) j4 = H - 4;  // pad columns duplicate the row's last real chunk (same data, same address)
             const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;  // rows past R duplicate row R-1
             off_lds[k] = rr * C::LDH + j4;
@@ -246,7 +275,13 @@ struct ScanFlush {
             const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;
             o8_lds = rr * C::LDH + j16;
             o8_glb = (unsigned)(rsrc * C::HP + j16);
+            if (tid < chunks16 && row0 + rr < R) real |= 1u << 31;  // (pad columns of the LDS buffer hold zeros: they count nothing)
         }
+    }
+    // at the end of a scan body: this wave's count -> the segment's counter (one atomic per wave)
+    template <int OUT>
+    __device__ __forceinline__ void finish(unsigned long long* count) const {
+        if constexpr (!(OUT & 1)) wave_count_add(count, cnt);
     }
     // stores this wave issues per flushed frame (the counted waits of the scan bodies need it)
     template <int OUT, bool SC1>
@@ -256,19 +291,25 @@ struct ScanFlush {
     }
     template <int OUT, bool SC1 = false>
     __device__ __forceinline__ void run(const int8_t* hsrc, float* __restrict__ spikes_f32, int8_t* __restrict__ spikes_i8, int ts,
-                                        int R, int H) const {
+                                        int R, int H) {
         if constexpr (C::NSTF > 0) {
+            constexpr bool CNT = !(OUT & 1);  // no fp32 spike tensor: count what is flushed
             if (OUT & 256) ts = 0;  // (bit 8: timing experiment, fixed frame)
             float* pf = spikes_f32 + (size_t)ts * R * H;
             int8_t* p8 = spikes_i8 + (size_t)ts * R * C::HP;
             if constexpr (SC1 && (OUT & 2)) {
-                if (nact8) store16_sc1(p8, o8_glb, *reinterpret_cast<const v4i*>(hsrc + o8_lds));  // wave-uniform branch
+                if (nact8) {  // wave-uniform branch
+                    const v4i d8 = *reinterpret_cast<const v4i*>(hsrc + o8_lds);
+                    store16_sc1(p8, o8_glb, d8);
+                    if constexpr (CNT) cnt += (real >> 31) ? popc16(d8) : 0u;
+                }
             }
             if constexpr (SC1 && !(OUT & 1)) return;
 #pragma unroll
             for (int k = 0; k < C::FL; ++k) {
                 if (k >= nact) break;  // wave-uniform
                 const unsigned pk = *reinterpret_cast<const unsigned*>(hsrc + off_lds[k]);
+                if constexpr (CNT && !SC1) cnt += ((real >> k) & 1u) ? (unsigned)__builtin_popcount(pk) : 0u;
                 if ((OUT & 2) && !SC1) *reinterpret_cast<unsigned*>(p8 + off_i8[k]) = pk;
                 if (OUT & 1) {
                     const v4f sp = {(float)(pk & 0xffu), (float)((pk >> 8) & 0xffu), (float)((pk >> 16) & 0xffu), (float)(pk >> 24)};
@@ -354,7 +395,8 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
                                           float* __restrict__ spikes_f32, int8_t* __restrict__ spikes_i8,
                                           float* __restrict__ membrane, float* __restrict__ h_state, float* __restrict__ c_state,
                                           char* smem, int T, int H, int NT, int R, int row0, int rowc, int n, int q, int tid,
-                                          int wave, int rpw, const StackLink* lk = nullptr, int* gate_word = nullptr) {
+                                          int wave, int rpw, const StackLink* lk = nullptr, int* gate_word = nullptr,
+                                          unsigned long long* count = nullptr) {
     using C = ScanCfg<G, KS, NW, TPW, OUT, LP>;
     constexpr int LDH = C::LDH, HP = C::HP, D = C::RING_D;
     constexpr bool GATED = (FLG & 1) != 0, PUB = (FLG & 2) != 0;
@@ -390,6 +432,7 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+        fl.template finish<OUT>(count);
         return;
     } else {
         const int ldz = G * H;
@@ -599,6 +642,7 @@ __device__ __forceinline__ void scan_body(const float* __restrict__ zin, const i
             __builtin_amdgcn_s_barrier();
             if (wave == 0 && lane == 0) stack_publish(*lk, T);  // (also after an expired spin: consumers must not wait for us)
         }
+        fl.template finish<OUT>(count);
         // final state (duplicate rows write the same values to the same place)
         const int8_t* hl = hbuf + (T & 1) * 16 * LDH;  // h_{T-1} (or the untouched initial state when T == 0)
 #pragma unroll

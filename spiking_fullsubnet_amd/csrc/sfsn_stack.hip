@@ -58,6 +58,7 @@ struct StackRoleDev {
     int src;      // producer role (-1: the input is complete before the launch)
     int src_rpw;  // rows per workgroup of the producer role
     int pub;      // 1: another role of this launch consumes what this role writes
+    unsigned long long* count;  // nullable: without fp32 spikes the role adds the number of spikes it wrote (ScanSegDev::count)
 };
 
 struct StackParams {
@@ -69,6 +70,8 @@ struct StackParams {
     int gate_off;    // byte offset of the gate word in the dynamic LDS allocation (behind every role's layout)
     int v2;          // 1: round 2's scan body in the wide flavour (SFSN_SCAN_V2=1: A/B runs)
     int exp_flags;   // timing experiments (SFSN_STACK_EXP, wrong results): see proj3_role
+    int lsplit;      // 8-row IO-wave roles: fp32 store instructions per frame issued by the loader wave (SFSN_S3_LSPLIT)
+    int lsplit_x;    // ... of the FUSEDX3 role
 };
 
 
@@ -275,6 +278,7 @@ __device__ __forceinline__ void stack_fused_body(const StackRoleDev& rl, const S
         __builtin_amdgcn_s_barrier();
         if (wave == 0 && lane == 0) stack_publish(lk, T);
     }
+    fl.template finish<OUT>(rl.count);
     const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
 #pragma unroll
     for (int i = 0; i < NTL; ++i) {
@@ -505,10 +509,10 @@ __device__ __forceinline__ void stack_zin_role(const StackRoleDev& rl, const Sta
     const int n_hi = NT - NW * (TPW - 1);  // waves [0, n_hi) own TPW tiles, the others TPW-1
     if (wave < n_hi)
         scan_body<1, KS, NW, TPW, OUT, LP, TPW, FLG>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, nullptr, sg.h_state, sg.c_state, smem, T, H,
-                                                     NT, R, row0, rowc, n, q, tid, wave, rpw, &lk, gate_word);
+                                                     NT, R, row0, rowc, n, q, tid, wave, rpw, &lk, gate_word, rl.count);
     else
         scan_body<1, KS, NW, TPW, OUT, LP, TPW - 1, FLG>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, nullptr, sg.h_state, sg.c_state, smem, T,
-                                                         H, NT, R, row0, rowc, n, q, tid, wave, rpw, &lk, gate_word);
+                                                         H, NT, R, row0, rowc, n, q, tid, wave, rpw, &lk, gate_word, rl.count);
 }
 
 // =====================================================================================================================
@@ -654,10 +658,10 @@ __device__ __forceinline__ void stack_zin16_role(const StackRoleDev& rl, const S
     scan_prologue<1, KS, NW, 1, OUT, 0>(sg, smem, tid, H, NT, R, row0, rpw);
     if (wave < NT)
         scan_body<1, KS, NW, 1, OUT, 0, 1, FLG>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, nullptr, sg.h_state, sg.c_state, smem, T, H, NT, R, row0,
-                                                rowc, n, q, tid, wave, rpw, &lk, gate_word);
+                                                rowc, n, q, tid, wave, rpw, &lk, gate_word, rl.count);
     else
         scan_body<1, KS, NW, 1, OUT, 0, 0, FLG>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, nullptr, sg.h_state, sg.c_state, smem, T, H, NT, R, row0,
-                                                rowc, n, q, tid, wave, rpw, &lk, gate_word);
+                                                rowc, n, q, tid, wave, rpw, &lk, gate_word, rl.count);
 }
 
 template <int KS, int OUT>
@@ -693,7 +697,7 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         Scan3xRole rx;
         rx.x = rl.x; rx.w_ih = rl.w_ih_f32; rx.I = rl.I; rx.w_hh = rl.w_hh; rx.w_dq = rl.w_dq; rx.bias = rl.bias;
         rx.bn_alpha = rl.bn_alpha; rx.bn_beta = rl.bn_beta; rx.h_state = rl.h_state; rx.c_state = rl.c_state;
-        rx.spikes_f32 = rl.spikes_f32; rx.spikes_i8 = rl.spikes_i8; rx.R = rl.R; rx.row0 = blk * 8;
+        rx.spikes_f32 = rl.spikes_f32; rx.spikes_i8 = rl.spikes_i8; rx.R = rl.R; rx.row0 = blk * 8; rx.count = rl.count; rx.lsplit = p.lsplit_x;
         const bool tl = (H & 63) != 0 && (H & 63) <= 32;
 #define X3_CASE(TL_, F_)                                                                    \
     {                                                                                       \
@@ -712,7 +716,7 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         Scan3iRole ri;
         ri.spikes_in = rl.spikes_in; ri.w_ih = rl.w_ih; ri.w_ih_dq = rl.w_ih_dq; ri.w_hh = rl.w_hh; ri.w_dq = rl.w_dq; ri.bias = rl.bias;
         ri.bn_alpha = rl.bn_alpha; ri.bn_beta = rl.bn_beta; ri.h_state = rl.h_state; ri.c_state = rl.c_state;
-        ri.spikes_f32 = rl.spikes_f32; ri.spikes_i8 = rl.spikes_i8; ri.R = rl.R; ri.row0 = blk * 8;
+        ri.spikes_f32 = rl.spikes_f32; ri.spikes_i8 = rl.spikes_i8; ri.R = rl.R; ri.row0 = blk * 8; ri.count = rl.count;
         const bool tl = (H & 63) != 0 && (H & 63) <= 32;  // the k tail as one 16x16x32 step
         // (KS = 4 with at most 14 tiles is H = 208 or 224: always the tail form -- four full k-steps of both matrices do not fit)
         if (rl.pub) {
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
             Scan3Role r3;
             r3.zin = rl.zin; r3.w_hh = rl.w_hh; r3.w_dq = rl.w_dq; r3.bias = rl.bias; r3.bn_alpha = rl.bn_alpha; r3.bn_beta = rl.bn_beta;
             r3.h_state = rl.h_state; r3.c_state = rl.c_state; r3.spikes_f32 = rl.spikes_f32; r3.spikes_i8 = rl.spikes_i8;
-            r3.R = rl.R; r3.row0 = blk * rl.rpw;
+            r3.R = rl.R; r3.row0 = blk * rl.rpw; r3.count = rl.count; r3.lsplit = p.lsplit;
 #define S3_CASE(RPW_, F) \
     if (rl.rpw == RPW_ && flg == F) scan3_role<KS, RPW_, OUT, F>(r3, lk, scan_smem, T, H, NT, p.exp_flags);
             S3_CASE(4, 0) S3_CASE(4, 1) S3_CASE(4, 2) S3_CASE(4, 3)
@@ -929,7 +933,7 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
             StackRoleDev& r = p.role[nroles];
             r = StackRoleDev{};
             r.w_hh = s.w_hh; r.w_dq = s.w_dq; r.bias = s.bias; r.bn_alpha = s.bn_alpha; r.bn_beta = s.bn_beta;
-            r.h_state = s.h_state; r.c_state = s.c_state; r.spikes_f32 = s.spikes_f32; r.spikes_i8 = s.spikes_i8;
+            r.h_state = s.h_state; r.c_state = s.c_state; r.spikes_f32 = s.spikes_f32; r.spikes_i8 = s.spikes_i8; r.count = s.spike_count;
             r.zin = const_cast<float*>(s.zin);
             r.R = s.R; r.rpw = rpw; r.block0 = blocks; r.nblocks = (s.R + rpw - 1) / rpw;
             r.pub = last ? 0 : 1;
@@ -994,6 +998,8 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
     if (getenv("SFSN_STACK_DEBUG") && (size_t)(blocks + 2) * 5 * sizeof(unsigned) <= scratch_bytes) p.dbg = p.prog + blocks + 2;
     p.nroles = nroles; p.T = T; p.H = H; p.NT = NT; p.lag = lag; p.nblocks = blocks;
     p.v2 = getenv("SFSN_SCAN_V2") ? 1 : 0;
+    p.lsplit = sfsn_s3_lsplit_host();
+    p.lsplit_x = sfsn_s3x_lsplit_host();
     // timing switches of the hand-off roles (wrong results by design: stores dropped, waits skipped): compiled in only with
     // -DSFSN_EXPERIMENTS (make EXTRA=-DSFSN_EXPERIMENTS, scripts/exp_stack_r03.sh) -- a stray environment variable must not be
     // able to corrupt a production launch

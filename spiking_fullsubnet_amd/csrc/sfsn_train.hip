@@ -1012,6 +1012,28 @@ static int seq_multi_geometry(const int* R, int n, int H, int shared, int* wgs, 
     return SFSN_OK;
 }
 
+// Will the per-step launches (sfsn_gsn_train_step_fwd / _bwd: round 3's kernels, what training.py falls back to when the one-launch
+// layer call cannot hold its workgroups resident, and what the eval-mode-BatchNorm path always runs) take (R, H)?  Their own LDS
+// formulas (smaller than the one-launch kernels': no carried membrane, no packed spike rows), and -- with more than one row block --
+// the same residency condition per step launch (the row blocks of a step exchange their partial sums inside the launch).
+extern "C" int sfsn_gsn_train_step_check(int R, int H, int shared) {
+    if (R <= 0 || H <= 0) return SFSN_EINVAL;
+    if (H % TR_TILE != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
+    int RB, rpb;
+    const int G = shared ? 1 : 2, tiles = H / TR_TILE;
+    train_geometry(R, H, G, &RB, &rpb);
+    if (RB > 16) return SFSN_EUNSUPPORTED;
+    const size_t lds_f = ((size_t)G * TR_TILE * (H + 1) + (size_t)rpb * TR_TILE + (size_t)RB * TR_PART) * sizeof(float) + (size_t)rpb * H;
+    const size_t lds_b = ((size_t)rpb * TR_TILE + (size_t)RB * TR_PART + (size_t)G * H * (TR_TILE + rpb)) * sizeof(float);
+    if (lds_f > 150 * 1024 || lds_b > 150 * 1024) return SFSN_EUNSUPPORTED;
+    if (RB > 1) {
+        const int sf = seq_slots(reinterpret_cast<const void*>(gsn_train_step_fwd_kernel), lds_f), sb = seq_slots(reinterpret_cast<const void*>(gsn_train_step_bwd_kernel), lds_b);
+        if (sf < 0 || sb < 0) return SFSN_EHIP;
+        if (tiles * RB > sf || tiles * RB > sb) return SFSN_EUNSUPPORTED;
+    }
+    return SFSN_OK;
+}
+
 // SFSN_OK when ONE launch per direction can hold the workgroups of all n layer calls (rows R[i], same H / gate sharing) resident
 // together; SFSN_EUNSUPPORTED otherwise (issue the calls one after the other, or in smaller sets).  Needs the device.
 extern "C" int sfsn_gsn_train_multi_check(const int* R, int n, int H, int shared) {

@@ -186,6 +186,33 @@ class SpikeSummary:
         return f"SpikeSummary(shape={tuple(self.shape)})"
 
 
+SOAKED_HW_QUEUES = (4, 24)  # GPU_MAX_HW_QUEUES values the two-stream schedule has been soaked under (unset = HIP's default of 4)
+_hw_queues_warned = False
+
+
+def _check_hw_queues() -> int:
+    """The overlapped schedule of a forward alone runs two launches of resident workgroups with in-launch waits on two HIP streams
+    (the sub-band pair launch and the full-band stack), and bench.py's timed region a dozen forwards on as many streams.  How the
+    runtime maps streams onto hardware queues is `GPU_MAX_HW_QUEUES` (read by HIP once, at its initialisation).  Three such launches
+    on three streams stopped being dispatched within 3-120 iterations at 4 and 8 queues and never at 2 (the training path's layer
+    calls, scripts/dbg_train_hang.py, profiles/EXPERIMENTS.md; root cause unknown -- training was moved to one grid).  The inference
+    schedules were soaked at the default (4: the -m gpu suite, scripts/soak_r04.py, 3000 forwards) and at 24 (bench.py): every
+    in-launch wait is bounded and reported, so another value can cost a loud failure, never wrong results -- warn once."""
+    global _hw_queues_warned
+    raw = os.environ.get("GPU_MAX_HW_QUEUES", "")
+    try:
+        n = int(raw) if raw else 4
+    except ValueError:
+        n = 4
+    if n not in SOAKED_HW_QUEUES and not _hw_queues_warned:
+        _hw_queues_warned = True
+        import warnings
+        warnings.warn(f"GPU_MAX_HW_QUEUES={raw}: the two-stream schedule of spiking_fullsubnet_amd was soaked at {SOAKED_HW_QUEUES} "
+                      "hardware queues only (see README.md, limits); in-launch waits are bounded and raise, results are never silently wrong",
+                      RuntimeWarning, stacklevel=3)
+    return n
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -235,6 +262,7 @@ class Engine:
         _ss = os.environ.get('SFSN_STACK_SCAN', 'auto')
         self.stack_scan = "auto" if _ss == "auto" else bool(int(_ss))
         self.stack_rows_fb_auto = int(os.environ.get("SFSN_FB_STACK_ROWS", "4"))  # rows per workgroup of the full-band stack under "auto"
+        self.count_in_scan = os.environ.get("SFSN_COUNT_IN_SCAN", "1") != "0"  # layer_outputs="counts": counted by the scans themselves
         self.pair_scan = os.environ.get("SFSN_PAIR_SCAN", "1") != "0"  # H <= 224 stacks as one launch of FUSED3 roles (see _stack_choice)
         self.stack_rows_per_wg = {"fb": 4, "sb": 8}  # rows per workgroup of every layer of a stack: sum of workgroups <= CUs
         self.stack_lag = 16
@@ -265,6 +293,7 @@ class Engine:
         self._stack_err_pending: List[tuple] = []  # (event, pinned copy of a launch's error word): polled at the next forward
         self._defer_err = None  # overlapped schedule: [(what, scratch)] of the running forward's stack launches (one copy per forward)
         self._err_stream = None
+        self.hw_queues = _check_hw_queues()
 
     # ---------------------------------------------------------------------------------------------
     def _stream(self):
@@ -358,7 +387,7 @@ class Engine:
                         check(L.sfsn_spike_proj(ctypes.c_void_p(src.data_ptr() + t0 * R * src.shape[2]), _ptr(pk), _ptr(dq), bp, zp, M,
                                                 H, H, G * H, st), "sfsn_spike_proj")
 
-    def _stage_scan(self, seqs, l, zins, states, spks, s8s, mems, t0, nt, st, tag, rpw):
+    def _stage_scan(self, seqs, l, zins, states, spks, s8s, mems, t0, nt, st, tag, rpw, cnts=None):
         L, spec = self.lib, self.spec
         H = seqs[0].H
         HP = (H + 63) // 64 * 64
@@ -371,6 +400,7 @@ class Engine:
             sg.membrane = None if mems[i] is None else ctypes.c_void_p(mems[i].data_ptr() + t0 * R * H * 4)
             sg.spikes_i8 = ctypes.c_void_p(s8s[i].data_ptr() + t0 * R * HP)
             sg.R = R
+            sg.spike_count = None if cnts is None else _ptr(cnts[i])
         with self.timed("scan:" + tag, st):
             rc = _lib.SFSN_EUNSUPPORTED
             if self.weight_bits == 16 and self.w16_fast:  # the two-plane scan where the library has it (same results)
@@ -393,7 +423,7 @@ class Engine:
         return bool(self.fuse_input and self.spec.shared and 128 < seq.H <= 256 and rpw == 16 and not want_membrane
                     and seq.I % 2 == 0 and seq.I <= 64 and x.shape[1] % 16 == 0)
 
-    def _stage_scan_fused_x(self, seqs, xs_, states, spks, s8s, t0, nt, st, tag):
+    def _stage_scan_fused_x(self, seqs, xs_, states, spks, s8s, t0, nt, st, tag, cnts=None):
         """Layer 0 of the given sequence models, input product inside the scan."""
         L = self.lib
         H = seqs[0].H
@@ -408,13 +438,14 @@ class Engine:
             sg.membrane = None
             sg.spikes_i8 = ctypes.c_void_p(s8s[i].data_ptr() + t0 * R * HP)
             sg.R = R
+            sg.spike_count = None if cnts is None else _ptr(cnts[i])
             fin[i].x = x.data_ptr() + t0 * R * seq.I * 4
             fin[i].w_ih, fin[i].I = cell.w_ih_f32.data_ptr(), seq.I
         self.launches["fused_x"] = self.launches.get("fused_x", 0) + 1
         with self.timed("scanx:" + tag, st):
             check(L.sfsn_gsn_layer_scan_fused_x(segs, fin, len(seqs), nt, H, st), "sfsn_gsn_layer_scan_fused_x")
 
-    def _stage_scan_fused(self, seqs, l, states, spks, s8s, t0, nt, st, tag):
+    def _stage_scan_fused(self, seqs, l, states, spks, s8s, t0, nt, st, tag, cnts=None):
         L = self.lib
         H = seqs[0].H
         HP = (H + 63) // 64 * 64
@@ -429,6 +460,7 @@ class Engine:
             sg.membrane = None
             sg.spikes_i8 = ctypes.c_void_p(s8s[l][i].data_ptr() + t0 * R * HP)
             sg.R = R
+            sg.spike_count = None if cnts is None else _ptr(cnts[i])
             fin[i].spikes_in = s8s[l - 1][i].data_ptr() + t0 * R * HP
             fin[i].w_ih, fin[i].w_ih_dq = pk.data_ptr(), dq.data_ptr()
         self.launches["fused"] = self.launches.get("fused", 0) + 1
@@ -511,6 +543,7 @@ class Engine:
                 sg.membrane = None
                 sg.spikes_i8 = ctypes.c_void_p(d["s8"][l][i].data_ptr() + t0 * R * HP)
                 sg.R = R
+                sg.spike_count = _ptr(d["cnt"][l][i]) if d.get("cnt") is not None else None
                 if l > 0:
                     pk, dq = cell.w_ih_q[0]
                     fin[l * ns + i].spikes_in = d["s8"][l - 1][i].data_ptr() + t0 * R * HP
@@ -615,7 +648,7 @@ class Engine:
             out.append(row)
         return out
 
-    def _alloc_stack(self, seqs, Rs, T, nt_max, want_layers, want_membrane, tag, state_flat=None):
+    def _alloc_stack(self, seqs, Rs, T, nt_max, want_layers, want_membrane, tag, state_flat=None, counts=None):
         """Per-forward tensors of a stack of sequence models sharing (H, L): API outputs are fresh, scratch is cached."""
         dev, H, G, nl = self.device, seqs[0].H, seqs[0].cells[0].G, len(seqs[0].cells)
         HP = (H + 63) // 64 * 64
@@ -636,7 +669,9 @@ class Engine:
             states=self._zero_states(Rs, H, nl, state_flat),  # zero init, modeling:100-106
             spk=[[torch.empty((T, R, H), **f32) if want_layers else None for R in Rs] for _ in range(nl)],
             mem=[[torch.empty((T, R, H), **f32) if want_membrane else None for R in Rs] for _ in range(nl)],
-            proj=[torch.empty((T, R, seq.P), **f32) for seq, R in zip(seqs, Rs)])
+            proj=[torch.empty((T, R, seq.P), **f32) for seq, R in zip(seqs, Rs)],
+            # in-scan spike counters (layer_outputs="counts"): one zeroed int64 per (layer, sequence model), or None
+            cnt=None if counts is None else [[counts[l * len(Rs) + i] for i in range(len(Rs))] for l in range(nl)])
 
     def _feature_groups(self, which: str, xs, mu, sd=None):
         spec = self.spec
@@ -846,10 +881,18 @@ class Engine:
         n_fb = 2 * nl_fb * B * self.fb.H
         n_sb = 2 * nl_sb * sum(x.shape[1] for x in xs) * self.sb[0].H
         fold = os.environ.get("SFSN_ZERO_FOLD", "1") != "0"  # (0: a fill launch of its own, for comparison)
-        state_flat = torch.empty((n_fb + n_sb,), **f32) if fold else torch.zeros((n_fb + n_sb,), **f32)
+        # layer_outputs="counts": the scans count the spikes they write (sfsn_scan_segment.spike_count) -- the int64 counters sit behind
+        # the states in the same zeroed buffer (two floats each; the buffer's length stays a multiple of 16 bytes)
+        in_scan = bool(want_counts and not want_layers and self.count_in_scan)
+        n_cnt = (nl_fb + ng * nl_sb) if in_scan else 0
+        n_cnt_f = (2 * n_cnt + 3) // 4 * 4
+        state_flat = torch.empty((n_fb + n_sb + n_cnt_f,), **f32) if fold else torch.zeros((n_fb + n_sb + n_cnt_f,), **f32)
         zero_job = [state_flat] if fold else []
-        fb = self._alloc_stack([self.fb], [B], T, T if prep_ahead else nt_max, want_layers, want_membrane, "fb", state_flat[:n_fb])
-        sb = self._alloc_stack(self.sb, [x.shape[1] for x in xs], T, nt_max, want_layers, want_membrane, "sb", state_flat[n_fb:])
+        cnt_all = state_flat[n_fb + n_sb:n_fb + n_sb + 2 * n_cnt].view(torch.int64) if in_scan else None
+        fb = self._alloc_stack([self.fb], [B], T, T if prep_ahead else nt_max, want_layers, want_membrane, "fb", state_flat[:n_fb],
+                               None if cnt_all is None else cnt_all[:nl_fb])
+        sb = self._alloc_stack(self.sb, [x.shape[1] for x in xs], T, nt_max, want_layers, want_membrane, "sb", state_flat[n_fb:n_fb + n_sb],
+                               None if cnt_all is None else cnt_all[nl_fb:])
         enh = torch.empty((B, S, F, T), dtype=torch.complex64, device=dev)
         enh_mag = torch.empty((B, S, F, T), **f32)
         enh_ri = torch.view_as_real(enh)
@@ -956,6 +999,7 @@ class Engine:
             # layer 0: groups whose real-valued input product can run inside the scan / the rest (input product first)
             fx = [i for i in range(len(seqs)) if self._fusable_x(seqs[i], xs_[i], rpw, want_membrane)]
             rest = [i for i in range(len(seqs)) if i not in fx]
+            cn = d.get("cnt")
             for c, (t0, nt) in enumerate(bounds):
                 for l in range(nl):
                     si = first + l
@@ -976,14 +1020,16 @@ class Engine:
                     if l == 0:
                         if fx:
                             self._stage_scan_fused_x(pick(seqs, fx), pick(xs_, fx), pick(d["states"][0], fx), pick(d["spk"][0], fx),
-                                                     pick(d["s8"][0], fx), t0, nt, hS[si], tag)
+                                                     pick(d["s8"][0], fx), t0, nt, hS[si], tag, cnts=None if cn is None else pick(cn[0], fx))
                         if rest:
                             self._stage_scan(pick(seqs, rest), 0, pick(d["zin"][0], rest), pick(d["states"][0], rest), pick(d["spk"][0], rest),
-                                             pick(d["s8"][0], rest), pick(d["mem"][0], rest), t0, nt, hS[si], tag, rpw)
+                                             pick(d["s8"][0], rest), pick(d["mem"][0], rest), t0, nt, hS[si], tag, rpw,
+                                             cnts=None if cn is None else pick(cn[0], rest))
                     elif fused:
-                        self._stage_scan_fused(seqs, l, d["states"][l], d["spk"][l], d["s8"], t0, nt, hS[si], tag)
+                        self._stage_scan_fused(seqs, l, d["states"][l], d["spk"][l], d["s8"], t0, nt, hS[si], tag, cnts=None if cn is None else cn[l])
                     else:
-                        self._stage_scan(seqs, l, d["zin"][l], d["states"][l], d["spk"][l], d["s8"][l], d["mem"][l], t0, nt, hS[si], tag, rpw)
+                        self._stage_scan(seqs, l, d["zin"][l], d["states"][l], d["spk"][l], d["s8"][l], d["mem"][l], t0, nt, hS[si], tag, rpw,
+                                         cnts=None if cn is None else cn[l])
                     if staged:
                         link(sc, g)  # the chunk-local zin buffer is reused by the next chunk's input product
                     # ---- after the last layer: projection and whatever follows the model
@@ -1077,10 +1123,15 @@ class Engine:
         self._defer_err = None
 
         if want_counts and not want_layers:
-            # SynOPs without the fp32 spike tensors: count the int8 spikes, one launch for all layers
+            # SynOPs without the fp32 spike tensors: the scans have counted what they wrote (no launch, no pass over
+            # the int8 copies); `count_in_scan = False`: round 3's counting launch over the int8 spikes, one launch for all layers
             tens = [fb["s8"][l][0] for l in range(nl_fb)] + [sb["s8"][l][g] for g in range(ng) for l in range(nl_sb)]
             shapes = [(T, B, self.fb.H)] * nl_fb + [(T, xs[g].shape[1], self.sb[g].H) for g in range(ng) for _ in range(nl_sb)]
-            summ = self._count_spikes(tens, shapes, self._handle(main))
+            if in_scan:
+                summ = [SpikeSummary(fb["cnt"][l][0], shapes[l]) for l in range(nl_fb)] + \
+                       [SpikeSummary(sb["cnt"][l][g], shapes[nl_fb + g * nl_sb + l]) for g in range(ng) for l in range(nl_sb)]
+            else:
+                summ = self._count_spikes(tens, shapes, self._handle(main))
             for l in range(nl_fb):
                 fb["spk"][l][0] = summ[l]
             for g in range(ng):

@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import List
 
 import torch
@@ -46,30 +47,69 @@ _EXCHANGE_FAILED = ("sfsn_gsn_train_step: the row blocks of a step did not all a
                     "the outputs of that layer call are invalid")
 launch_log = None  # bench.py --training sets a list: (direction, T, [(R, H, G*H) per layer call], start event, end event) per launch
 _debug_scratch = None  # scripts/dbg_train_hang.py sets a list: every layer call appends (what, R, H, T, scratch tensor)
-_pending: list = []  # (event, pinned copy of a forward call's error word): looked at, without blocking, by the next layer call
+_pending: list = []  # (event, pinned copy of a layer call's error word); forward thread and autograd thread both touch it: _lock
+_lock = threading.Lock()
+_final_check_queued = False
 
 
 def check_pending() -> None:
     """Wait for every layer call issued so far and raise if one of them reported a failed row-block exchange (its outputs and
-    gradients are invalid; the gradients are NaN).  A training loop may call this before its optimiser step; without it the next
-    layer call raises."""
+    gradients are invalid; the gradients are NaN).  Called by the package itself at the end of every backward pass (see
+    _queue_final_check), so a training loop needs no call of its own."""
     _poll_pending(block=True)
 
 
 def _poll_pending(block: bool = False) -> None:
     """Raise if an earlier layer call reported a failed row-block exchange (a forward nobody followed with a backward, or a
     backward: its gradients are NaN)."""
-    keep = []
-    for ev, pin in _pending:
+    with _lock:
+        items, _pending[:] = list(_pending), []
+    keep, failed = [], False
+    for ev, pin in items:
         if block:
             ev.synchronize()
         if ev.query():
-            if int(pin.max().item()) != 0:
-                _pending.clear()
-                raise RuntimeError(_EXCHANGE_FAILED)
+            failed = failed or int(pin.max().item()) != 0
         else:
             keep.append((ev, pin))
-    _pending[:] = keep
+    with _lock:
+        if failed:
+            _pending.clear()
+        else:
+            _pending[:0] = keep
+    if failed:
+        raise RuntimeError(_EXCHANGE_FAILED)
+
+
+def _push_pending(ev, pin) -> None:
+    with _lock:
+        _pending.append((ev, pin))
+
+
+def _queue_final_check() -> None:
+    """Called from a layer call's backward(): have the autograd engine run check_pending() ONCE when the backward pass that is
+    executing has finished (the mechanism DistributedDataParallel uses for its final reductions).  `loss.backward()` then raises on a
+    failed exchange itself -- before the recipe's `optimizer.step()` can apply NaN gradients to the weights (round-4 advisor finding:
+    the reference's trainer never calls check_pending(), recipes/intel_ndns/spiking_fullsubnet/trainer.py:24-48).  One host
+    synchronisation per training step, at a point where every launch of the step has been enqueued; the layer calls themselves
+    still do not block (the sub-band groups share a grid, the autograd thread keeps enqueueing)."""
+    global _final_check_queued
+    with _lock:
+        if _final_check_queued:
+            return
+        _final_check_queued = True
+
+    def _final():
+        global _final_check_queued
+        with _lock:
+            _final_check_queued = False
+        check_pending()
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_final)
+    except Exception:  # (not inside a backward pass of the engine -- e.g. a test calling backward() by hand): block here instead
+        with _lock:
+            _final_check_queued = False
+        check_pending()
 
 
 class _Logged:
@@ -106,8 +146,23 @@ class GSNLayerTrainFn(torch.autograd.Function):
         T, R, I = x.shape
         GH, H = w_hh.shape
         dev = x.device
-        # both directions' geometry up front: the backward step needs more LDS than the forward one at large R
-        check(L.sfsn_gsn_train_check(R, H, int(shared)), f"sfsn_gsn_train_check(R={R}, H={H})")
+        # both directions' geometry up front (a forward pass must not succeed -- and update the BatchNorm buffers -- where the backward
+        # pass would be refused): the one-launch layer call needs every workgroup of BOTH directions resident (LDS and occupancy:
+        # sfsn_gsn_train_multi_check with one call).  Where it cannot be, round 3's launch per step is taken IF those kernels can hold
+        # a step's workgroups (sfsn_gsn_train_step_check: their own, smaller LDS needs -- the eval-mode-BatchNorm path always runs them);
+        # a geometry neither form holds (e.g. H = 320, R ~ 1200: 300 workgroups against 256 slots of either backward kernel) is
+        # refused here, before anything has run
+        use_bn = bn_w is not None
+        fold = use_bn and not batch_stats  # eval-mode BatchNorm: y = x * alpha + beta with the running statistics
+        seq = not fold and not STEP_LAUNCHES
+        if seq:
+            rc = L.sfsn_gsn_train_multi_check((ctypes.c_int * 1)(R), 1, H, int(shared))
+            if rc == _lib.SFSN_EUNSUPPORTED:
+                seq = False
+            else:
+                check(rc, f"sfsn_gsn_train_multi_check(R={R}, H={H})")
+        if not seq:
+            check(L.sfsn_gsn_train_step_check(R, H, int(shared)), f"sfsn_gsn_train_step_check(R={R}, H={H})")
         if bn_w is not None and batch_stats:
             if R == 1:  # nn.BatchNorm1d in training mode (torch/nn/functional.py: _verify_batch_size)
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([{R}, {H}])")
@@ -125,8 +180,6 @@ class GSNLayerTrainFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         spikes, u = torch.empty((T, R, H), **f32), torch.empty((T, R, H), **f32)
         fg, gg = torch.empty((T, R, H), **f32), torch.empty((T, R, H), **f32)
-        use_bn = bn_w is not None
-        fold = use_bn and not batch_stats  # eval-mode BatchNorm: y = x * alpha + beta with the running statistics
         if fold:
             rm, rv = stats[0].float(), stats[1].float()
             alpha = bn_w.detach().float() / torch.sqrt(rv + eps)
@@ -149,7 +202,6 @@ class GSNLayerTrainFn(torch.autograd.Function):
         a_bw, a_bb, a_rm, a_rv = _p(bw), _p(bb), _p(rmean), _p(rvar)
         mom, ep, sh = float(0.1 if momentum is None else momentum), float(eps), int(shared)
         fwd = L.sfsn_gsn_train_step_fwd
-        seq = not fold and not STEP_LAUNCHES
         # zeroed per call: packed-spike slots and publish counters of the one-launch layer call, partial-sum granules, error word (last 4 words)
         scr = torch.zeros(((L.sfsn_train_seq_scratch_bytes(R, H) if seq else L.sfsn_train_scratch_bytes(H)) // 4,), dtype=torch.int32, device=dev)
         p_scr = P(scr.data_ptr())
@@ -183,12 +235,13 @@ class GSNLayerTrainFn(torch.autograd.Function):
                 pin.copy_(scr[-4:], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(dev))
-                _pending.append((ev, pin))
+                _push_pending(ev, pin)
         if use_bn and batch_stats and stats is not None and stats[2] is not None:
             stats[2].add_(T)  # num_batches_tracked: one BatchNorm call per time step
         ctx.save_for_backward(x, w_ih_c, w_hh_c, spikes, u, fg, gg, xhat if xhat is not None else zero, invstd if invstd is not None else zero,
                               bw if bw is not None else zero, alpha if fold else zero)
         ctx.meta = (bool(shared), use_bn, fold, T, R, I, H, GH)
+        ctx.seq = seq  # (backward takes the same form as forward did)
         return spikes
 
     @staticmethod
@@ -218,7 +271,7 @@ class GSNLayerTrainFn(torch.autograd.Function):
         pdc = [dc_buf[0].data_ptr(), dc_buf[1].data_ptr()]
         sh = int(shared)
         bwd = L.sfsn_gsn_train_step_bwd
-        seq = not fold and not STEP_LAUNCHES
+        seq = ctx.seq
         scr = torch.zeros(((L.sfsn_train_seq_scratch_bytes(R, H) if seq else L.sfsn_train_scratch_bytes(H)) // 4,), dtype=torch.int32, device=dev)
         p_scr = P(scr.data_ptr())
         if _debug_scratch is not None:
@@ -253,18 +306,19 @@ class GSNLayerTrainFn(torch.autograd.Function):
                              P(pdz + t * sRG) if shared else None, P(pdc[t & 1]), a_dw, a_db, p_scr, T - t, st)
                 if rc:
                     check(rc, "sfsn_gsn_train_step_bwd")
-        # a failed row-block exchange (this call's or its forward's) must not yield gradients that look like numbers -- and this
-        # function must not block the host either: the autograd engine walks the graph on one thread, and the sub-band groups'
-        # layer calls run side by side on their own streams (forward_live) only as long as nobody waits here.  So: every returned
-        # gradient is poisoned with NaN ON THE DEVICE when either error word is set, and the words travel to pinned memory for the
-        # next layer call (or training.check_pending()) to raise on.
+        # a failed row-block exchange (this call's or its forward's) must not yield gradients that look like numbers.  This function
+        # does not block the host (the autograd thread keeps enqueueing the layers below while this one runs): every returned gradient
+        # is poisoned with NaN ON THE DEVICE when either error word is set, the words travel to pinned memory, and the autograd
+        # engine runs check_pending() when THIS backward pass has finished (_queue_final_check): `loss.backward()` raises, so the
+        # recipe's optimizer.step() never sees the NaN gradients.
         bad = (scr[-4:].max() + ctx.scr[-4:].max()) > 0
         poison = torch.where(bad, torch.full((), float("nan"), **f32), torch.zeros((), **f32))
         pin = torch.empty((4,), dtype=torch.int32, pin_memory=True)
         pin.copy_(torch.maximum(scr[-4:], ctx.scr[-4:]), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        _pending.append((ev, pin))
+        _push_pending(ev, pin)
+        _queue_final_check()
         dz = (d_z if shared else d_gates).reshape(T * R, GH)
         dx = torch.mm(dz, w_ih).view(T, R, I).add_(poison)
         dw_ih = torch.mm(dz.t(), x.reshape(T * R, I)).add_(poison)
@@ -352,7 +406,7 @@ class GSNLayersTrainFn(torch.autograd.Function):
             pin.copy_(errs.reshape(1), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
-            _pending.append((ev, pin))
+            _push_pending(ev, pin)
         if use_bn:
             for i in range(n):
                 stats = meta["stats"][i]
@@ -391,14 +445,15 @@ class GSNLayersTrainFn(torch.autograd.Function):
         with torch.cuda.device(dev), _Logged("bwd", T, [(R, H, GH) for R, _ in geo]):
             check(L.sfsn_gsn_train_seq_bwd_multi(calls, n, T, H, int(shared), st), "sfsn_gsn_train_seq_bwd_multi")
         # no host synchronisation here (see GSNLayerTrainFn.backward): NaN-poisoned gradients on a failed exchange, the error word to
-        # pinned memory for the next layer call / check_pending()
+        # pinned memory, check_pending() when the backward pass has finished
         errs = torch.maximum(torch.stack([w[5][-4:] for w in work]).max(), ctx.fwd_err)
         poison = torch.where(errs > 0, torch.full((), float("nan"), **f32), torch.zeros((), **f32))
         pin = torch.empty((1,), dtype=torch.int32, pin_memory=True)
         pin.copy_(errs.reshape(1), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        _pending.append((ev, pin))
+        _push_pending(ev, pin)
+        _queue_final_check()
         grads = []
         for i in range(n):
             x, w_ih, w_hh, spikes, u, fg, gg, xhat, invstd, bw = saved[10 * i:10 * i + 10]

@@ -588,24 +588,32 @@ def test_full_size_properties():
     assert torch.equal(torch.view_as_real(sub["enh_stft"]), torch.view_as_real(r1["enh_stft"][5:13]))
     assert torch.equal(sub["fb_all"][2], r1["fb_all"][2][:, 5:13])
     # oracle on 8 clips spread over the batch (first, middle, last) x ALL 1000 frames: clips are independent, so the long run
-    # restricted to those clips must match the oracle run of those clips -- for the default schedule (full-band stack launch +
-    # per-layer sub-band scans at 4 rows per workgroup: the IO-wave scan of round 3) AND for the geometry the bench's timed
-    # region uses (full-band stack at 8, sub-band scans at 16 rows per workgroup with both fused-input variants).  The causal
-    # rule handles late divergence: a chain may leave the reference only where the reference membrane is inside the don't-care
-    # band (own_unexplained == 0 is asserted per layer; the per-layer first-flip frames go to the parity report).
+    # restricted to those clips must match the oracle run of those clips -- for THREE launch geometries: (i) the default schedule
+    # of a forward alone (full-band stack launch + both sub-band layers side by side in ONE launch at 8 rows per workgroup:
+    # FUSEDX3 / scan3 roles for layer 1, FUSED3 roles for layer 2 -- round 4's pair launch); (ii) `pair_scan = False`: the
+    # per-layer sub-band launches of round 3 (the IO-wave scan at 4 rows per workgroup + sfsn_spike_proj), which every model with
+    # more sub-band workgroups than n_cu - 40, H > 224 or unshared gates still takes; (iii) the geometry the bench's timed region
+    # uses (full-band stack at 8, sub-band scans at 16 rows per workgroup with both fused-input variants).  The causal rule
+    # handles late divergence: a chain may leave the reference only where the reference membrane is inside the don't-care band
+    # (own_unexplained == 0 is asserted per layer; the per-layer first-flip frames go to the parity report).
     Tc, clips = T, [0, 1, 30, 31, 32, 33, 62, 63]
     spec = omodel.spec_from_live_kwargs(kw)
     ora = omodel.forward_from_stft(spec, sd, stft[clips, :, :Tc].cpu().numpy(), "f32", want_membrane=True)
     gold_sub = parity.gold_from_oracle(ora)
     eng = model.engine()
-    for label, rpw in (("default", (0, 0)), ("timed-region geometry", (8, 16))):
-        eng.rows_per_wg = rpw
+    pair0 = eng.pair_scan
+    for label, rpw, pair in (("default", (0, 0), pair0), ("per-layer sub-band scans at 4 rows", (0, 0), False), ("timed-region geometry", (8, 16), pair0)):
+        eng.rows_per_wg, eng.pair_scan = rpw, pair
         eng.stack_rows_fb_auto = 8 if rpw[0] == 8 else 4  # (bench.py's set_geometry: the full-band stack at 8 rows per workgroup)
         n0 = dict(eng.launches)
-        rr = r1 if rpw == (0, 0) else model.forward_stft(stft)
+        rr = r1 if (rpw == (0, 0) and pair == pair0) else model.forward_stft(stft)
         torch.cuda.synchronize()
         if rpw != (0, 0):
             assert eng.launches.get("fused", 0) > n0.get("fused", 0) and eng.launches.get("fused_x", 0) > n0.get("fused_x", 0)
+        elif not pair:
+            # only the full-band stack went through a stack launch (one per chunk); the sub-band layers were per-layer launches
+            assert eng.launches.get("stack", 0) - n0.get("stack", 0) == rr["n_chunks"], (eng.launches, n0, rr["n_chunks"])
+            assert torch.equal(torch.view_as_real(rr["enh_stft"]), torch.view_as_real(r1["enh_stft"]))  # (and the pair launch agrees bit for bit)
         ci = torch.tensor(clips, device=DEV)
         out = dict(enh_stft=rr["enh_stft"][ci][:, :, :, :Tc].cpu().numpy(), fb_all=[a[:Tc, ci].cpu().numpy() for a in rr["fb_all"]], sb_all=[])
         for g, lst in enumerate(rr["sb_all"]):
@@ -619,7 +627,7 @@ def test_full_size_properties():
             assert st["valid_frac"] > 0.5, st             # ... and most chain-frames are compared strictly (a full-band flip voids the clip's sub-band rows from there on)
         # 8 clips x 14 rows x 4 layers x 1000 frames: a handful of chains leave the reference at a near-threshold membrane
         assert sum(st["diverged"] for st in stats) <= 0.1 * sum(st["rows"] for st in stats), stats
-    eng.rows_per_wg, eng.stack_rows_fb_auto = (0, 0), 4
+    eng.rows_per_wg, eng.stack_rows_fb_auto, eng.pair_scan = (0, 0), 4, pair0
     rates = [float(a.mean()) for a in r1["fb_all"][1:3]]
     assert all(0.02 < r < 0.98 for r in rates), rates  # the synthetic model is alive, not saturated
 
@@ -986,6 +994,54 @@ def test_spike_counts_replace_the_fp32_spike_tensors(front, kw, seed):
     assert metric.compute_neuronops(fb_c, sb_c) == metric.compute_neuronops(fb_f, sb_f)
     oracle_syn = omodel.compute_synops([t.cpu().numpy() for t in fb_f], [[t.cpu().numpy() for t in l] for l in sb_f], shared)
     assert metric.compute_synops(fb_c, sb_c, shared) == pytest.approx(oracle_syn, rel=1e-6)
+
+
+@pytest.mark.parametrize("front,kw,seed,geoms", [
+    ("live", rw.LIVE_M, 5, [((0, 0), True), ((0, 0), False), ((8, 16), True), ((16, 16), True), ((4, 8), True)]),
+    ("frozen", rw.FROZEN_S, 6, [((0, 0), True), ((8, 16), True)]),
+    ("live", rw.LIVE_TINY_UNSHARED, 7, [((0, 0), True), ((16, 16), True)]),
+    ("frozen", XL_CUM, 34, [((0, 0), True)]),
+])
+def test_spikes_are_counted_inside_the_scans(front, kw, seed, geoms):
+    """SURVEY 8f-1 as worded: layer_outputs="counts" launches NOTHING extra -- every scan kernel family counts the spikes it flushes
+    (sfsn_scan_segment.spike_count: the IO-wave roles' storer waves, round 2's flush, the streamed-weight kernel) and the counters
+    are zeroed with the states by the forward's first feature launch.  For every launch geometry a model can take (pair launch /
+    stack launches, per-layer IO-wave scans, the 16-row fused-input kernels of the timed region, chunked sequences with carried
+    state, separate gate weights, the streamed-weight kernel of baseline_xl) the in-scan counts equal the sums of the fp32 spike
+    tensors AND round 3's counting launch over the int8 copies, and the other outputs stay bit-identical."""
+    from spiking_fullsubnet_amd import SpikeSummary
+    sd = rw.live_state_dict(kw, seed) if front == "live" else rw.frozen_state_dict(kw, seed)
+    model = build_module(front, kw, sd)
+    B, T = 3, 300  # (>= 96 frames per chunk: the default schedule cuts the sequence in three and carries the state)
+    wave = torch.from_numpy(rw.synth_wave(B, T, seed)).to(DEV)
+    stft = model._stft(wave)
+    eng = model.engine()
+    keep = (eng.rows_per_wg, eng.pair_scan, eng.stack_rows_fb_auto, eng.count_in_scan)
+    try:
+        for rpw, pair in geoms:
+            eng.rows_per_wg, eng.pair_scan = rpw, pair
+            eng.stack_rows_fb_auto = rpw[0] if rpw[0] in (4, 8, 16) else 4
+            full = eng.forward_stft(stft, want_layers=True)
+            eng.count_in_scan = True
+            n0 = dict(eng.launches)
+            lean = eng.forward_stft(stft, want_layers=False, want_counts=True)
+            eng.count_in_scan = False
+            old = eng.forward_stft(stft, want_layers=False, want_counts=True)
+            torch.cuda.synchronize()
+            eng.check_stack_errors()
+            assert torch.equal(torch.view_as_real(full["enh_stft"]), torch.view_as_real(lean["enh_stft"])), (rpw, pair)
+            n = 0
+            for a, b, c in zip([full["fb_all"]] + full["sb_all"], [lean["fb_all"]] + lean["sb_all"], [old["fb_all"]] + old["sb_all"]):
+                assert torch.equal(a[0], b[0]) and torch.equal(a[-1], b[-1])
+                for x, y, z in zip(a[1:-1], b[1:-1], c[1:-1]):
+                    assert isinstance(y, SpikeSummary) and tuple(y.shape) == tuple(x.shape)
+                    want = int((x > 0).sum().item())
+                    assert int(y.count.item()) == want == int(z.count.item()), (rpw, pair, n, int(y.count.item()), want, int(z.count.item()))
+                    assert want > 0
+                    n += 1
+            assert n == eng.spec.fb_layers + eng.spec.n_groups * eng.spec.sb_layers
+    finally:
+        eng.rows_per_wg, eng.pair_scan, eng.stack_rows_fb_auto, eng.count_in_scan = keep
 
 
 def test_spike_count_rejects_bad_arguments(hip):

@@ -1,6 +1,8 @@
 """Training-mode path: the HIP training-step kernels behind GSNLayerTrainFn and the differentiable forward of
 the live module, against fixtures made by the REFERENCE in .train() mode with loss.backward() (tests/golden/make_golden.py:
 gsn_train_cells.npz = StackedGSU alone, live_tiny_train.npz = the whole tiny model)."""
+import copy
+import ctypes
 import os
 
 import numpy as np
@@ -269,6 +271,77 @@ def test_training_layer_call_checks_before_it_launches():
     assert outs[-1].shape == (6, 40, 32) and set(outs[-1].unique().tolist()) <= {0.0, 1.0}
     assert int(stack.layers[0].cell.batchnorm.num_batches_tracked) == 6
     training._poll_pending(block=True)
+
+
+def test_layer_call_that_cannot_be_resident_is_refused_before_anything_runs():
+    """Round-4 advisor finding: H = 320 with ~1200 rows needs 20 tiles x 15 row blocks = 300 workgroups, more than either form of the
+    layer call can hold resident (the one-launch kernels and round 3's step kernels both stage (G H + 4) x (16 + rows per block)
+    floats for the backward product: one workgroup per compute unit, 256 slots; the row blocks of a step wait for each other inside the
+    launch).  sfsn_gsn_train_multi_check / sfsn_gsn_train_step_check say so, and the layer call raises BEFORE its first launch -- never
+    a forward that succeeds, updates the BatchNorm buffers, and a backward that is refused.  A geometry that fits (R = 900: 12 row blocks,
+    240 workgroups) runs, agrees with the same loop written as per-step ATen operations (fp32 torch reference of a floating-point
+    kernel: the products round differently, so agreement, not equality), and its backward pass ends with the error words collected
+    (training._queue_final_check: `loss.backward()` itself raises on a failed exchange, nothing is left pending)."""
+    import spiking_fullsubnet_amd.modeling_spiking_fullsubnet as M
+    from spiking_fullsubnet_amd import _lib, training
+    L = _lib.lib()
+    I, H, T = 24, 320, 3
+    assert L.sfsn_gsn_train_multi_check((ctypes.c_int * 1)(1200), 1, H, 1) == _lib.SFSN_EUNSUPPORTED
+    assert L.sfsn_gsn_train_step_check(1200, H, 1) == _lib.SFSN_EUNSUPPORTED
+    assert L.sfsn_gsn_train_multi_check((ctypes.c_int * 1)(900), 1, H, 1) == _lib.SFSN_OK and L.sfsn_gsn_train_step_check(64, H, 1) == _lib.SFSN_OK
+    torch.manual_seed(11)
+    stack = M.StackedGSU(I, H, 1, True, True).to(DEV).train()
+    bn = stack.layers[0].cell.batchnorm
+    rm, nb = bn.running_mean.clone(), int(bn.num_batches_tracked)
+    with pytest.raises(NotImplementedError):
+        training.gsn_stack(torch.randn(T, 1200, I, device=DEV).requires_grad_(True), stack, training=True)
+    assert torch.equal(rm, bn.running_mean) and int(bn.num_batches_tracked) == nb  # nothing ran
+    R = 900
+    twin = copy.deepcopy(stack)
+    x = torch.randn(T, R, I, device=DEV)
+    cot = torch.randn(T, R, H, device=DEV)
+
+    class Tri(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, u):
+            ctx.save_for_backward(u)
+            return (u >= 0).float()
+
+        @staticmethod
+        def backward(ctx, g):
+            (u,) = ctx.saved_tensors
+            return g * torch.clamp(1 - u.abs(), min=0)
+
+    def aten_layer(xi, cell):
+        h = torch.zeros(R, H, device=DEV)
+        c = torch.zeros(R, H, device=DEV)
+        ys = []
+        for t in range(T):
+            pre = torch.mm(xi[t], cell.weight_ih.t()) + torch.mm(h, cell.weight_hh.t())
+            f = torch.sigmoid(pre + cell.bias_ih[:H])
+            g = pre + cell.bias_ih[H:]
+            c = cell.batchnorm(f * c + (1 - f) * g)
+            h = Tri.apply(c)
+            ys.append(h)
+        return torch.stack(ys)
+
+    xa = x.clone().requires_grad_(True)
+    outs = training.gsn_stack(xa, stack, training=True)
+    (outs[-1] * cot).sum().backward()
+    assert len(training._pending) == 0  # the autograd engine's end-of-pass callback has collected the error words
+    xb = x.clone().requires_grad_(True)
+    ref = aten_layer(xb, twin.layers[0].cell)
+    (ref * cot).sum().backward()
+    agree = float((outs[-1] == ref).float().mean())
+    assert agree > 0.9995, agree
+    assert int(bn.num_batches_tracked) == nb + T
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+    assert rel(xa.grad, xb.grad) < 5e-2, rel(xa.grad, xb.grad)
+    for (k, p), (_, q) in zip(stack.named_parameters(), twin.named_parameters()):
+        assert torch.isfinite(p.grad).all() and rel(p.grad, q.grad) < 5e-2, (k, rel(p.grad, q.grad))
+    _close(bn.running_mean.cpu().numpy(), twin.layers[0].cell.batchnorm.running_mean.cpu().numpy(), "running_mean", rtol=1e-3, atol_frac=1e-4)
 
 
 @pytest.mark.parametrize("shared,bn", [(True, True), (False, True), (True, False)])
