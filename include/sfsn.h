@@ -278,6 +278,29 @@ int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_fused_input*
  * ---------------------------------------------------------------------------------------------------- */
 int sfsn_input_proj_f32(const float* x, const float* w, const float* bias /* [N], nullable */, float* z, int M, int K, int N,
                         int ldz /* >= N: row stride of z */, void* stream);
+
+/* Several products in ONE launch (ABI 16): the projections (or the layer-0 input products) of the sub-band groups of a chunk are
+ * independent of one another (MODEL:118,141 per sequence model); each alone leaves compute units idle and pays a launch boundary.
+ * Same results as one sfsn_spike_proj / sfsn_input_proj_f32 call per job (every workgroup runs its job's own tiling).  n <= 8; all
+ * spike jobs share ceil(K / 64).  SFSN_EUNSUPPORTED when a job would not take the single entry's fast kernel (N % 4, ld % 4, M < 64,
+ * an unaligned output, N > 256, odd K / K > 192 for the real-valued product): issue the calls one by one then. */
+typedef struct sfsn_proj_job {
+    const int8_t* s;        /* [M][pad64(K)] int8 spikes */
+    const int8_t* w_packed; /* sfsn_w3_pack(W [N][K])     */
+    const float* w_dq;
+    const float* bias;      /* [N], nullable */
+    float* y;               /* [M][ldy] */
+    int M, K, N, ldy;
+} sfsn_proj_job;
+int sfsn_spike_proj_multi(const sfsn_proj_job* jobs /* host */, int n, void* stream);
+typedef struct sfsn_inproj_job {
+    const float* x;    /* [M][K] */
+    const float* w;    /* [N][K] */
+    const float* bias; /* [N], nullable */
+    float* z;          /* [M][ldz] */
+    int M, K, N, ldz;
+} sfsn_inproj_job;
+int sfsn_input_proj_f32_multi(const sfsn_inproj_job* jobs /* host */, int n, void* stream);
 int sfsn_spike_proj(const int8_t* s, const int8_t* w_packed, const float* w_dq, const float* bias /* nullable */,
                     float* y, int M, int K, int N, int ldy /* >= N: row stride of y */, void* stream);
 

@@ -17,7 +17,8 @@ the scans wait longer for something (memory latency under load, LDS-DMA starved)
 
 Writes gpurun_out/diag_r05/clock.json and prints a digest.  scripts/ledger_r05.py does the CU-time ledger from kernel traces.
 """
-import ctypes, json, os, sys, time
+import ctypes, faulthandler, json, os, sys, time
+faulthandler.dump_traceback_later(int(os.environ.get("DIAG_WATCHDOG_S", "240")), exit=True)  # a hang prints where, then exits
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -63,7 +64,12 @@ def set_geometry(g):
     eng.stack_rows_fb_auto = g[0] if g[0] in (4, 8, 16) else 4
 
 
+def say(msg):
+    print(f"[{time.perf_counter():9.3f}] {msg}", file=sys.stderr, flush=True)
+
+
 def run_with_probe(name, fn, est_ms, want_layers=True):
+    say("phase " + name)
     n = int(est_ms * 1e3 / 50) + 40
     buf = torch.zeros((WGS, n, 4), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
@@ -118,12 +124,14 @@ SCAN_TAGS = {"scan:sb", "scan:fb", "stack:sb", "stack:fb", "scanx:sb", "scanf:sb
 # warm-up (allocations, LDS attributes).  The strict schedule (pair launch + full-band stack: workgroups that wait for each other inside a
 # launch) runs ALONE on the chip, one forward at a time on the main stream -- never on the lanes: a dozen such launches side by side
 # cannot be resident together (README, limits).  The lanes are warmed in the region's geometry only.
+say("inputs made; warm-up of the strict schedule")
 set_geometry((0, 0))
 eng.overlap_chunks = 3
 for _ in range(2):
     fwd(inputs[0])
     fwd(inputs[0], False)
 torch.cuda.synchronize()
+say("warm-up of the lanes")
 set_geometry((8, 16))
 eng.overlap_chunks = 0
 for want in (True, False):
@@ -151,6 +159,7 @@ for want_layers in (True, False):
     # ---- strict: the engine's default schedule for a forward alone
     set_geometry((0, 0))
     eng.overlap_chunks = 3
+    say("phase strict" + sfx)
     # (no probe here: its stream would be a third one beside the two resident-workgroup launches of the schedule -- README, limits)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -2,7 +2,7 @@
 # SFSN_S3X_LSPLIT: the FUSEDX3 role; csrc/sfsn_scan3_dev.h).  Per pair of values: the strict forward (ms per forward) and the pair
 # launch alone as one whole-sequence launch (HIP events), B = 64, T = 1000.
 cd $GRAFT_REPO_ROOT
-for v in ${LSPLITS:-"0,0 2,2 2,0 2,1 3,0 3,1 7,0 7,1 7,2 1,1"}; do
+for v in ${LSPLITS:-0,0 2,2 2,0 2,1 3,0 3,1 7,0 7,1 7,2 1,1}; do
   a=${v%,*}; b=${v#*,}
   SFSN_S3_LSPLIT=$a SFSN_S3X_LSPLIT=$b timeout 240 python bench.py --no-cpu-baseline --no-streaming-leg --sequential --steps 10 --warmup 3 2>/dev/null | tail -1 | python -c "
 import sys,json

@@ -36,7 +36,9 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out
         for (int k = 0; k < 32; ++k)
             asm volatile(
                 ".rept 64\n s_add_u32 %0, %0, 1\n .endr\n"
-                : "+s"(acc));
+                : "+s"(acc)
+                :
+                : "scc");  // (s_add_u32 writes SCC: without the clobber the loop's own compare was overwritten and it never ended)
         unsigned long long m1 = __builtin_readcyclecounter();
         unsigned long long c1 = __builtin_amdgcn_s_memrealtime();
         o[4 * i + 0] = m0;

@@ -46,6 +46,14 @@ class DfGroup(ctypes.Structure):
     _fields_ = [("proj", _P), ("n_units", _I), ("fc", _I), ("df", _I)]
 
 
+class ProjJob(ctypes.Structure):
+    _fields_ = [("s", _P), ("w_packed", _P), ("w_dq", _P), ("bias", _P), ("y", _P), ("M", _I), ("K", _I), ("N", _I), ("ldy", _I)]
+
+
+class InProjJob(ctypes.Structure):
+    _fields_ = [("x", _P), ("w", _P), ("bias", _P), ("z", _P), ("M", _I), ("K", _I), ("N", _I), ("ldz", _I)]
+
+
 class CountTensor(ctypes.Structure):
     _fields_ = [("spikes_i8", _P), ("n_bytes", ctypes.c_ulonglong), ("count", _P)]
 
@@ -188,6 +196,10 @@ def lib() -> ctypes.CDLL:
     L.sfsn_input_proj_f32.argtypes = [_P, _P, _P, _P, _I, _I, _I, _I, _P]
     L.sfsn_spike_proj.restype = _I
     L.sfsn_spike_proj.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]
+    L.sfsn_spike_proj_multi.restype = _I
+    L.sfsn_spike_proj_multi.argtypes = [ctypes.POINTER(ProjJob), _I, _P]
+    L.sfsn_input_proj_f32_multi.restype = _I
+    L.sfsn_input_proj_f32_multi.argtypes = [ctypes.POINTER(InProjJob), _I, _P]
     L.sfsn_features.restype = _I
     L.sfsn_features.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _I, _I, _P]
     L.sfsn_features_z.restype = _I
@@ -227,7 +239,8 @@ EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device
            "sfsn_input_proj_f32", "sfsn_spike_proj", "sfsn_features",
            "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_stream_hop_resident", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft", "sfsn_gsn_train_step_fwd", "sfsn_gsn_train_step_bwd", "sfsn_train_scratch_bytes",
            "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16", "sfsn_gsn_train_check", "sfsn_gsn_stack_scan_x", "sfsn_train_seq_scratch_bytes", "sfsn_gsn_train_multi_check",
-           "sfsn_gsn_train_seq_fwd_multi", "sfsn_gsn_train_seq_bwd_multi", "sfsn_features_z", "sfsn_gaussian_stats", "sfsn_gsn_train_step_check")
+           "sfsn_gsn_train_seq_fwd_multi", "sfsn_gsn_train_seq_bwd_multi", "sfsn_features_z", "sfsn_gaussian_stats", "sfsn_gsn_train_step_check",
+           "sfsn_spike_proj_multi", "sfsn_input_proj_f32_multi")
 
 
 def check(rc: int, what: str = "") -> None:

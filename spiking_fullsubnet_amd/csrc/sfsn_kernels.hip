@@ -45,6 +45,7 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15;  // row within the tile (B / D column)
     const int q = lane >> 4;  // k group for A/B fragments; 4-neuron group for D
+    SFSN_WG_STAMP(p.wg_times, 0);
 
     int s = 0;
     for (int i = 1; i < p.nseg; ++i)
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(NW * 64) void gsn_scan_kernel(const ScanParams p) {
     else
         scan_body<G, KS, NW, TPW, OUT, LP, TPW - 1>(sg.zin, sg.w_hh, sg.spikes_f32, sg.spikes_i8, sg.membrane, sg.h_state, sg.c_state,
                                                 smem, T, H, NT, R, row0, rowc, n, q, tid, wave, rpw, nullptr, nullptr, sg.count);
+    SFSN_WG_STAMP(p.wg_times, 1);
 }
 
 
@@ -282,10 +284,12 @@ __global__ __launch_bounds__(512) void gsn_scan_fused_kernel(const ScanParams p)
         *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
     }
     __syncthreads();
+    SFSN_WG_STAMP(p.wg_times, 0);
     if (wave < NT - NW)  // waves [0, NT - 8) own two tiles, the others one (8 < NT <= 16)
         fused_body<KS, OUT, 2>(sg, smem, T, H, NT, R, row0, rowc, n, q, tid, wave);
     else
         fused_body<KS, OUT, 1>(sg, smem, T, H, NT, R, row0, rowc, n, q, tid, wave);
+    SFSN_WG_STAMP(p.wg_times, 1);
 }
 
 // ---- streamed-weights scan: the shapes whose W_hh cannot live in one CU (unshared gates with H > 256: baseline_xl's
@@ -562,11 +566,13 @@ __global__ __launch_bounds__(512) void input_proj_kernel(const float* __restrict
 // Both kernels are software pipelined over 64-row super tiles: the next tile's left operand is requested from HBM
 // (coalesced, one pass, into registers) before the current tile is computed, and parked in the second LDS buffer
 // after it -- the HBM latency hides under the MFMA phase, and no wave re-reads what another already fetched.
+// (blk, nblk): this workgroup's index and the number of workgroups that share the job -- blockIdx.x / gridDim.x for a launch of
+// one product, a block range of the launch for several products side by side (proj_multi_kernel)
 template <int TPW, int KS>
-__global__ __launch_bounds__(512) void spike_proj_fast_kernel(const int8_t* __restrict__ s, const int8_t* __restrict__ w,
-                                                               const float* __restrict__ dq, const float* __restrict__ bias,
-                                                               float* __restrict__ y, int M, int N, int ldy, int NT, int NWN) {
-    extern __shared__ __attribute__((aligned(16))) char gemm_smem_c[];
+__device__ __forceinline__ void spike_proj_fast_body(const int8_t* __restrict__ s, const int8_t* __restrict__ w,
+                                                     const float* __restrict__ dq, const float* __restrict__ bias,
+                                                     float* __restrict__ y, int M, int N, int ldy, int NT, int NWN, int blk, int nblk,
+                                                     char* gemm_smem_c) {
     constexpr int KP = KS * 64;
     constexpr int SROW = KP + 16;                     // +16 B: the 16 rows of a B fragment hit distinct banks
     constexpr int SBUF = 64 * SROW;                   // one spike tile
@@ -625,14 +631,14 @@ __global__ __launch_bounds__(512) void spike_proj_fast_kernel(const int8_t* __re
         }
     };
     int cur = 0;
-    if ((int)blockIdx.x < NS) {
-        fetch(blockIdx.x);
+    if (blk < NS) {
+        fetch(blk);
         park(0);
     }
     __syncthreads();
-    for (int st = blockIdx.x; st < NS; st += gridDim.x) {
+    for (int st = blk; st < NS; st += nblk) {
         const int m0 = st * 64;
-        const int nxt = st + gridDim.x;
+        const int nxt = st + nblk;
         if (nxt < NS) fetch(nxt);
         if (worker) {
             for (int mi = mw; mi < GEMM_MB; mi += MW) {
@@ -675,6 +681,42 @@ __global__ __launch_bounds__(512) void spike_proj_fast_kernel(const int8_t* __re
         }
         __syncthreads();
     }
+}
+
+template <int TPW, int KS>
+__global__ __launch_bounds__(512) void spike_proj_fast_kernel(const int8_t* __restrict__ s, const int8_t* __restrict__ w,
+                                                               const float* __restrict__ dq, const float* __restrict__ bias,
+                                                               float* __restrict__ y, int M, int N, int ldy, int NT, int NWN) {
+    extern __shared__ __attribute__((aligned(16))) char gemm_smem_c[];
+    spike_proj_fast_body<TPW, KS>(s, w, dq, bias, y, M, N, ldy, NT, NWN, (int)blockIdx.x, (int)gridDim.x, gemm_smem_c);
+}
+
+// Several spike products of the same K in ONE launch (round 5): the projections of the sub-band groups of a chunk are independent
+// (MODEL:118 per sequence model) and each alone leaves compute units idle or pays a launch boundary (three launches of 15-25 us with
+// ~8 us between them per 380-frame chunk).  Every workgroup takes the job whose block range it falls into and runs that job's OWN
+// tiling (the body of its single launch, instruction for instruction: same results).
+struct ProjJobDev {
+    const int8_t* s;
+    const int8_t* w;
+    const float* dq;
+    const float* bias;
+    float* y;
+    int M, N, ldy, NT, NWN, tpw, block0, nblocks;
+};
+struct ProjMultiParams {
+    ProjJobDev job[SFSN_MAX_SEGMENTS];
+    int n;
+};
+template <int KS>
+__global__ __launch_bounds__(512) void spike_proj_multi_kernel(const ProjMultiParams p) {
+    extern __shared__ __attribute__((aligned(16))) char gemm_smem_c[];
+    int j = 0;
+    for (int i = 1; i < p.n; ++i)
+        if ((int)blockIdx.x >= p.job[i].block0) j = i;
+    const ProjJobDev& b = p.job[j];
+    const int blk = (int)blockIdx.x - b.block0;
+    if (b.tpw == 1) spike_proj_fast_body<1, KS>(b.s, b.w, b.dq, b.bias, b.y, b.M, b.N, b.ldy, b.NT, b.NWN, blk, b.nblocks, gemm_smem_c);
+    else spike_proj_fast_body<2, KS>(b.s, b.w, b.dq, b.bias, b.y, b.M, b.N, b.ldy, b.NT, b.NWN, blk, b.nblocks, gemm_smem_c);
 }
 
 template <int TPW, int KC>
@@ -798,10 +840,9 @@ __global__ __launch_bounds__(512) void input_proj_fast_kernel(const float* __res
 // (bf8 / split3: sfsn_scan_dev.h -- shared with the FUSEDX3 role of the stack launch)
 
 template <int TPW, int KS>
-__global__ __launch_bounds__(512) void input_proj_bf3_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, float* __restrict__ z, int M, int K, int N,
-                                                              int ldz, int NT, int NWN) {
-    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+__device__ __forceinline__ void input_proj_bf3_body(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ z, int M, int K, int N,
+                                                    int ldz, int NT, int NWN, int blk, int nblk, float* gemm_smem) {
     constexpr int KQ = KS * 32;          // padded K
     constexpr int LDX = KQ + 8;          // bf16 elements per row: row stride = 16 B * odd -> conflict-free ds_read_b128
     constexpr int PLANE = 64 * LDX / 2;  // dwords per piece plane
@@ -872,14 +913,14 @@ __global__ __launch_bounds__(512) void input_proj_bf3_kernel(const float* __rest
                 xb[2 * PLANE + o] = p3;
             }
     };
-    if ((int)blockIdx.x < NS) {
-        fetch(blockIdx.x);
+    if (blk < NS) {
+        fetch(blk);
         park();
     }
     __syncthreads();
-    for (int st = blockIdx.x; st < NS; st += gridDim.x) {
+    for (int st = blk; st < NS; st += nblk) {
         const int m0 = st * 64;
-        const int nxt = st + gridDim.x;
+        const int nxt = st + nblk;
         if (nxt < NS) fetch(nxt);
         if (worker) {
             for (int mi = mw; mi < GEMM_MB; mi += MW) {
@@ -929,6 +970,43 @@ __global__ __launch_bounds__(512) void input_proj_bf3_kernel(const float* __rest
         }
         __syncthreads();
     }
+}
+
+template <int TPW, int KS>
+__global__ __launch_bounds__(512) void input_proj_bf3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ z, int M, int K, int N,
+                                                              int ldz, int NT, int NWN) {
+    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+    input_proj_bf3_body<TPW, KS>(x, w, bias, z, M, K, N, ldz, NT, NWN, (int)blockIdx.x, (int)gridDim.x, gemm_smem);
+}
+
+// Several real-valued input products in ONE launch (the layer-0 products of the sub-band groups whose feature rows are too wide for
+// the in-scan form: two launches per chunk at baseline_m).  As spike_proj_multi_kernel: a block range per job, the job's own tiling.
+struct InProjJobDev {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* z;
+    int M, K, N, ldz, NT, NWN, tpw, ksb, block0, nblocks;
+};
+struct InProjMultiParams {
+    InProjJobDev job[SFSN_MAX_SEGMENTS];
+    int n;
+};
+__global__ __launch_bounds__(512) void input_proj_multi_kernel(const InProjMultiParams p) {
+    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+    int j = 0;
+    for (int i = 1; i < p.n; ++i)
+        if ((int)blockIdx.x >= p.job[i].block0) j = i;
+    const InProjJobDev& b = p.job[j];
+    const int blk = (int)blockIdx.x - b.block0;
+#define IPM_CASE(TPW_, KS_)                                                                                                               \
+    if (b.tpw == TPW_ && b.ksb == KS_) {                                                                                                  \
+        input_proj_bf3_body<TPW_, KS_>(b.x, b.w, b.bias, b.z, b.M, b.K, b.N, b.ldz, b.NT, b.NWN, blk, b.nblocks, gemm_smem);              \
+        return;                                                                                                                           \
+    }
+    IPM_CASE(1, 2) IPM_CASE(1, 3) IPM_CASE(1, 5) IPM_CASE(1, 6) IPM_CASE(2, 2) IPM_CASE(2, 3) IPM_CASE(2, 5)
+#undef IPM_CASE
 }
 
 // ---- fused real-valued input scan (layer 0 of a group with narrow feature rows: baseline_m group 0, 8 units x 38) ----------------
@@ -1163,10 +1241,12 @@ __global__ __launch_bounds__(512) void gsn_scan_fusedx_kernel(const ScanParams p
         *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
     }
     __syncthreads();
+    SFSN_WG_STAMP(p.wg_times, 0);
     if (wave < NT - NW)
         fusedx_body<KS, OUT, 2>(sg, smem, T, H, NT, R, row0, rowc, n, q, tid, wave);
     else
         fusedx_body<KS, OUT, 1>(sg, smem, T, H, NT, R, row0, rowc, n, q, tid, wave);
+    SFSN_WG_STAMP(p.wg_times, 1);
 }
 
 // =====================================================================================================
@@ -1727,6 +1807,26 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 extern "C" int sfsn_abi_version(void) { return SFSN_ABI_VERSION; }
 
+#ifdef SFSN_EXPERIMENTS
+// the workgroup-stamp probe (sfsn_scan_dev.h): a caller-owned device buffer of 2 x capacity stamps, handed out launch by launch;
+// kind 1 = gsn_scan_kernel, 2 = the fused scan, 3 = the fused-x scan, 4 = the narrow stack launch.  Single-threaded use only.
+static struct { unsigned long long* buf; int cap, used, nrec; int rec[16384][3]; } g_wgp;
+unsigned long long* sfsn_wgprobe_take(int kind, int n) {
+    if (!g_wgp.buf || g_wgp.used + n > g_wgp.cap || g_wgp.nrec >= 16384) return nullptr;
+    unsigned long long* p = g_wgp.buf + 2 * (size_t)g_wgp.used;
+    g_wgp.rec[g_wgp.nrec][0] = kind; g_wgp.rec[g_wgp.nrec][1] = g_wgp.used; g_wgp.rec[g_wgp.nrec][2] = n;
+    ++g_wgp.nrec;
+    g_wgp.used += n;
+    return p;
+}
+extern "C" void sfsn_debug_wg_times(unsigned long long* buf, int capacity_wgs) { g_wgp.buf = buf; g_wgp.cap = capacity_wgs; g_wgp.used = 0; g_wgp.nrec = 0; }
+extern "C" int sfsn_debug_wg_log(int* out /* [max][3]: kind, first workgroup, workgroups */, int max_rec) {
+    const int n = g_wgp.nrec < max_rec ? g_wgp.nrec : max_rec;
+    for (int i = 0; i < n; ++i) { out[3 * i] = g_wgp.rec[i][0]; out[3 * i + 1] = g_wgp.rec[i][1]; out[3 * i + 2] = g_wgp.rec[i][2]; }
+    return n;
+}
+#endif
+
 extern "C" const char* sfsn_strerror(int code) {
     switch (code) {
         case SFSN_OK: return "ok";
@@ -1755,7 +1855,9 @@ static int launch_scan_variant(const ScanParams& p, int tiles, hipStream_t st) {
         static int seen[SFSN_MAX_DEVICES] = {0};
         if (raise_lds(reinterpret_cast<const void*>(kern), C::LDS_BYTES, seen) != SFSN_OK) return SFSN_EHIP;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NW * 64), C::LDS_BYTES, st, p);
+    ScanParams q = p;
+    q.wg_times = sfsn_wgprobe_take(1, tiles);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NW * 64), C::LDS_BYTES, st, q);
     return hip_ok(hipGetLastError());
 }
 
@@ -1820,6 +1922,7 @@ static int layer_scan_impl(const sfsn_scan_segment* segs, int n_segs, int T, int
     if (!segs || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0) return SFSN_EINVAL;
     if (H % 16 != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     ScanParams p;
+    p.wg_times = nullptr;
     p.w16 = w16;
     p.lsplit = sfsn_s3_lsplit_host();
     // rows per workgroup: as few as it takes to spread the launch over ~all 256 CUs (see the kernel comment)
@@ -1913,6 +2016,7 @@ extern "C" int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs, const sf
     if (!segs || !fin || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0) return SFSN_EINVAL;
     if (H % 16 != 0 || H <= 128 || H > 256) return SFSN_EUNSUPPORTED;  // two output tiles per wave: 8 < H/16 <= 16
     ScanParams p;
+    p.wg_times = nullptr;
     p.rpw = 16;
     p.w16 = 0;
     p.lsplit = sfsn_s3_lsplit_host();
@@ -1944,6 +2048,7 @@ extern "C" int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs, const sf
         auto kern = gsn_scan_fused_kernel<KS_, OUT_>;                                                                      \
         static int seen[SFSN_MAX_DEVICES] = {0}; /* per device, raised to the largest size seen (not a stream operation) */ \
         if (raise_lds(reinterpret_cast<const void*>(kern), lds, seen) != SFSN_OK) return SFSN_EHIP;                        \
+        p.wg_times = sfsn_wgprobe_take(2, tiles);                                                                          \
         hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, st, p);                                                      \
         return hip_ok(hipGetLastError());                                                                                  \
     }
@@ -1957,6 +2062,7 @@ extern "C" int sfsn_gsn_layer_scan_fused_x(const sfsn_scan_segment* segs, const 
     if (!segs || !fin || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0) return SFSN_EINVAL;
     if (H % 16 != 0 || H <= 128 || H > 256) return SFSN_EUNSUPPORTED;
     ScanParams p;
+    p.wg_times = nullptr;
     p.rpw = 16;
     p.w16 = 0;
     p.lsplit = sfsn_s3_lsplit_host();
@@ -1992,6 +2098,7 @@ extern "C" int sfsn_gsn_layer_scan_fused_x(const sfsn_scan_segment* segs, const 
         auto kern = gsn_scan_fusedx_kernel<KS_, OUT_>;                                                                     \
         static int seen[SFSN_MAX_DEVICES] = {0}; /* per device, raised to the largest size seen (not a stream operation) */ \
         if (raise_lds(reinterpret_cast<const void*>(kern), lds, seen) != SFSN_OK) return SFSN_EHIP;                        \
+        p.wg_times = sfsn_wgprobe_take(3, tiles);                                                                          \
         hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, st, p);                                                      \
         return hip_ok(hipGetLastError());                                                                                  \
     }
@@ -2048,6 +2155,99 @@ extern "C" int sfsn_spike_proj(const int8_t* s, const int8_t* w_packed, const fl
     SP_CASE(3, 1) SP_CASE(3, 2) SP_CASE(3, 3) SP_CASE(3, 4) SP_CASE(3, 5)
 #undef SP_CASE
     return SFSN_EUNSUPPORTED;
+}
+
+// block ranges of a multi-job launch: `total` workgroups dealt in proportion to the jobs' bytes, at least one and at most NS each
+static void deal_blocks(const double* weight, const int* ns, int n, int total, int* nblocks) {
+    double sum = 0;
+    for (int i = 0; i < n; ++i) sum += weight[i];
+    for (int i = 0; i < n; ++i) {
+        int b = (int)(total * weight[i] / sum + 0.5);
+        if (b < 1) b = 1;
+        if (b > ns[i]) b = ns[i];
+        nblocks[i] = b;
+    }
+}
+
+extern "C" int sfsn_spike_proj_multi(const sfsn_proj_job* jobs, int n, void* stream) {
+    if (!jobs || n <= 0 || n > SFSN_MAX_SEGMENTS) return SFSN_EINVAL;
+    ProjMultiParams p;
+    p.n = n;
+    int KS0 = 0, ns[SFSN_MAX_SEGMENTS], nb[SFSN_MAX_SEGMENTS];
+    double wt[SFSN_MAX_SEGMENTS];
+    size_t lds = 0;
+    for (int i = 0; i < n; ++i) {
+        const sfsn_proj_job& j = jobs[i];
+        if (!j.s || !j.w_packed || !j.w_dq || !j.y || j.M <= 0 || j.K <= 0 || j.N <= 0 || j.ldy < j.N) return SFSN_EINVAL;
+        if (!aligned16(j.s) || !aligned16(j.w_packed) || !aligned16(j.w_dq) || (reinterpret_cast<uintptr_t>(j.y) & 3u)) return SFSN_EINVAL;
+        const int NT = (j.N + 15) / 16, KS = (j.K + 63) / 64;
+        int TPW, NWN;
+        pick_tiling(NT, TPW, NWN);
+        if (i == 0) KS0 = KS;
+        const size_t l = (size_t)2 * 64 * (KS * 64 + 16) + (size_t)64 * (j.N + 4) * sizeof(float);
+        // (only what the single entry would run on its fast kernel; anything else: the caller issues the products one by one)
+        if (KS != KS0 || KS > 5 || TPW > 2 || (j.N % 4) || (j.ldy % 4) || j.M < 64 || l > 150 * 1024 || !aligned16(j.y)) return SFSN_EUNSUPPORTED;
+        if (l > lds) lds = l;
+        ProjJobDev& d = p.job[i];
+        d.s = j.s; d.w = j.w_packed; d.dq = j.w_dq; d.bias = j.bias; d.y = j.y; d.M = j.M; d.N = j.N; d.ldy = j.ldy; d.NT = NT; d.NWN = NWN; d.tpw = TPW;
+        ns[i] = (j.M + 63) / 64;
+        wt[i] = (double)ns[i] * (64.0 * KS * 64 + 64.0 * j.N * 4);
+    }
+    deal_blocks(wt, ns, n, cu_count(), nb);
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) { p.job[i].block0 = blocks; p.job[i].nblocks = nb[i]; blocks += nb[i]; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define SPM_CASE(KS_)                                                                                                    \
+    if (KS0 == KS_) {                                                                                                    \
+        auto kern = spike_proj_multi_kernel<KS_>;                                                                        \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) \
+            return SFSN_EHIP;                                                                                            \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, p);                                                   \
+        return hip_ok(hipGetLastError());                                                                                \
+    }
+    SPM_CASE(1) SPM_CASE(2) SPM_CASE(3) SPM_CASE(4) SPM_CASE(5)
+#undef SPM_CASE
+    return SFSN_EUNSUPPORTED;
+}
+
+extern "C" int sfsn_input_proj_f32_multi(const sfsn_inproj_job* jobs, int n, void* stream) {
+    if (!jobs || n <= 0 || n > SFSN_MAX_SEGMENTS) return SFSN_EINVAL;
+    static const bool no_bf3 = getenv("SFSN_INPROJ_F32") != nullptr;
+    if (no_bf3) return SFSN_EUNSUPPORTED;
+    InProjMultiParams p;
+    p.n = n;
+    int ns[SFSN_MAX_SEGMENTS], nb[SFSN_MAX_SEGMENTS];
+    double wt[SFSN_MAX_SEGMENTS];
+    size_t lds = 0;
+    for (int i = 0; i < n; ++i) {
+        const sfsn_inproj_job& j = jobs[i];
+        if (!j.x || !j.w || !j.z || j.M <= 0 || j.K <= 0 || j.N <= 0 || j.ldz < j.N) return SFSN_EINVAL;
+        if (!aligned16(j.z)) return SFSN_EINVAL;
+        const int NT = (j.N + 15) / 16;
+        int TPW, NWN;
+        pick_tiling(NT, TPW, NWN);
+        const int KSB = j.K <= 64 ? 2 : (j.K <= 96 ? 3 : (j.K <= 160 ? 5 : 6));
+        const size_t l = ((size_t)3 * 64 * (KSB * 32 + 8) * 2) + (size_t)64 * (j.N + 4) * sizeof(float);
+        const bool inst = (TPW == 1 && (KSB == 2 || KSB == 3 || KSB == 5 || KSB == 6)) || (TPW == 2 && (KSB == 2 || KSB == 3 || KSB == 5));
+        // (only what the single entry runs on input_proj_bf3_kernel)
+        if (!inst || (j.K % 2) || j.K > 192 || (j.N % 4) || (j.ldz % 4) || j.M < 64 || TPW * KSB > 12 || l > 150 * 1024 ||
+            (reinterpret_cast<uintptr_t>(j.x) & 7))
+            return SFSN_EUNSUPPORTED;
+        if (l > lds) lds = l;
+        InProjJobDev& d = p.job[i];
+        d.x = j.x; d.w = j.w; d.bias = j.bias; d.z = j.z; d.M = j.M; d.K = j.K; d.N = j.N; d.ldz = j.ldz; d.NT = NT; d.NWN = NWN; d.tpw = TPW; d.ksb = KSB;
+        ns[i] = (j.M + 63) / 64;
+        wt[i] = (double)ns[i] * (64.0 * j.K * 4 + 64.0 * j.N * 4);
+    }
+    deal_blocks(wt, ns, n, cu_count(), nb);
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) { p.job[i].block0 = blocks; p.job[i].nblocks = nb[i]; blocks += nb[i]; }
+    auto kern = input_proj_multi_kernel;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+        return SFSN_EHIP;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, static_cast<hipStream_t>(stream), p);
+    return hip_ok(hipGetLastError());
 }
 
 extern "C" int sfsn_input_proj_f32(const float* x, const float* w, const float* bias, float* z, int M, int K, int N, int ldz,

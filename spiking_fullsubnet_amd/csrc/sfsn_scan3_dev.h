@@ -51,8 +51,15 @@
 // tensor), the publishing role's loader 7 x 60 + 7 x 140 = 1400 clk (0.9 us measured on an idle chip).  The loader wave takes the first
 // SFSN_S3_LSPLIT store instructions of a frame's fp32 block and the storer wave the rest: 7 x 60 + 3 x 140 = 840 against (4 + 2) x 140 =
 // 840 clk -- neither IO wave is the step any more.  (Scan3Role::lsplit overrides it at run time for A/B runs: SFSN_S3_LSPLIT in the
-// environment of the host library.)
-#define SFSN_S3_LSPLIT 3
+// environment of the host library.)  Measured (scripts/exp_lsplit_r05.sh, B = 64, T = 1000, the pair launch as one whole-sequence
+// launch; run-to-run noise ~2 %): loader share 0 / 1 / 2 / 3 / 7 of the scan3 roles x 0 / 1 / 2 of the FUSEDX3 role: 1.08-1.09 ms at
+// (0, 0), 1.03-1.05 at (2, 1), (2, 2), (1, 1), 1.08-1.12 at (3, 0), (3, 1), 1.05-1.09 at (7, *) -- four per cent, not the forty
+// the issue arithmetic promised: with the IO waves relieved the pair runs at its FUSED3 roles' compute floor (0.9-0.93 us per step
+// alone).  Defaults: 2 for the scan3 roles, 1 for FUSEDX3 (whose loader wave also converts the feature rows).
+#define SFSN_S3_LSPLIT 2
+#endif
+#ifndef SFSN_S3X_LSPLIT
+#define SFSN_S3X_LSPLIT 1
 #endif
 #ifndef SFSN_S3_PFMAX
 #define SFSN_S3_PFMAX 8   // frames of a publishing storer's stores that may be in flight (24 measured the same: the limit is elsewhere)
@@ -69,7 +76,7 @@ inline int sfsn_s3_lsplit_host() {
 inline int sfsn_s3x_lsplit_host() {  // the FUSEDX3 role's own value (its loader wave also converts the features: less room)
     static const int v = [] {
         const char* e = getenv("SFSN_S3X_LSPLIT");
-        const int x = e ? atoi(e) : sfsn_s3_lsplit_host();
+        const int x = e ? atoi(e) : SFSN_S3X_LSPLIT;
         return x < 0 ? 0 : (x > 16 ? 16 : x);
     }();
     return v;

@@ -52,7 +52,7 @@ struct Scan3xRole {
     int8_t* spikes_i8;
     int R, row0;
     unsigned long long* count = nullptr;  // (as Scan3Role::count)
-    int lsplit = SFSN_S3_LSPLIT;          // fp32 store instructions per frame issued by the loader wave (see SFSN_S3_LSPLIT)
+    int lsplit = SFSN_S3X_LSPLIT;         // fp32 store instructions per frame issued by the loader wave (see SFSN_S3_LSPLIT)
 };
 
 // KSB: 32-wide k-chunks of the input product (2: 32 < I <= 64, 1: I <= 32) -- compile time, so that a step is straight-line code (a

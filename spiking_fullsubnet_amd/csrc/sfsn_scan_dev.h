@@ -49,7 +49,23 @@ struct ScanParams {
     int rpw;             // rows per workgroup (16, 8 or 4): fewer rows per CU = less HBM traffic per CU per step
     int w16;             // 1: 16-bit weights, digit plane 0 is zero (sfsn_gsn_layer_scan_w16): the scan3 kernels skip it
     int lsplit;          // 8-row IO-wave scans: fp32 store instructions per frame issued by the loader wave (SFSN_S3_LSPLIT)
+    unsigned long long* wg_times;  // EXPERIMENTS builds: [2 x workgroups] 100 MHz stamps of every workgroup's first and last instruction
 };
+
+// ---- per-workgroup residency stamps (make EXTRA=-DSFSN_EXPERIMENTS; scripts/exp_wgtimes_r05.py) -----------------------------------
+// A kernel's duration in a trace runs from its FIRST workgroup's start to its LAST workgroup's end; inside bench.py's timed region a
+// scan launch's workgroups each need a whole compute unit and start as units fall free.  These stamps say how long every workgroup
+// was resident (the exact CU-time of a launch) and how far apart the starts were.  Not compiled into the product.
+#ifdef SFSN_EXPERIMENTS
+#define SFSN_WG_STAMP(ptr, which)                                                                                        \
+    do {                                                                                                                 \
+        if ((ptr) != nullptr && threadIdx.x == 0) (ptr)[2 * blockIdx.x + (which)] = __builtin_amdgcn_s_memrealtime();    \
+    } while (0)
+unsigned long long* sfsn_wgprobe_take(int kind, int nblocks);  // host: a slice of the probe buffer for one launch (or NULL)
+#else
+#define SFSN_WG_STAMP(ptr, which) do {} while (0)
+static inline unsigned long long* sfsn_wgprobe_take(int, int) { return nullptr; }
+#endif
 
 // Wave-wide sum of a per-lane counter (DPP row shifts / broadcasts, as sfsn_feat_dev.h's wave_sum), then ONE 64-bit atomic per wave:
 // the exit of a scan workgroup that counted the spikes it flushed (a launch that writes no fp32 spike tensor, ScanSegDev::count).

@@ -72,6 +72,7 @@ struct StackParams {
     int exp_flags;   // timing experiments (SFSN_STACK_EXP, wrong results): see proj3_role
     int lsplit;      // 8-row IO-wave roles: fp32 store instructions per frame issued by the loader wave (SFSN_S3_LSPLIT)
     int lsplit_x;    // ... of the FUSEDX3 role
+    unsigned long long* wg_times;  // EXPERIMENTS builds: per-workgroup residency stamps (sfsn_scan_dev.h)
 };
 
 
@@ -780,6 +781,7 @@ __global__ __launch_bounds__(512) void gsn_stack_kernel(const StackParams p) {
         stack_exit(p, gate_word_p);
         return;
     }
+    SFSN_WG_STAMP(p.wg_times, 0);
     const StackRoleDev& rl = p.role[ri];
     const int blk = (int)blockIdx.x - rl.block0;
     StackLink lk;
@@ -824,6 +826,7 @@ __global__ __launch_bounds__(512) void gsn_stack_kernel(const StackParams p) {
         }
 #undef ZIN_CASE
     }
+    SFSN_WG_STAMP(p.wg_times, 1);
     stack_exit(p, gate_word_p);
 }
 
@@ -845,7 +848,9 @@ static int launch_stack(const StackParams& p, int blocks, int lds, hipStream_t s
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return SFSN_EHIP;  // (per device, cheap: set on every launch -- a process may drive several GPUs)
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, p);
+    StackParams q = p;
+    q.wg_times = sfsn_wgprobe_take(4, blocks);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, q);
     return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;
 }
 
@@ -880,6 +885,7 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
     if (n_segs * (1 + (n_layers - 1) * roles_per_layer) > STACK_MAX_ROLES) return SFSN_EUNSUPPORTED;
     if (lag < 0) return SFSN_EINVAL;
     StackParams p;
+    p.wg_times = nullptr;
     const int out = 2 | (segs[0].spikes_f32 ? 1 : 0);
     int blocks = 0, nroles = 0, lds = 0, rows_total = 0;
     int prev_role[SFSN_MAX_SEGMENTS];

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CountTensor, DfGroup, FeatureGroup, FusedInput, FusedX, ScanSegment, check
+from ._lib import CountTensor, DfGroup, FeatureGroup, FusedInput, FusedX, InProjJob, ProjJob, ScanSegment, check
 
 
 @dataclass
@@ -262,6 +262,7 @@ class Engine:
         _ss = os.environ.get('SFSN_STACK_SCAN', 'auto')
         self.stack_scan = "auto" if _ss == "auto" else bool(int(_ss))
         self.stack_rows_fb_auto = int(os.environ.get("SFSN_FB_STACK_ROWS", "4"))  # rows per workgroup of the full-band stack under "auto"
+        self.merge_products = os.environ.get("SFSN_MERGE_PRODUCTS", "1") != "0"  # the independent products of a stage in one launch
         self.count_in_scan = os.environ.get("SFSN_COUNT_IN_SCAN", "1") != "0"  # layer_outputs="counts": counted by the scans themselves
         self.pair_scan = os.environ.get("SFSN_PAIR_SCAN", "1") != "0"  # H <= 224 stacks as one launch of FUSED3 roles (see _stack_choice)
         self.stack_rows_per_wg = {"fb": 4, "sb": 8}  # rows per workgroup of every layer of a stack: sum of workgroups <= CUs
@@ -372,20 +373,41 @@ class Engine:
         previous layer's int8 spikes (l >= 1, full [T,R,HP])."""
         L = self.lib
         with self.timed(("inproj:" if l == 0 else "spikeproj_in:") + tag, st):
+            jobs = []  # (x or s, w, dq, bias, z, M, K, N, ld) per (sequence model, gate)
             for seq, src, z in zip(seqs, srcs, zins):
                 cell, H, G, R = seq.cells[l], seq.H, seq.cells[l].G, src.shape[1]
                 M = nt * R
                 for g in range(G):
-                    zp = ctypes.c_void_p(z.data_ptr() + g * H * 4)
-                    bp = ctypes.c_void_p(cell.bias.data_ptr() + g * H * 4)
+                    zp = z.data_ptr() + g * H * 4
+                    bp = cell.bias.data_ptr() + g * H * 4
                     if l == 0:
-                        check(L.sfsn_input_proj_f32(ctypes.c_void_p(src.data_ptr() + t0 * R * seq.I * 4),
-                                                    ctypes.c_void_p(cell.w_ih_f32.data_ptr() + g * H * seq.I * 4), bp, zp, M, seq.I, H,
-                                                    G * H, st), "sfsn_input_proj_f32")
+                        jobs.append((src.data_ptr() + t0 * R * seq.I * 4, cell.w_ih_f32.data_ptr() + g * H * seq.I * 4, None, bp, zp, M, seq.I, H, G * H))
                     else:
                         pk, dq = cell.w_ih_q[g]
-                        check(L.sfsn_spike_proj(ctypes.c_void_p(src.data_ptr() + t0 * R * src.shape[2]), _ptr(pk), _ptr(dq), bp, zp, M,
-                                                H, H, G * H, st), "sfsn_spike_proj")
+                        jobs.append((src.data_ptr() + t0 * R * src.shape[2], pk.data_ptr(), dq.data_ptr(), bp, zp, M, H, H, G * H))
+            if self.merge_products and 1 < len(jobs) <= _lib.MAX_SEGMENTS:
+                # the products of a stage in ONE launch (a block range per job, every job its own tiling: the same results)
+                if l == 0:
+                    arr = (InProjJob * len(jobs))()
+                    for a, (x_, w_, _, b_, z_, M, K, N, ld) in zip(arr, jobs):
+                        a.x, a.w, a.bias, a.z, a.M, a.K, a.N, a.ldz = x_, w_, b_, z_, M, K, N, ld
+                    rc = L.sfsn_input_proj_f32_multi(arr, len(jobs), st)
+                else:
+                    arr = (ProjJob * len(jobs))()
+                    for a, (s_, w_, dq_, b_, z_, M, K, N, ld) in zip(arr, jobs):
+                        a.s, a.w_packed, a.w_dq, a.bias, a.y, a.M, a.K, a.N, a.ldy = s_, w_, dq_, b_, z_, M, K, N, ld
+                    rc = L.sfsn_spike_proj_multi(arr, len(jobs), st)
+                if rc == 0:
+                    self.launches["merged_products"] = self.launches.get("merged_products", 0) + 1
+                    return
+                if rc != _lib.SFSN_EUNSUPPORTED:
+                    check(rc, "sfsn_input_proj_f32_multi" if l == 0 else "sfsn_spike_proj_multi")
+            P = ctypes.c_void_p
+            for a_, w_, dq_, b_, z_, M, K, N, ld in jobs:
+                if l == 0:
+                    check(L.sfsn_input_proj_f32(P(a_), P(w_), P(b_), P(z_), M, K, N, ld, st), "sfsn_input_proj_f32")
+                else:
+                    check(L.sfsn_spike_proj(P(a_), P(w_), P(dq_), P(b_), P(z_), M, K, N, ld, st), "sfsn_spike_proj")
 
     def _stage_scan(self, seqs, l, zins, states, spks, s8s, mems, t0, nt, st, tag, rpw, cnts=None):
         L, spec = self.lib, self.spec
@@ -626,6 +648,18 @@ class Engine:
     def _stage_proj(self, seqs, s8s, projs, t0, nt, st, tag):
         L = self.lib
         with self.timed("proj:" + tag, st):
+            if self.merge_products and 1 < len(seqs) <= _lib.MAX_SEGMENTS:  # the groups' projections in ONE launch
+                arr = (ProjJob * len(seqs))()
+                for a, seq, s8, y in zip(arr, seqs, s8s, projs):
+                    R = s8.shape[1]
+                    a.s, a.w_packed, a.w_dq, a.bias = s8.data_ptr() + t0 * R * s8.shape[2], seq.proj_q.data_ptr(), seq.proj_dq.data_ptr(), seq.proj_b.data_ptr()
+                    a.y, a.M, a.K, a.N, a.ldy = y.data_ptr() + t0 * R * seq.P * 4, nt * R, seq.H, seq.P, seq.P
+                rc = L.sfsn_spike_proj_multi(arr, len(seqs), st)
+                if rc == 0:
+                    self.launches["merged_products"] = self.launches.get("merged_products", 0) + 1
+                    return
+                if rc != _lib.SFSN_EUNSUPPORTED:
+                    check(rc, "sfsn_spike_proj_multi(proj)")
             for seq, s8, y in zip(seqs, s8s, projs):
                 R = s8.shape[1]
                 check(L.sfsn_spike_proj(ctypes.c_void_p(s8.data_ptr() + t0 * R * s8.shape[2]), _ptr(seq.proj_q), _ptr(seq.proj_dq),

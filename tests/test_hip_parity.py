@@ -357,6 +357,61 @@ def test_input_proj_f32(hip, M, K, N):
     np.testing.assert_allclose(z.cpu().numpy(), exact, atol=3e-6, rtol=1e-5)  # k-ordered fp32 fma chain, K <= 160
 
 
+def test_products_of_several_groups_in_one_launch_equal_the_single_launches(hip):
+    """sfsn_spike_proj_multi / sfsn_input_proj_f32_multi (round 5): the independent products of a stage -- the sub-band groups'
+    projections, their layer-0 input products -- in ONE launch, a block range per job and every job on its own tiling: bit for bit
+    what one call per job writes (baseline_m's shapes at a chunk's row counts, a ragged last tile, a single-tile job); jobs the
+    single entries would not run on their fast kernels are refused (the engine then issues them one by one)."""
+    from spiking_fullsubnet_amd._lib import InProjJob, ProjJob, SFSN_EUNSUPPORTED, check
+    from spiking_fullsubnet_amd.engine import pack_w3
+    rng = np.random.default_rng(77)
+    K = 224
+    KP = (K + 63) // 64 * 64
+    keep = []
+    shapes = [(512 * 5 + 13, 40), (192 * 7, 192), (128 * 9 + 1, 128), (64, 64)]
+    jobs = (ProjJob * len(shapes))()
+    ya, yb = [], []
+    for a, (M, N) in zip(jobs, shapes):
+        s8 = np.zeros((M, KP), np.int8)
+        s8[:, :K] = rng.random((M, K)) > 0.7
+        w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        pk, dq = pack_w3(w)
+        ts = [_t(s8), _t(pk), _t(dq), _t(rng.standard_normal(N).astype(np.float32))]
+        y1, y2 = torch.full((M, N), float("nan"), device=DEV), torch.full((M, N), float("nan"), device=DEV)
+        check(hip.sfsn_spike_proj(_p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]), _p(y1), M, K, N, N, None), "single")
+        a.s, a.w_packed, a.w_dq, a.bias, a.y, a.M, a.K, a.N, a.ldy = [t.data_ptr() for t in ts] + [y2.data_ptr(), M, K, N, N]
+        keep.append(ts)
+        ya.append(y1)
+        yb.append(y2)
+    check(hip.sfsn_spike_proj_multi(jobs, len(shapes), None), "sfsn_spike_proj_multi")
+    torch.cuda.synchronize()
+    for y1, y2 in zip(ya, yb):
+        assert torch.equal(y1, y2)
+    jobs[1].M = 40  # fewer than 64 rows: not the fast kernel's shape
+    assert hip.sfsn_spike_proj_multi(jobs, len(shapes), None) == SFSN_EUNSUPPORTED
+    jobs[1].M, jobs[1].K = shapes[1][0], 100  # another k-step count than the other jobs
+    assert hip.sfsn_spike_proj_multi(jobs, len(shapes), None) == SFSN_EUNSUPPORTED
+    # ---- the real-valued input products (groups 1, 2 of baseline_m: I = 94 / 158 -> H = 224; and a narrow one)
+    ishapes = [(192 * 6 + 5, 94, 224), (128 * 8, 158, 224), (300, 38, 160), (64 * 3, 64, 64)]
+    ij = (InProjJob * len(ishapes))()
+    za, zb = [], []
+    for a, (M, Ki, N) in zip(ij, ishapes):
+        ts = [_t(rng.standard_normal((M, Ki)).astype(np.float32)), _t(rng.uniform(-0.1, 0.1, (N, Ki)).astype(np.float32)),
+              _t(rng.standard_normal(N).astype(np.float32))]
+        z1, z2 = torch.full((M, N), float("nan"), device=DEV), torch.full((M, N), float("nan"), device=DEV)
+        check(hip.sfsn_input_proj_f32(_p(ts[0]), _p(ts[1]), _p(ts[2]), _p(z1), M, Ki, N, N, None), "single")
+        a.x, a.w, a.bias, a.z, a.M, a.K, a.N, a.ldz = [t.data_ptr() for t in ts] + [z2.data_ptr(), M, Ki, N, N]
+        keep.append(ts)
+        za.append(z1)
+        zb.append(z2)
+    check(hip.sfsn_input_proj_f32_multi(ij, len(ishapes), None), "sfsn_input_proj_f32_multi")
+    torch.cuda.synchronize()
+    for z1, z2 in zip(za, zb):
+        assert torch.equal(z1, z2)
+    ij[0].K = 93  # odd K: the fp32-MFMA fallback's shape
+    assert hip.sfsn_input_proj_f32_multi(ij, len(ishapes), None) == SFSN_EUNSUPPORTED
+
+
 MODEL_CASES = [
     ("live_tiny.npz", "live", rw.LIVE_TINY, 11), ("live_tiny_2spk.npz", "live", rw.LIVE_TINY_2SPK, 12),
     ("live_tiny_unshared.npz", "live", rw.LIVE_TINY_UNSHARED, 13), ("live_m.npz", "live", rw.LIVE_M, 21),
