@@ -29,7 +29,7 @@ Prints ONE JSON line on rank 0 (see the task contract), carrying
                    HIP-event launch duration -- the north star's "HBM roofline on the sub-band scan"), `dominant_kernel_timed_region`
                    (the fused sub-band scan of the timed region's geometry, alone on the chip and as a time share inside the
                    region), `full_band_stack` (MFMA utilisation).  PMC-derived fields (`traffic`, `mfma.pmc`) come from
-                   profiles/r04_pmc.json and are attached only when that file was taken with the library build that is running
+                   profiles/r05_pmc.json and are attached only when that file was taken with the library build that is running
                    (source hash) on this workload (B, T, geometry, forwards in flight);
   cpu_baseline  -- the CPU oracle (oracle/, a C restatement of the reference) timed on this host's cores on the whole workload
                    (all B clips x all T frames, groups of clips side by side; rank 0, N=1 only).
@@ -92,7 +92,7 @@ def _self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env, stdout=JSON_OUT.fileno()))  # (the ranks get the real stdout as their fd 1)
 
 
-PROFILE_JSON = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r05_pmc.json")
 
 
 def _pmc_profile():
@@ -465,7 +465,7 @@ def main():
                     kernel=f"gsn_scan_fused_kernel<KS={(Hs + 63) // 64},OUT=fp32+int8 spikes> (sub-band layer 2, input product inside, {geom_b[1]} rows per "
                            f"workgroup, {wgs(sb_rows, geom_b[1])} workgroups, {spec.n_groups} groups in one launch)",
                     alone_on_chip=hbm(kf["mean_ms"]), per_step_us=round(1e3 * kf["mean_ms"] / T, 3),
-                    in_region_time_share=hbm(t_b["scanf:sb"]["mean_ms"]) if t_b.get("scanf:sb") else None,  # (--time-region; profiles/r05_region_ledger.json has the trace's figure)
+                    in_region_time_share=hbm(t_b["scanf:sb"]["mean_ms"]) if t_b.get("scanf:sb") else None,  # (--time-region; profiles/r05_region_wg_residency.json has the exact per-workgroup figures)
                     launches=(t_b.get("scanf:sb") or kf)["n"],
                     algorithmic_bytes_per_launch=int(alg), frames_per_launch=B * T,
                     traffic=(pj or {}).get("sb_fused_hbm_bytes_per_launch"),

@@ -15,6 +15,9 @@ import torch
 import refweights as rw
 import spiking_fullsubnet_amd as pkg
 from spiking_fullsubnet_amd import _lib
+_exp = os.path.join(ROOT, "spiking_fullsubnet_amd", "csrc_exp", "libsfsn_hip.so")  # (an EXPERIMENTS build beside the product's: scripts/build_exp_lib.sh)
+if os.path.exists(_exp):
+    _lib.LIB_PATH = _exp
 
 B, T, LANES, STEPS, WARM = 64, 1000, int(os.environ.get("LANES", 12)), 36, 12
 dev = torch.device("cuda", 0)
@@ -62,7 +65,11 @@ def run(n_lanes, steps, warm):
         s, e = st[base:base + nb, 0], st[base:base + nb, 1]
         ok = (s > 0) & (e > 0)  # (padding blocks of a stack launch never stamp)
         s, e = s[ok], e[ok]
-        d = out.setdefault(kind, dict(res=[], spread=[], span=[], wgs=[]))
+        d = out.setdefault(kind, dict(res=[], spread=[], span=[], wgs=[], slot_delay=[[] for _ in range(8)], slot_n=[0] * 8))
+        idx = np.nonzero(ok)[0]
+        for j, ss in zip(idx, s):  # workgroup j of the launch sits on XCD (j mod 8) (the dispatcher deals workgroups round-robin over the eight XCDs)
+            d["slot_delay"][j % 8].append((ss - s.min()) / 100.0)
+            d["slot_n"][j % 8] += 1
         d["res"].append((e - s) / 100.0)                 # us per workgroup
         d["spread"].append((s.max() - s.min()) / 100.0)  # us between the first and the last start
         d["span"].append((e.max() - s.min()) / 100.0)    # us: what a trace calls the kernel's duration
@@ -77,7 +84,9 @@ def run(n_lanes, steps, warm):
                                    residency_ms_median=round(float(np.median(res)) / 1e3, 4), residency_ms_p10=round(float(np.percentile(res, 10)) / 1e3, 4),
                                    residency_ms_p90=round(float(np.percentile(res, 90)) / 1e3, 4), us_per_step_median=round(float(np.median(res)) / T, 4),
                                    start_spread_ms_median=round(float(np.median(d["spread"])) / 1e3, 4), start_spread_ms_p90=round(float(np.percentile(d["spread"], 90)) / 1e3, 4),
-                                   launch_span_ms_median=round(float(np.median(d["span"])) / 1e3, 4), cu_ms_per_forward=round(cu_ms, 1)))
+                                   launch_span_ms_median=round(float(np.median(d["span"])) / 1e3, 4), cu_ms_per_forward=round(cu_ms, 1),
+                                   workgroups_per_xcd_slot=[round(n_ / len(d["span"]), 2) for n_ in d["slot_n"]],
+                                   mean_start_delay_ms_per_xcd_slot=[round(float(np.mean(v)) / 1e3, 3) if v else None for v in d["slot_delay"]]))
     rep["scan_cu_ms_per_forward"] = round(tot, 1)
     rep["cu_ms_available_per_forward"] = round(256 * 1e3 * wall / steps, 1)
     return rep
@@ -95,3 +104,4 @@ for rep in reports:
         print("  %-58s wgs %3d  residency %.3f ms (p10 %.3f, p90 %.3f) = %.3f us/step | starts spread %.3f ms (p90 %.3f) | span %.3f ms | %.1f CU-ms/fwd" % (
             k["kernel"], k["workgroups"], k["residency_ms_median"], k["residency_ms_p10"], k["residency_ms_p90"], k["us_per_step_median"],
             k["start_spread_ms_median"], k["start_spread_ms_p90"], k["launch_span_ms_median"], k["cu_ms_per_forward"]))
+        print("      workgroups per XCD slot (blockIdx mod 8):", k["workgroups_per_xcd_slot"], " mean start delay (ms):", k["mean_start_delay_ms_per_xcd_slot"])

@@ -679,7 +679,11 @@ __device__ __forceinline__ void spike_proj_fast_body(const int8_t* __restrict__ 
             const int r = idx / n4, c4 = idx - r * n4;
             *reinterpret_cast<v4f*>(y + (size_t)(m0 + r) * ldy + c4 * 4) = *reinterpret_cast<const v4f*>(&obuf[r * NP + c4 * 4]);
         }
-        __syncthreads();
+        // Only the LDS reads above have to be done before the next tile rewrites obuf: a raw barrier behind lgkmcnt(0).  (Round 5:
+        // __syncthreads() is a workgroup-scope release -- hipcc puts s_waitcnt vmcnt(0) in front of it, so every tile's row stores had
+        // to RETIRE in HBM before the next tile's prefetch was even issued: 7-8 us per 64-row tile against ~2.5 us of work.)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
     }
 }
 
@@ -825,7 +829,8 @@ __global__ __launch_bounds__(512) void input_proj_fast_kernel(const float* __res
             const int r = idx / n4, c4 = idx - r * n4;
             *reinterpret_cast<v4f*>(z + (size_t)(m0 + r) * ldz + c4 * 4) = *reinterpret_cast<const v4f*>(&obuf[r * NP + c4 * 4]);
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // (LDS reads of obuf done; the row stores stay in flight: see spike_proj_fast_body)
+        __builtin_amdgcn_s_barrier();
     }
 }
 
@@ -968,7 +973,8 @@ __device__ __forceinline__ void input_proj_bf3_body(const float* __restrict__ x,
             const int r = idx / n4, c4 = idx - r * n4;
             *reinterpret_cast<v4f*>(z + (size_t)(m0 + r) * ldz + c4 * 4) = *reinterpret_cast<const v4f*>(&obuf[r * NP + c4 * 4]);
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // (LDS reads of obuf done; the row stores stay in flight: see spike_proj_fast_body)
+        __builtin_amdgcn_s_barrier();
     }
 }
 
@@ -1417,14 +1423,18 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
         const int kch = FEAT_CHUNK / g.I;  // units per chunk (>= 1: I <= 256)
         for (int k0 = 0; k0 < g.N; k0 += kch) {
             const int nk = (g.N - k0 < kch) ? g.N - k0 : kch;
-            __syncthreads();  // tiles loaded / previous chunk's table no longer read
+            // tiles loaded / previous chunk's table no longer read: LDS traffic only, so a raw barrier behind lgkmcnt(0) -- __syncthreads()
+            // is a workgroup-scope release and made every chunk's row stores retire in HBM before the next chunk began (round 5)
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
             // gather table of the chunk: entry >= 0 = offset of the bin's row in magT, < 0 = -1 - full-band column
             for (int idx = tid; idx < nk * g.I; idx += 256) {
                 const int k = idx / g.I, j = idx - k * g.I, ku = k0 + k;
                 offs[idx] = j < g.I1 ? (reflect_bin(g.lo + ku * g.ctr - g.nbr + j, nf) - p.f_lo) * 33
                                      : -1 - reflect_bin(g.lo + ku * g.ctr_fb - g.nbr_fb + (j - g.I1), nf) % FB;
             }
-            __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
 #define FEAT_ROWS(NU_)                                                                                                             \
     do {                                                                                                                           \
         if (g.norm == SFSN_NORM_LAYERNORM) feat_chunk_rows<NU_, SFSN_NORM_LAYERNORM>(g, magT, fbT, offs, stage, k0, nk, b, B, FB, t0, tend, lane, wave); \
@@ -1700,7 +1710,10 @@ __global__ __launch_bounds__(DFP_THREADS) void deepfilter_pass_kernel(const floa
         const int k0 = pp.pk0[ps], U = pp.pnu[ps];
         const int P = 2 * g.fc * g.df * S, UP = U * P, LD = UP + 1, Q = UP >> 2;
         const int nb = U * g.fc, XW = 32 + g.df - 1;
-        __syncthreads();
+        // (LDS only: the previous pass's reads of the tiles are done.  A raw barrier -- __syncthreads() would wait for the previous pass's
+        //  enh / mag stores to retire in HBM before this pass's loads are issued)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
         // coefficient tile: row r = frame t0 + r, UP contiguous floats
         for (int c4 = lane; c4 < Q; c4 += 64) {
 #pragma unroll
@@ -1735,7 +1748,8 @@ __global__ __launch_bounds__(DFP_THREADS) void deepfilter_pass_kernel(const floa
                 }
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
         if (t < tend) {
             const float* pr = ct + tt * LD;
             int u = 0, fci = fs;
