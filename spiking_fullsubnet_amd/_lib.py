@@ -95,7 +95,7 @@ class HopDesc(ctypes.Structure):
 def _sources():
     """The files the library is made of, in the order the Makefile hashes them (SRCS)."""
     return [os.path.join(_HERE, "..", "include", "sfsn.h")] + [
-        os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_scan3_dev.h", "sfsn_scan3i_dev.h", "sfsn_scan3x_dev.h", "sfsn_feat_dev.h", "sfsn_fft_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_hop.hip", "sfsn_fft.hip", "sfsn_train.hip",
+        os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_scan3_dev.h", "sfsn_scan3i_dev.h", "sfsn_scan3x_dev.h", "sfsn_scan3w_dev.h", "sfsn_feat_dev.h", "sfsn_fft_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_hop.hip", "sfsn_fft.hip", "sfsn_train.hip",
                                   "sfsn_pack.cpp")]
 
 
@@ -123,9 +123,11 @@ _lib = None
 
 def lib() -> ctypes.CDLL:
     """The loaded library; raises ImportError with the build recipe when it is missing (no fallback)."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is not None:
         return _lib
+    if os.environ.get("SFSN_LIB_PATH"):  # an experiment build beside the product's (scripts/build_exp_lib.sh); same ABI / source-hash checks
+        LIB_PATH = os.environ["SFSN_LIB_PATH"]
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is not built. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "

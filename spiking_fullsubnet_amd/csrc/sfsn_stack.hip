@@ -29,6 +29,7 @@
 #include "sfsn_scan3_dev.h"
 #include "sfsn_scan3i_dev.h"
 #include "sfsn_scan3x_dev.h"
+#include "sfsn_scan3w_dev.h"
 
 #define STACK_MAX_ROLES 24
 #define STACK_ZIN 0
@@ -355,11 +356,11 @@ struct ProjLayout {
     __device__ __host__ static constexpr int bytes(int NT) { return W_OFF + NT * KS * 1024; }
 };
 
-template <int KS, int NTL>
+template <int KS, int NTL, int NW = 8>
 __device__ __forceinline__ void stack_proj_body(const StackRoleDev& rl, const StackLink& lk, char* smem, int* gate_word, int T, int H,
                                                 int NT, int row0, int rowc, int n, int q, int tid, int wave) {
     using L = ProjLayout<KS>;
-    constexpr int HP = L::HP, D = L::D, NW = 8, NCH = L::NCH, SLOT = L::SLOT;
+    constexpr int HP = L::HP, D = L::D, NCH = L::NCH, SLOT = L::SLOT;
     const int R = rl.R;
     const float(*cst)[HP] = reinterpret_cast<const float(*)[HP]>(smem + L::CST_OFF);  // bias_f, dq_ih
     const int lane = tid & 63;
@@ -454,11 +455,12 @@ __device__ __forceinline__ void stack_proj_body(const StackRoleDev& rl, const St
     if (wave == 0 && lane == 0) stack_publish(lk, T);
 }
 
-template <int KS>
+// NW waves (8 in the 512-thread kernel, 12 in gsn_stack_fb_kernel): tiles dealt round-robin over all of them
+template <int KS, int NW = 8>
 __device__ __forceinline__ void stack_proj_role(const StackRoleDev& rl, const StackLink& lk, char* smem, int* gate_word, int T, int H,
                                                 int NT, int blk) {
     using L = ProjLayout<KS>;
-    constexpr int HP = L::HP, NW = 8;
+    constexpr int HP = L::HP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
@@ -479,13 +481,13 @@ __device__ __forceinline__ void stack_proj_role(const StackRoleDev& rl, const St
     __syncthreads();
     const int ntl = (NT - wave + NW - 1) / NW;  // tiles wave, wave + 8, ... < NT
     if (ntl >= 3)
-        stack_proj_body<KS, 3>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+        stack_proj_body<KS, 3, NW>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
     else if (ntl == 2)
-        stack_proj_body<KS, 2>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+        stack_proj_body<KS, 2, NW>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
     else if (ntl == 1)
-        stack_proj_body<KS, 1>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+        stack_proj_body<KS, 1, NW>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
     else
-        stack_proj_body<KS, 0>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+        stack_proj_body<KS, 0, NW>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -830,6 +832,58 @@ __global__ __launch_bounds__(512) void gsn_stack_kernel(const StackParams p) {
     stack_exit(p, gate_word_p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the full-band stack (256 < H <= 320) with IO-specialised waves -- 768 threads per workgroup: scan roles = scan3w_role
+// (sfsn_scan3w_dev.h: ten compute waves x two tiles + loader + storer), PROJ roles = stack_proj_role on twelve waves.  Same roles,
+// links and arithmetic as gsn_stack_kernel<5, OUT>; bit-identical results.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int OUT>
+__global__ __launch_bounds__(768) void gsn_stack_fb_kernel(const StackParams p) {
+    extern __shared__ __attribute__((aligned(16))) char scan_smem[];
+    constexpr int KS = 5;
+    int* gate_word_p = reinterpret_cast<int*>(scan_smem + p.gate_off);
+    int ri = -1;
+    for (int i = 0; i < p.nroles; ++i)
+        if ((int)blockIdx.x >= p.role[i].block0 && (int)blockIdx.x < p.role[i].block0 + p.role[i].nblocks) ri = i;
+    if (ri < 0) {  // padding block
+        stack_exit(p, gate_word_p);
+        return;
+    }
+    SFSN_WG_STAMP(p.wg_times, 0);
+    const StackRoleDev& rl = p.role[ri];
+    const int blk = (int)blockIdx.x - rl.block0;
+    StackLink lk;
+    lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = p.prog; lk.lag = p.lag; lk.dbg = nullptr;
+    if (rl.pub) lk.out = p.prog + 2 + blockIdx.x;
+    const int my_rpw = rl.kind == STACK_PROJ ? 16 : rl.rpw;
+    if (rl.src >= 0) {  // the producer workgroups that own my rows
+        const StackRoleDev& sr = p.role[rl.src];
+        const int r0 = blk * my_rpw;
+        int r1 = r0 + my_rpw - 1;
+        if (r1 > rl.R - 1) r1 = rl.R - 1;
+        const int b0 = r0 / rl.src_rpw, b1 = r1 / rl.src_rpw;
+        lk.in = p.prog + 2 + sr.block0 + b0;
+        lk.n_in = b1 - b0 + 1;
+    }
+    const int T = p.T, H = p.H, NT = p.NT;
+    if (rl.kind == STACK_PROJ) {
+        stack_proj_role<KS, 12>(rl, lk, scan_smem, gate_word_p, T, H, NT, blk);
+    } else {
+        const int flg = (rl.src >= 0 ? 1 : 0) | (rl.pub ? 2 : 0);
+        Scan3Role r3;
+        r3.zin = rl.zin; r3.w_hh = rl.w_hh; r3.w_dq = rl.w_dq; r3.bias = rl.bias; r3.bn_alpha = rl.bn_alpha; r3.bn_beta = rl.bn_beta;
+        r3.h_state = rl.h_state; r3.c_state = rl.c_state; r3.spikes_f32 = rl.spikes_f32; r3.spikes_i8 = rl.spikes_i8;
+        r3.R = rl.R; r3.row0 = blk * rl.rpw; r3.count = rl.count; r3.lsplit = p.lsplit;
+#define S3W_CASE(RPW_, F) \
+    if (rl.rpw == RPW_ && flg == F) scan3w_role<KS, RPW_, OUT, F>(r3, lk, scan_smem, T, H, NT);
+        S3W_CASE(4, 0) S3W_CASE(4, 1) S3W_CASE(4, 2) S3W_CASE(4, 3)
+        S3W_CASE(8, 0) S3W_CASE(8, 1) S3W_CASE(8, 2) S3W_CASE(8, 3)
+#undef S3W_CASE
+    }
+    SFSN_WG_STAMP(p.wg_times, 1);
+    stack_exit(p, gate_word_p);
+}
+
 // =====================================================================================================
 // host side
 // =====================================================================================================
@@ -840,6 +894,18 @@ extern "C" size_t sfsn_stack_scratch_bytes(int n_layers, int n_segs, int rows_to
     if (n_layers <= 0 || n_segs <= 0 || rows_total <= 0) return 0;
     const size_t blocks = (size_t)n_layers * ((size_t)(rows_total + 3) / 4 + (size_t)(rows_total + 15) / 16 + 16 * (size_t)n_segs);
     return (blocks + 1 + 16) * sizeof(unsigned) * 5;  // counters + (optional) two debug words per workgroup
+}
+
+template <int OUT>
+static int launch_stack_fb(const StackParams& p, int blocks, int lds, hipStream_t st) {
+    auto kern = gsn_stack_fb_kernel<OUT>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return SFSN_EHIP;
+    StackParams q = p;
+    q.wg_times = sfsn_wgprobe_take(4, blocks);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(768), lds, st, q);
+    return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;
 }
 
 template <int KS, int OUT>
@@ -881,6 +947,26 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
         if ((rows_per_wg ? rows_per_wg[l] : 8) != 8) inscan = false;
     if (inscan) wide = true;
     if (wide) fused = false;
+    // round 5: 256 < H <= 320 at 4 / 8 rows per workgroup: the 768-thread kernel with IO-specialised scan roles (SFSN_SCAN_V2=1 keeps
+    // round 2's bodies: A/B runs)
+    // Where it is used -- measured, not derived (scripts/exp_fb3_r05.py, scripts/exp_fb3_seq_r05.sh; B = 64): the stack ALONE on the
+    // chip 1.09 / 1.34 ms per 1000 frames at 4 / 8 rows against 1.30 / 1.60 for round 2's body, the twelve-lane region (8 rows) +1.5 %;
+    // but as a 240-380 frame chunk BESIDE the sub-band pair launch (the strict forward's overlapped schedule, 4 rows) it runs 1.95 us per
+    // frame against round 2's 1.76 and the forward 2.82-2.97 ms against 2.74-2.75: beside 208 workgroups writing 1.9 GB per ms the
+    // hand-off chain layer 1 -> PROJ -> layer 2 (write-through stores that must retire before they are published, sc1 loads behind
+    // them) is what a frame costs, and one loader / one storer wave per workgroup ride that out worse than eight waves that each fetch
+    // and flush their own share.  So: 8 rows always; 4 rows only for launches of >= 512 frames (whole sequences: the full-band model
+    // of the frozen front-ends runs alone on the chip; a chunk of the overlapped schedule keeps round 2's body).  SFSN_STACK_FB3=1 / 0
+    // forces it on / off (A/B runs).
+    bool fb3 = !fused && !wide && KS == 5 && !getenv("SFSN_SCAN_V2") && !getenv("SFSN_STACK_FB_V2");
+    bool any4 = false;
+    for (int l = 0; l < n_layers && fb3; ++l) {
+        const int rp = rows_per_wg ? rows_per_wg[l] : 8;
+        if (rp != 4 && rp != 8) fb3 = false;
+        if (rp == 4) any4 = true;
+    }
+    if (const char* e = getenv("SFSN_STACK_FB3")) fb3 = fb3 && atoi(e) != 0;
+    else if (any4 && T < 512) fb3 = false;
     const int roles_per_layer = (fused || inscan) ? 1 : 2;
     if (n_segs * (1 + (n_layers - 1) * roles_per_layer) > STACK_MAX_ROLES) return SFSN_EUNSUPPORTED;
     if (lag < 0) return SFSN_EINVAL;
@@ -993,6 +1079,7 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
                     case 4: need = ScanCfg<1, 4, 8, 2, 3, 0>::LDS_BYTES; break;
                     default: need = ScanCfg<1, 5, 8, 3, 3, 1>::LDS_BYTES; break;
                 }
+                if (fb3) need = rpw == 4 ? Scan3wCfg<5, 4, 3>::lds_bytes(NT) : Scan3wCfg<5, 8, 3>::lds_bytes(NT);
             }
             if (need > lds) lds = need;
         }
@@ -1033,6 +1120,8 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
     }
     WIDE_CASE(1, 2) WIDE_CASE(1, 3) WIDE_CASE(2, 2) WIDE_CASE(2, 3) WIDE_CASE(3, 2) WIDE_CASE(3, 3) WIDE_CASE(4, 2) WIDE_CASE(4, 3)
 #undef WIDE_CASE
+    if (fb3 && out == 2) return launch_stack_fb<2>(p, blocks, lds, st);
+    if (fb3 && out == 3) return launch_stack_fb<3>(p, blocks, lds, st);
 #define STACK_CASE(KS_, OUT_) \
     if (KS == KS_ && out == OUT_) return launch_stack<KS_, OUT_>(p, blocks, lds, st);
     STACK_CASE(1, 2) STACK_CASE(1, 3) STACK_CASE(2, 2) STACK_CASE(2, 3) STACK_CASE(3, 2) STACK_CASE(3, 3) STACK_CASE(4, 2) STACK_CASE(4, 3)

@@ -115,6 +115,37 @@ STACKS = [  # I, H, layers, rows per segment, T, rows per workgroup
 ]
 
 
+@pytest.mark.parametrize("H,nl,Rs,T,rpw,want_f32", [
+    (320, 2, [21], 37, 4, True), (320, 3, [35, 6], 30, 8, True), (320, 2, [64], 90, 4, False), (320, 2, [64], 61, 8, False),
+    (272, 2, [13], 25, 4, True), (288, 2, [9, 4], 19, 8, True), (304, 3, [11], 1, 4, True), (304, 2, [7], 2, 8, True),
+])
+def test_full_band_stack_with_io_waves_equals_round_2_bodies(hip, H, nl, Rs, T, rpw, want_f32):
+    """Round 5: 256 < H <= 320 stacks at 4 / 8 rows per workgroup run scan3w_role (sfsn_scan3w_dev.h: ten compute waves x two tiles +
+    loader + storer, 768 threads, PROJ roles on twelve waves) where the library chooses it (8 rows; 4 rows from 512 frames on).  Forced
+    on and off here (SFSN_STACK_FB3, read per call): every output of every layer -- fp32 / int8 spikes, final h and c -- bit for bit equal to round 2's bodies, which the test below holds to the oracle; every
+    tile count 17..20, one / two / odd numbers of frames, ragged row blocks, three layers (a scan role that is gated AND publishes)."""
+    rng = np.random.default_rng(H + nl + T)
+    cells = _cells(rng, 40, H, nl)
+    o = Oracle("f32")
+    zin0 = [o.linear(rng.standard_normal((T, R, 40)).astype(np.float32), cells[0][0]["weight_ih"]) for R in Rs]
+    h0 = [[(rng.random((R, H)) > 0.5).astype(np.float32) for R in Rs] for _ in range(nl)]
+    c0 = [[rng.standard_normal((R, H)).astype(np.float32) for R in Rs] for _ in range(nl)]
+    res = {}
+    for flag in ("1", "0"):
+        os.environ["SFSN_STACK_FB3"] = flag
+        try:
+            res[flag] = run_stack(hip, zin0, cells, T, H, rpw, want_f32=want_f32, h0=h0, c0=c0)
+        finally:
+            del os.environ["SFSN_STACK_FB3"]
+    for l in range(nl):
+        for i in range(len(Rs)):
+            for a, b, what in zip(res["1"][l][i], res["0"][l][i], ("fp32 spikes", "int8 spikes", "h", "c")):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    np.testing.assert_array_equal(a, b, err_msg=f"layer {l} segment {i}: {what}")
+            assert res["1"][l][i][1].any()
+
+
 @pytest.mark.parametrize("wide", [True, False], ids=["wide", "narrow"])
 @pytest.mark.parametrize("I,H,nl,Rs,T,rpw", STACKS)
 def test_stack_scan_vs_oracle_and_per_layer_calls(hip, I, H, nl, Rs, T, rpw, wide):
