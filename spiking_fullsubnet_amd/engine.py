@@ -276,6 +276,8 @@ class Engine:
         # are in flight anyway (bench.py's timed region sets 0).
         self.overlap_chunks = int(os.environ.get("SFSN_OVERLAP_CHUNKS", "3"))
         self.overlap_fracs = None  # optional explicit chunk lengths (fractions of T) of the overlapped schedule
+        if os.environ.get("SFSN_OVERLAP_FRACS"):
+            self.overlap_fracs = [float(v) for v in os.environ["SFSN_OVERLAP_FRACS"].split(",")]
         # frames of the first chunk: -1 = 0.24 T (measured, scripts/exp_overlap.py: 3.55 -> 3.40 ms at B=64, the same 3-4 % at B=4..32 and
         # T=500; 64..128 frames and 0.32 T gain nothing), 0 = equal chunks
         self.overlap_first = int(os.environ.get("SFSN_OVERLAP_FIRST", "-1"))
@@ -976,6 +978,16 @@ class Engine:
         else:
             sstreams = gstreams = [main] * n_stage
             rpw_fb, rpw_sb = self.rows_per_wg
+        if rpw_sb == 0 and self.fuse_input and spec.shared and 128 < self.sb[0].H <= 256:
+            # Many sub-band rows (baseline_l: 43 units per clip = 2752 rows at B = 64): left to itself the library spreads them at 8
+            # rows per workgroup (344 workgroups: two rounds on 256 compute units, round 2's body for 16 tiles) behind a separate
+            # layer-0 input product and a layer-2 spike product (5.6 GB of fp32 input terms written and read).  At 16 rows per workgroup
+            # the launch is one round and the fused-input kernels apply (input products inside the scan, defined at 16 rows): said
+            # explicitly here whenever 8 rows would not fit the chip in one round.
+            n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+            rows_sb = sum(x.shape[1] for x in xs)
+            if (rows_sb + 7) // 8 > n_cu:
+                rpw_sb = 16
         staged = pipeline or overlap  # several streams chained by events
         hS = [self._handle(s_) for s_ in sstreams]
         hG = [self._handle(s_) for s_ in gstreams]
