@@ -1158,14 +1158,14 @@ extern "C" int sfsn_stream_hop(const sfsn_hop_desc* desc, void* stream) {
     const int fit = hop_fits_device(local.nblocks);
     if (fit != SFSN_OK) return fit;
     if (hipGetDevice(&dev) != hipSuccess) return SFSN_EHIP;
-    static int lds_set[2][64];
+    static int lds_set[2][2][64];  // per kernel instantiation (hop == 1 or not, one or two gate matrices) and device (round-4 advisor finding)
     const int one = local.hop == 1 ? 1 : 0;
     const bool g2 = local.G == 2;
     const void* kern = one ? (g2 ? reinterpret_cast<const void*>(stream_hop_kernel<true, 2>) : reinterpret_cast<const void*>(stream_hop_kernel<true, 1>))
                            : (g2 ? reinterpret_cast<const void*>(stream_hop_kernel<false, 2>) : reinterpret_cast<const void*>(stream_hop_kernel<false, 1>));
-    if (lds > 64 * 1024 && dev < 64 && !lds_set[one][dev]) {
+    if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || !lds_set[one][g2 ? 1 : 0][dev])) {  // (devices beyond the cache: set on every launch)
         if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SFSN_EHIP;
-        lds_set[one][dev] = 1;
+        if (dev >= 0 && dev < 64) lds_set[one][g2 ? 1 : 0][dev] = 1;
     }
     if (lds > 160 * 1024) return SFSN_EUNSUPPORTED;
     if (one)

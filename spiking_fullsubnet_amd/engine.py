@@ -297,6 +297,7 @@ class Engine:
         self._defer_err = None  # overlapped schedule: [(what, scratch)] of the running forward's stack launches (one copy per forward)
         self._err_stream = None
         self.hw_queues = _check_hw_queues()
+        self._last_forward: Dict[int, torch.cuda.Event] = {}  # per calling stream: recorded behind its most recent forward
 
     # ---------------------------------------------------------------------------------------------
     def _stream(self):
@@ -521,7 +522,13 @@ class Engine:
         # dozen forwards in flight, sets 16 and keeps its per-layer launches.  Measured at B = 64, T = 1000 (scripts/exp_pair.py):
         # 1.03 ms against 1.43 (scan3 at 4 rows + sfsn_spike_proj), 1.72 (8-wave FUSED roles), 2.4 (PROJ roles).
         wgs8 = nl * sum((R + 7) // 8 for R in Rs)
-        if self.pair_scan and H <= 224 and self.rows_per_wg[1] in (0, 8) and wgs8 <= n_cu - 40:
+        # (the launch assumes the forward has the chip to itself: its 2 x 104 workgroups wait for each other inside the launch.  A second
+        #  forward of this engine still in flight on another stream (its end-of-forward event has not fired) takes the per-layer
+        #  launches instead: round-4 advisor finding.  Work of OTHER processes or libraries cannot be seen from here; the waits
+        #  are bounded and reported.)
+        me = torch.cuda.current_stream(self.device).cuda_stream
+        alone = all(ev.query() for k, ev in self._last_forward.items() if k != me)
+        if self.pair_scan and alone and H <= 224 and self.rows_per_wg[1] in (0, 8) and wgs8 <= n_cu - 40:
             return True, False, 8
         if rows <= n_cu:       # every layer's workgroups at 8 rows + the PROJ workgroups fit several times over
             return True, True, 8
@@ -534,7 +541,8 @@ class Engine:
         the layout H <= 224 stacks without input-term buffers get (8 rows per workgroup), even I <= 64, whole 8-row blocks, and at
         least 64 row-frames (below that sfsn_input_proj_f32 itself takes its fp32-MFMA form: the schedules would differ in the last bit)."""
         if not (self.fuse_input and self.pair_scan and self.spec.shared and not wide and rpw_stack == 8 and not want_membrane
-                and seqs[0].H <= 224 and len(seqs[0].cells) >= 2 and not os.environ.get("SFSN_STACK_FUSED8")):
+                and seqs[0].H <= 224 and len(seqs[0].cells) >= 2 and not os.environ.get("SFSN_STACK_FUSED8")
+                and not os.environ.get("SFSN_SCAN_V2")):  # (the library refuses the FUSEDX3 role under either switch)
             return []
         return [i for i, (seq, x) in enumerate(zip(seqs, xs_))
                 if seq.I % 2 == 0 and seq.I <= 64 and x.shape[1] % 8 == 0 and nt * x.shape[1] >= 64]
@@ -819,6 +827,12 @@ class Engine:
             if self._stack_err_pending:
                 self._poll_stack_errors()
             out = self._forward_stft(stft, want_layers, want_membrane, pipeline, want_counts)
+            if not torch.cuda.is_current_stream_capturing():
+                cur = torch.cuda.current_stream(self.device)
+                ev = self._last_forward.get(cur.cuda_stream)
+                if ev is None:
+                    ev = self._last_forward[cur.cuda_stream] = torch.cuda.Event()
+                ev.record(cur)  # (what _stack_choice asks: is another stream's forward still running?)
             if self.strict_errors and self._stack_err_pending:
                 # results are only handed out once every stack launch of THIS forward is known to have completed its hand-offs
                 # (one stream synchronisation per forward: for callers that keep several forwards in flight leave it off and
