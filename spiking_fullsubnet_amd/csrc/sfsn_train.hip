@@ -744,8 +744,12 @@ __device__ __forceinline__ void train_seq_fwd_body(const TrainFwdParams& p, cons
             p.invstd[(size_t)t * H + nj] = invstd;
             if (p.running_mean) {
                 const float unb = p.R > 1 ? var * ((float)p.R / (float)(p.R - 1)) : var;
-                rmean = (1.0f - p.momentum) * rmean + p.momentum * mean;
-                rvar = (1.0f - p.momentum) * rvar + p.momentum * unb;
+                // momentum < 0: nn.BatchNorm1d(momentum=None), the cumulative moving average -- factor 1 / num_batches_tracked AFTER this
+                // step's increment (torch/nn/modules/batchnorm.py: exponential_average_factor = 1.0 / float(num_batches_tracked));
+                // the caller passes -(num_batches_tracked before the call + 1)
+                const float mom = p.momentum >= 0.0f ? p.momentum : 1.0f / (-p.momentum + (float)t);
+                rmean = (1.0f - mom) * rmean + mom * mean;
+                rvar = (1.0f - mom) * rvar + mom * unb;
             }
         }
         __syncthreads();

@@ -166,8 +166,6 @@ class GSNLayerTrainFn(torch.autograd.Function):
         if bn_w is not None and batch_stats:
             if R == 1:  # nn.BatchNorm1d in training mode (torch/nn/functional.py: _verify_batch_size)
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([{R}, {H}])")
-            if momentum is None:
-                raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative moving average) is not implemented by the HIP training step")
             if stats is not None:
                 for nm, t_ in (("running_mean", stats[0]), ("running_var", stats[1])):
                     # the step kernel updates these in place through raw float pointers
@@ -200,7 +198,10 @@ class GSNLayerTrainFn(torch.autograd.Function):
         pis = invstd.data_ptr() if invstd is not None else 0
         pzero, pw, pb = zero.data_ptr(), w_hh_c.data_ptr(), bias_c.data_ptr()
         a_bw, a_bb, a_rm, a_rv = _p(bw), _p(bb), _p(rmean), _p(rvar)
-        mom, ep, sh = float(0.1 if momentum is None else momentum), float(eps), int(shared)
+        # momentum=None = cumulative moving average (torch/nn/modules/batchnorm.py): the factor of step t is 1 / num_batches_tracked after
+        # that step's increment; handed to the kernels as -(count before the call + 1) (one host read of the counter per layer call)
+        n0 = int(stats[2].item()) if (momentum is None and use_bn and batch_stats and stats is not None and stats[2] is not None) else 0
+        mom, ep, sh = float(-(n0 + 1) if momentum is None else momentum), float(eps), int(shared)
         fwd = L.sfsn_gsn_train_step_fwd
         # zeroed per call: packed-spike slots and publish counters of the one-launch layer call, partial-sum granules, error word (last 4 words)
         scr = torch.zeros(((L.sfsn_train_seq_scratch_bytes(R, H) if seq else L.sfsn_train_scratch_bytes(H)) // 4,), dtype=torch.int32, device=dev)
@@ -214,7 +215,7 @@ class GSNLayerTrainFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             for t in (() if seq else range(T)):
                 rc = fwd(P(pz + t * sRG), P(pw), P(pb), P(pzero if t == 0 else psp + (t - 1) * sRH), P(pzero if t == 0 else pu + (t - 1) * sRH),
-                         a_bw, a_bb, a_rm, a_rv, mom, ep, R, H, sh, P(psp + t * sRH), P(pu + t * sRH), P(pxh + t * sRH) if pxh else None,
+                         a_bw, a_bb, a_rm, a_rv, (mom if mom >= 0 else 1.0 / (n0 + t + 1)), ep, R, H, sh, P(psp + t * sRH), P(pu + t * sRH), P(pxh + t * sRH) if pxh else None,
                          P(pf + t * sRH), P(pg + t * sRH), P(pis + t * H * 4) if pis else None, p_scr, t + 1, st)
                 if rc:
                     check(rc, "sfsn_gsn_train_step_fwd")
@@ -368,8 +369,6 @@ class GSNLayersTrainFn(torch.autograd.Function):
             if use_bn:
                 if R == 1:  # nn.BatchNorm1d in training mode (torch/nn/functional.py: _verify_batch_size)
                     raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([{R}, {H}])")
-                if meta["momentum"][i] is None:
-                    raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative moving average) is not implemented by the HIP training step")
                 if stats is not None:
                     for nm, t_ in (("running_mean", stats[0]), ("running_var", stats[1])):
                         if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != dev or t_.numel() != H:
@@ -388,7 +387,12 @@ class GSNLayersTrainFn(torch.autograd.Function):
             c.z, c.w_hh, c.bias, c.bn_w, c.bn_b = z.data_ptr(), w_hh_c.data_ptr(), bias_c.data_ptr(), _dp(bw), _dp(bb)
             c.running_mean = _dp(stats[0]) if (use_bn and stats is not None) else None
             c.running_var = _dp(stats[1]) if (use_bn and stats is not None) else None
-            c.momentum, c.eps, c.R = float(0.1 if meta["momentum"][i] is None else meta["momentum"][i]), float(meta["eps"][i]), R
+            if meta["momentum"][i] is None:  # cumulative moving average: see GSNLayerTrainFn.forward
+                n0 = int(stats[2].item()) if (use_bn and stats is not None and stats[2] is not None) else 0
+                c.momentum = float(-(n0 + 1))
+            else:
+                c.momentum = float(meta["momentum"][i])
+            c.eps, c.R = float(meta["eps"][i]), R
             c.spikes, c.u, c.xhat, c.f, c.g, c.invstd, c.scratch = spikes.data_ptr(), u.data_ptr(), _dp(xhat), fg.data_ptr(), gg.data_ptr(), _dp(invstd), scr.data_ptr()
             keep.append((z, scr))
             zero = torch.zeros((1,), **f32)

@@ -243,7 +243,7 @@ def test_training_layer_call_checks_before_it_launches():
     """Round-3 advisor findings: (a) both step kernels' geometry is validated before the first forward launch (the backward step
     needs more LDS than the forward one: R = 2048 at H = 224 used to pass forward and fail in backward()); (b) BatchNorm running
     statistics are handed to the kernel as raw float pointers: anything but contiguous float32 on the input's device is refused;
-    (c) R = 1 in training mode raises like nn.BatchNorm1d; momentum = None is refused; (d) a forward with nothing to differentiate
+    (c) R = 1 in training mode raises like nn.BatchNorm1d; momentum = None (cumulative moving average) follows nn.BatchNorm1d (round 5); (d) a forward with nothing to differentiate
     (no backward will follow) has its row-block exchange checked before the outputs are handed out."""
     import spiking_fullsubnet_amd.modeling_spiking_fullsubnet as M
     from spiking_fullsubnet_amd import _lib, training
@@ -257,10 +257,26 @@ def test_training_layer_call_checks_before_it_launches():
     assert torch.equal(rm, stack.layers[0].cell.batchnorm.running_mean)
     with pytest.raises(ValueError):
         training.gsn_stack(torch.randn(5, 1, 12, device=DEV), stack, training=True)
-    stack.layers[0].cell.batchnorm.momentum = None
-    with pytest.raises(NotImplementedError):
-        training.gsn_stack(torch.randn(5, 4, 12, device=DEV), stack, training=True)
-    stack.layers[0].cell.batchnorm.momentum = 0.1
+    # momentum = None (cumulative moving average, torch/nn/modules/batchnorm.py): the running statistics after T steps are the plain
+    # means of the T batch statistics (weighted with what was there: num_batches_tracked counts on) -- against nn.BatchNorm1d itself
+    cma = M.StackedGSU(12, 32, 1, True, True).to(DEV).train()
+    cma.layers[0].cell.batchnorm.momentum = None
+    twin = copy.deepcopy(cma)
+    xc = torch.randn(7, 40, 12, device=DEV)
+    for rep_ in range(2):  # (the second call continues the count)
+        outs = training.gsn_stack(xc.clone().requires_grad_(True), cma, training=True)
+        cell = twin.layers[0].cell
+        h, c = torch.zeros(40, 32, device=DEV), torch.zeros(40, 32, device=DEV)
+        with torch.no_grad():
+            for t in range(7):
+                pre = xc[t] @ cell.weight_ih.t() + h @ cell.weight_hh.t()
+                f = torch.sigmoid(pre + cell.bias_ih[:32])
+                c = cell.batchnorm(f * c + (1 - f) * (pre + cell.bias_ih[32:]))
+                h = (c >= 0).float()
+        assert int(cma.layers[0].cell.batchnorm.num_batches_tracked) == int(cell.batchnorm.num_batches_tracked) == 7 * (rep_ + 1)
+        _close(cma.layers[0].cell.batchnorm.running_mean.cpu().numpy(), cell.batchnorm.running_mean.cpu().numpy(), "CMA running_mean", rtol=1e-4, atol_frac=1e-5)
+        _close(cma.layers[0].cell.batchnorm.running_var.cpu().numpy(), cell.batchnorm.running_var.cpu().numpy(), "CMA running_var", rtol=1e-4, atol_frac=1e-5)
+        assert float((outs[-1][-1] == h).float().mean()) > 0.995
     half = M.StackedGSU(12, 32, 1, True, True).to(DEV).train()
     half.layers[0].cell.batchnorm.running_var = half.layers[0].cell.batchnorm.running_var.double()
     with pytest.raises(TypeError):
