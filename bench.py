@@ -433,7 +433,9 @@ def main():
                 useful = 2.0 * B * Hf * Hf * (2 * nl - 1) * T  # int8 MACs x 2 of the recurrent + layer>=1 input products, one digit plane
                 # executed by the matrix cores: x3 digit planes, 16-column MFMA tiles for 4 (scan) / 16 (input product) rows
                 executed = 2.0 * Hf * Hf * 3 * T * (nl * (B / 4) * 16 + (nl - 1) * B)
-                full_band = dict(kernel=f"gsn_stack_kernel<KS={(Hf + 63) // 64}> (scan roles: W_hh two digit planes in registers + one in LDS; PROJ role feeds layer 2)",
+                full_band = dict(kernel=f"gsn_stack_fb_kernel (round 5: IO-specialised waves -- ten compute waves x two tiles + loader + storer, W_hh two digit planes in "
+                                        f"registers + one in LDS; PROJ role on twelve waves feeds layer 2) for this whole-sequence launch; the chunks of the strict "
+                                        f"schedule keep gsn_stack_kernel<KS={(Hf + 63) // 64}> (DESIGN 5.6b)",
                                  launch_ms=round(steps_ms, 4), per_step_us=round(1e3 * steps_ms / T, 3),
                                  workgroups=nl * ((B + 3) // 4) + (nl - 1) * ((B + 15) // 16), launches_per_forward=1,
                                  mfma=dict(useful_TOPS=round(useful / (steps_ms * 1e-3) / 1e12, 2), executed_TOPS=round(executed / (steps_ms * 1e-3) / 1e12, 2),

@@ -58,7 +58,7 @@ kp = [x for x in f if "gsn_stack_wide_kernel<4" in x]
 k4l = [x for x in f if "gsn_scan3_kernel<4, 4" in x]
 k4 = (kp or k4l)[0]
 kfu = [x for x in jf if "gsn_scan_fused_kernel" in x][0]
-kst = [x for x in s2 if "gsn_stack_kernel<5" in x][0]
+kst = ([x for x in s2 if "gsn_stack_fb_kernel" in x] or [x for x in s2 if "gsn_stack_kernel<5" in x])[0]  # (round 5: the IO-wave full-band kernel for whole-sequence launches)
 m = s2[kst]
 n_cu, simd = 256, 4
 wg = 36  # full-band stack: 16 + 16 scan workgroups + 4 PROJ workgroups, one per CU
