@@ -62,6 +62,8 @@ def run(n_lanes, steps, warm):
     out = {}
     for r in range(n):
         kind, base, nb = log[3 * r], log[3 * r + 1], log[3 * r + 2]
+        if kind == 5:  # the IO-wave full-band stack: its slice holds the stamps of nb / 25 workgroups, then the per-wave stall counters
+            kind, nb = 4, nb // 25
         s, e = st[base:base + nb, 0], st[base:base + nb, 1]
         ok = (s > 0) & (e > 0)  # (padding blocks of a stack launch never stamp)
         s, e = s[ok], e[ok]

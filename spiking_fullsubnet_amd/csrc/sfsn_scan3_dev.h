@@ -204,7 +204,30 @@ struct Scan3Role {
     int R, row0;
     unsigned long long* count = nullptr;  // nullable: a role without fp32 spikes adds the number of spikes it wrote (ScanSegDev::count)
     int lsplit = SFSN_S3_LSPLIT;          // 8-row roles: fp32 store instructions per frame issued by the loader wave (the storer takes the rest)
+#ifdef SFSN_EXPERIMENTS
+    unsigned long long* probe = nullptr;  // [wave][4] shader-clock cycles: at the step barrier / in counted vmcnt waits / in hand-off polls / in all
+#endif
 };
+
+// ---- per-wave stall accounting (make EXTRA=-DSFSN_EXPERIMENTS; scripts/exp_beside_r05.py): which wave of a workgroup is the one the
+// others wait for at the step barrier, and what that wave waits for itself.  Not compiled into the product.
+#ifdef SFSN_EXPERIMENTS
+#define S3_PB_DECL() unsigned long long pb_[3] = {0, 0, 0}, pb_a_ = 0; const unsigned long long pb_0_ = __builtin_amdgcn_s_memtime()
+#define S3_PB_TIC() pb_a_ = __builtin_amdgcn_s_memtime()
+#define S3_PB_TOC(k) pb_[k] += __builtin_amdgcn_s_memtime() - pb_a_
+#define S3_PB_OUT(rl, wave, lane)                                                                                        \
+    do {                                                                                                                 \
+        if ((rl).probe && (lane) == 0) {                                                                                 \
+            unsigned long long* q_ = (rl).probe + 4 * (wave);                                                            \
+            q_[0] = pb_[0]; q_[1] = pb_[1]; q_[2] = pb_[2]; q_[3] = __builtin_amdgcn_s_memtime() - pb_0_;                 \
+        }                                                                                                                \
+    } while (0)
+#else
+#define S3_PB_DECL() do {} while (0)
+#define S3_PB_TIC() do {} while (0)
+#define S3_PB_TOC(k) do {} while (0)
+#define S3_PB_OUT(rl, wave, lane) do {} while (0)
+#endif
 
 // FLG bit 0: the input term is written by other workgroups of this launch (gated on lk.in, sc1 loads); bit 1: the int8 spikes
 // feed other workgroups of this launch (sc1 stores, progress in lk.out).  OUT bit 0: fp32 spikes, bit 1: int8 spikes.

@@ -39,6 +39,9 @@
 #ifndef SFSN_S3W_PF
 #define SFSN_S3W_PF 3
 #endif
+#ifndef SFSN_S3W_DP
+#define SFSN_S3W_DP SFSN_S3W_DG  // ring of a role that publishes but is not gated itself (its depth is no part of any lag)
+#endif
 template <int KS, int RPW, int FLG = 0>
 struct Scan3wCfg {
     static constexpr int NTHR = 768, NWAVES = 12, NTMAX = 20;
@@ -48,7 +51,7 @@ struct Scan3wCfg {
     __host__ __device__ static constexpr int slot_bytes(int NT) { return pieces(NT) * 1024; }
     static constexpr int MAXP = (RPW * NTMAX * 4 + 63) / 64;  // pieces at NT = 20: 5 / 10 at 4 / 8 rows
     static constexpr bool GATED = (FLG & 1) != 0, PUB = (FLG & 2) != 0;
-    static constexpr int DWANT = (GATED || PUB) ? SFSN_S3W_DG : 6;
+    static constexpr int DWANT = GATED ? SFSN_S3W_DG : (PUB ? SFSN_S3W_DP : 6);
     // what the 160 KiB leave beside the digit plane (NTMAX x KS KiB) and the state buffers; LDS-DMA destinations stay below 64 KiB
     static constexpr int ROOM = 160 * 1024 - 512 - NTMAX * KS * 1024 - 2 * 16 * LDH;
     static constexpr int DFIT = (ROOM < 65536 ? ROOM : 65536) / (MAXP * 1024);
@@ -224,14 +227,18 @@ __device__ __forceinline__ void scan3w_compute(const Scan3Role& rl, char* smem, 
     __syncthreads();                       // initial state in hbuf[0], digit plane 0 in LDS
     __builtin_amdgcn_s_barrier();          // the loader's prologue frames have landed
     int stop = 0;
+    S3_PB_DECL();
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         if constexpr (GATED) stop = flag[t & 1];  // written by the loader during step t-1 (or before)
         ts.step(hbuf + (t & 1) * 16 * LDH, hbuf + ((t & 1) ^ 1) * 16 * LDH, smem + (t % D) * SLOT, wplane);
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        S3_PB_TIC();
         __builtin_amdgcn_s_barrier();
+        S3_PB_TOC(0);
         if constexpr (GATED) if (__builtin_amdgcn_readfirstlane(stop)) break;
     }
+    S3_PB_OUT(rl, tiles[0], lane);
     ts.finish(rl, H, hbuf + (T & 1) * 16 * LDH);
 }
 
@@ -333,20 +340,33 @@ __device__ __forceinline__ void scan3w_role(const Scan3Role& rl, const StackLink
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
         int stop = 0;
+        S3_PB_DECL();
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             if constexpr (GATED) stop = failed;
             const int td = (t + D - 1 < T) ? t + D - 1 : T - 1;
+            S3_PB_TIC();
             ensure(td + 1);
+#ifndef SFSN_PB_ISSUE  // (-DSFSN_PB_ISSUE: the DMA issue is counted with the polls)
+            S3_PB_TOC(2);
+#endif
             if (!failed) issue((t + D - 1) % D, td);
+#ifdef SFSN_PB_ISSUE
+            S3_PB_TOC(2);
+#endif
             if constexpr (GATED) if (failed && lane == 0) flag[(t + 1) & 1] = 1;  // read during step t+1 (see scan3_role)
             if constexpr (LSF) if (t > 0) ff.run(hbuf + (t & 1) * 16 * LDH, rl.spikes_f32 + ((size_t)(t - 1) * R + row0) * H, lane);
             if constexpr (SFSN_S3W_IOTILES) ts.step(hbuf + (t & 1) * 16 * LDH, hbuf + ((t & 1) ^ 1) * 16 * LDH, smem + (t % D) * SLOT, wplane);
+            S3_PB_TIC();
             wait_vmcnt_n(allow);
+            S3_PB_TOC(1);
             __builtin_amdgcn_s_waitcnt(0xc07f);
+            S3_PB_TIC();
             __builtin_amdgcn_s_barrier();
+            S3_PB_TOC(0);
             if constexpr (GATED) if (stop) break;
         }
+        S3_PB_OUT(rl, NCW, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs past the end are invisible to the compiler
         if constexpr (LSF) if (T > 0 && !(GATED && stop)) ff.run(hbuf + (T & 1) * 16 * LDH, rl.spikes_f32 + ((size_t)(T - 1) * R + row0) * H, lane);
         if constexpr (SFSN_S3W_IOTILES) ts.finish(rl, H, hbuf + (T & 1) * 16 * LDH);
@@ -397,6 +417,7 @@ __device__ __forceinline__ void scan3w_role(const Scan3Role& rl, const StackLink
         __syncthreads();
         __builtin_amdgcn_s_barrier();
         int stop = 0;
+        S3_PB_DECL();
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             if constexpr (GATED) stop = flag[t & 1];
@@ -408,14 +429,19 @@ __device__ __forceinline__ void scan3w_role(const Scan3Role& rl, const StackLink
             if constexpr (SFSN_S3W_IOTILES) ts.step(hbuf + (t & 1) * 16 * LDH, hbuf + ((t & 1) ^ 1) * 16 * LDH, smem + (t % D) * SLOT, wplane);
             if constexpr (PUB) {
                 if (t > 0) {
+                    S3_PB_TIC();
                     wait_vmcnt_n(pf * spf);
+                    S3_PB_TOC(1);
                     if (lane == 0 && t - pf > 0) stack_publish(lk, t - pf);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);  // my LDS reads are done before the buffer is rewritten (step t+1)
+            S3_PB_TIC();
             __builtin_amdgcn_s_barrier();
+            S3_PB_TOC(0);
             if constexpr (GATED) if (__builtin_amdgcn_readfirstlane(stop)) break;
         }
+        S3_PB_OUT(rl, NCW + 1, lane);
         if (T > 0 && !(GATED && __builtin_amdgcn_readfirstlane(stop))) {
             const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
             flush8(hl, T - 1);

@@ -170,6 +170,9 @@ struct StackLink {
     unsigned* err;       // launch-wide error word (non-zero = a bounded spin expired)
     int lag;             // frames a consumer lets its producer run ahead before it starts / resumes (amortises the polls)
     unsigned* dbg;       // optional: [0] += hand-off waits entered, [1] += poll iterations spent in them (who waits for whom)
+#ifdef SFSN_EXPERIMENTS
+    unsigned long long* probe = nullptr;  // per-wave stall counters of this workgroup (S3_PB_*, sfsn_scan3_dev.h)
+#endif
 };
 
 #define SFSN_STACK_SPIN_LIMIT 400000  // x (s_sleep 32 + one L2 round trip) ~ 1 s

@@ -58,6 +58,7 @@ struct StackRoleDev {
     int R, block0, nblocks, kind, rpw;
     int src;      // producer role (-1: the input is complete before the launch)
     int src_rpw;  // rows per workgroup of the producer role
+    int split;    // PROJ role of the narrow kernels: workgroups per 16-row block, each owning NT / split column tiles (1 elsewhere)
     int pub;      // 1: another role of this launch consumes what this role writes
     unsigned long long* count;  // nullable: without fp32 spikes the role adds the number of spikes it wrote (ScanSegDev::count)
 };
@@ -348,9 +349,12 @@ __device__ __forceinline__ void stack_fused_role(const StackRoleDev& rl, const S
 // Digit plane 0 of W_ih in LDS, planes 1-2 in registers (8 waves x up to 3 tiles).  Output fragments leave as 16-byte
 // write-through stores.  LDS: [input-spike ring D x 16 x HP][bias, dq: 2 x HP floats][W_ih p0].
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef SFSN_PROJ_D
+#define SFSN_PROJ_D 3
+#endif
 template <int KS>
 struct ProjLayout {
-    static constexpr int HP = KS * 64, D = 3, NCH = KS * 4;
+    static constexpr int HP = KS * 64, D = SFSN_PROJ_D, NCH = KS * 4;
     static constexpr int SLOT = 16 * HP;
     static constexpr int CST_OFF = D * SLOT, W_OFF = CST_OFF + 2 * HP * 4;
     __device__ __host__ static constexpr int bytes(int NT) { return W_OFF + NT * KS * 1024; }
@@ -358,7 +362,7 @@ struct ProjLayout {
 
 template <int KS, int NTL, int NW = 8>
 __device__ __forceinline__ void stack_proj_body(const StackRoleDev& rl, const StackLink& lk, char* smem, int* gate_word, int T, int H,
-                                                int NT, int row0, int rowc, int n, int q, int tid, int wave) {
+                                                int NT, int row0, int rowc, int n, int q, int tid, int wave, int t_lo) {
     using L = ProjLayout<KS>;
     constexpr int HP = L::HP, D = L::D, NCH = L::NCH, SLOT = L::SLOT;
     const int R = rl.R;
@@ -371,7 +375,7 @@ __device__ __forceinline__ void stack_proj_body(const StackRoleDev& rl, const St
     unsigned wl_off[NTL > 0 ? NTL : 1];
 #pragma unroll
     for (int i = 0; i < NTL; ++i) {
-        const int ct = wave + NW * i;
+        const int ct = t_lo + wave + NW * i;
         col[i] = ct * 16 + q * 4;
         wl_off[i] = (unsigned)((ct * KS) * 64 + lane) * 16u;
 #pragma unroll
@@ -404,13 +408,16 @@ __device__ __forceinline__ void stack_proj_body(const StackRoleDev& rl, const St
     __builtin_amdgcn_s_barrier();
 
     const unsigned zrow = (unsigned)(rowc * H) * 4u;
+    S3_PB_DECL();
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         if (t > 0) {
             const int need = (t + D < T) ? t + D : T;
+            S3_PB_TIC();
             if (avail >= 0 && need > avail) avail = stack_refresh(lk, need, T, gate_word, wave, lane);
-            // stores issued at steps <= t-3 are complete for every wave (see the wait below): frames [0, t-2)
-            if (wave == 0 && lane == 0 && t - 2 > 0) stack_publish(lk, t - 2);
+            S3_PB_TOC(2);
+            // stores issued at steps <= t-D are complete for every wave (see the wait below): frames [0, t-D+1)
+            if (wave == 0 && lane == 0 && t - D + 1 > 0) stack_publish(lk, t - D + 1);
         }
         if (avail < 0) break;
         {
@@ -441,21 +448,30 @@ __device__ __forceinline__ void stack_proj_body(const StackRoleDev& rl, const St
             __builtin_memcpy(&zi, &z, 16);
             store16_sc1(zt, zrow + (unsigned)cc * 4u, zi);  // rows past R are clamped duplicates (same value, same address)
         }
-        // my piece of step t+1's slot was issued at the top of step t-1; since then: this step's DMA and 2 x NTL stores
+        // my piece of step t+1's slot was issued at the top of step t-D+2; since then: D-2 more DMAs and D-1 steps' NTL stores
+        S3_PB_TIC();
         if (t < D) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CBASE) : "memory");
         }
+        S3_PB_TOC(1);
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        S3_PB_TIC();
         __builtin_amdgcn_s_barrier();
+        S3_PB_TOC(0);
     }
+    S3_PB_OUT(lk, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wave == 0 && lane == 0) stack_publish(lk, T);
 }
 
-// NW waves (8 in the 512-thread kernel, 12 in gsn_stack_fb_kernel): tiles dealt round-robin over all of them
+// NW waves (8 in the 512-thread kernel, 12 in gsn_stack_fb_kernel).  Workgroup blk of the role = 16-row block blk / split, column part
+// blk % split: the tiles [part NT / split, (part + 1) NT / split), dealt round-robin over the waves.  Round 5: the role's step is
+// bound by how fast ONE compute unit gets 16 rows x H floats of write-through stores out (scripts/exp_beside_r05.py: 2,720 clk per
+// frame alone, 3,420 beside the sub-band pair launch, with < 100 clk of counted vmcnt waits -- the store instructions themselves do
+// not issue), and the role's block range is padded to a multiple of eight anyway: the padding workgroups take column parts.
 template <int KS, int NW = 8>
 __device__ __forceinline__ void stack_proj_role(const StackRoleDev& rl, const StackLink& lk, char* smem, int* gate_word, int T, int H,
                                                 int NT, int blk) {
@@ -465,7 +481,9 @@ __device__ __forceinline__ void stack_proj_role(const StackRoleDev& rl, const St
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     const int R = rl.R;
-    const int row0 = blk * 16;
+    const int part = blk % rl.split;
+    const int row0 = (blk / rl.split) * 16;
+    const int t_lo = part * NT / rl.split, t_hi = (part + 1) * NT / rl.split;
     const int rowc = (row0 + n < R) ? row0 + n : R - 1;
     float(*cst)[HP] = reinterpret_cast<float(*)[HP]>(smem + L::CST_OFF);
     for (int j = tid; j < HP; j += NW * 64) {
@@ -476,18 +494,18 @@ __device__ __forceinline__ void stack_proj_role(const StackRoleDev& rl, const St
     {
         v4i* d1 = reinterpret_cast<v4i*>(smem + L::W_OFF);
         const v4i* s1 = reinterpret_cast<const v4i*>(rl.w_ih);
-        for (int i = tid; i < NT * KS * 64; i += NW * 64) d1[i] = s1[i];
+        for (int i = t_lo * KS * 64 + tid; i < t_hi * KS * 64; i += NW * 64) d1[i] = s1[i];  // (my tiles of digit plane 0)
     }
     __syncthreads();
-    const int ntl = (NT - wave + NW - 1) / NW;  // tiles wave, wave + 8, ... < NT
+    const int ntl = wave < t_hi - t_lo ? (t_hi - t_lo - wave + NW - 1) / NW : 0;  // tiles t_lo + wave, t_lo + wave + NW, ... < t_hi
     if (ntl >= 3)
-        stack_proj_body<KS, 3, NW>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+        stack_proj_body<KS, 3, NW>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave, t_lo);
     else if (ntl == 2)
-        stack_proj_body<KS, 2, NW>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+        stack_proj_body<KS, 2, NW>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave, t_lo);
     else if (ntl == 1)
-        stack_proj_body<KS, 1, NW>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+        stack_proj_body<KS, 1, NW>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave, t_lo);
     else
-        stack_proj_body<KS, 0, NW>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave);
+        stack_proj_body<KS, 0, NW>(rl, lk, smem, gate_word, T, H, NT, row0, rowc, n, q, tid, wave, t_lo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -792,14 +810,14 @@ __global__ __launch_bounds__(512) void gsn_stack_kernel(const StackParams p) {
     if (lk.dbg && threadIdx.x == 0) lk.dbg[2] = (unsigned)wall_clock64();
     if (rl.pub) lk.out = p.prog + 2 + blockIdx.x;
     const int my_rpw = rl.kind == STACK_PROJ ? 16 : rl.rpw;
-    if (rl.src >= 0) {  // the producer workgroups that own my rows
+    if (rl.src >= 0) {  // the producer workgroups that own my rows (a PROJ producer: `split` workgroups per 16-row block)
         const StackRoleDev& sr = p.role[rl.src];
-        const int r0 = blk * my_rpw;
+        const int r0 = (rl.kind == STACK_PROJ ? blk / rl.split : blk) * my_rpw;
         int r1 = r0 + my_rpw - 1;
         if (r1 > rl.R - 1) r1 = rl.R - 1;
         const int b0 = r0 / rl.src_rpw, b1 = r1 / rl.src_rpw;
-        lk.in = p.prog + 2 + sr.block0 + b0;
-        lk.n_in = b1 - b0 + 1;
+        lk.in = p.prog + 2 + sr.block0 + b0 * sr.split;
+        lk.n_in = (b1 - b0 + 1) * sr.split;
     }
     const int T = p.T, H = p.H, NT = p.NT;
     if (rl.kind == STACK_FUSED) {
@@ -843,6 +861,8 @@ __global__ __launch_bounds__(768) void gsn_stack_fb_kernel(const StackParams p) 
     constexpr int KS = 5;
     int* gate_word_p = reinterpret_cast<int*>(scan_smem + p.gate_off);
     int ri = -1;
+    StackLink lk;
+    lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = p.prog; lk.lag = p.lag; lk.dbg = nullptr;
     for (int i = 0; i < p.nroles; ++i)
         if ((int)blockIdx.x >= p.role[i].block0 && (int)blockIdx.x < p.role[i].block0 + p.role[i].nblocks) ri = i;
     if (ri < 0) {  // padding block
@@ -852,18 +872,19 @@ __global__ __launch_bounds__(768) void gsn_stack_fb_kernel(const StackParams p) 
     SFSN_WG_STAMP(p.wg_times, 0);
     const StackRoleDev& rl = p.role[ri];
     const int blk = (int)blockIdx.x - rl.block0;
-    StackLink lk;
-    lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = p.prog; lk.lag = p.lag; lk.dbg = nullptr;
+#ifdef SFSN_EXPERIMENTS
+    lk.probe = p.wg_times ? p.wg_times + 2 * gridDim.x + 48 * blockIdx.x : nullptr;  // (behind the launch's stamps: launch_stack_fb)
+#endif
     if (rl.pub) lk.out = p.prog + 2 + blockIdx.x;
-    const int my_rpw = rl.kind == STACK_PROJ ? 16 : rl.rpw;
-    if (rl.src >= 0) {  // the producer workgroups that own my rows
+    if (rl.src >= 0) {  // the producer workgroups that own my rows (a PROJ producer: `split` workgroups per 16-row block)
+        const int my_rpw = rl.kind == STACK_PROJ ? 16 : rl.rpw;
         const StackRoleDev& sr = p.role[rl.src];
-        const int r0 = blk * my_rpw;
+        const int r0 = (rl.kind == STACK_PROJ ? blk / rl.split : blk) * my_rpw;
         int r1 = r0 + my_rpw - 1;
         if (r1 > rl.R - 1) r1 = rl.R - 1;
         const int b0 = r0 / rl.src_rpw, b1 = r1 / rl.src_rpw;
-        lk.in = p.prog + 2 + sr.block0 + b0;
-        lk.n_in = b1 - b0 + 1;
+        lk.in = p.prog + 2 + sr.block0 + b0 * sr.split;
+        lk.n_in = (b1 - b0 + 1) * sr.split;
     }
     const int T = p.T, H = p.H, NT = p.NT;
     if (rl.kind == STACK_PROJ) {
@@ -874,6 +895,9 @@ __global__ __launch_bounds__(768) void gsn_stack_fb_kernel(const StackParams p) 
         r3.zin = rl.zin; r3.w_hh = rl.w_hh; r3.w_dq = rl.w_dq; r3.bias = rl.bias; r3.bn_alpha = rl.bn_alpha; r3.bn_beta = rl.bn_beta;
         r3.h_state = rl.h_state; r3.c_state = rl.c_state; r3.spikes_f32 = rl.spikes_f32; r3.spikes_i8 = rl.spikes_i8;
         r3.R = rl.R; r3.row0 = blk * rl.rpw; r3.count = rl.count; r3.lsplit = p.lsplit;
+#ifdef SFSN_EXPERIMENTS
+        r3.probe = lk.probe;
+#endif
 #define S3W_CASE(RPW_, F) \
     if (rl.rpw == RPW_ && flg == F) scan3w_role<KS, RPW_, OUT, F>(r3, lk, scan_smem, T, H, NT);
         S3W_CASE(4, 0) S3W_CASE(4, 1) S3W_CASE(4, 2) S3W_CASE(4, 3)
@@ -896,6 +920,15 @@ extern "C" size_t sfsn_stack_scratch_bytes(int n_layers, int n_segs, int rows_to
     return (blocks + 1 + 16) * sizeof(unsigned) * 5;  // counters + (optional) two debug words per workgroup
 }
 
+// column parts per 16-row block of a narrow PROJ role: the largest of 1 / 2 / 4 that fits the padding (SFSN_PROJ_SPLIT caps it: A/B runs)
+static int proj_split_host(int room) {
+    int cap = 4;
+    if (const char* e = getenv("SFSN_PROJ_SPLIT")) cap = atoi(e);
+    int sp = 1;
+    while (sp * 2 <= room && sp * 2 <= cap) sp *= 2;
+    return sp;
+}
+
 template <int OUT>
 static int launch_stack_fb(const StackParams& p, int blocks, int lds, hipStream_t st) {
     auto kern = gsn_stack_fb_kernel<OUT>;
@@ -903,7 +936,7 @@ static int launch_stack_fb(const StackParams& p, int blocks, int lds, hipStream_
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return SFSN_EHIP;
     StackParams q = p;
-    q.wg_times = sfsn_wgprobe_take(4, blocks);
+    q.wg_times = sfsn_wgprobe_take(5, 25 * blocks);  // 2 stamps + 12 waves x 4 stall counters per workgroup (S3_PB_*)
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(768), lds, st, q);
     return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;
 }
@@ -949,15 +982,14 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
     if (wide) fused = false;
     // round 5: 256 < H <= 320 at 4 / 8 rows per workgroup: the 768-thread kernel with IO-specialised scan roles (SFSN_SCAN_V2=1 keeps
     // round 2's bodies: A/B runs)
-    // Where it is used -- measured, not derived (scripts/exp_fb3_r05.py, scripts/exp_fb3_seq_r05.sh; B = 64): the stack ALONE on the
-    // chip 1.09 / 1.34 ms per 1000 frames at 4 / 8 rows against 1.30 / 1.60 for round 2's body, the twelve-lane region (8 rows) +1.5 %;
-    // but as a 240-380 frame chunk BESIDE the sub-band pair launch (the strict forward's overlapped schedule, 4 rows) it runs 1.95 us per
-    // frame against round 2's 1.76 and the forward 2.82-2.97 ms against 2.74-2.75: beside 208 workgroups writing 1.9 GB per ms the
-    // hand-off chain layer 1 -> PROJ -> layer 2 (write-through stores that must retire before they are published, sc1 loads behind
-    // them) is what a frame costs, and one loader / one storer wave per workgroup ride that out worse than eight waves that each fetch
-    // and flush their own share.  So: 8 rows always; 4 rows only for launches of >= 512 frames (whole sequences: the full-band model
-    // of the frozen front-ends runs alone on the chip; a chunk of the overlapped schedule keeps round 2's body).  SFSN_STACK_FB3=1 / 0
-    // forces it on / off (A/B runs).
+    // Where it is used -- measured (scripts/exp_fb3_r05.py, exp_fb3_chunks_r05.sh; B = 64): the stack ALONE on the chip 1.09 / 1.34 ms
+    // per 1000 frames at 4 / 8 rows against 1.30 / 1.60 for round 2's bodies, the twelve-lane region (8 rows) +1.5 %.  As a 240-380 frame
+    // chunk BESIDE the sub-band pair launch (the strict forward's overlapped schedule, 4 rows) it first LOST to round 2's bodies (2.82-2.97
+    // against 2.74-2.75 ms per forward); the per-wave stall counters of an EXPERIMENTS build (S3_PB_*, scripts/exp_beside_r05.py) found
+    // the 16-frame hand-off hysteresis and the store-bound PROJ role (see stack_proj_role) -- with lag 4 and the PROJ role split by
+    // columns the IO-wave kernel wins or ties there too (B = 4 / 16 / 32 / 64: 1.86 / 1.99 / 2.22 / 2.58-2.63 against 1.95 / 2.08 / 2.30 /
+    // 2.61-2.64; no fp32 spike tensors 2.42-2.45 against 2.52-2.53; T = 2000 +1.4 %).  Only very short launches keep round 2's bodies (the
+    // new kernel's hand-off chain costs ~24 us more to fill).  SFSN_STACK_FB3=1 / 0 forces it on / off (A/B runs, tests).
     bool fb3 = !fused && !wide && KS == 5 && !getenv("SFSN_SCAN_V2") && !getenv("SFSN_STACK_FB_V2");
     bool any4 = false;
     for (int l = 0; l < n_layers && fb3; ++l) {
@@ -966,7 +998,7 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
         if (rp == 4) any4 = true;
     }
     if (const char* e = getenv("SFSN_STACK_FB3")) fb3 = fb3 && atoi(e) != 0;
-    else if (any4 && T < 512) fb3 = false;
+    else if (any4 && T < 128) fb3 = false;
     const int roles_per_layer = (fused || inscan) ? 1 : 2;
     if (n_segs * (1 + (n_layers - 1) * roles_per_layer) > STACK_MAX_ROLES) return SFSN_EUNSUPPORTED;
     if (lag < 0) return SFSN_EINVAL;
@@ -1011,6 +1043,12 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
                 r.bias = s.bias; r.zin = const_cast<float*>(s.zin); r.spikes_in = f.spikes_in; r.w_ih = f.w_ih; r.w_ih_dq = f.w_ih_dq;
                 const int prows = wide ? 32 : 16;
                 r.R = s.R; r.kind = STACK_PROJ; r.rpw = prows; r.block0 = blocks; r.nblocks = (s.R + prows - 1) / prows;
+                r.split = 1;
+                if (!wide) {  // the role's block range is padded to a multiple of eight: the padding takes column parts (stack_proj_role)
+                    const int pad = (r.nblocks + 7) & ~7;
+                    r.split = proj_split_host(pad / r.nblocks);
+                    r.nblocks *= r.split;
+                }
                 r.src = prev_role[i]; r.src_rpw = p.role[prev_role[i]].rpw; r.pub = 1;
                 blocks = (blocks + r.nblocks + 7) & ~7;
                 prev_role[i] = nroles++;
@@ -1027,7 +1065,7 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
             r.w_hh = s.w_hh; r.w_dq = s.w_dq; r.bias = s.bias; r.bn_alpha = s.bn_alpha; r.bn_beta = s.bn_beta;
             r.h_state = s.h_state; r.c_state = s.c_state; r.spikes_f32 = s.spikes_f32; r.spikes_i8 = s.spikes_i8; r.count = s.spike_count;
             r.zin = const_cast<float*>(s.zin);
-            r.R = s.R; r.rpw = rpw; r.block0 = blocks; r.nblocks = (s.R + rpw - 1) / rpw;
+            r.R = s.R; r.rpw = rpw; r.block0 = blocks; r.nblocks = (s.R + rpw - 1) / rpw; r.split = 1;
             r.pub = last ? 0 : 1;
             if (xrole) {
                 r.kind = STACK_FUSEDX3; r.src = -1; r.src_rpw = rpw; r.x = fx[i].x; r.w_ih_f32 = fx[i].w_ih; r.I = fx[i].I; r.zin = nullptr;

@@ -266,7 +266,10 @@ class Engine:
         self.count_in_scan = os.environ.get("SFSN_COUNT_IN_SCAN", "1") != "0"  # layer_outputs="counts": counted by the scans themselves
         self.pair_scan = os.environ.get("SFSN_PAIR_SCAN", "1") != "0"  # H <= 224 stacks as one launch of FUSED3 roles (see _stack_choice)
         self.stack_rows_per_wg = {"fb": 4, "sb": 8}  # rows per workgroup of every layer of a stack: sum of workgroups <= CUs
-        self.stack_lag = 16
+        # frames a consumer role that had to wait lets its producers run ahead before it resumes (the hand-offs' hysteresis).  Round 2: 16
+        # (every wave of a workgroup stood in the poll); since the IO-wave roles one lane polls, and a launch ends lag + ring frames after
+        # its first layer does: 16 / 8 / 4 / 2 / 1 -> strict forward 2.74-2.76 / 2.65-2.70 / 2.62 / 2.63 / 2.63 ms (scripts/exp_lag_r05.sh)
+        self.stack_lag = int(os.environ.get("SFSN_STACK_LAG", "4"))
         # full-band / sub-band overlap of ONE forward: the sequence is cut into this many chunks, the full-band model runs them
         # on one stream, the sub-band models follow one chunk behind on a second stream (they need the full-band output of the
         # SAME frames only, MODEL:441-447; states are carried by the ABI's h_state / c_state).  The full-band chain (few
@@ -901,8 +904,17 @@ class Engine:
             # stays ahead)
             first = self.overlap_first if self.overlap_first >= 0 else int(round(0.24 * T / 8.0)) * 8
             first = min(max(int(first), 0), T // 2)
-            if self.overlap_fracs:  # explicit chunk lengths as fractions of T (experiments: scripts/exp_forward_r04.py)
-                cuts = [int(round(f * T / 8.0)) * 8 for f in self.overlap_fracs]
+            fracs = self.overlap_fracs
+            if (not fracs and self.overlap_first < 0 and self.overlap_chunks == 3 and T >= 256
+                    and B * sum(spec.units(g) for g in range(spec.n_groups)) < 600):
+                # round 5 (scripts/exp_chunks_ab*_r05.sh, interleaved A/B on two boxes): below ~600 sub-band rows (B <= 32 of
+                # baseline_m) a LONGER lead-in chunk wins -- (.36,.32,.32) T: 2.03-2.06 / 2.13 / 2.34 ms at B = 4 / 16 / 32 against
+                # 2.08-2.10 / 2.19 / 2.39-2.42 with 0.24 T.  At B = 64 the balance sits on a knife edge (full-band chunk c+1 must fit
+                # beside sub-band chunk c): (.32,.33,.35) measured 2.65-2.69 on one box and 2.80-2.82 on the next against 2.70-2.76
+                # for 0.24 T on both, so 0.24 T stays there.
+                fracs = (0.36, 0.32, 0.32)
+            if fracs:  # explicit chunk lengths as fractions of T (experiments: scripts/exp_forward_r04.py)
+                cuts = [int(round(f * T / 8.0)) * 8 for f in fracs]
                 lens = [c for c in cuts if c > 0]
                 lens = lens[:-1] + [T - sum(lens[:-1])] if sum(lens[:-1]) < T else [T]
                 bounds, t0 = [], 0
