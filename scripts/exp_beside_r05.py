@@ -141,6 +141,44 @@ def probes(beside):
                 print(f"       {cls:14s} per frame: at the barrier {m[0]:6.0f} clk (min over waves {mn:5.0f}), vmcnt waits {m[1]:6.0f}, hand-off polls {m[2]:6.0f}, all {m[3]:6.0f}")
 
 
+def probes_pair(beside):
+    """one probed replay of the pair launch (alone / beside the full-band launch): per role and wave class, cycles per frame"""
+    cap = 16384
+    buf = torch.zeros((cap, 2), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    L.sfsn_debug_wg_times(buf.data_ptr(), cap)
+    if beside:
+        launch(fbc, sA)
+    launch(sbc, sB)
+    torch.cuda.synchronize()
+    log = (ctypes.c_int * (3 * 64))()
+    n = L.sfsn_debug_wg_log(log, 64)
+    L.sfsn_debug_wg_times(None, 0)
+    st = buf.cpu().numpy().reshape(-1)
+    for r in range(n):
+        kind, base, nb = log[3 * r], log[3 * r + 1], log[3 * r + 2]
+        if kind != 6:
+            continue
+        blocks = nb // 33
+        w = st[2 * base: 2 * base + 66 * blocks]
+        stamps = w[:2 * blocks].reshape(blocks, 2)
+        pb = w[2 * blocks:].reshape(blocks, 16, 4).astype(np.float64) / NT
+        res = (stamps[:, 1] - stamps[:, 0]) / 100.0
+        Rs = [B * u for u in (8, 3, 2)]
+        roles, b0 = [], 0
+        for l in (1, 2):
+            for g, R in enumerate(Rs):
+                nbk = (R + 7) // 8
+                roles.append((f"layer {l} group {g} ({'in-scan x product' if l == 1 and g == 0 else 'input term from memory' if l == 1 else 'in-scan spike product'})", b0, b0 + nbk))
+                b0 = (b0 + nbk + 7) & ~7
+        for name, b0, b1 in roles:
+            print(f"    {name} ({b1 - b0} workgroups): resident {res[b0:b1].mean():.0f} us = {res[b0:b1].mean() / NT:.3f} us per frame")
+            for cls, ws in (("compute waves", slice(0, 14)), ("loader wave", slice(14, 15)), ("storer wave", slice(15, 16))):
+                m = pb[b0:b1, ws].mean(axis=(0, 1))
+                mn = pb[b0:b1, ws, 0].mean(axis=0).min()
+                print(f"       {cls:14s} per frame: at the barrier {m[0]:6.0f} clk (least-waiting wave {mn:5.0f}), vmcnt waits {m[1]:6.0f}, polls / bf16 split {m[2]:6.0f}, all {m[3]:6.0f}")
+
+
 pa = pair_alone()
 print(f"B={B}: chunk of {NT} frames; pair launch alone {1e3 * pa:.0f} us = {1e3 * pa / NT:.3f} us per frame", flush=True)
 for fb3 in ("0", "1"):
@@ -155,4 +193,8 @@ for fb3 in ("0", "1"):
             for beside in (False, True):
                 print(f"  stall ledger of the IO-wave kernel, {'beside the pair launch' if beside else 'alone'}:")
                 probes(beside)
+if probe:
+    for beside in (False, True):
+        print(f"stall ledger of the sub-band pair launch, {'beside the full-band launch' if beside else 'alone'}:")
+        probes_pair(beside)
 eng.check_stack_errors()

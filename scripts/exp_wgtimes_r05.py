@@ -38,7 +38,7 @@ lanes = [torch.cuda.Stream(device=dev) for _ in range(LANES)]
 eng.rows_per_wg, eng.stack_rows_fb_auto, eng.overlap_chunks = (8, 16), 8, 0
 want_layers = os.environ.get("LAYERS", "1") != "0"
 NAMES = {1: "gsn_scan_kernel (plain 16-row scan, groups 1-2 layer 1)", 2: "gsn_scan_fused_kernel (layer 2)", 3: "gsn_scan_fusedx_kernel (group 0 layer 1)",
-         4: "gsn_stack_kernel (full-band stack, 8 rows)"}
+         4: "gsn_stack_kernel (full-band stack, 8 rows)", 6: "gsn_stack_wide_kernel (sub-band layers side by side)"}
 
 
 def run(n_lanes, steps, warm):
@@ -62,6 +62,8 @@ def run(n_lanes, steps, warm):
     out = {}
     for r in range(n):
         kind, base, nb = log[3 * r], log[3 * r + 1], log[3 * r + 2]
+        if kind == 6:  # the wide (pair) launch: stamps of nb / 33 workgroups, then per-wave stall counters
+            nb = nb // 33
         if kind == 5:  # the IO-wave full-band stack: its slice holds the stamps of nb / 25 workgroups, then the per-wave stall counters
             kind, nb = 4, nb // 25
         s, e = st[base:base + nb, 0], st[base:base + nb, 1]

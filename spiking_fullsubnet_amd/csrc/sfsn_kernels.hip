@@ -1823,7 +1823,8 @@ extern "C" int sfsn_abi_version(void) { return SFSN_ABI_VERSION; }
 
 #ifdef SFSN_EXPERIMENTS
 // the workgroup-stamp probe (sfsn_scan_dev.h): a caller-owned device buffer of 2 x capacity stamps, handed out launch by launch;
-// kind 1 = gsn_scan_kernel, 2 = the fused scan, 3 = the fused-x scan, 4 = the narrow stack launch.  Single-threaded use only.
+// kind 1 = gsn_scan_kernel, 2 = the fused scan, 3 = the fused-x scan, 4 = the narrow stack launch, 5 = the IO-wave full-band launch
+// (25 slots per workgroup: stamps, then 12 waves x 4 stall counters), 6 = the wide launch (33 slots: 16 waves).  Single-threaded use only.
 static struct { unsigned long long* buf; int cap, used, nrec; int rec[16384][3]; } g_wgp;
 unsigned long long* sfsn_wgprobe_take(int kind, int n) {
     if (!g_wgp.buf || g_wgp.used + n > g_wgp.cap || g_wgp.nrec >= 16384) return nullptr;

@@ -304,6 +304,7 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
         float sp[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) sp[j] = 0.f;
+        S3_PB_DECL();
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
@@ -368,9 +369,12 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
             else if constexpr (NV == 2) *reinterpret_cast<unsigned short*>(hn + hoff) = (unsigned short)pk;
             else hn[hoff] = (int8_t)pk;
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            S3_PB_TIC();
             __builtin_amdgcn_s_barrier();
+            S3_PB_TOC(0);
             if constexpr (GATED) if (__builtin_amdgcn_readfirstlane(stop)) break;
         }
+        S3_PB_OUT(rl, wave, lane);
         if constexpr (CWF) if (T > 0 && !(GATED && __builtin_amdgcn_readfirstlane(stop))) s3_store_spikes<NV>(rl.spikes_f32 + (size_t)(T - 1) * fframe, foff, sp);
         // final state
         const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
@@ -424,22 +428,30 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
         int stop = 0;
+        S3_PB_DECL();
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             if constexpr (GATED) stop = failed;  // what the other waves read from flag[t & 1] during this step
             const int td = (t + D - 1 < T) ? t + D - 1 : T - 1;
+            S3_PB_TIC();
             ensure(td + 1);
+            S3_PB_TOC(2);
             if (!failed) issue((t + D - 1) % D, td);
             // a failure is published in the word the OTHER parity reads: written during step t, read during step t+1 (a word
             // read during the step it is written in would be seen by some waves and not by others)
             if constexpr (GATED) if (failed && lane == 0) flag[(t + 1) & 1] = 1;
             if constexpr (LSF) if (t > 0) ff.run(hbuf + (t & 1) * 16 * LDH, rl.spikes_f32 + ((size_t)(t - 1) * R + row0) * H, lane);
             // frames t+2 .. t+D-1 may stay in flight: frame t+1 has landed when the barrier releases step t+1
+            S3_PB_TIC();
             wait_vmcnt_n(allow);
+            S3_PB_TOC(1);
             __builtin_amdgcn_s_waitcnt(0xc07f);
+            S3_PB_TIC();
             __builtin_amdgcn_s_barrier();
+            S3_PB_TOC(0);
             if constexpr (GATED) if (stop) break;
         }
+        S3_PB_OUT(rl, 14, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs past the end are invisible to the compiler
         if constexpr (LSF) if (T > 0 && !(GATED && stop)) ff.run(hbuf + (T & 1) * 16 * LDH, rl.spikes_f32 + ((size_t)(T - 1) * R + row0) * H, lane);
         return;
@@ -486,6 +498,7 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
         __syncthreads();
         __builtin_amdgcn_s_barrier();
         int stop = 0;
+        S3_PB_DECL();
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             if constexpr (GATED) stop = flag[t & 1];
@@ -498,14 +511,19 @@ __device__ __forceinline__ void scan3_role(const Scan3Role& rl, const StackLink&
                     // [0, t-PF) are complete in memory (the int8 rows were written through).  PF as deep as the 6-bit counter
                     // allows: a write-through store takes microseconds to retire under load, and this wave stalling at the
                     // step barrier would stall the compute waves with it (measured: producers 1.0-1.4 us per step with PF = 2)
+                    S3_PB_TIC();
                     if (!(exp_flags & 16)) wait_vmcnt_n(pf * spf);  // (bit 4: timing experiment, publish without the wait)
+                    S3_PB_TOC(1);
                     if (lane == 0 && t - pf > 0) stack_publish(lk, t - pf);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);  // my LDS reads are done before the buffer is rewritten (step t+1)
+            S3_PB_TIC();
             __builtin_amdgcn_s_barrier();
+            S3_PB_TOC(0);
             if constexpr (GATED) if (__builtin_amdgcn_readfirstlane(stop)) break;
         }
+        S3_PB_OUT(rl, 15, lane);
         if (T > 0 && !(GATED && __builtin_amdgcn_readfirstlane(stop))) {
             const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
             flush8(hl, T - 1);

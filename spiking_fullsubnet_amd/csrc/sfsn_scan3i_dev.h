@@ -60,6 +60,9 @@ struct Scan3iRole {
     int8_t* spikes_i8;
     int R, row0;
     unsigned long long* count = nullptr;  // (as Scan3Role::count)
+#ifdef SFSN_EXPERIMENTS
+    unsigned long long* probe = nullptr;  // (as Scan3Role::probe)
+#endif
 };
 
 // TL = 1: H mod 64 is in (0, 32]: the last k-step of the RECURRENT product is ONE 16x16x32 matrix instruction whose 8-byte fragments
@@ -219,6 +222,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
         in_finish(*reinterpret_cast<const v4f*>(smem + cqoff));
         int stop = 0;
         float sp[2] = {0.f, 0.f};
+        S3_PB_DECL();
 #pragma unroll 1
         for (int t2 = 0; t2 < T && !stop; t2 += 2) {
 #pragma unroll
@@ -292,13 +296,16 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
                 pf_mfma(par == 0 ? 0 : NKA);
                 if (par == 1) in_finish(cq);
                 __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+                S3_PB_TIC();
                 __builtin_amdgcn_s_barrier();
+                S3_PB_TOC(0);
                 if constexpr (GATED) {
                     stop = __builtin_amdgcn_readfirstlane(stop);
                     if (stop) break;
                 }
             }
         }
+        S3_PB_OUT(rl, wave, lane);
         if constexpr (CWF) if (T > 0 && !stop) s3_store_spikes<2>(rl.spikes_f32 + (size_t)(T - 1) * fframe, foff, sp);
         // final state
         const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
@@ -351,19 +358,27 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
         int stop = 0;
+        S3_PB_DECL();
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             if constexpr (GATED) stop = failed;  // what the other waves read from flag[t & 1] during this step
             const int td = (t + A < T) ? t + A : T - 1;
+            S3_PB_TIC();
             ensure(td + 1);
+            S3_PB_TOC(2);
             if (!failed) issue((t + A) % D, td);
             if constexpr (GATED) if (failed && lane == 0) flag[(t + 1) & 1] = 1;  // read during step t+1 (see scan3_role)
             if constexpr (LSF) if (t > 0) ff.run(hbuf + (t & 1) * 16 * LDH, rl.spikes_f32 + ((size_t)(t - 1) * R + row0) * H, lane);
+            S3_PB_TIC();
             wait_vmcnt_n(allow);
+            S3_PB_TOC(1);
             __builtin_amdgcn_s_waitcnt(0xc07f);
+            S3_PB_TIC();
             __builtin_amdgcn_s_barrier();
+            S3_PB_TOC(0);
             if constexpr (GATED) if (stop) break;
         }
+        S3_PB_OUT(rl, 14, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs past the end are invisible to the compiler
         if constexpr (LSF) if (T > 0 && !(GATED && stop)) ff.run(hbuf + (T & 1) * 16 * LDH, rl.spikes_f32 + ((size_t)(T - 1) * R + row0) * H, lane);
         return;
@@ -408,6 +423,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
         __syncthreads();
         __builtin_amdgcn_s_barrier();
         int stop = 0;
+        S3_PB_DECL();
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             if constexpr (GATED) stop = flag[t & 1];
@@ -416,14 +432,19 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
                 flush8(hc, t - 1);
                 flushf(hc, t - 1);
                 if constexpr (PUB) {
+                    S3_PB_TIC();
                     wait_vmcnt_n(pf * spf);
+                    S3_PB_TOC(1);
                     if (lane == 0 && t - pf > 0) stack_publish(lk, t - pf);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);  // my LDS reads are done before the buffer is rewritten (step t+1)
+            S3_PB_TIC();
             __builtin_amdgcn_s_barrier();
+            S3_PB_TOC(0);
             if constexpr (GATED) if (__builtin_amdgcn_readfirstlane(stop)) break;
         }
+        S3_PB_OUT(rl, 15, lane);
         if (T > 0 && !(GATED && __builtin_amdgcn_readfirstlane(stop))) {
             const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
             flush8(hl, T - 1);

@@ -53,6 +53,9 @@ struct Scan3xRole {
     int R, row0;
     unsigned long long* count = nullptr;  // (as Scan3Role::count)
     int lsplit = SFSN_S3X_LSPLIT;         // fp32 store instructions per frame issued by the loader wave (see SFSN_S3_LSPLIT)
+#ifdef SFSN_EXPERIMENTS
+    unsigned long long* probe = nullptr;  // (as Scan3Role::probe)
+#endif
 };
 
 // KSB: 32-wide k-chunks of the input product (2: 32 < I <= 64, 1: I <= 32) -- compile time, so that a step is straight-line code (a
@@ -187,6 +190,7 @@ __device__ __forceinline__ void scan3x_role(const Scan3xRole& rl, const StackLin
         pf_mfma(0);
         if constexpr (KSB > 1) { pf_load(0, 1, 0); pf_load(0, 1, 1); pf_mfma(1); }
         in_finish(*reinterpret_cast<const v2f*>(smem + bqoff));
+        S3_PB_DECL();
 #pragma unroll 1
         for (int t2 = 0; t2 < T; t2 += 2) {
 #pragma unroll
@@ -252,9 +256,12 @@ __device__ __forceinline__ void scan3x_role(const Scan3xRole& rl, const StackLin
                 if (par < KSB && !(SFSN_X3_EXP & 1)) pf_mfma(par);
                 if (par == 1 && !(SFSN_X3_EXP & 4)) in_finish(bq);
                 __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+                S3_PB_TIC();
                 __builtin_amdgcn_s_barrier();
+                S3_PB_TOC(0);
             }
         }
+        S3_PB_OUT(rl, wave, lane);
         const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
         if (live) {
 #pragma unroll
@@ -323,6 +330,7 @@ __device__ __forceinline__ void scan3x_role(const Scan3xRole& rl, const StackLin
         for (int fr = 0; fr < 4; ++fr) convert(fr);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
+        S3_PB_DECL();
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             issue((t + A) % DX, (t + A < T) ? t + A : T - 1);
@@ -330,13 +338,20 @@ __device__ __forceinline__ void scan3x_role(const Scan3xRole& rl, const StackLin
             // frames t + 5, t + 6 may stay in flight: frame t + 4 has landed -> convert it (its planes are read from step t + 1 or
             // t + 2 on; the slot it overwrites held frame t - 2, dead for two barriers -- also at step 0 / 1, where a compute wave may
             // still be reading frames 0, 1 for the product it forms before the loop)
+            S3_PB_TIC();
             wait_vmcnt_n(allow);
+            S3_PB_TOC(1);
 #ifndef SFSN_X3_NOCONVERT  // (timing experiment: wrong results)
+            S3_PB_TIC();
             convert(t + 4);
+            S3_PB_TOC(2);  // (this role has no hand-off polls: the third counter is the bf16 split of a frame)
 #endif
             __builtin_amdgcn_s_waitcnt(0xc07f);
+            S3_PB_TIC();
             __builtin_amdgcn_s_barrier();
+            S3_PB_TOC(0);
         }
+        S3_PB_OUT(rl, 14, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (OUT & 1) if (T > 0) ffl.run(hbuf + (T & 1) * 16 * LDH, rl.spikes_f32 + ((size_t)(T - 1) * R + row0) * H, lane);
         return;
@@ -378,18 +393,24 @@ __device__ __forceinline__ void scan3x_role(const Scan3xRole& rl, const StackLin
         const int pf = spf > 0 ? (62 / spf < SFSN_S3_PFMAX ? 62 / spf : SFSN_S3_PFMAX) : 8;
         __syncthreads();
         __builtin_amdgcn_s_barrier();
+        S3_PB_DECL();
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             if (t > 0) {
                 flush(hbuf + (t & 1) * 16 * LDH, t - 1);
                 if constexpr (PUB) {
+                    S3_PB_TIC();
                     wait_vmcnt_n(pf * spf);
+                    S3_PB_TOC(1);
                     if (lane == 0 && t - pf > 0) stack_publish(lk, t - pf);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
+            S3_PB_TIC();
             __builtin_amdgcn_s_barrier();
+            S3_PB_TOC(0);
         }
+        S3_PB_OUT(rl, 15, lane);
         if (T > 0) flush(hbuf + (T & 1) * 16 * LDH, T - 1);
         if constexpr (PUB) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -390,16 +390,29 @@ __device__ __forceinline__ void scan_prologue(const ScanSegDev& sg, char* smem, 
 
 }
 
-__device__ __forceinline__ void wait_vmcnt_n(int n) {  // s_waitcnt vmcnt(n) for any wave-uniform runtime n (the field is an immediate)
-    switch (n) {
-#define W_(K) case K: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
-        W_(0) W_(1) W_(2) W_(3) W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15)
-        W_(16) W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25) W_(26) W_(27) W_(28) W_(29) W_(30) W_(31)
-        W_(32) W_(33) W_(34) W_(35) W_(36) W_(37) W_(38) W_(39) W_(40) W_(41) W_(42) W_(43) W_(44) W_(45) W_(46) W_(47)
-        W_(48) W_(49) W_(50) W_(51) W_(52) W_(53) W_(54) W_(55) W_(56) W_(57) W_(58) W_(59) W_(60) W_(61) W_(62)
-#undef W_
-        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
-    }
+// s_waitcnt vmcnt(n) for any wave-uniform runtime n (the field is an immediate): a computed jump into a table of 64 two-instruction
+// entries {s_waitcnt vmcnt(i); s_branch end}.  Round 5: the first form was a switch over 64 cases, which hipcc lowers to a tree of
+// compares and branches -- ~400 clk per call on a SIMD shared with three compute waves (the per-wave stall counters of an EXPERIMENTS
+// build showed the same 400-420 clk of "waiting" whether or not anything was in flight), once per step in every loader and storer
+// wave: a fifth of a 2,200-clk step, on the wave the layer-1 roles' step ends with.  s96-s98 are scratch for the address.
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+    n = n < 0 ? 0 : (n > 63 ? 63 : n);
+    asm volatile(
+        "s_getpc_b64 s[96:97]\n\t"            // = the address of the next instruction; the table starts 20 bytes behind it
+        "s_lshl_b32 s98, %0, 3\n\t"
+        "s_add_u32 s98, s98, 20\n\t"
+        "s_add_u32 s96, s96, s98\n\t"
+        "s_addc_u32 s97, s97, 0\n\t"
+        "s_setpc_b64 s[96:97]\n\t"
+        ".set sfsn_wv_i, 0\n\t"
+        ".rept 64\n\t"
+        "s_waitcnt ((sfsn_wv_i & 15) | 0x0F70 | ((sfsn_wv_i >> 4) << 14))\n\t"  // vmcnt(i), expcnt / lgkmcnt not waited for
+        "s_branch sfsn_wv_end_%=\n\t"
+        ".set sfsn_wv_i, sfsn_wv_i + 1\n\t"
+        ".endr\n"
+        "sfsn_wv_end_%=:"
+        ::"s"(__builtin_amdgcn_readfirstlane(n))
+        : "s96", "s97", "s98", "scc", "memory");
 }
 
 // ---- the scan body for a wave that owns NTL (compile-time) output tiles -------------------------------------

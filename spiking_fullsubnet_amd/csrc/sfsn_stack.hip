@@ -696,11 +696,15 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         stack_exit(p, gate_word_p);
         return;
     }
+    SFSN_WG_STAMP(p.wg_times, 0);
     const StackRoleDev& rl = p.role[ri];
     const int blk = (int)blockIdx.x - rl.block0;
     StackLink lk;
     lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = p.prog; lk.lag = p.lag;
     lk.dbg = p.dbg ? p.dbg + 4 * blockIdx.x : nullptr;
+#ifdef SFSN_EXPERIMENTS
+    lk.probe = p.wg_times ? p.wg_times + 2 * gridDim.x + 64 * blockIdx.x : nullptr;  // 16 waves x 4 stall counters (WIDE_CASE)
+#endif
     if (lk.dbg && threadIdx.x == 0) lk.dbg[2] = (unsigned)wall_clock64();
     if (rl.pub) lk.out = p.prog + 2 + blockIdx.x;
     const int my_rpw = rl.kind == STACK_PROJ ? Proj16Layout<KS>::ROWS : rl.rpw;
@@ -719,6 +723,9 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         rx.x = rl.x; rx.w_ih = rl.w_ih_f32; rx.I = rl.I; rx.w_hh = rl.w_hh; rx.w_dq = rl.w_dq; rx.bias = rl.bias;
         rx.bn_alpha = rl.bn_alpha; rx.bn_beta = rl.bn_beta; rx.h_state = rl.h_state; rx.c_state = rl.c_state;
         rx.spikes_f32 = rl.spikes_f32; rx.spikes_i8 = rl.spikes_i8; rx.R = rl.R; rx.row0 = blk * 8; rx.count = rl.count; rx.lsplit = p.lsplit_x;
+#ifdef SFSN_EXPERIMENTS
+        rx.probe = lk.probe;
+#endif
         const bool tl = (H & 63) != 0 && (H & 63) <= 32;
 #define X3_CASE(TL_, F_)                                                                    \
     {                                                                                       \
@@ -738,6 +745,9 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         ri.spikes_in = rl.spikes_in; ri.w_ih = rl.w_ih; ri.w_ih_dq = rl.w_ih_dq; ri.w_hh = rl.w_hh; ri.w_dq = rl.w_dq; ri.bias = rl.bias;
         ri.bn_alpha = rl.bn_alpha; ri.bn_beta = rl.bn_beta; ri.h_state = rl.h_state; ri.c_state = rl.c_state;
         ri.spikes_f32 = rl.spikes_f32; ri.spikes_i8 = rl.spikes_i8; ri.R = rl.R; ri.row0 = blk * 8; ri.count = rl.count;
+#ifdef SFSN_EXPERIMENTS
+        ri.probe = lk.probe;
+#endif
         const bool tl = (H & 63) != 0 && (H & 63) <= 32;  // the k tail as one 16x16x32 step
         // (KS = 4 with at most 14 tiles is H = 208 or 224: always the tail form -- four full k-steps of both matrices do not fit)
         if (rl.pub) {
@@ -766,6 +776,9 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
             r3.zin = rl.zin; r3.w_hh = rl.w_hh; r3.w_dq = rl.w_dq; r3.bias = rl.bias; r3.bn_alpha = rl.bn_alpha; r3.bn_beta = rl.bn_beta;
             r3.h_state = rl.h_state; r3.c_state = rl.c_state; r3.spikes_f32 = rl.spikes_f32; r3.spikes_i8 = rl.spikes_i8;
             r3.R = rl.R; r3.row0 = blk * rl.rpw; r3.count = rl.count; r3.lsplit = p.lsplit;
+#ifdef SFSN_EXPERIMENTS
+            r3.probe = lk.probe;
+#endif
 #define S3_CASE(RPW_, F) \
     if (rl.rpw == RPW_ && flg == F) scan3_role<KS, RPW_, OUT, F>(r3, lk, scan_smem, T, H, NT, p.exp_flags);
             S3_CASE(4, 0) S3_CASE(4, 1) S3_CASE(4, 2) S3_CASE(4, 3)
@@ -785,6 +798,7 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         }
     }
     if (lk.dbg && threadIdx.x == 0) lk.dbg[3] = (unsigned)wall_clock64();
+    SFSN_WG_STAMP(p.wg_times, 1);
     stack_exit(p, gate_word_p);
 }
 
@@ -1153,7 +1167,9 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
         if (lds > 64 * 1024 &&                                                                                                \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
             return SFSN_EHIP;                                                                                                 \
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, st, p);                                                       \
+        StackParams q = p;                                                                                                    \
+        q.wg_times = sfsn_wgprobe_take(6, 33 * blocks); /* 2 stamps + 16 waves x 4 stall counters per workgroup (S3_PB_*) */  \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, st, q);                                                       \
         return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;                                                         \
     }
     WIDE_CASE(1, 2) WIDE_CASE(1, 3) WIDE_CASE(2, 2) WIDE_CASE(2, 3) WIDE_CASE(3, 2) WIDE_CASE(3, 3) WIDE_CASE(4, 2) WIDE_CASE(4, 3)
