@@ -103,7 +103,7 @@ def run_stack(hip, zin0s, cells, T, H, rpw, lag=4, want_f32=True, h0=None, c0=No
 
 
 STACKS = [  # I, H, layers, rows per segment, T, rows per workgroup
-    (38, 224, 2, [40, 9, 17], 50, 8), (38, 224, 3, [33], 41, 4), (64, 320, 2, [21], 37, 4), (64, 320, 3, [35, 6], 30, 8),
+    (38, 224, 2, [40, 9, 17], 50, 8), (38, 224, 3, [33], 41, 4), (64, 320, 2, [21], 37, 4), (64, 320, 3, [35, 6], 30, 8), (40, 320, 2, [130], 9, 8),
     (12, 32, 3, [5, 20], 33, 16), (38, 160, 2, [64], 64, 8), (30, 256, 2, [18, 3], 26, 16), (64, 240, 4, [7], 29, 4),
     (20, 96, 2, [1], 19, 8),
     # round 4: layers >= 1 at 8 rows per workgroup without an input-term buffer run the FUSED3 role (input product inside the
@@ -118,6 +118,7 @@ STACKS = [  # I, H, layers, rows per segment, T, rows per workgroup
 @pytest.mark.parametrize("H,nl,Rs,T,rpw,want_f32", [
     (320, 2, [21], 37, 4, True), (320, 3, [35, 6], 30, 8, True), (320, 2, [64], 90, 4, False), (320, 2, [64], 61, 8, False),
     (272, 2, [13], 25, 4, True), (288, 2, [9, 4], 19, 8, True), (304, 3, [11], 1, 4, True), (304, 2, [7], 2, 8, True),
+    (320, 2, [130], 14, 8, True),  # nine 16-row blocks: the PROJ role is NOT split by columns (21 / 35 / 6 / 64 rows: four / two parts)
 ])
 def test_full_band_stack_with_io_waves_equals_round_2_bodies(hip, H, nl, Rs, T, rpw, want_f32):
     """Round 5: 256 < H <= 320 stacks at 4 / 8 rows per workgroup run scan3w_role (sfsn_scan3w_dev.h: ten compute waves x two tiles +
