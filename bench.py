@@ -427,6 +427,13 @@ def main():
             # --- the full-band stack (phase S): both layers + the layer-2 input product in ONE layer-pipelined launch
             fb = t_s.get("stack:fb")
             full_band = None
+
+            def proj_wgs(rows):  # 16-row blocks x the column parts that fit the role's padding to eight blocks (sfsn_stack.hip, proj_split_host)
+                nb = (rows + 15) // 16
+                room, sp = ((nb + 7) // 8 * 8) // nb, 1
+                while sp * 2 <= room and sp * 2 <= 4:
+                    sp *= 2
+                return nb * sp
             if fb:
                 Hf, nl = kw["fb_hidden_size"], kw["fb_num_layers"]
                 steps_ms = fb["mean_ms"]
@@ -434,10 +441,10 @@ def main():
                 # executed by the matrix cores: x3 digit planes, 16-column MFMA tiles for 4 (scan) / 16 (input product) rows
                 executed = 2.0 * Hf * Hf * 3 * T * (nl * (B / 4) * 16 + (nl - 1) * B)
                 full_band = dict(kernel=f"gsn_stack_fb_kernel (round 5: IO-specialised waves -- ten compute waves x two tiles + loader + storer, W_hh two digit planes in "
-                                        f"registers + one in LDS; PROJ role on twelve waves feeds layer 2) for this whole-sequence launch; the chunks of the strict "
-                                        f"schedule keep gsn_stack_kernel<KS={(Hf + 63) // 64}> (DESIGN 5.6b)",
+                                        f"registers + one in LDS; PROJ role on twelve waves, split by columns over its padding workgroups, feeds layer 2): this "
+                                        f"whole-sequence launch and the chunks of the strict schedule alike (DESIGN 5.6b)",
                                  launch_ms=round(steps_ms, 4), per_step_us=round(1e3 * steps_ms / T, 3),
-                                 workgroups=nl * ((B + 3) // 4) + (nl - 1) * ((B + 15) // 16), launches_per_forward=1,
+                                 workgroups=nl * ((B + 3) // 4) + (nl - 1) * proj_wgs(B), launches_per_forward=1,
                                  mfma=dict(useful_TOPS=round(useful / (steps_ms * 1e-3) / 1e12, 2), executed_TOPS=round(executed / (steps_ms * 1e-3) / 1e12, 2),
                                            peak_TOPS=INT8_PEAK_TOPS, useful_frac_of_peak=round(useful / (steps_ms * 1e-3) / 1e12 / INT8_PEAK_TOPS, 5),
                                            pmc=(pj or {}).get("full_band_stack_mfma"),
