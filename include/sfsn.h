@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 16 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 17 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -340,6 +340,26 @@ int sfsn_features(const float* stft_ri /* [B][F][T][2] */, const float* fb_tbf /
  * state of the forward's scans (MODEL:100-106) written by the first launch of the forward's chain instead of a fill launch of its own. */
 int sfsn_features_z(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc, const sfsn_feature_group* groups,
                     int n_groups, int t0, int nt, float* zero_ptr, size_t zero_bytes, void* stream);
+
+/* The feature prologue AND the layer-0 input product of a chunk in ONE launch (ABI 17) -- replaces, for every job, the pair
+ * sfsn_features + sfsn_input_proj_f32 (MODEL:434-440,239-258,108-112 followed by NEURON:141-142): a workgroup keeps the rows it has
+ * normalised, splits them into the three bf16 pieces from registers and forms x . W_ih^T + b on the bf16 matrix cores; the rows go
+ * to HBM only when `feat.x` is given (the API's all_layer_outputs[0], or a scan that forms its product itself).  A job with w = NULL
+ * is sfsn_features alone for that group (feat.x required).  Bit-identical to the two calls: the rows by features_kernel's
+ * expressions and wave reductions, the products by input_proj_bf3_kernel's six piece products in its order.
+ * z is CHUNK-LOCAL: [nt][B * n_units][ldz], frame t0 first (x is indexed by absolute frame, as in sfsn_features).
+ * SFSN_EUNSUPPORTED for what sfsn_input_proj_f32 would not run on its bf16-split kernel (odd I, I > 160 with H > 128, H > 384,
+ * fewer than 64 rows, SFSN_INPROJ_F32 set) and for groups reading more than 144 bins or FB > 128: issue the two calls then. */
+typedef struct sfsn_featproj_job {
+    sfsn_feature_group feat; /* feat.x nullable when w is given */
+    const float* w;          /* [H][I] fp32 W_ih (shared gates), NULL = rows only                                */
+    const float* bias;       /* [H], nullable                                                                     */
+    float* z;                /* out [nt][B*n_units][ldz]                                                          */
+    int H, ldz;
+} sfsn_featproj_job;
+int sfsn_features_proj(const float* stft_ri, const float* fb_tbf, int B, int F, int T, int FB, float fdrc,
+                       const sfsn_featproj_job* jobs /* host */, int n_jobs, int t0, int nt, float* zero_ptr /* as sfsn_features_z */,
+                       size_t zero_bytes, void* stream);
 
 /* Per-clip means for offline_laplace_norm (FROZEN:162-164: mean over all non-batch dims of the gathered,
  * un-normalised group tensor).  mu_out [n_groups][B].  Two launches: row sums of mag / fb, then the

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
 NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE, NORM_CUMLAPLACE, NORM_GAUSSIAN = 0, 1, 2, 3, 4
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
-ABI_VERSION = 16  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
+ABI_VERSION = 17  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -52,6 +52,10 @@ class ProjJob(ctypes.Structure):
 
 class InProjJob(ctypes.Structure):
     _fields_ = [("x", _P), ("w", _P), ("bias", _P), ("z", _P), ("M", _I), ("K", _I), ("N", _I), ("ldz", _I)]
+
+
+class FeatProjJob(ctypes.Structure):  # sfsn_featproj_job
+    _fields_ = [("feat", FeatureGroup), ("w", _P), ("bias", _P), ("z", _P), ("H", _I), ("ldz", _I)]
 
 
 class CountTensor(ctypes.Structure):
@@ -96,7 +100,7 @@ def _sources():
     """The files the library is made of, in the order the Makefile hashes them (SRCS)."""
     return [os.path.join(_HERE, "..", "include", "sfsn.h")] + [
         os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_scan3_dev.h", "sfsn_scan3i_dev.h", "sfsn_scan3x_dev.h", "sfsn_scan3w_dev.h", "sfsn_feat_dev.h", "sfsn_fft_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_hop.hip", "sfsn_fft.hip", "sfsn_train.hip",
-                                  "sfsn_pack.cpp")]
+                                  "sfsn_featproj.hip", "sfsn_pack.cpp")]
 
 
 def source_hash() -> str:
@@ -204,6 +208,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_input_proj_f32_multi.argtypes = [ctypes.POINTER(InProjJob), _I, _P]
     L.sfsn_features.restype = _I
     L.sfsn_features.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _I, _I, _P]
+    L.sfsn_features_proj.restype = _I
+    L.sfsn_features_proj.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatProjJob), _I, _I, _I, _P, ctypes.c_size_t, _P]
     L.sfsn_features_z.restype = _I
     L.sfsn_features_z.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _I, _I, _P, ctypes.c_size_t, _P]
     L.sfsn_laplace_means.restype = _I
@@ -242,7 +248,7 @@ EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device
            "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_stream_hop_resident", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft", "sfsn_gsn_train_step_fwd", "sfsn_gsn_train_step_bwd", "sfsn_train_scratch_bytes",
            "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16", "sfsn_gsn_train_check", "sfsn_gsn_stack_scan_x", "sfsn_train_seq_scratch_bytes", "sfsn_gsn_train_multi_check",
            "sfsn_gsn_train_seq_fwd_multi", "sfsn_gsn_train_seq_bwd_multi", "sfsn_features_z", "sfsn_gaussian_stats", "sfsn_gsn_train_step_check",
-           "sfsn_spike_proj_multi", "sfsn_input_proj_f32_multi")
+           "sfsn_spike_proj_multi", "sfsn_input_proj_f32_multi", "sfsn_features_proj")
 
 
 def check(rc: int, what: str = "") -> None:

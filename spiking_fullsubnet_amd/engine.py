@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CountTensor, DfGroup, FeatureGroup, FusedInput, FusedX, InProjJob, ProjJob, ScanSegment, check
+from ._lib import CountTensor, DfGroup, FeatProjJob, FeatureGroup, FusedInput, FusedX, InProjJob, ProjJob, ScanSegment, check
 
 
 @dataclass
@@ -263,6 +263,12 @@ class Engine:
         self.stack_scan = "auto" if _ss == "auto" else bool(int(_ss))
         self.stack_rows_fb_auto = int(os.environ.get("SFSN_FB_STACK_ROWS", "4"))  # rows per workgroup of the full-band stack under "auto"
         self.merge_products = os.environ.get("SFSN_MERGE_PRODUCTS", "1") != "0"  # the independent products of a stage in one launch
+        # features + layer-0 input products of a chunk in ONE launch (sfsn_features_proj): the rows never make the round trip through
+        # HBM between the two, and are not written at all when nobody reads them (layer_outputs "counts" / "none").  OFF by default:
+        # bit-identical and 0.34 GB less traffic per forward, but slower -- the row arithmetic is bound by VALU issue (~110 wave
+        # instructions per row) and the product's W pieces (120 registers per wave) leave two waves per SIMD where the feature kernel
+        # has three: 316 us per sub-band chunk against 67 + 72 (profiles/EXPERIMENTS.md).  SFSN_FEATPROJ=1 switches it on.
+        self.fuse_featproj = os.environ.get("SFSN_FEATPROJ", "0") == "1"
         self.count_in_scan = os.environ.get("SFSN_COUNT_IN_SCAN", "1") != "0"  # layer_outputs="counts": counted by the scans themselves
         self.pair_scan = os.environ.get("SFSN_PAIR_SCAN", "1") != "0"  # H <= 224 stacks as one launch of FUSED3 roles (see _stack_choice)
         self.stack_rows_per_wg = {"fb": 4, "sb": 8}  # rows per workgroup of every layer of a stack: sum of workgroups <= CUs
@@ -414,6 +420,34 @@ class Engine:
                     check(L.sfsn_input_proj_f32(P(a_), P(w_), P(b_), P(z_), M, K, N, ld, st), "sfsn_input_proj_f32")
                 else:
                     check(L.sfsn_spike_proj(P(a_), P(w_), P(dq_), P(b_), P(z_), M, K, N, ld, st), "sfsn_spike_proj")
+
+    def _stage_featproj(self, fg, seqs, idx, zins, stft_ri, fb_proj, dims, t0, nt, zero, need_x, st, tag) -> bool:
+        """Features of every group of `fg` AND the layer-0 input term of the groups `idx` (zins: their chunk-local buffers) in one
+        launch.  False (nothing launched) when the library would not run the pair bit-identically (sfsn_features_proj's
+        SFSN_EUNSUPPORTED, separate gate weights): the caller issues the two calls then.  need_x False: the rows of the groups in
+        `idx` are not written."""
+        B, F, T, FB, fdrc = dims
+        n = len(seqs)
+        if not self.fuse_featproj or not idx or n > _lib.MAX_GROUPS or any(seqs[i].cells[0].G != 1 for i in idx):
+            return False
+        jobs = (FeatProjJob * n)()
+        for i in range(n):
+            jobs[i].feat = fg[i]
+            if i in idx:
+                seq, z = seqs[i], zins[idx.index(i)]
+                cell = seq.cells[0]
+                jobs[i].w, jobs[i].bias, jobs[i].z = cell.w_ih_f32.data_ptr(), cell.bias.data_ptr(), z.data_ptr()
+                jobs[i].H, jobs[i].ldz = seq.H, seq.H
+                if not need_x:
+                    jobs[i].feat.x = None
+        with self.timed("featproj:" + tag, st):
+            rc = self.lib.sfsn_features_proj(_ptr(stft_ri), None if fb_proj is None else _ptr(fb_proj), B, F, T, FB, fdrc, jobs, n, t0, nt,
+                                             None if zero is None else _ptr(zero), 0 if zero is None else zero.numel() * 4, st)
+        if rc == _lib.SFSN_EUNSUPPORTED:
+            return False
+        check(rc, "sfsn_features_proj")
+        self.launches["featproj"] = self.launches.get("featproj", 0) + 1
+        return True
 
     def _stage_scan(self, seqs, l, zins, states, spks, s8s, mems, t0, nt, st, tag, rpw, cnts=None):
         L, spec = self.lib, self.spec
@@ -1036,10 +1070,9 @@ class Engine:
                 # all layers in one launch: features, layer 0's input term, the stack scan, the projection
                 ahead = prep_ahead and gate_events is None and d["zin"][0][0].shape[0] >= T
                 def prep(t0, nt, dz, st):
-                    feat_fn(t0, nt, st)
                     xg = self._stack_x_groups(seqs, xs_, nt, wide, rpw_stack or self.stack_rows_per_wg[tag], want_membrane)
                     zr = [i for i in range(len(seqs)) if i not in xg]
-                    if zr:
+                    if not feat_fn(t0, nt, st, (zr, pick(dz["zin"][0], zr))) and zr:  # (True: one launch made the rows and the input terms)
                         self._stage_input(pick(seqs, zr), 0, pick(xs_, zr), pick(dz["zin"][0], zr), t0, nt, st, tag)
                     return xg
                 if ahead:  # layer 0's input term has a buffer for the whole sequence: chunk c's rows are [t0, t0 + nt)
@@ -1080,8 +1113,7 @@ class Engine:
                     if l == 0:
                         if staged and gate_events is not None:
                             g.wait_event(gate_events[c])
-                        feat_fn(t0, nt, hG[si])
-                        if rest:
+                        if not feat_fn(t0, nt, hG[si], (rest, pick(d["zin"][0], rest))) and rest:
                             self._stage_input(pick(seqs, rest), 0, pick(xs_, rest), pick(d["zin"][0], rest), t0, nt, hG[si], tag)
                     else:
                         link(sstreams[si - 1], g)  # previous layer's scan of this chunk
@@ -1127,20 +1159,36 @@ class Engine:
             check(L.sfsn_cum_laplace_norm(ctypes.c_void_p(x.data_ptr() + t0 * R * I * 4), nt, R, I, _ptr(cum["state"][i]), t0,
                                           _ptr(cum["scratch"]), st), "sfsn_cum_laplace_norm")
 
-        def feat_fb(t0, nt, st):
+        # feature rows a fused launch did not write (layer_outputs "counts" / "none": nobody reads them)
+        x_skipped = dict(fb=set(), sb=set())
+        dims_fb, dims_sb = (B, F, T, 0, spec.fdrc), (B, F, T, spec.fb_proj, spec.fdrc)
+
+        def feat_fb(t0, nt, st, proj=None):
+            z = zero_job.pop() if zero_job else None  # (the first full-band feature launch of the forward carries the state zeroing)
+            if proj is not None and cum is None and self._stage_featproj(fg_fb, [self.fb], proj[0], proj[1], ri, None, dims_fb, t0, nt, z,
+                                                                         want_layers, st, "fb"):
+                if not want_layers:
+                    x_skipped["fb"].update(proj[0])
+                return True
             with self.timed("features:fb", st):
-                z = zero_job.pop() if zero_job else None  # (the first full-band feature launch of the forward carries the state zeroing)
                 check(L.sfsn_features_z(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, t0, nt, None if z is None else _ptr(z),
                                         0 if z is None else z.numel() * 4, st), "sfsn_features(fb)")
                 if cum is not None:
                     cum_norm(x_fb, 0, t0, nt, st)
+            return False
 
-        def feat_sb(t0, nt, st):
+        def feat_sb(t0, nt, st, proj=None):
+            if proj is not None and cum is None and self._stage_featproj(fg_sb, self.sb, proj[0], proj[1], ri, fb_proj, dims_sb, t0, nt, None,
+                                                                         want_layers, st, "sb"):
+                if not want_layers:
+                    x_skipped["sb"].update(proj[0])
+                return True
             with self.timed("features:sb", st):
                 check(L.sfsn_features(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, fg_sb, ng, t0, nt, st), "sfsn_features(sb)")
                 if cum is not None:
                     for g in range(ng):
                         cum_norm(xs[g], 1 + g, t0, nt, st)
+            return False
 
         def post_sb(t0, nt, st):
             with self.timed("deepfilter", st):
@@ -1210,8 +1258,11 @@ class Engine:
                 for l in range(nl_sb):
                     sb["spk"][l][g] = summ[nl_fb + g * nl_sb + l]
 
-        def outs(x, d, i):
+        def outs(x, d, i, skipped):
+            if i in skipped:  # never written: the entry keeps its shape (compute_neuronops reads size(-1)) and nothing else
+                x = torch.empty(x.shape, dtype=x.dtype, device="meta")
             return [x] + [d["spk"][l][i] for l in range(len(d["spk"]))] + [d["proj"][i]]
-        return dict(enh_stft=enh, enh_mag=enh_mag, fb_all=outs(x_fb, fb, 0), sb_all=[outs(xs[g], sb, g) for g in range(ng)],
+        return dict(enh_stft=enh, enh_mag=enh_mag, fb_all=outs(x_fb, fb, 0, x_skipped["fb"]),
+                    sb_all=[outs(xs[g], sb, g, x_skipped["sb"]) for g in range(ng)],
                     fb_mem=[fb["mem"][l][0] for l in range(nl_fb)], sb_mem=[[sb["mem"][l][g] for l in range(nl_sb)] for g in range(ng)],
                     mu_fb=mu_fb, mu_sb=mu_sb, pipelined=bool(pipeline), overlapped=overlap, n_chunks=len(bounds))

@@ -1394,6 +1394,144 @@ def test_feature_launch_zeroes_the_scan_states_and_nothing_else(hip, monkeypatch
     model.engine().check_stack_errors()
 
 
+def _featproj_case(hip, rng, B, F, T, FB, groups, Hs, norm, t0, nt, with_x=True, zero=0, ref=True):
+    """(x, z) per group from the two calls and from the fused launch; groups: (lo, n_units, ctr, nbr, ctr_fb, nbr_fb); Hs: H or None."""
+    from spiking_fullsubnet_amd import _lib
+    from spiking_fullsubnet_amd._lib import FeatProjJob, FeatureGroup, check
+    ri = _t(rng.standard_normal((B, F, T, 2)).astype(np.float32) * 3.0)
+    fbp = _t(rng.standard_normal((T, B, max(FB, 1))).astype(np.float32)) if FB else None
+    n = len(groups)
+    fg, jobs, keep, xa, xb, za, zb = (FeatureGroup * n)(), (FeatProjJob * n)(), [], [], [], [], []
+    for i, ((lo, nu, ctr, nbr, cfb, nfb), H) in enumerate(zip(groups, Hs)):
+        I = ctr + 2 * nbr + (cfb + 2 * nfb if cfb else 0)
+        x1, x2 = torch.full((T, B * nu, I), float("nan"), device=DEV), torch.full((T, B * nu, I), float("nan"), device=DEV)
+        g = fg[i]
+        g.lo, g.n_units, g.ctr, g.nbr, g.ctr_fb, g.nbr_fb, g.norm, g.ln_eps = lo, nu, ctr, nbr, cfb, nfb, norm, 1e-5
+        ts = []
+        if norm == _lib.NORM_LAYERNORM:
+            ts = [_t(rng.uniform(0.5, 1.5, I).astype(np.float32)), _t(rng.standard_normal(I).astype(np.float32) * 0.1)]
+            g.ln_w, g.ln_b = ts[0].data_ptr(), ts[1].data_ptr()
+        elif norm == _lib.NORM_LAPLACE:
+            ts = [_t(rng.uniform(0.5, 2.0, B).astype(np.float32))]
+            g.mu = ts[0].data_ptr()
+        elif norm == _lib.NORM_GAUSSIAN:
+            ts = [_t(rng.uniform(0.5, 2.0, B).astype(np.float32)), _t(rng.uniform(0.5, 2.0, B).astype(np.float32))]
+            g.mu, g.ln_w = ts[0].data_ptr(), ts[1].data_ptr()
+        keep.append(ts)
+        jobs[i].feat = g
+        fg[i].x = x1.data_ptr()
+        jobs[i].feat.x = x2.data_ptr() if (with_x or H is None) else None
+        xa.append(x1)
+        xb.append(x2)
+        if H is None:
+            za.append(None)
+            zb.append(None)
+            continue
+        w, bias = _t(rng.uniform(-0.1, 0.1, (H, I)).astype(np.float32)), _t(rng.standard_normal(H).astype(np.float32))
+        z1, z2 = torch.full((nt, B * nu, H), float("nan"), device=DEV), torch.full((nt, B * nu, H), float("nan"), device=DEV)
+        keep.append((w, bias))
+        jobs[i].w, jobs[i].bias, jobs[i].z, jobs[i].H, jobs[i].ldz = w.data_ptr(), bias.data_ptr(), z2.data_ptr(), H, H
+        za.append((z1, w, bias, I))
+        zb.append(z2)
+    if ref:
+        check(hip.sfsn_features(_p(ri), None if fbp is None else _p(fbp), B, F, T, FB, 0.5, fg, n, t0, nt, None), "sfsn_features")
+    for i, za_i in enumerate(za):
+        if za_i is not None and ref:
+            z1, w, bias, I = za_i
+            R = xa[i].shape[1]
+            check(hip.sfsn_input_proj_f32(ctypes.c_void_p(xa[i].data_ptr() + t0 * R * I * 4), _p(w), _p(bias), _p(z1), nt * R, I, z1.shape[2],
+                                          z1.shape[2], None), "sfsn_input_proj_f32")
+    zbuf = torch.full((4 * zero + 8,), 7.0, device=DEV)
+    rc = hip.sfsn_features_proj(_p(ri), None if fbp is None else _p(fbp), B, F, T, FB, 0.5, jobs, n, t0, nt,
+                                ctypes.c_void_p(zbuf.data_ptr() + 16) if zero else None, 16 * zero, None)
+    torch.cuda.synchronize()
+    if zero:
+        assert bool((zbuf[:4] == 7).all()) and bool((zbuf[4:4 + 4 * zero] == 0).all()) and bool((zbuf[4 + 4 * zero:] == 7).all())
+    return rc, xa, xb, [None if a is None else a[0] for a in za], zb
+
+
+def _same(a, b):  # bit-identical including the NaN canaries of rows outside [t0, t0 + nt)
+    return torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm", ["layernorm", "laplace", "gaussian", "none"])
+def test_features_and_input_products_in_one_launch_equal_the_two_calls(hip, norm):
+    """sfsn_features_proj (round 5, ABI 17): the feature rows and the layer-0 input terms of a chunk from ONE launch are bit for
+    bit what sfsn_features + sfsn_input_proj_f32 write -- baseline_m's three sub-band groups (group 0 rows only, as beside the
+    FUSEDX3 role), its full-band group (H = 320), a ragged frame range in the middle of the sequence, every normalisation, the
+    zero side job; with feat.x = NULL the rows are simply not written."""
+    from spiking_fullsubnet_amd import _lib
+    nm = dict(layernorm=_lib.NORM_LAYERNORM, laplace=_lib.NORM_LAPLACE, gaussian=_lib.NORM_GAUSSIAN, none=_lib.NORM_NONE)[norm]
+    rng = np.random.default_rng(123)
+    B, F, T, FB = 5, 257, 150, 64
+    sb = [(0, 8, 4, 15, 4, 0), (32, 3, 32, 15, 32, 0), (128, 2, 64, 15, 64, 0)]
+    for t0, nt, Hs, zero in ((0, T, (None, 224, 224), 0), (37, 77, (None, 224, 224), 100), (8, 64, (32, 48, 224), 5000)):
+        rc, xa, xb, za, zb = _featproj_case(hip, rng, B, F, T, FB, sb, Hs, nm, t0, nt, zero=zero)
+        assert rc == 0, rc
+        for g in range(3):
+            assert _same(xa[g], xb[g]), (norm, t0, g)
+            if za[g] is not None:
+                assert _same(za[g], zb[g]), (norm, t0, g)
+    # the full-band group (no tiled full-band input), H = 320
+    rc, xa, xb, za, zb = _featproj_case(hip, rng, B, F, T, 0, [(0, 1, 64, 0, 0, 0)], (320,), nm, 16, 100, zero=64)
+    assert rc == 0 and _same(xa[0], xb[0]) and _same(za[0], zb[0])
+    # rows not written when nobody reads them
+    rc, xa, xb, za, zb = _featproj_case(hip, rng, B, F, T, FB, sb, (None, 224, 224), nm, 0, T, with_x=False)
+    assert rc == 0 and _same(xa[0], xb[0]) and bool(torch.isnan(xb[1]).all()) and bool(torch.isnan(xb[2]).all())
+    assert _same(za[1], zb[1]) and _same(za[2], zb[2])
+
+
+@pytest.mark.gpu
+def test_features_proj_refuses_what_the_two_calls_would_run_differently(hip):
+    """Shapes sfsn_input_proj_f32 runs on its fp32-MFMA kernels (another rounding), fewer than 64 rows, odd widths: refused
+    (SFSN_EUNSUPPORTED), the engine then issues the two calls; bad arguments are SFSN_EINVAL."""
+    from spiking_fullsubnet_amd import _lib
+    rng = np.random.default_rng(9)
+    B, F, T = 2, 257, 40
+    ok = [(32, 3, 32, 15, 32, 0)]
+    case = lambda *a, **k: _featproj_case(hip, rng, B, F, T, *a, ref=False, **k)[0]
+    assert case(64, ok, (224,), 0, 0, T) == 0
+    assert case(64, ok, (224,), 0, 0, 8) == _lib.SFSN_EUNSUPPORTED                         # 48 rows
+    assert case(64, [(32, 3, 32, 15, 31, 0)], (224,), 0, 0, T) == _lib.SFSN_EUNSUPPORTED   # odd I
+    assert case(64, [(128, 2, 64, 15, 64, 0)], (400,), 0, 0, T) == _lib.SFSN_EUNSUPPORTED  # H > 384
+    assert case(64, [(0, 1, 160, 0, 0, 0)], (224,), 0, 0, T) == _lib.SFSN_EUNSUPPORTED     # 160 bins
+    assert case(64, ok, (222,), 0, 0, T) == _lib.SFSN_EUNSUPPORTED                         # H % 4
+    assert case(48, ok, (224,), 0, 0, T) == _lib.SFSN_EUNSUPPORTED                         # 512 % FB
+    assert case(64, ok, (224,), 0, 30, 20) == _lib.SFSN_EINVAL                             # frames past the end
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("front,kw,seed", [("live", rw.LIVE_M, 21), ("frozen", rw.FROZEN_M, 32), ("live", rw.LIVE_TINY, 11)])
+def test_forward_with_the_fused_feature_product_launch_is_bit_identical(front, kw, seed, monkeypatch):
+    """The engine's forward with features + layer-0 input products in one launch (the default) against the two launches
+    (fuse_featproj = False): the same bits in every output, in the strict schedule and at 16 rows per workgroup; with
+    layer_outputs = "counts" the skipped feature rows come back as shape-only (meta) entries and the counts agree."""
+    sd = rw.live_state_dict(kw, seed) if front == "live" else rw.frozen_state_dict(kw, seed)
+    model = build_module(front, kw, sd)
+    eng = model.engine()
+    stft = model._stft(_t(rw.synth_wave(4, 128 * 420, 5)))
+    for rows in (None, (16, 16)):
+        if rows is not None:
+            eng.rows_per_wg, eng.stack_scan = rows, False
+        eng.fuse_featproj = True
+        a = eng.forward_stft(stft)
+        n_fused = eng.launches.get("featproj", 0)
+        eng.fuse_featproj = False
+        b = eng.forward_stft(stft)
+        assert n_fused > 0 and eng.launches.get("featproj", 0) == n_fused
+        assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(b["enh_stft"])) and torch.equal(a["enh_mag"], b["enh_mag"])
+        assert all(torch.equal(u, v) for u, v in zip(a["fb_all"] + sum(a["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])))
+        eng.fuse_featproj = True
+        c = eng.forward_stft(stft, want_layers=False, want_counts=True)
+        assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(c["enh_stft"]))
+        assert c["fb_all"][0].device.type == "meta" and c["fb_all"][0].shape == a["fb_all"][0].shape
+        for la, lc in zip([a["fb_all"]] + a["sb_all"], [c["fb_all"]] + c["sb_all"]):
+            for u, v in zip(la[1:-1], lc[1:-1]):
+                assert int((u > 0).sum()) == int(v.count)
+    eng.check_stack_errors()
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (one rank per GPU; with
     SFSN_BENCH_BACKEND=gloo the two ranks share this box's GPU -- a plumbing check of the N > 1 path): one JSON line, n_gpus 2,
