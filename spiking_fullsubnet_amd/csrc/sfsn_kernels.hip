@@ -844,10 +844,22 @@ __global__ __launch_bounds__(512) void input_proj_fast_kernel(const float* __res
 // one; two independent MFMA chains) and are added once at the end.  6 MFMAs of 16 clk per 32 k instead of 8 of 32 clk.
 // (bf8 / split3: sfsn_scan_dev.h -- shared with the FUSEDX3 role of the stack launch)
 
+typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte load from a dword-aligned address
+
+#ifdef IP_STAMPS  // scripts/micro/inproj_stamps.sh: shader-clock sums per phase as wave 0 of a launch's first workgroup sees them
+__device__ unsigned long long ip_dbg[8];
+#define IP_T(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); dbg_[k] += now_ - last_; last_ = now_; } while (0)
+#else
+#define IP_T(k) do {} while (0)
+#endif
+
 template <int TPW, int KS>
 __device__ __forceinline__ void input_proj_bf3_body(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ z, int M, int K, int N,
                                                     int ldz, int NT, int NWN, int blk, int nblk, float* gemm_smem) {
+#ifdef IP_STAMPS
+    unsigned long long dbg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int KQ = KS * 32;          // padded K
     constexpr int LDX = KQ + 8;          // bf16 elements per row: row stride = 16 B * odd -> conflict-free ds_read_b128
     constexpr int PLANE = 64 * LDX / 2;  // dwords per piece plane
@@ -876,13 +888,29 @@ __device__ __forceinline__ void input_proj_bf3_body(const float* __restrict__ x,
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             unsigned pw[3][4];
+            // a k-step that lies wholly inside K (wave-uniform): the lane's eight weights as two 16-byte loads from a clamped row (K is
+            // even and w 16-byte aligned: rows are 8-byte aligned, which a global dwordx4 load takes) instead of eight 4-byte loads --
+            // the workgroup's prologue was 80 scalar loads per lane, 11.6 of a 43 us launch (scripts/micro/inproj_stamps.sh)
+            float wv[8];
+            if (ks * 32 + 32 <= K) {
+                const int wrc = wr < N ? wr : N - 1;
+                const v4fu* src = reinterpret_cast<const v4fu*>(w + (size_t)wrc * K + ks * 32 + q * 8);
+                const v4fu lo4 = src[0], hi4 = src[1];
+                const bool live = have && wr < N;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = ks * 32 + q * 8 + 2 * e;
-                const float a = (have && wr < N && k < K) ? w[(size_t)wr * K + k] : 0.0f;
-                const float b = (have && wr < N && k + 1 < K) ? w[(size_t)wr * K + k + 1] : 0.0f;
-                split3(a, b, pw[0][e], pw[1][e], pw[2][e]);
+                for (int e = 0; e < 4; ++e) {
+                    wv[e] = live ? lo4[e] : 0.0f;
+                    wv[4 + e] = live ? hi4[e] : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = ks * 32 + q * 8 + e;
+                    wv[e] = (have && wr < N && k < K) ? w[(size_t)wr * K + k] : 0.0f;
+                }
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3(wv[2 * e], wv[2 * e + 1], pw[0][e], pw[1][e], pw[2][e]);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) W[i][ks][pl] = *reinterpret_cast<const bf8*>(pw[pl]);
         }
@@ -923,59 +951,89 @@ __device__ __forceinline__ void input_proj_bf3_body(const float* __restrict__ x,
         park();
     }
     __syncthreads();
+    IP_T(0);
     for (int st = blk; st < NS; st += nblk) {
         const int m0 = st * 64;
         const int nxt = st + nblk;
         if (nxt < NS) fetch(nxt);
         if (worker) {
-            for (int mi = mw; mi < GEMM_MB; mi += MW) {
-                v4f hi[TPW], lo[TPW];
+            // Two row blocks at a time and NO branch around an absent column tile (its W pieces are zero, its result is not stored:
+            // the waves that lack one would wait at the barrier anyway): 2 x TPW independent accumulator chains side by side.  Every
+            // accumulator still sees its six products per k-step in the same order -- the same bits.  (Round 5: with the `continue`
+            // the chains of the two column tiles sat in separate exec-masked blocks, and one tile's `lo` chain is five dependent
+            // matrix instructions per k-step: the product phase ran at 1.8 x its issue time, scripts/micro/inproj_stamps.sh.)
+            constexpr int MP = (TPW <= 2 && TPW * KS <= 6) ? 2 : 1;  // row blocks side by side where the registers allow it (W pieces: 12 TPW KS)
+            for (int mi0 = mw; mi0 < GEMM_MB; mi0 += MP * MW) {
+                const bool two = MP == 2 && mi0 + MW < GEMM_MB;  // wave-uniform
+                const int mis[2] = {mi0, two ? mi0 + MW : mi0};
+                v4f hi[MP][TPW], lo[MP][TPW];
 #pragma unroll
-                for (int i = 0; i < TPW; ++i) hi[i] = lo[i] = v4f{0, 0, 0, 0};
+                for (int m = 0; m < MP; ++m)
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) hi[m][i] = lo[m][i] = v4f{0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const unsigned* src = xb + (((mi * 16 + n) * LDX + ks * 32 + q * 8) >> 1);
-                    const bf8 b1 = *reinterpret_cast<const bf8*>(src), b2 = *reinterpret_cast<const bf8*>(src + PLANE),
-                              b3 = *reinterpret_cast<const bf8*>(src + 2 * PLANE);
+                    bf8 b1[MP], b2[MP], b3[MP];
+#pragma unroll
+                    for (int m = 0; m < MP; ++m) {
+                        const unsigned* src = xb + (((mis[m] * 16 + n) * LDX + ks * 32 + q * 8) >> 1);
+                        b1[m] = *reinterpret_cast<const bf8*>(src);
+                        b2[m] = *reinterpret_cast<const bf8*>(src + PLANE);
+                        b3[m] = *reinterpret_cast<const bf8*>(src + 2 * PLANE);
+                    }
+#define IPB_STEP(ACC, PL, B)                                                                                          \
+    _Pragma("unroll") for (int m = 0; m < MP; ++m) _Pragma("unroll") for (int i = 0; i < TPW; ++i)                    \
+        ACC[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][PL], B[m], ACC[m][i], 0, 0, 0);
+                    IPB_STEP(lo, 2, b1)
+                    IPB_STEP(hi, 0, b1)
+                    IPB_STEP(lo, 1, b2)
+                    IPB_STEP(lo, 0, b3)
+                    IPB_STEP(lo, 1, b1)
+                    IPB_STEP(lo, 0, b2)
+#undef IPB_STEP
+                }
+#pragma unroll
+                for (int m = 0; m < MP; ++m) {
+                    if (m == 1 && !two) break;
+                    const int mi = mis[m];
 #pragma unroll
                     for (int i = 0; i < TPW; ++i) {
                         if (col[i] < 0) continue;
-                        lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][2], b1, lo[i], 0, 0, 0);
-                        hi[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][0], b1, hi[i], 0, 0, 0);
-                        lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][1], b2, lo[i], 0, 0, 0);
-                        lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][0], b3, lo[i], 0, 0, 0);
-                        lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][1], b1, lo[i], 0, 0, 0);
-                        lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[i][ks][0], b2, lo[i], 0, 0, 0);
-                    }
-                }
+                        v4f acc;
 #pragma unroll
-                for (int i = 0; i < TPW; ++i) {
-                    if (col[i] < 0) continue;
-                    v4f acc;
+                        for (int r = 0; r < 4; ++r) acc[r] = (hi[m][i][r] + lo[m][i][r]) + bv[i][r];
+                        if (col[i] + 3 < N) {
+                            *reinterpret_cast<v4f*>(&obuf[(mi * 16 + n) * NP + col[i]]) = acc;
+                        } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = (hi[i][r] + lo[i][r]) + bv[i][r];
-                    if (col[i] + 3 < N) {
-                        *reinterpret_cast<v4f*>(&obuf[(mi * 16 + n) * NP + col[i]]) = acc;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (col[i] + r < N) obuf[(mi * 16 + n) * NP + col[i] + r] = acc[r];
+                            for (int r = 0; r < 4; ++r)
+                                if (col[i] + r < N) obuf[(mi * 16 + n) * NP + col[i] + r] = acc[r];
+                        }
                     }
                 }
             }
         }
+        IP_T(1);
         __syncthreads();  // every wave is done with the x pieces of this tile; obuf is complete
+        IP_T(2);
         // park the prefetched tile BEFORE issuing this tile's stores (vmcnt retires in order: the wait for the prefetch
         // would otherwise also wait for the stores)
         if (nxt < NS) park();
+        IP_T(3);
         const int rows = (M - m0 < 64) ? M - m0 : 64;
         for (int idx = tid; idx < rows * n4; idx += 512) {
             const int r = idx / n4, c4 = idx - r * n4;
             *reinterpret_cast<v4f*>(z + (size_t)(m0 + r) * ldz + c4 * 4) = *reinterpret_cast<const v4f*>(&obuf[r * NP + c4 * 4]);
         }
+        IP_T(4);
         __builtin_amdgcn_s_waitcnt(0xc07f);  // (LDS reads of obuf done; the row stores stay in flight: see spike_proj_fast_body)
         __builtin_amdgcn_s_barrier();
+        IP_T(5);
     }
+#ifdef IP_STAMPS
+    if (blk == 0 && threadIdx.x == 0)
+        for (int k = 0; k < 8; ++k) ip_dbg[k] = dbg_[k];
+#endif
 }
 
 template <int TPW, int KS>
@@ -2549,3 +2607,9 @@ extern "C" int sfsn_deepfilter(const float* stft_ri, int B, int F, int T, int S,
     hipLaunchKernelGGL(deepfilter_kernel, dim3((nt + 31) / 32, B), dim3(256), lds, st, stft_ri, p, enh_ri, enh_mag);
     return hip_ok(hipGetLastError());
 }
+
+#ifdef IP_STAMPS
+extern "C" int sfsn_ip_debug(unsigned long long* out /* [8] host */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ip_dbg), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
