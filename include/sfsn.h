@@ -186,12 +186,24 @@ typedef struct {
     int R;
     float *spikes, *u, *xhat, *f, *g, *invstd;
     void* scratch;
+    /* ABI 17: a layer call cut into CHUNKS of frames (so that layer l + 1 can work on chunk c while layer l works on chunk c + 1 in the
+     * same launch: two calls of one multi launch).  h0 / c0 [R][H], both or neither: the spikes and the (post-BatchNorm) membrane of the
+     * frame before this call's first -- rows `spikes[-1]` / `u[-1]` of the previous chunk's call; NULL = zero state.  The running
+     * statistics continue through the calls in launch order; momentum < 0 counts from the batches tracked before THIS call. */
+    const float *h0, *c0;
 } SfsnTrainSeqFwd;
 typedef struct {
     const float *w_hh, *dh_up, *u, *xhat, *f, *g, *invstd, *bn_w;
     int R;
     float *d_gates, *d_z, *d_bn_w, *d_bn_b;
     void* scratch;
+    /* ABI 17, chunked calls (issued last chunk first): dc_in [R][H] = dL/dc carried out of the chunk BEHIND this one (its dc_out); with it
+     * the tensors must continue behind this call's T frames -- d_z / d_gates frame T is that chunk's first, already written.  dc_out
+     * [R][H], nullable: dL/dc carried out of this call's first frame.  has_prev: `u` has a frame before this call's first (u - R*H floats:
+     * the membrane the first step's forget gate multiplied), i.e. this is not the sequence's first chunk. */
+    const float* dc_in;
+    float* dc_out;
+    int has_prev;
 } SfsnTrainSeqBwd;
 int sfsn_gsn_train_multi_check(const int* R, int n, int H, int shared);
 int sfsn_gsn_train_seq_fwd_multi(const SfsnTrainSeqFwd* calls, int n, int T, int H, int shared, void* stream);

@@ -612,8 +612,21 @@ __device__ __forceinline__ void train_seq_fwd_body(const TrainFwdParams& p, cons
         wt[(gi * TR_TILE + jj) * WLD + k] = p.w_hh[((size_t)gi * H + n0 + jj) * H + k];
     }
     if (tid == 0) __hip_atomic_fetch_add(x.rbcnt + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (diagnostics: workgroups started)
-    for (int i = tid; i < p.rpb * TR_TILE; i += TR_THREADS) cprev[i] = 0.f;
-    for (int i = tid; i < p.rpb * H4; i += TR_THREADS) hb[i] = 0u;
+    // initial state: zero (MODEL:100-106), or -- a layer call cut into chunks of frames (sfsn.h: h0 / c0) -- the spikes and the
+    // membrane of the frame before this call's first
+    for (int i = tid; i < p.rpb * TR_TILE; i += TR_THREADS) {
+        const int r = r_lo + (i >> 4);
+        cprev[i] = (p.c_prev && r < r_hi) ? p.c_prev[(size_t)r * H + n0 + (i & 15)] : 0.f;
+    }
+    for (int i = tid; i < p.rpb * H4; i += TR_THREADS) {
+        unsigned w = 0u;
+        const int rr = i / H4, r = r_lo + rr;
+        if (p.h_prev && r < r_hi) {
+            const tr_v4f h4 = *reinterpret_cast<const tr_v4f*>(p.h_prev + (size_t)r * H + 4 * (i - rr * H4));
+            w = (h4[0] != 0.f ? 1u : 0u) | (h4[1] != 0.f ? 0x100u : 0u) | (h4[2] != 0.f ? 0x10000u : 0u) | (h4[3] != 0.f ? 0x1000000u : 0u);
+        }
+        hb[i] = w;
+    }
     const float bf = p.bias[nj], bg = p.bias[H + nj];
     const float gam = p.use_bn ? p.bn_w[nj] : 1.f, bet = p.use_bn ? p.bn_b[nj] : 0.f;
     const bool stat_owner = rsub == 0 && rb == 0;
@@ -803,7 +816,14 @@ __device__ __forceinline__ void train_seq_bwd_body(const TrainBwdParams& p, cons
     }
     for (int i = tid; i < p.rpb * DLD; i += TR_THREADS) dzb[i] = 0.f;
     if (tid == 0) __hip_atomic_fetch_add(x.rbcnt + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (diagnostics: workgroups started)
-    for (int i = tid; i < p.rpb * TR_TILE; i += TR_THREADS) dcn[i] = 0.f;
+    // A layer call cut into chunks of frames (sfsn.h: dc_in / dc_out / has_prev): `later` = the frames behind this call's last one have
+    // been processed by an earlier launch -- their d_z sits behind this call's in the same tensor (frame T: plain loads, the launch
+    // boundary ordered it) and dL/dc carried out of them is dc_next [R][H]
+    const bool later = p.dc_next != nullptr;
+    for (int i = tid; i < p.rpb * TR_TILE; i += TR_THREADS) {
+        const int r = r_lo + (i >> 4);
+        dcn[i] = (later && r < r_hi) ? p.dc_next[(size_t)r * H + tile * TR_TILE + (i & 15)] : 0.f;
+    }
     const size_t RH = (size_t)p.R * H, RG = (size_t)p.R * GH;
     float* dzs = p.shared ? p.d_z : p.d_gates;  // the gradient of the (shared or per-gate) products: [T][R][G*H]
     const float gam = p.use_bn ? p.bn_w[nj] : 1.f;
@@ -817,7 +837,7 @@ __device__ __forceinline__ void train_seq_bwd_body(const TrainBwdParams& p, cons
         const int s = x.T - 1 - t;
         const float *i_u = p.u + (size_t)t * RH, *i_f = p.f + (size_t)t * RH, *i_g = p.g + (size_t)t * RH, *i_up = p.dh_up + (size_t)t * RH;
         const float* i_x = p.xhat ? p.xhat + (size_t)t * RH : nullptr;
-        const float* i_cp = t ? p.u + (size_t)(t - 1) * RH : nullptr;
+        const float* i_cp = t ? p.u + (size_t)(t - 1) * RH : p.c_prev;  // (c_prev: the membrane of the frame before a chunk's first, or null)
         // this step's own inputs (forward-saved tensors, the upstream gradient) do not depend on anybody: requested before the wait
         float upp[TR_PF], uup[TR_PF], xhp[TR_PF];
 #pragma unroll
@@ -828,8 +848,8 @@ __device__ __forceinline__ void train_seq_bwd_body(const TrainBwdParams& p, cons
             uup[i] = i_u[o];
             xhp[i] = p.use_bn ? i_x[o] : 0.f;
         }
-        if (s > 0) {  // d_z of step t+1 of my rows: every tile workgroup of my row block has published it
-            if (!tr_wait_counter(x.rbcnt + rb, (unsigned)s * (unsigned)tiles, err)) return;
+        if (s > 0 || later) {  // d_z of step t+1 of my rows: every tile workgroup of my row block has published it (or an earlier launch wrote it)
+            if (s > 0 && !tr_wait_counter(x.rbcnt + rb, (unsigned)s * (unsigned)tiles, err)) return;
             TR_STAMP(0);
             const float* src = dzs + (size_t)(t + 1) * RG + (size_t)r_lo * GH;
             tr_copy16_sc1(dzb, src, (nr * GH) >> 2, GH >> 2, DLD >> 2);
@@ -857,11 +877,11 @@ __device__ __forceinline__ void train_seq_bwd_body(const TrainBwdParams& p, cons
             const size_t o = (size_t)r * H + nj;
             float dh = 0.f;
             dh += pi < TR_PF ? tr_pick(upp, pi) : i_up[o];
-            if (s > 0) dh += recb[(size_t)(r - r_lo) * TR_TILE + j];  // dL/dh_t through step t+1's recurrent product
+            if (s > 0 || later) dh += recb[(size_t)(r - r_lo) * TR_TILE + j];  // dL/dh_t through step t+1's recurrent product
             const float uu = pi < TR_PF ? tr_pick(uup, pi) : i_u[o];
             const float tri = fmaxf(0.f, 1.0f - fabsf(uu));
             float du = dh * tri;
-            if (s > 0) du += dcn[(r - r_lo) * TR_TILE + j];
+            if (s > 0 || later) du += dcn[(r - r_lo) * TR_TILE + j];
             dbuf[(r - r_lo) * TR_TILE + j] = du;
             if (p.use_bn) {
                 s1 += du;
@@ -928,6 +948,9 @@ __device__ __forceinline__ void train_seq_bwd_body(const TrainBwdParams& p, cons
         TR_STAMP(6);
     }
     if (p.use_bn && stat_owner) { p.d_bn_w[nj] = acc_w; p.d_bn_b[nj] = acc_b; }
+    if (p.dc_prev) {  // dL/dc carried out of this call's first frame: what the launch of the frames before it starts from
+        for (int r = r_lo + rsub; r < r_hi; r += TR_THREADS / TR_TILE) p.dc_prev[(size_t)r * H + nj] = dcn[(r - r_lo) * TR_TILE + j];
+    }
 }
 
 __global__ __launch_bounds__(TR_THREADS) void gsn_train_seq_bwd_kernel(const TrainSeqBwdMulti m) {
@@ -1057,6 +1080,7 @@ extern "C" int sfsn_gsn_train_seq_fwd_multi(const SfsnTrainSeqFwd* c, int n, int
         if (c[i].bn_w && (!c[i].bn_b || !c[i].xhat || !c[i].invstd)) return SFSN_EINVAL;
         if ((c[i].bn_w != nullptr) != (c[0].bn_w != nullptr)) return SFSN_EINVAL;
         if ((c[i].running_mean == nullptr) != (c[i].running_var == nullptr)) return SFSN_EINVAL;
+        if ((c[i].h0 == nullptr) != (c[i].c0 == nullptr) || (reinterpret_cast<uintptr_t>(c[i].h0) & 15)) return SFSN_EINVAL;
         Rs[i] = c[i].R;
     }
     int wgs; size_t lds, lds_b;
@@ -1077,7 +1101,7 @@ extern "C" int sfsn_gsn_train_seq_fwd_multi(const SfsnTrainSeqFwd* c, int n, int
         train_geometry(R, H, shared ? 1 : 2, &p.RB, &p.rpb);
         char* base = static_cast<char*>(c[i].scratch);
         float* step_scr = reinterpret_cast<float*>(base + seq_head_bytes(R, H));
-        p.z = c[i].z; p.w_hh = c[i].w_hh; p.bias = c[i].bias; p.h_prev = nullptr; p.c_prev = nullptr; p.bn_w = c[i].bn_w; p.bn_b = c[i].bn_b;
+        p.z = c[i].z; p.w_hh = c[i].w_hh; p.bias = c[i].bias; p.h_prev = c[i].h0; p.c_prev = c[i].c0; p.bn_w = c[i].bn_w; p.bn_b = c[i].bn_b;
         p.running_mean = c[i].running_mean; p.running_var = c[i].running_var; p.spikes = c[i].spikes; p.u = c[i].u; p.xhat = c[i].xhat;
         p.f = c[i].f; p.g = c[i].g; p.invstd = c[i].invstd; p.momentum = c[i].momentum; p.eps = c[i].eps; p.R = R; p.H = H; p.shared = shared;
         p.use_bn = c[i].bn_w != nullptr; p.epoch = 0; p.scratch = step_scr;
@@ -1122,9 +1146,9 @@ extern "C" int sfsn_gsn_train_seq_bwd_multi(const SfsnTrainSeqBwd* c, int n, int
         train_geometry(R, H, shared ? 1 : 2, &p.RB, &p.rpb);
         char* base = static_cast<char*>(c[i].scratch);
         float* step_scr = reinterpret_cast<float*>(base + seq_head_bytes(R, H));
-        p.dz_next = nullptr; p.w_hh = c[i].w_hh; p.dh_up = c[i].dh_up; p.dh_rec = nullptr; p.dc_next = nullptr; p.u = c[i].u; p.xhat = c[i].xhat;
-        p.f = c[i].f; p.g = c[i].g; p.c_prev = nullptr; p.invstd = c[i].invstd; p.bn_w = c[i].bn_w; p.d_gates = c[i].d_gates; p.d_z = c[i].d_z;
-        p.dc_prev = nullptr; p.d_bn_w = c[i].d_bn_w; p.d_bn_b = c[i].d_bn_b;
+        p.dz_next = nullptr; p.w_hh = c[i].w_hh; p.dh_up = c[i].dh_up; p.dh_rec = nullptr; p.dc_next = c[i].dc_in; p.u = c[i].u; p.xhat = c[i].xhat;
+        p.f = c[i].f; p.g = c[i].g; p.c_prev = c[i].has_prev ? c[i].u - (size_t)c[i].R * H : nullptr; p.invstd = c[i].invstd; p.bn_w = c[i].bn_w;
+        p.d_gates = c[i].d_gates; p.d_z = c[i].d_z; p.dc_prev = c[i].dc_out; p.d_bn_w = c[i].d_bn_w; p.d_bn_b = c[i].d_bn_b;
         p.R = R; p.H = H; p.shared = shared; p.use_bn = c[i].bn_w != nullptr; p.epoch = 0; p.scratch = step_scr;
         p.counters = reinterpret_cast<unsigned*>(step_scr + (size_t)tiles * 16 * TR_PARTG * 2);
         x.T = T;
@@ -1146,6 +1170,7 @@ extern "C" int sfsn_gsn_train_seq_fwd(const float* z, const float* w_hh, const f
                                       int shared, const float* /*zero: unused since ABI 14*/, float* spikes, float* u, float* xhat, float* f, float* g,
                                       float* invstd, void* scratch, void* stream) {
     SfsnTrainSeqFwd c;
+    c.h0 = nullptr; c.c0 = nullptr;
     c.z = z; c.w_hh = w_hh; c.bias = bias; c.bn_w = bn_w; c.bn_b = bn_b; c.running_mean = running_mean; c.running_var = running_var;
     c.momentum = momentum; c.eps = eps; c.R = R; c.spikes = spikes; c.u = u; c.xhat = xhat; c.f = f; c.g = g; c.invstd = invstd; c.scratch = scratch;
     return sfsn_gsn_train_seq_fwd_multi(&c, 1, T, H, shared, stream);
@@ -1157,6 +1182,7 @@ extern "C" int sfsn_gsn_train_seq_bwd(const float* w_hh, const float* dh_up, con
                                       const float* /*zero: unused since ABI 14*/, float* d_gates, float* d_z, float* /*dc_work: unused since ABI 14*/,
                                       float* d_bn_w, float* d_bn_b, void* scratch, void* stream) {
     SfsnTrainSeqBwd c;
+    c.dc_in = nullptr; c.dc_out = nullptr; c.has_prev = 0;
     c.w_hh = w_hh; c.dh_up = dh_up; c.u = u; c.xhat = xhat; c.f = f; c.g = g; c.invstd = invstd; c.bn_w = bn_w; c.R = R;
     c.d_gates = d_gates; c.d_z = d_z; c.d_bn_w = d_bn_w; c.d_bn_b = d_bn_b; c.scratch = scratch;
     return sfsn_gsn_train_seq_bwd_multi(&c, 1, T, H, shared, stream);

@@ -28,6 +28,73 @@ def _close(a, b, name, rtol=2e-3, atol_frac=2e-4):
     assert not bad.any(), f"{name}: {int(bad.sum())} of {a.size} outside tolerance, max abs err {np.abs(a - b).max():.3g} (scale {np.abs(b).max():.3g})"
 
 
+@pytest.fixture
+def chunked_stacks():
+    """training.gsn_stack with the layers of a stack pipelined over chunks of frames (GSNStackTrainFn) even on the short fixtures."""
+    from spiking_fullsubnet_amd import training
+    old = training.STACK_CHUNKS, training.STACK_MIN_FRAMES
+    training.STACK_CHUNKS, training.STACK_MIN_FRAMES = 3, 2
+    yield training
+    training.STACK_CHUNKS, training.STACK_MIN_FRAMES = old
+
+
+@pytest.mark.parametrize("ci", [0, 1, 3, 4, 5])
+def test_gsn_stack_pipelined_over_chunks_matches_the_reference(ci, chunked_stacks):
+    """The same reference fixtures with the two layers of the stack in ONE grid, layer 2 a chunk of frames behind layer 1
+    (training.GSNStackTrainFn: 2 or 3 chunks of 2 .. 8 frames here; chunked layer calls continue from the spikes / membrane /
+    carried dL/dc of the neighbouring chunk): spikes equal, BatchNorm buffers and every gradient as for the unchunked calls."""
+    training = chunked_stacks
+    n0 = training._STACK_CALLS
+    test_gsn_stack_training_forward_and_backward_match_the_reference(ci)
+    g = np.load(os.path.join(GOLD, "gsn_train_cells.npz"))
+    if str(g["cases"][ci]) != "train_sb_recipe":  # (512 rows: two layers side by side would not be resident -- one call after the other)
+        assert training._STACK_CALLS == n0 + 1
+
+
+@pytest.mark.parametrize("shared,bn,R,H", [(True, True, 64, 320), (True, True, 40, 48), (False, True, 24, 32), (True, False, 100, 64)])
+def test_pipelined_stack_equals_the_layer_calls_one_after_the_other(shared, bn, R, H):
+    """GSNStackTrainFn against GSNLayerTrainFn per layer on a longer sequence (T = 120 in 5 chunks; 3 layers in the small case): the
+    same spikes, BatchNorm buffers and gradients (the layer >= 1 input products are library GEMMs over a chunk instead of the whole
+    sequence: gradients are compared to 1e-5 relative, everything the kernels produce bit for bit)."""
+    import copy
+    import spiking_fullsubnet_amd.modeling_spiking_fullsubnet as M
+    from spiking_fullsubnet_amd import training
+    torch.manual_seed(11)
+    T, I, L = 120, 20, (3 if H == 48 else 2)
+    stack = M.StackedGSU(I, H, L, shared, bn).to(DEV).train()
+    if bn:
+        for layer in stack.layers:
+            layer.cell.batchnorm.weight.data.uniform_(0.5, 1.5)
+            layer.cell.batchnorm.bias.data.uniform_(-0.3, 0.3)
+    twin = copy.deepcopy(stack)
+    x, cot = torch.randn(T, R, I, device=DEV), torch.randn(T, R, H, device=DEV)
+
+    def run(st, chunks):
+        old = training.STACK_CHUNKS
+        training.STACK_CHUNKS = chunks
+        try:
+            xi = x.clone().requires_grad_(True)
+            outs = training.gsn_stack(xi, st, True)
+            ((outs[-1] * cot).sum() + 0.5 * (outs[1] * cot).sum()).backward()
+            training.check_pending()
+        finally:
+            training.STACK_CHUNKS = old
+        return xi, outs
+    n0 = training._STACK_CALLS
+    xa, oa = run(stack, 5)
+    assert training._STACK_CALLS == n0 + 1
+    xb, ob = run(twin, 1)
+    assert training._STACK_CALLS == n0 + 1
+    for l in range(1, L + 1):
+        assert torch.equal(oa[l], ob[l]), f"layer {l}: {(oa[l] != ob[l]).sum().item()} spikes differ"
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert rel(xa.grad, xb.grad) < 1e-5
+    for (na, pa), (nb, pb) in zip(stack.named_parameters(), twin.named_parameters()):
+        assert na == nb and rel(pa.grad, pb.grad) < 1e-5, (na, rel(pa.grad, pb.grad))
+    for (na, ba), (nb, bb) in zip(stack.named_buffers(), twin.named_buffers()):
+        assert torch.equal(ba, bb) if na.endswith("num_batches_tracked") else rel(ba.float(), bb.float()) < 1e-6, na
+
+
 @pytest.mark.parametrize("ci", range(6))
 def test_gsn_stack_training_forward_and_backward_match_the_reference(ci):
     """StackedGSU in training mode: spike trains of every layer, BatchNorm buffers after the forward (running statistics updated once
