@@ -338,9 +338,9 @@ static int train_wg_target() {
     return 160;  // (220 / 160 / 110 / 70 measured at B = 64, three groups in one launch: 9.4 / 8.3 / 8.1 / 8.3 ms forward, 13.6 / 12.5 / 13.1 / 14.7 backward per 200 steps x 2 layers)
 #endif
 }
-static void train_geometry(int R, int H, int G, int* RB, int* rpb) {
+static void train_geometry(int R, int H, int G, int* RB, int* rpb, int target = 0) {
     const int tiles = H / TR_TILE;
-    int rb = train_wg_target() / tiles;
+    int rb = (target > 0 ? target : train_wg_target()) / tiles;
     if (rb < 1) rb = 1;
     int per = 16;
     for (;; ++rb) {
@@ -1007,7 +1007,7 @@ static int seq_slots(const void* kern, size_t lds) {
     // (asked before every launch: the last few answers are remembered per (device, kernel, LDS size) -- the occupancy query costs tens of
     //  microseconds, a training step makes sixteen launches)
     struct Memo { int dev; const void* kern; size_t lds; int slots; };
-    static thread_local Memo memo[8];
+    static thread_local Memo memo[48];
     static thread_local int n_memo = 0;
     int dev = 0, cus = 0, per = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -1016,27 +1016,43 @@ static int seq_slots(const void* kern, size_t lds) {
         if (memo[i].dev == dev && memo[i].kern == kern && memo[i].lds == lds) return memo[i].slots;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, TR_THREADS, lds) != hipSuccess) return -1;
-    memo[n_memo < 8 ? n_memo++ : 7] = Memo{dev, kern, lds, per * cus};
+    memo[n_memo < 48 ? n_memo++ : 47] = Memo{dev, kern, lds, per * cus};
     return per * cus;
 }
 
-static int seq_multi_geometry(const int* R, int n, int H, int shared, int* wgs, size_t* lds_f, size_t* lds_b) {
+// Geometry of a multi-call launch in ONE direction (dir 0 forward, 1 backward): rows per block / row blocks of every call, the launch's
+// LDS, its workgroups.  Every call starts from the single call's geometry (~160 workgroups); when the launch would not be resident
+// (more calls side by side than the chip has slots: the layers of several stacks in one grid, GSNStackTrainFn) all calls take fewer,
+// larger row blocks -- the step time hardly depends on the rows per block (220 / 160 / 110 / 70 workgroups per call measured 9.4 / 8.3 /
+// 8.1 / 8.3 ms forward) -- until it is, or until a block's rows no longer fit the LDS.  A chunked call's state travels through global
+// memory, so the geometry may differ from launch to launch and between the directions.
+static int seq_dir_geometry(const int* R, int n, int H, int shared, int dir, int* RBs, int* rpbs, int* wgs, size_t* lds) {
     if (!R || n <= 0 || n > TR_MAXG || H <= 0) return SFSN_EINVAL;
     if (H % TR_TILE != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     const int G = shared ? 1 : 2, tiles = H / TR_TILE;
-    *wgs = 0; *lds_f = 0; *lds_b = 0;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (R[i] <= 0) return SFSN_EINVAL;
-        int RB, rpb;
-        train_geometry(R[i], H, G, &RB, &rpb);
-        if (RB > 16) return SFSN_EUNSUPPORTED;
-        const size_t lf = seq_lds_fwd(G, H, RB, rpb), lb = seq_lds_bwd(G, H, RB, rpb);
-        if (lf > 150 * 1024 || lb > 150 * 1024) return SFSN_EUNSUPPORTED;
-        *lds_f = lf > *lds_f ? lf : *lds_f;
-        *lds_b = lb > *lds_b ? lb : *lds_b;
-        *wgs += tiles * RB;
+    const void* kern = dir ? reinterpret_cast<const void*>(gsn_train_seq_bwd_kernel) : reinterpret_cast<const void*>(gsn_train_seq_fwd_kernel);
+    static const int targets[] = {0, 128, 96, 80, 64, 48, 40, 32, 24, 16};
+    for (int target : targets) {
+        int total = 0;
+        size_t l = 0;
+        bool fits_lds = true;
+        for (int i = 0; i < n; ++i) {
+            train_geometry(R[i], H, G, &RBs[i], &rpbs[i], target);
+            if (RBs[i] > 16) return SFSN_EUNSUPPORTED;
+            const size_t li = dir ? seq_lds_bwd(G, H, RBs[i], rpbs[i]) : seq_lds_fwd(G, H, RBs[i], rpbs[i]);
+            if (li > 150 * 1024) fits_lds = false;
+            l = li > l ? li : l;
+            total += tiles * RBs[i];
+        }
+        if (!fits_lds) return SFSN_EUNSUPPORTED;  // (train_geometry already took as many row blocks as the LDS needs: fewer cannot fit either)
+        const int slots = seq_slots(kern, l);
+        if (slots < 0) return SFSN_EHIP;
+        *wgs = total; *lds = l;
+        if (total <= slots) return SFSN_OK;
     }
-    return SFSN_OK;
+    return SFSN_EUNSUPPORTED;
 }
 
 // Will the per-step launches (sfsn_gsn_train_step_fwd / _bwd: round 3's kernels, what training.py falls back to when the one-launch
@@ -1064,12 +1080,12 @@ extern "C" int sfsn_gsn_train_step_check(int R, int H, int shared) {
 // SFSN_OK when ONE launch per direction can hold the workgroups of all n layer calls (rows R[i], same H / gate sharing) resident
 // together; SFSN_EUNSUPPORTED otherwise (issue the calls one after the other, or in smaller sets).  Needs the device.
 extern "C" int sfsn_gsn_train_multi_check(const int* R, int n, int H, int shared) {
-    int wgs; size_t lf, lb;
-    const int rc = seq_multi_geometry(R, n, H, shared, &wgs, &lf, &lb);
+    int RBs[TR_MAXG], rpbs[TR_MAXG], wgs;
+    size_t lds;
+    if (n > TR_MAXG) return SFSN_EINVAL;
+    const int rc = seq_dir_geometry(R, n, H, shared, 0, RBs, rpbs, &wgs, &lds);
     if (rc != SFSN_OK) return rc;
-    const int sf = seq_slots(reinterpret_cast<const void*>(gsn_train_seq_fwd_kernel), lf), sb = seq_slots(reinterpret_cast<const void*>(gsn_train_seq_bwd_kernel), lb);
-    if (sf < 0 || sb < 0) return SFSN_EHIP;
-    return (wgs <= sf && wgs <= sb) ? SFSN_OK : SFSN_EUNSUPPORTED;
+    return seq_dir_geometry(R, n, H, shared, 1, RBs, rpbs, &wgs, &lds);
 }
 
 extern "C" int sfsn_gsn_train_seq_fwd_multi(const SfsnTrainSeqFwd* c, int n, int T, int H, int shared, void* stream) {
@@ -1083,13 +1099,11 @@ extern "C" int sfsn_gsn_train_seq_fwd_multi(const SfsnTrainSeqFwd* c, int n, int
         if ((c[i].h0 == nullptr) != (c[i].c0 == nullptr) || (reinterpret_cast<uintptr_t>(c[i].h0) & 15)) return SFSN_EINVAL;
         Rs[i] = c[i].R;
     }
-    int wgs; size_t lds, lds_b;
-    int rc = seq_multi_geometry(Rs, n, H, shared, &wgs, &lds, &lds_b);
+    int wgs, RBs[TR_MAXG], rpbs[TR_MAXG];
+    size_t lds;
+    int rc = seq_dir_geometry(Rs, n, H, shared, 0, RBs, rpbs, &wgs, &lds);
     if (rc != SFSN_OK) return rc;
     auto kern = gsn_train_seq_fwd_kernel;
-    const int slots = seq_slots(reinterpret_cast<const void*>(kern), lds);
-    if (slots < 0) return SFSN_EHIP;
-    if (wgs > slots) return SFSN_EUNSUPPORTED;
     const int tiles = H / TR_TILE;
     TrainSeqFwdMulti m;
     m.n = n;
@@ -1098,7 +1112,7 @@ extern "C" int sfsn_gsn_train_seq_fwd_multi(const SfsnTrainSeqFwd* c, int n, int
         TrainFwdParams& p = m.p[i];
         TrainSeqExtra& x = m.x[i];
         const int R = c[i].R;
-        train_geometry(R, H, shared ? 1 : 2, &p.RB, &p.rpb);
+        p.RB = RBs[i]; p.rpb = rpbs[i];
         char* base = static_cast<char*>(c[i].scratch);
         float* step_scr = reinterpret_cast<float*>(base + seq_head_bytes(R, H));
         p.z = c[i].z; p.w_hh = c[i].w_hh; p.bias = c[i].bias; p.h_prev = c[i].h0; p.c_prev = c[i].c0; p.bn_w = c[i].bn_w; p.bn_b = c[i].bn_b;
@@ -1128,13 +1142,11 @@ extern "C" int sfsn_gsn_train_seq_bwd_multi(const SfsnTrainSeqBwd* c, int n, int
         if ((c[i].bn_w != nullptr) != (c[0].bn_w != nullptr)) return SFSN_EINVAL;
         Rs[i] = c[i].R;
     }
-    int wgs; size_t lds_f, lds;
-    int rc = seq_multi_geometry(Rs, n, H, shared, &wgs, &lds_f, &lds);
+    int wgs, RBs[TR_MAXG], rpbs[TR_MAXG];
+    size_t lds;
+    int rc = seq_dir_geometry(Rs, n, H, shared, 1, RBs, rpbs, &wgs, &lds);
     if (rc != SFSN_OK) return rc;
     auto kern = gsn_train_seq_bwd_kernel;
-    const int slots = seq_slots(reinterpret_cast<const void*>(kern), lds);
-    if (slots < 0) return SFSN_EHIP;
-    if (wgs > slots) return SFSN_EUNSUPPORTED;
     const int tiles = H / TR_TILE;
     TrainSeqBwdMulti m;
     m.n = n;
@@ -1143,7 +1155,7 @@ extern "C" int sfsn_gsn_train_seq_bwd_multi(const SfsnTrainSeqBwd* c, int n, int
         TrainBwdParams& p = m.p[i];
         TrainSeqExtra& x = m.x[i];
         const int R = c[i].R;
-        train_geometry(R, H, shared ? 1 : 2, &p.RB, &p.rpb);
+        p.RB = RBs[i]; p.rpb = rpbs[i];
         char* base = static_cast<char*>(c[i].scratch);
         float* step_scr = reinterpret_cast<float*>(base + seq_head_bytes(R, H));
         p.dz_next = nullptr; p.w_hh = c[i].w_hh; p.dh_up = c[i].dh_up; p.dh_rec = nullptr; p.dc_next = c[i].dc_in; p.u = c[i].u; p.xhat = c[i].xhat;

@@ -482,67 +482,79 @@ class GSNLayersTrainFn(torch.autograd.Function):
 
 
 class GSNStackTrainFn(torch.autograd.Function):
-    """All L layers of ONE cell stack, pipelined over chunks of frames (round 5): a layer call is T dependent steps on <= ~100
-    workgroups, and layer l + 1 needs layer l's spikes of frame t only at frame t (NEURON:50-62 runs layer l over all T first only
-    because it is written layer by layer).  The sequence is cut into K chunks; stage s = 0 .. K + L - 2 is ONE launch
-    (sfsn_gsn_train_seq_fwd_multi) of the calls {(layer l, chunk s - l)}, layer l >= 1's input product of that chunk (a GEMM over the
-    chunk) just in front of it; a call continues from the state its previous chunk left (SfsnTrainSeqFwd.h0 / c0 = rows of the spike /
-    membrane tensors), the BatchNorm running statistics continue in launch order.  Backward the same in reverse (last chunk and last
-    layer first; SfsnTrainSeqBwd.dc_in / dc_out carry dL/dc across the cut, d_z of the later chunk is read from the tensor).  Value for
-    value what L GSNLayerTrainFn calls compute -- the same kernels on the same numbers.  K + L - 1 launches of T / K steps per direction
-    instead of L of T steps.  ``forward(ctx, meta, x, *flat)``: flat = L x (w_ih, w_hh, bias, bn_w, bn_b); meta = dict(shared, stats
-    [L x (running_mean, running_var, num_batches_tracked) or None], momentum [L], eps [L], chunks K); returns the L spike tensors."""
+    """All L layers of n independent cell stacks (one stack, or the sub-band groups of a model), pipelined over chunks of frames
+    (round 5): a layer call is T dependent steps on <= ~160 workgroups, and layer l + 1 needs layer l's spikes of frame t only at frame
+    t (NEURON:50-62 runs layer l over all T first only because it is written layer by layer).  The sequence is cut into K chunks; stage
+    s = 0 .. K + L - 2 is ONE launch (sfsn_gsn_train_seq_fwd_multi) of the calls {(stack i, layer l, chunk s - l)}, layer l >= 1's input
+    product of that chunk (a GEMM over the chunk) just in front of it; a call continues from the state its previous chunk left
+    (SfsnTrainSeqFwd.h0 / c0 = rows of the spike / membrane tensors), the BatchNorm running statistics continue in launch order.
+    Backward the same in reverse (last chunk and last layer first; SfsnTrainSeqBwd.dc_in / dc_out carry dL/dc across the cut, d_z of
+    the later chunk is read from the tensor).  The arithmetic of L GSNLayerTrainFn calls per stack -- the same kernels on the same
+    numbers; where the library gives the calls fewer, larger row blocks to fit them side by side, the BatchNorm partial sums are merged
+    in another blocking (last-bit differences).  K + L - 1 launches of T / K steps per direction instead of L of T steps.
+    ``forward(ctx, meta, *xs, *flat)``: xs = n x [T, R_i, I_i]; flat = n x L x (w_ih, w_hh, bias, bn_w, bn_b); meta = dict(n, shared,
+    stats [n][L] of (running_mean, running_var, num_batches_tracked) or None, momentum [n][L], eps [n][L], chunks K); returns the
+    n x L spike tensors (stack-major)."""
 
     @staticmethod
-    def forward(ctx, meta, x, *flat):
+    def forward(ctx, meta, *args):
         L_ = _lib.lib()
         _poll_pending()
-        nl, K, shared = len(flat) // 5, int(meta["chunks"]), bool(meta["shared"])
-        x = x.contiguous().float()
-        T, R, I0 = x.shape
+        n, K, shared = int(meta["n"]), int(meta["chunks"]), bool(meta["shared"])
+        xs, flat = [a.contiguous().float() for a in args[:n]], args[n:]
+        nl = len(flat) // (5 * n)
+        T = xs[0].shape[0]
         GH, H = flat[1].shape
         Tc = T // K
-        assert Tc * K == T and nl >= 2
-        dev = x.device
+        assert Tc * K == T and nl >= 2 and n * nl <= 8 * nl
+        dev = xs[0].device
         use_bn = flat[3] is not None
         f32 = dict(dtype=torch.float32, device=dev)
-        sRH, sRG, sH = R * H * 4, R * GH * 4, H * 4
-        nscr = L_.sfsn_train_seq_scratch_bytes(R, H) // 4      # words of one call's scratch (the error word: its last four)
-        nscr_pad = (nscr + 63) // 64 * 64                      # (one zeroed buffer per layer, a 256-byte aligned row per chunk)
-        lay = []
-        for l in range(nl):
-            w_ih, w_hh, bias, bn_w, bn_b = flat[5 * l:5 * l + 5]
-            stats = meta["stats"][l]
-            assert tuple(w_hh.shape) == (GH, H) and (bn_w is not None) == use_bn
-            if use_bn:
-                if R == 1:  # nn.BatchNorm1d in training mode (torch/nn/functional.py: _verify_batch_size)
-                    raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([{R}, {H}])")
-                if stats is not None:
-                    for nm, t_ in (("running_mean", stats[0]), ("running_var", stats[1])):
-                        if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != dev or t_.numel() != H:
-                            raise TypeError(f"BatchNorm {nm} must be a contiguous float32 tensor of {H} elements on {dev}, got "
-                                            f"{t_.dtype} {tuple(t_.shape)} on {t_.device}")
-            d = dict(w_ih=w_ih.detach().contiguous().float(), w_hh=w_hh.detach().contiguous().float(), bias=bias.detach().contiguous().float(),
-                     bw=bn_w.detach().contiguous().float() if use_bn else None, bb=bn_b.detach().contiguous().float() if use_bn else None,
-                     stats=stats, spikes=torch.empty((T, R, H), **f32), u=torch.empty((T, R, H), **f32), f=torch.empty((T, R, H), **f32),
-                     g=torch.empty((T, R, H), **f32), xhat=torch.empty((T, R, H), **f32) if use_bn else None,
-                     invstd=torch.empty((T, H), **f32) if use_bn else None,
-                     scr=torch.zeros((K, nscr_pad), dtype=torch.int32, device=dev))
-            # layer 0's input term for all T at once; the deeper layers' chunk by chunk, behind the chunk's spikes
-            d["z"] = torch.mm(x.reshape(T * R, I0), d["w_ih"].t()).view(T, R, GH) if l == 0 else torch.empty((T, R, GH), **f32)
-            mom = meta["momentum"][l]
-            d["n0"] = int(stats[2].item()) if (mom is None and use_bn and stats is not None and stats[2] is not None) else 0
-            d["mom"], d["eps"] = mom, float(meta["eps"][l])
-            lay.append(d)
+        sH = H * 4
+        stk = []  # per stack: dict(R, I0, x, lay=[per layer dict])
+        for i in range(n):
+            x = xs[i]
+            Ti, R, I0 = x.shape
+            assert Ti == T
+            nscr = L_.sfsn_train_seq_scratch_bytes(R, H) // 4      # words of one call's scratch (the error word: its last four)
+            nscr_pad = (nscr + 63) // 64 * 64                      # (one zeroed buffer per layer, a 256-byte aligned row per chunk)
+            lay = []
+            for l in range(nl):
+                w_ih, w_hh, bias, bn_w, bn_b = flat[5 * (i * nl + l):5 * (i * nl + l) + 5]
+                stats = meta["stats"][i][l]
+                assert tuple(w_hh.shape) == (GH, H) and (bn_w is not None) == use_bn
+                if use_bn:
+                    if R == 1:  # nn.BatchNorm1d in training mode (torch/nn/functional.py: _verify_batch_size)
+                        raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([{R}, {H}])")
+                    if stats is not None:
+                        for nm, t_ in (("running_mean", stats[0]), ("running_var", stats[1])):
+                            if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != dev or t_.numel() != H:
+                                raise TypeError(f"BatchNorm {nm} must be a contiguous float32 tensor of {H} elements on {dev}, got "
+                                                f"{t_.dtype} {tuple(t_.shape)} on {t_.device}")
+                d = dict(w_ih=w_ih.detach().contiguous().float(), w_hh=w_hh.detach().contiguous().float(), bias=bias.detach().contiguous().float(),
+                         bw=bn_w.detach().contiguous().float() if use_bn else None, bb=bn_b.detach().contiguous().float() if use_bn else None,
+                         stats=stats, spikes=torch.empty((T, R, H), **f32), u=torch.empty((T, R, H), **f32), f=torch.empty((T, R, H), **f32),
+                         g=torch.empty((T, R, H), **f32), xhat=torch.empty((T, R, H), **f32) if use_bn else None,
+                         invstd=torch.empty((T, H), **f32) if use_bn else None,
+                         scr=torch.zeros((K, nscr_pad), dtype=torch.int32, device=dev))
+                # layer 0's input term for all T at once; the deeper layers' chunk by chunk, behind the chunk's spikes
+                d["z"] = torch.mm(x.reshape(T * R, I0), d["w_ih"].t()).view(T, R, GH) if l == 0 else torch.empty((T, R, GH), **f32)
+                mom = meta["momentum"][i][l]
+                d["n0"] = int(stats[2].item()) if (mom is None and use_bn and stats is not None and stats[2] is not None) else 0
+                d["mom"], d["eps"] = mom, float(meta["eps"][i][l])
+                lay.append(d)
+            stk.append(dict(R=R, I0=I0, x=x, lay=lay, nscr=nscr))
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
             for s_ in range(K + nl - 1):
-                todo = [(l, s_ - l) for l in range(nl) if 0 <= s_ - l < K]
+                todo = [(i, l, s_ - l) for l in range(nl) if 0 <= s_ - l < K for i in range(n)]
                 calls = (_lib.TrainSeqFwd * len(todo))()
-                for c, (l, ch) in zip(calls, todo):
-                    d, t0 = lay[l], ch * Tc
+                for c, (i, l, ch) in zip(calls, todo):
+                    sk = stk[i]
+                    d, t0, R = sk["lay"][l], ch * Tc, sk["R"]
+                    sRH, sRG = R * H * 4, R * GH * 4
                     if l >= 1:
-                        torch.mm(lay[l - 1]["spikes"][t0:t0 + Tc].reshape(Tc * R, H), d["w_ih"].t(), out=d["z"][t0:t0 + Tc].view(Tc * R, GH))
+                        torch.mm(sk["lay"][l - 1]["spikes"][t0:t0 + Tc].reshape(Tc * R, H), d["w_ih"].t(), out=d["z"][t0:t0 + Tc].view(Tc * R, GH))
                     c.z, c.w_hh, c.bias, c.bn_w, c.bn_b = d["z"].data_ptr() + t0 * sRG, d["w_hh"].data_ptr(), d["bias"].data_ptr(), _dp(d["bw"]), _dp(d["bb"])
                     stats = d["stats"]
                     c.running_mean = _dp(stats[0]) if (use_bn and stats is not None) else None
@@ -555,9 +567,9 @@ class GSNStackTrainFn(torch.autograd.Function):
                     c.scratch = d["scr"][ch].data_ptr()
                     if ch > 0:
                         c.h0, c.c0 = d["spikes"].data_ptr() + (t0 - 1) * sRH, d["u"].data_ptr() + (t0 - 1) * sRH
-                with _Logged("fwd", Tc, [(R, H, GH)] * len(todo)):
+                with _Logged("fwd", Tc, [(stk[i]["R"], H, GH) for i, _, _ in todo]):
                     check(L_.sfsn_gsn_train_seq_fwd_multi(calls, len(todo), Tc, H, int(shared), st), "sfsn_gsn_train_seq_fwd_multi(stack)")
-        errs = torch.stack([d["scr"][:, nscr - 4:nscr].max() for d in lay]).max()
+        errs = torch.stack([d["scr"][:, sk["nscr"] - 4:sk["nscr"]].max() for sk in stk for d in sk["lay"]]).max()
         if not any(ctx.needs_input_grad):
             if int(errs.item()) != 0:
                 raise RuntimeError(_EXCHANGE_FAILED)
@@ -568,54 +580,63 @@ class GSNStackTrainFn(torch.autograd.Function):
             ev.record(torch.cuda.current_stream(dev))
             _push_pending(ev, pin)
         zero = torch.zeros((1,), **f32)
-        saved = [x]
-        for d in lay:
-            if use_bn and d["stats"] is not None and d["stats"][2] is not None:
-                d["stats"][2].add_(T)  # num_batches_tracked: one BatchNorm call per time step
-            saved += [d["w_ih"], d["w_hh"], d["spikes"], d["u"], d["f"], d["g"], d["xhat"] if use_bn else zero, d["invstd"] if use_bn else zero,
-                      d["bw"] if use_bn else zero]
+        saved = []
+        for sk in stk:
+            saved.append(sk["x"])
+            for d in sk["lay"]:
+                if use_bn and d["stats"] is not None and d["stats"][2] is not None:
+                    d["stats"][2].add_(T)  # num_batches_tracked: one BatchNorm call per time step
+                saved += [d["w_ih"], d["w_hh"], d["spikes"], d["u"], d["f"], d["g"], d["xhat"] if use_bn else zero, d["invstd"] if use_bn else zero,
+                          d["bw"] if use_bn else zero]
         ctx.save_for_backward(*saved)
         ctx.fwd_err = errs
-        ctx.meta = (shared, use_bn, nl, K, T, R, I0, H, GH)
-        return tuple(d["spikes"] for d in lay)
+        ctx.meta = (shared, use_bn, n, nl, K, T, H, GH, [(sk["R"], sk["I0"]) for sk in stk])
+        return tuple(d["spikes"] for sk in stk for d in sk["lay"])
 
     @staticmethod
     def backward(ctx, *dys):
-        shared, use_bn, nl, K, T, R, I0, H, GH = ctx.meta
+        shared, use_bn, n, nl, K, T, H, GH, geo = ctx.meta
         saved = ctx.saved_tensors
-        x = saved[0]
         L_ = _lib.lib()
-        dev = x.device
+        dev = saved[0].device
         f32 = dict(dtype=torch.float32, device=dev)
         Tc = T // K
-        sRH, s2H, sH = R * H * 4, R * 2 * H * 4, H * 4
-        nscr = L_.sfsn_train_seq_scratch_bytes(R, H) // 4
-        nscr_pad = (nscr + 63) // 64 * 64
-        lay = []
-        for l in range(nl):
-            w_ih, w_hh, spikes, u, fg, gg, xhat, invstd, bw = saved[1 + 9 * l:10 + 9 * l]
-            dy = dys[l]
-            d = dict(w_ih=w_ih, w_hh=w_hh, spikes=spikes, u=u, f=fg, g=gg, xhat=xhat, invstd=invstd, bw=bw,
-                     d_gates=torch.empty((T, R, 2 * H), **f32), d_z=torch.empty((T, R, H), **f32) if shared else None,
-                     d_bn_w=torch.zeros((H,), **f32) if use_bn else None, d_bn_b=torch.zeros((H,), **f32) if use_bn else None,
-                     dc=torch.empty((2, R, H), **f32), scr=torch.zeros((K, nscr_pad), dtype=torch.int32, device=dev))
-            # the gradient w.r.t. this layer's spikes: from the layer above (formed chunk by chunk, below) plus whatever reads the
-            # returned tensor directly (all_layer_outputs)
-            if l == nl - 1:
-                d["dh"] = torch.zeros((T, R, H), **f32) if dy is None else dy.contiguous().float()
-            else:
-                d["dh"], d["dy"] = torch.empty((T, R, H), **f32), (None if dy is None else dy.contiguous().float())
-            d["dzs"] = d["d_z"] if shared else d["d_gates"]  # the gradient of the (shared or per-gate) products: [T][R][G*H]
-            lay.append(d)
+        sH = H * 4
+        per = 1 + 9 * nl
+        stk = []
+        for i in range(n):
+            R, I0 = geo[i]
+            x = saved[per * i]
+            nscr = L_.sfsn_train_seq_scratch_bytes(R, H) // 4
+            nscr_pad = (nscr + 63) // 64 * 64
+            lay = []
+            for l in range(nl):
+                w_ih, w_hh, spikes, u, fg, gg, xhat, invstd, bw = saved[per * i + 1 + 9 * l:per * i + 10 + 9 * l]
+                dy = dys[i * nl + l]
+                d = dict(w_ih=w_ih, w_hh=w_hh, spikes=spikes, u=u, f=fg, g=gg, xhat=xhat, invstd=invstd, bw=bw,
+                         d_gates=torch.empty((T, R, 2 * H), **f32), d_z=torch.empty((T, R, H), **f32) if shared else None,
+                         d_bn_w=torch.zeros((H,), **f32) if use_bn else None, d_bn_b=torch.zeros((H,), **f32) if use_bn else None,
+                         dc=torch.empty((2, R, H), **f32), scr=torch.zeros((K, nscr_pad), dtype=torch.int32, device=dev))
+                # the gradient w.r.t. this layer's spikes: from the layer above (formed chunk by chunk, below) plus whatever reads the
+                # returned tensor directly (all_layer_outputs)
+                if l == nl - 1:
+                    d["dh"] = torch.zeros((T, R, H), **f32) if dy is None else dy.contiguous().float()
+                else:
+                    d["dh"], d["dy"] = torch.empty((T, R, H), **f32), (None if dy is None else dy.contiguous().float())
+                d["dzs"] = d["d_z"] if shared else d["d_gates"]  # the gradient of the (shared or per-gate) products: [T][R][G*H]
+                lay.append(d)
+            stk.append(dict(R=R, I0=I0, x=x, lay=lay, nscr=nscr))
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
             for s_ in range(K + nl - 1):
-                todo = [(nl - 1 - k, K - 1 - (s_ - k)) for k in range(nl) if 0 <= s_ - k < K]
+                todo = [(i, nl - 1 - k, K - 1 - (s_ - k)) for k in range(nl) if 0 <= s_ - k < K for i in range(n)]
                 calls = (_lib.TrainSeqBwd * len(todo))()
-                for c, (l, ch) in zip(calls, todo):
-                    d, t0 = lay[l], ch * Tc
+                for c, (i, l, ch) in zip(calls, todo):
+                    sk = stk[i]
+                    d, t0, R = sk["lay"][l], ch * Tc, sk["R"]
+                    sRH, s2H = R * H * 4, R * 2 * H * 4
                     if l < nl - 1:  # dL/d(spikes of layer l), chunk ch = d_z of layer l + 1 (made by the previous stage) . W_ih of layer l + 1
-                        up = lay[l + 1]
+                        up = sk["lay"][l + 1]
                         torch.mm(up["dzs"][t0:t0 + Tc].reshape(Tc * R, GH), up["w_ih"], out=d["dh"][t0:t0 + Tc].view(Tc * R, H))
                         if d["dy"] is not None:
                             d["dh"][t0:t0 + Tc].add_(d["dy"][t0:t0 + Tc])
@@ -629,11 +650,11 @@ class GSNStackTrainFn(torch.autograd.Function):
                     c.dc_in = d["dc"][(ch + 1) & 1].data_ptr() if ch < K - 1 else None
                     c.dc_out = d["dc"][ch & 1].data_ptr() if ch > 0 else None
                     c.has_prev = int(ch > 0)
-                with _Logged("bwd", Tc, [(R, H, GH)] * len(todo)):
+                with _Logged("bwd", Tc, [(stk[i]["R"], H, GH) for i, _, _ in todo]):
                     check(L_.sfsn_gsn_train_seq_bwd_multi(calls, len(todo), Tc, H, int(shared), st), "sfsn_gsn_train_seq_bwd_multi(stack)")
         # no host synchronisation here (see GSNLayerTrainFn.backward): NaN-poisoned gradients on a failed exchange, the error word to
         # pinned memory, check_pending() when the backward pass has finished
-        errs = torch.maximum(torch.stack([d["scr"][:, nscr - 4:nscr].max() for d in lay]).max(), ctx.fwd_err)
+        errs = torch.maximum(torch.stack([d["scr"][:, sk["nscr"] - 4:sk["nscr"]].max() for sk in stk for d in sk["lay"]]).max(), ctx.fwd_err)
         poison = torch.where(errs > 0, torch.full((), float("nan"), **f32), torch.zeros((), **f32))
         pin = torch.empty((1,), dtype=torch.int32, pin_memory=True)
         pin.copy_(errs.reshape(1), non_blocking=True)
@@ -641,19 +662,21 @@ class GSNStackTrainFn(torch.autograd.Function):
         ev.record(torch.cuda.current_stream(dev))
         _push_pending(ev, pin)
         _queue_final_check()
-        grads = []
-        for l, d in enumerate(lay):
-            dz = d["dzs"].reshape(T * R, GH)
-            inp = x.reshape(T * R, I0) if l == 0 else lay[l - 1]["spikes"].reshape(T * R, H)
-            dw_ih = torch.mm(dz.t(), inp).add_(poison)
-            dw_hh = (torch.mm(dz[R:].t(), d["spikes"][:-1].reshape((T - 1) * R, H)) if T > 1 else torch.zeros((GH, H), **f32)).add_(poison)
-            dbias = d["d_gates"].reshape(T * R, 2 * H).sum(0).add_(poison)
-            if use_bn:
-                d["d_bn_w"].add_(poison)
-                d["d_bn_b"].add_(poison)
-            grads += [dw_ih, dw_hh, dbias, d["d_bn_w"], d["d_bn_b"]]
-        dx = torch.mm(lay[0]["dzs"].reshape(T * R, GH), lay[0]["w_ih"]).view(T, R, I0).add_(poison)
-        return (None, dx, *grads)
+        dxs, grads = [], []
+        for sk in stk:
+            R, I0, lay = sk["R"], sk["I0"], sk["lay"]
+            for l, d in enumerate(lay):
+                dz = d["dzs"].reshape(T * R, GH)
+                inp = sk["x"].reshape(T * R, I0) if l == 0 else lay[l - 1]["spikes"].reshape(T * R, H)
+                dw_ih = torch.mm(dz.t(), inp).add_(poison)
+                dw_hh = (torch.mm(dz[R:].t(), d["spikes"][:-1].reshape((T - 1) * R, H)) if T > 1 else torch.zeros((GH, H), **f32)).add_(poison)
+                dbias = d["d_gates"].reshape(T * R, 2 * H).sum(0).add_(poison)
+                if use_bn:
+                    d["d_bn_w"].add_(poison)
+                    d["d_bn_b"].add_(poison)
+                grads += [dw_ih, dw_hh, dbias, d["d_bn_w"], d["d_bn_b"]]
+            dxs.append(torch.mm(lay[0]["dzs"].reshape(T * R, GH), lay[0]["w_ih"]).view(T, R, I0).add_(poison))
+        return (None, *dxs, *grads)
 
 
 def _dp(t):
@@ -674,6 +697,10 @@ def gsn_stacks(xs, stacks, training: bool):
     the launch can hold their workgroups together (same depth / hidden size / gate sharing / BatchNorm use, training-mode statistics
     or no BatchNorm); one stack after the other otherwise.  Returns a list of [x, S1, ..., SL] lists."""
     n = len(stacks)
+    if GROUPS_TOGETHER and 1 < n:
+        K = _stack_chunks(xs, stacks, training)
+        if K > 1:
+            return _pipelined_stacks([x.contiguous() for x in xs], stacks, K)
     def same(fn):
         return len({fn(st) for st in stacks}) == 1
     ok = (GROUPS_TOGETHER and not STEP_LAUNCHES and 1 < n <= _lib.TRAIN_MAX_CALLS and same(lambda st: len(st.layers))
@@ -707,47 +734,60 @@ def gsn_stacks(xs, stacks, training: bool):
     return outs
 
 
-def _stack_chunks(x, stack, training: bool) -> int:
-    """Chunks of frames for GSNStackTrainFn, or 1: at least two layers of one shape (hidden size, gate sharing, BatchNorm use), the
-    one-launch layer calls (training-mode BatchNorm or none), every layer's workgroups resident TOGETHER (sfsn_gsn_train_multi_check with
-    one call per layer), and T a multiple of the chunk count with chunks of at least 16 frames."""
-    layers = stack.layers
+def _stack_chunks(xs, stacks, training: bool) -> int:
+    """Chunks of frames for GSNStackTrainFn, or 1: stacks of one depth >= 2 and one cell shape (hidden size, gate sharing, BatchNorm
+    use) in every layer of every stack, the one-launch layer calls (training-mode BatchNorm or none), two layers of every stack resident
+    TOGETHER (sfsn_gsn_train_multi_check with one call per stack and layer in flight -- the library gives them larger row blocks when
+    it must), and T a multiple of the chunk count with chunks of at least STACK_MIN_FRAMES frames."""
     K = STACK_CHUNKS
-    if K < 2 or STEP_LAUNCHES or len(layers) < 2 or len(layers) > _lib.TRAIN_MAX_CALLS or not x.is_cuda or x.dim() != 3:
+    nl = len(stacks[0].layers)
+    if K < 2 or STEP_LAUNCHES or nl < 2 or any(len(st.layers) != nl for st in stacks) or len(stacks) * nl > _lib.TRAIN_MAX_CALLS:
         return 1
-    cells = [layer.cell for layer in layers]
+    if not all(x.is_cuda and x.dim() == 3 and x.shape[0] == xs[0].shape[0] for x in xs):
+        return 1
+    cells = [layer.cell for st in stacks for layer in st.layers]
     if len({(tuple(c.weight_hh.shape), bool(c.shared_weights), bool(c.use_bn)) for c in cells}) != 1 or (cells[0].use_bn and not training):
         return 1
-    if any(c.weight_ih.shape[1] != cells[0].weight_hh.shape[1] for c in cells[1:]):
+    H = cells[0].weight_hh.shape[1]
+    if any(layer.cell.weight_ih.shape[1] != H for st in stacks for layer in st.layers[1:]):
         return 1
-    T, R = int(x.shape[0]), int(x.shape[1])
+    T = int(xs[0].shape[0])
     while K > 1 and (T % K or T // K < STACK_MIN_FRAMES):
         K -= 1
     if K < 2:
         return 1
-    H = cells[0].weight_hh.shape[1]
-    Rs = (ctypes.c_int * len(cells))(*([R] * len(cells)))
-    with torch.cuda.device(x.device):
-        if _lib.lib().sfsn_gsn_train_multi_check(Rs, len(cells), H, int(bool(cells[0].shared_weights))) != _lib.SFSN_OK:
+    Rs = [int(x.shape[1]) for x in xs] * nl  # (every layer of every stack in flight at once: the pipeline's full stages)
+    with torch.cuda.device(xs[0].device):
+        if _lib.lib().sfsn_gsn_train_multi_check((ctypes.c_int * len(Rs))(*Rs), len(Rs), H, int(bool(cells[0].shared_weights))) != _lib.SFSN_OK:
             return 1
     return K
+
+
+def _pipelined_stacks(xs, stacks, K):
+    """[x, S1, ..., SL] per stack through GSNStackTrainFn."""
+    global _STACK_CALLS
+    nl = len(stacks[0].layers)
+    flat, stats, moms, epss = [], [], [], []
+    for st in stacks:
+        s_, m_, e_ = [], [], []
+        for layer in st.layers:
+            bn, stt, mom, eps = _cell_args(layer.cell)
+            flat += [layer.cell.weight_ih, layer.cell.weight_hh, layer.cell.bias_ih, None if bn is None else bn.weight, None if bn is None else bn.bias]
+            s_.append(stt); m_.append(mom); e_.append(eps)
+        stats.append(s_); moms.append(m_); epss.append(e_)
+    meta = dict(n=len(stacks), shared=bool(stacks[0].layers[0].cell.shared_weights), stats=stats, momentum=moms, eps=epss, chunks=K)
+    _STACK_CALLS += 1
+    res = GSNStackTrainFn.apply(meta, *xs, *flat)
+    return [[x] + list(res[i * nl:(i + 1) * nl]) for i, x in enumerate(xs)]
 
 
 def gsn_stack(x: torch.Tensor, stack, training: bool) -> List[torch.Tensor]:
     """StackedGSU.forward (efficient_spiking_neuron.py:50-62) on the module's parameter containers: [x, S1, ..., SL]."""
     outs = [x]
     cur = x
-    K = _stack_chunks(x, stack, training)
+    K = _stack_chunks([x], [stack], training)
     if K > 1:
-        flat, stats, moms, epss = [], [], [], []
-        for layer in stack.layers:
-            bn, stt, mom, eps = _cell_args(layer.cell)
-            flat += [layer.cell.weight_ih, layer.cell.weight_hh, layer.cell.bias_ih, None if bn is None else bn.weight, None if bn is None else bn.bias]
-            stats.append(stt); moms.append(mom); epss.append(eps)
-        meta = dict(shared=bool(stack.layers[0].cell.shared_weights), stats=stats, momentum=moms, eps=epss, chunks=K)
-        global _STACK_CALLS
-        _STACK_CALLS += 1
-        return outs + list(GSNStackTrainFn.apply(meta, x, *flat))
+        return _pipelined_stacks([x.contiguous()], [stack], K)[0]
     for layer in stack.layers:
         cell = layer.cell
         bn = getattr(cell, "batchnorm", None) if cell.use_bn else None
