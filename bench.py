@@ -636,7 +636,7 @@ def training_bench(args, model, dev, world, rank, rw, B, T):
         tot_ms = sum(d["ms"] for d in per.values())
         flop = sum(d["flop"] for d in per.values())
         roof = {"bound": "latency (two grid-wide exchanges per recurrent step: BatchNorm partial sums, then the new spikes / d_z)",
-                "kernel": "gsn_train_seq_fwd_kernel / gsn_train_seq_bwd_kernel (one launch per layer and direction for all T steps; the sub-band groups share a grid)",
+                "kernel": "gsn_train_seq_fwd_kernel / gsn_train_seq_bwd_kernel (the layers of a model's stacks in one grid, layer l+1 a chunk of frames behind layer l: training.GSNStackTrainFn; the sub-band groups share the grid)",
                 "layer_call_launches_ms": round(tot_ms, 2), "share_of_step": round(tot_ms / ms, 3),
                 "forward": {"launches": per.get("fwd", {}).get("launches"), "ms": round(per.get("fwd", {}).get("ms", 0.0), 2),
                             "us_per_recurrent_step": round(1e3 * per["fwd"]["ms"] / per["fwd"]["steps"], 2) if "fwd" in per else None},
@@ -655,7 +655,7 @@ def training_bench(args, model, dev, world, rank, rw, B, T):
                        "grad_norm": gn, "optimizer_step": "not included (the reference's optimiser; out of scope)",
                        "cell_steps_per_training_step": 2 * 4 * T,
                        "note": "the same loop written as ATen operations per cell step (the reference's structure) takes 2.65 s at B=16 and "
-                               "2.8 s at B=64 (scripts/exp_train.py); round 3 (one launch per cell step and direction): 315 ms at B=64"},
+                               "2.8 s at B=64 (scripts/exp_train.py); round 3 (one launch per cell step and direction): 315 ms at B=64; round 4 (one launch per layer call): 117 ms"},
             "roofline": roof}))
 
 

@@ -178,7 +178,10 @@ size_t sfsn_train_seq_scratch_bytes(int R, int H);
  * of one another, and a layer call leaves most of the chip idle: their workgroups sit side by side in one grid.  Per call the
  * tensors of sfsn_gsn_train_seq_fwd / _bwd and its own zeroed scratch buffer.  n <= 8.  All calls with BatchNorm or all without.
  * SFSN_EUNSUPPORTED when the launch could not hold every call's workgroups resident together (sfsn_gsn_train_multi_check says so
- * up front; it needs the device): issue the calls separately then. */
+ * up front; it needs the device): issue the calls separately then.  A launch with more calls than fit at the single call's geometry
+ * (~160 workgroups per call) gives ALL its calls fewer, larger row blocks, per direction, until it fits or a block's rows exceed the
+ * LDS (round 5: the layers of several stacks side by side, training.GSNStackTrainFn); the BatchNorm partial sums are then merged in
+ * another blocking (last-bit differences against the single call). */
 typedef struct {
     const float *z, *w_hh, *bias, *bn_w, *bn_b;
     float *running_mean, *running_var;

@@ -45,7 +45,7 @@ GROUPS_TOGETHER = os.environ.get("SFSN_TRAIN_GROUPS_TOGETHER", "1") != "0"
 
 # The layers of ONE stack in one grid, layer l + 1 a chunk of frames behind layer l (GSNStackTrainFn: the layer calls are cut into
 # STACK_CHUNKS chunks; stage s launches {layer l, chunk s - l} together).  0 / 1 = one layer call after the other.
-STACK_CHUNKS = int(os.environ.get("SFSN_TRAIN_STACK_CHUNKS", "10"))
+STACK_CHUNKS = int(os.environ.get("SFSN_TRAIN_STACK_CHUNKS", "20"))
 _STACK_CALLS = 0  # (tests: how many stacks went through GSNStackTrainFn)
 STACK_MIN_FRAMES = 16  # (a chunk shorter than this is all launch ramp; the tests lower it to run the reference's short fixtures in chunks)
 
