@@ -21,6 +21,7 @@ package this has no CPU path (a CPU module raises).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 import threading
@@ -46,6 +47,13 @@ GROUPS_TOGETHER = os.environ.get("SFSN_TRAIN_GROUPS_TOGETHER", "1") != "0"
 # The layers of ONE stack in one grid, layer l + 1 a chunk of frames behind layer l (GSNStackTrainFn: the layer calls are cut into
 # STACK_CHUNKS chunks; stage s launches {layer l, chunk s - l} together).  0 / 1 = one layer call after the other.
 STACK_CHUNKS = int(os.environ.get("SFSN_TRAIN_STACK_CHUNKS", "20"))
+# GSNStackTrainFn.backward: the weight gradients (and layer 0's dL/dx) in STACK_GRAD_BLOCKS blocks of chunks, optionally on a SIDE stream
+# beside the following stages' launches (they are not on the chain).  Measured at B = 64 and OFF: one block behind the last stage
+# 82.2 ms per step; 2 / 4 / 5 blocks on the side stream 83.8 / 81.9 / 82.3 (the launches beside the GEMMs take 31.7 instead of 28.5 ms:
+# what is hidden is paid back), 4 blocks on the main stream 85.4, a GEMM per chunk 96.5 (87 on the side stream).
+STACK_SIDE_STREAM = os.environ.get("SFSN_TRAIN_SIDE_STREAM", "0") != "0"
+STACK_GRAD_BLOCKS = int(os.environ.get("SFSN_TRAIN_GRAD_BLOCKS", "1"))  # the sequence's weight-gradient GEMMs in this many blocks of chunks
+_side_streams: dict = {}
 _STACK_CALLS = 0  # (tests: how many stacks went through GSNStackTrainFn)
 STACK_MIN_FRAMES = 16  # (a chunk shorter than this is all launch ramp; the tests lower it to run the reference's short fixtures in chunks)
 
@@ -626,7 +634,44 @@ class GSNStackTrainFn(torch.autograd.Function):
                 d["dzs"] = d["d_z"] if shared else d["d_gates"]  # the gradient of the (shared or per-gate) products: [T][R][G*H]
                 lay.append(d)
             stk.append(dict(R=R, I0=I0, x=x, lay=lay, nscr=nscr))
-        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        main = torch.cuda.current_stream(dev)
+        st = ctypes.c_void_p(main.cuda_stream)
+        side = None
+        if STACK_SIDE_STREAM and not torch.cuda.is_current_stream_capturing():
+            side = _side_streams.get((dev.index, main.cuda_stream))
+            if side is None:
+                side = _side_streams[(dev.index, main.cuda_stream)] = torch.cuda.Stream(device=dev)
+        for sk in stk:  # accumulators of the per-chunk weight gradients
+            for l, d in enumerate(sk["lay"]):
+                d["dw_ih"] = torch.zeros((GH, sk["I0"] if l == 0 else H), **f32)
+                d["dw_hh"], d["dbias"] = torch.zeros((GH, H), **f32), torch.zeros((2 * H,), **f32)
+            sk["dx"] = torch.empty((T, sk["R"], sk["I0"]), **f32)
+        if side is not None:
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            side.wait_event(ev0)  # (the zeroed accumulators)
+
+        GB = max(1, -(-K // STACK_GRAD_BLOCKS))  # chunks per block of the weight-gradient GEMMs (a GEMM per chunk: +15 ms at B = 64)
+
+        def chunk_grads(i, l, ch):
+            """what the chunks [ch, ch + GB) of (stack i, layer l) add to the weight gradients, once the first of them (the last one
+            processed) is done; layer 0: dL/dx of those frames"""
+            if ch % GB:
+                return
+            sk = stk[i]
+            d, t0, R, I0 = sk["lay"][l], ch * Tc, sk["R"], sk["I0"]
+            Tb = (min(ch + GB, K) - ch) * Tc
+            dz = d["dzs"][t0:t0 + Tb].reshape(Tb * R, GH)
+            inp = sk["x"][t0:t0 + Tb].reshape(Tb * R, I0) if l == 0 else sk["lay"][l - 1]["spikes"][t0:t0 + Tb].reshape(Tb * R, H)
+            d["dw_ih"].addmm_(dz.t(), inp)
+            # dL/dW_hh = sum_t dz_t^T h_{t-1}, h_{-1} = 0: frames t0 .. t0 + Tb - 1 against spikes t0 - 1 .. (views: no shifted copy)
+            a = 1 if t0 == 0 else 0
+            if Tb - a > 0:
+                d["dw_hh"].addmm_(d["dzs"][t0 + a:t0 + Tb].reshape((Tb - a) * R, GH).t(), d["spikes"][t0 + a - 1:t0 + Tb - 1].reshape((Tb - a) * R, H))
+            d["dbias"].add_(d["d_gates"][t0:t0 + Tb].reshape(Tb * R, 2 * H).sum(0))
+            if l == 0:
+                torch.mm(dz, d["w_ih"], out=sk["dx"][t0:t0 + Tb].view(Tb * R, I0))
+
         with torch.cuda.device(dev):
             for s_ in range(K + nl - 1):
                 todo = [(i, nl - 1 - k, K - 1 - (s_ - k)) for k in range(nl) if 0 <= s_ - k < K for i in range(n)]
@@ -652,6 +697,17 @@ class GSNStackTrainFn(torch.autograd.Function):
                     c.has_prev = int(ch > 0)
                 with _Logged("bwd", Tc, [(stk[i]["R"], H, GH) for i, _, _ in todo]):
                     check(L_.sfsn_gsn_train_seq_bwd_multi(calls, len(todo), Tc, H, int(shared), st), "sfsn_gsn_train_seq_bwd_multi(stack)")
+                if side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    for i, l, ch in todo:
+                        chunk_grads(i, l, ch)
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                main.wait_event(ev)
         # no host synchronisation here (see GSNLayerTrainFn.backward): NaN-poisoned gradients on a failed exchange, the error word to
         # pinned memory, check_pending() when the backward pass has finished
         errs = torch.maximum(torch.stack([d["scr"][:, sk["nscr"] - 4:sk["nscr"]].max() for sk in stk for d in sk["lay"]]).max(), ctx.fwd_err)
@@ -664,18 +720,12 @@ class GSNStackTrainFn(torch.autograd.Function):
         _queue_final_check()
         dxs, grads = [], []
         for sk in stk:
-            R, I0, lay = sk["R"], sk["I0"], sk["lay"]
-            for l, d in enumerate(lay):
-                dz = d["dzs"].reshape(T * R, GH)
-                inp = sk["x"].reshape(T * R, I0) if l == 0 else lay[l - 1]["spikes"].reshape(T * R, H)
-                dw_ih = torch.mm(dz.t(), inp).add_(poison)
-                dw_hh = (torch.mm(dz[R:].t(), d["spikes"][:-1].reshape((T - 1) * R, H)) if T > 1 else torch.zeros((GH, H), **f32)).add_(poison)
-                dbias = d["d_gates"].reshape(T * R, 2 * H).sum(0).add_(poison)
+            for d in sk["lay"]:
                 if use_bn:
                     d["d_bn_w"].add_(poison)
                     d["d_bn_b"].add_(poison)
-                grads += [dw_ih, dw_hh, dbias, d["d_bn_w"], d["d_bn_b"]]
-            dxs.append(torch.mm(lay[0]["dzs"].reshape(T * R, GH), lay[0]["w_ih"]).view(T, R, I0).add_(poison))
+                grads += [d["dw_ih"].add_(poison), d["dw_hh"].add_(poison), d["dbias"].add_(poison), d["d_bn_w"], d["d_bn_b"]]
+            dxs.append(sk["dx"].add_(poison))
         return (None, *dxs, *grads)
 
 
