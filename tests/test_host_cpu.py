@@ -434,3 +434,16 @@ def test_training_entry_points_check_their_arguments_without_a_gpu():
     assert L.sfsn_features_z(one, None, 1, 33, 8, 0, 0.5, g, 1, 0, 8, None, 16, None) == _lib.SFSN_EINVAL                   # bytes without a buffer
     assert L.sfsn_gaussian_stats(one, None, 1, 33, 1, 0, 0.5, g, 1, one, one, one, None) == _lib.SFSN_EINVAL                # one frame: no unbiased estimate
     assert L.sfsn_gaussian_stats(one, None, 1, 33, 8, 0, 0.5, g, 1, one, None, one, None) == _lib.SFSN_EINVAL
+    # round 5: chunked layer calls (h0 and c0 come together), the feature + input-product launch
+    c = (_lib.TrainSeqFwd * 1)()
+    for k in ("z", "w_hh", "bias", "spikes", "u", "f", "g", "scratch"):
+        setattr(c[0], k, 64)
+    c[0].R, c[0].h0 = 8, 64
+    assert L.sfsn_gsn_train_seq_fwd_multi(c, 1, 5, 32, 1, None) == _lib.SFSN_EINVAL          # h0 without c0
+    j = (_lib.FeatProjJob * 1)()
+    j[0].feat.n_units, j[0].feat.ctr = 1, 32
+    assert L.sfsn_features_proj(one, None, 1, 33, 8, 0, 0.5, j, 1, 0, 8, None, 0, None) == _lib.SFSN_EINVAL      # a job that produces nothing
+    assert L.sfsn_features_proj(one, None, 1, 33, 8, 0, 0.5, j, 1, 4, 8, None, 0, None) == _lib.SFSN_EINVAL      # frames past the end
+    assert L.sfsn_features_proj(one, None, 1, 33, 8, 0, 0.5, j, 0, 0, 8, None, 0, None) == _lib.SFSN_EINVAL      # no jobs
+    j[0].feat.x, j[0].w, j[0].z, j[0].H, j[0].ldz = 64, 64, 64, 30, 30
+    assert L.sfsn_features_proj(one, None, 1, 33, 8, 0, 0.5, j, 1, 0, 8, None, 0, None) == _lib.SFSN_EUNSUPPORTED  # H % 4 (and 8 rows: not the bf16-split kernel's shape)
