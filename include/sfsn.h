@@ -194,6 +194,7 @@ typedef struct {
      * frame before this call's first -- rows `spikes[-1]` / `u[-1]` of the previous chunk's call; NULL = zero state.  The running
      * statistics continue through the calls in launch order; momentum < 0 counts from the batches tracked before THIS call. */
     const float *h0, *c0;
+    int T; /* > 0: this call's own frame count (chunks of unequal length side by side); 0: the launch's T */
 } SfsnTrainSeqFwd;
 typedef struct {
     const float *w_hh, *dh_up, *u, *xhat, *f, *g, *invstd, *bn_w;
@@ -207,6 +208,7 @@ typedef struct {
     const float* dc_in;
     float* dc_out;
     int has_prev;
+    int T; /* > 0: this call's own frame count; 0: the launch's T */
 } SfsnTrainSeqBwd;
 int sfsn_gsn_train_multi_check(const int* R, int n, int H, int shared);
 int sfsn_gsn_train_seq_fwd_multi(const SfsnTrainSeqFwd* calls, int n, int T, int H, int shared, void* stream);

@@ -65,12 +65,12 @@ class CountTensor(ctypes.Structure):
 class TrainSeqFwd(ctypes.Structure):  # SfsnTrainSeqFwd: one layer call of a multi-call training launch
     _fields_ = [("z", _P), ("w_hh", _P), ("bias", _P), ("bn_w", _P), ("bn_b", _P), ("running_mean", _P), ("running_var", _P),
                 ("momentum", _F), ("eps", _F), ("R", _I), ("spikes", _P), ("u", _P), ("xhat", _P), ("f", _P), ("g", _P), ("invstd", _P),
-                ("scratch", _P), ("h0", _P), ("c0", _P)]
+                ("scratch", _P), ("h0", _P), ("c0", _P), ("T", _I)]
 
 
 class TrainSeqBwd(ctypes.Structure):  # SfsnTrainSeqBwd
     _fields_ = [("w_hh", _P), ("dh_up", _P), ("u", _P), ("xhat", _P), ("f", _P), ("g", _P), ("invstd", _P), ("bn_w", _P), ("R", _I),
-                ("d_gates", _P), ("d_z", _P), ("d_bn_w", _P), ("d_bn_b", _P), ("scratch", _P), ("dc_in", _P), ("dc_out", _P), ("has_prev", _I)]
+                ("d_gates", _P), ("d_z", _P), ("d_bn_w", _P), ("d_bn_b", _P), ("scratch", _P), ("dc_in", _P), ("dc_out", _P), ("has_prev", _I), ("T", _I)]
 
 
 TRAIN_MAX_CALLS = 8

@@ -1120,7 +1120,7 @@ extern "C" int sfsn_gsn_train_seq_fwd_multi(const SfsnTrainSeqFwd* c, int n, int
         p.f = c[i].f; p.g = c[i].g; p.invstd = c[i].invstd; p.momentum = c[i].momentum; p.eps = c[i].eps; p.R = R; p.H = H; p.shared = shared;
         p.use_bn = c[i].bn_w != nullptr; p.epoch = 0; p.scratch = step_scr;
         p.counters = reinterpret_cast<unsigned*>(step_scr + (size_t)tiles * 16 * TR_PARTG * 2);
-        x.T = T;
+        x.T = c[i].T > 0 ? c[i].T : T;
         x.hx = reinterpret_cast<unsigned*>(base);
         x.rbcnt = x.hx + (size_t)2 * R * (H / 4);
         x.gran2 = reinterpret_cast<float*>(base + seq_hx_bytes(R, H));
@@ -1163,7 +1163,7 @@ extern "C" int sfsn_gsn_train_seq_bwd_multi(const SfsnTrainSeqBwd* c, int n, int
         p.d_gates = c[i].d_gates; p.d_z = c[i].d_z; p.dc_prev = c[i].dc_out; p.d_bn_w = c[i].d_bn_w; p.d_bn_b = c[i].d_bn_b;
         p.R = R; p.H = H; p.shared = shared; p.use_bn = c[i].bn_w != nullptr; p.epoch = 0; p.scratch = step_scr;
         p.counters = reinterpret_cast<unsigned*>(step_scr + (size_t)tiles * 16 * TR_PARTG * 2);
-        x.T = T;
+        x.T = c[i].T > 0 ? c[i].T : T;
         x.hx = reinterpret_cast<unsigned*>(base);
         x.rbcnt = x.hx + (size_t)2 * R * (H / 4);
         x.gran2 = reinterpret_cast<float*>(base + seq_hx_bytes(R, H));
@@ -1182,7 +1182,7 @@ extern "C" int sfsn_gsn_train_seq_fwd(const float* z, const float* w_hh, const f
                                       int shared, const float* /*zero: unused since ABI 14*/, float* spikes, float* u, float* xhat, float* f, float* g,
                                       float* invstd, void* scratch, void* stream) {
     SfsnTrainSeqFwd c;
-    c.h0 = nullptr; c.c0 = nullptr;
+    c.h0 = nullptr; c.c0 = nullptr; c.T = 0;
     c.z = z; c.w_hh = w_hh; c.bias = bias; c.bn_w = bn_w; c.bn_b = bn_b; c.running_mean = running_mean; c.running_var = running_var;
     c.momentum = momentum; c.eps = eps; c.R = R; c.spikes = spikes; c.u = u; c.xhat = xhat; c.f = f; c.g = g; c.invstd = invstd; c.scratch = scratch;
     return sfsn_gsn_train_seq_fwd_multi(&c, 1, T, H, shared, stream);
@@ -1194,7 +1194,7 @@ extern "C" int sfsn_gsn_train_seq_bwd(const float* w_hh, const float* dh_up, con
                                       const float* /*zero: unused since ABI 14*/, float* d_gates, float* d_z, float* /*dc_work: unused since ABI 14*/,
                                       float* d_bn_w, float* d_bn_b, void* scratch, void* stream) {
     SfsnTrainSeqBwd c;
-    c.dc_in = nullptr; c.dc_out = nullptr; c.has_prev = 0;
+    c.dc_in = nullptr; c.dc_out = nullptr; c.has_prev = 0; c.T = 0;
     c.w_hh = w_hh; c.dh_up = dh_up; c.u = u; c.xhat = xhat; c.f = f; c.g = g; c.invstd = invstd; c.bn_w = bn_w; c.R = R;
     c.d_gates = d_gates; c.d_z = d_z; c.d_bn_w = d_bn_w; c.d_bn_b = d_bn_b; c.scratch = scratch;
     return sfsn_gsn_train_seq_bwd_multi(&c, 1, T, H, shared, stream);

@@ -513,8 +513,9 @@ class GSNStackTrainFn(torch.autograd.Function):
         nl = len(flat) // (5 * n)
         T = xs[0].shape[0]
         GH, H = flat[1].shape
-        Tc = T // K
-        assert Tc * K == T and nl >= 2 and n * nl <= 8 * nl
+        Tc = -(-T // K)  # frames per chunk; the last one may be shorter (every call carries its own frame count)
+        assert Tc * (K - 1) < T and nl >= 2
+        clen = lambda ch: min(Tc, T - ch * Tc)
         dev = xs[0].device
         use_bn = flat[3] is not None
         f32 = dict(dtype=torch.float32, device=dev)
@@ -561,8 +562,9 @@ class GSNStackTrainFn(torch.autograd.Function):
                     sk = stk[i]
                     d, t0, R = sk["lay"][l], ch * Tc, sk["R"]
                     sRH, sRG = R * H * 4, R * GH * 4
+                    tn = clen(ch)
                     if l >= 1:
-                        torch.mm(sk["lay"][l - 1]["spikes"][t0:t0 + Tc].reshape(Tc * R, H), d["w_ih"].t(), out=d["z"][t0:t0 + Tc].view(Tc * R, GH))
+                        torch.mm(sk["lay"][l - 1]["spikes"][t0:t0 + tn].reshape(tn * R, H), d["w_ih"].t(), out=d["z"][t0:t0 + tn].view(tn * R, GH))
                     c.z, c.w_hh, c.bias, c.bn_w, c.bn_b = d["z"].data_ptr() + t0 * sRG, d["w_hh"].data_ptr(), d["bias"].data_ptr(), _dp(d["bw"]), _dp(d["bb"])
                     stats = d["stats"]
                     c.running_mean = _dp(stats[0]) if (use_bn and stats is not None) else None
@@ -572,11 +574,12 @@ class GSNStackTrainFn(torch.autograd.Function):
                     c.spikes, c.u, c.f, c.g = (d[k].data_ptr() + t0 * sRH for k in ("spikes", "u", "f", "g"))
                     c.xhat = d["xhat"].data_ptr() + t0 * sRH if use_bn else None
                     c.invstd = d["invstd"].data_ptr() + t0 * sH if use_bn else None
-                    c.scratch = d["scr"][ch].data_ptr()
+                    c.scratch, c.T = d["scr"][ch].data_ptr(), tn
                     if ch > 0:
                         c.h0, c.c0 = d["spikes"].data_ptr() + (t0 - 1) * sRH, d["u"].data_ptr() + (t0 - 1) * sRH
-                with _Logged("fwd", Tc, [(stk[i]["R"], H, GH) for i, _, _ in todo]):
-                    check(L_.sfsn_gsn_train_seq_fwd_multi(calls, len(todo), Tc, H, int(shared), st), "sfsn_gsn_train_seq_fwd_multi(stack)")
+                tmax = max(clen(ch) for _, _, ch in todo)
+                with _Logged("fwd", tmax, [(stk[i]["R"], H, GH) for i, _, _ in todo]):
+                    check(L_.sfsn_gsn_train_seq_fwd_multi(calls, len(todo), tmax, H, int(shared), st), "sfsn_gsn_train_seq_fwd_multi(stack)")
         errs = torch.stack([d["scr"][:, sk["nscr"] - 4:sk["nscr"]].max() for sk in stk for d in sk["lay"]]).max()
         if not any(ctx.needs_input_grad):
             if int(errs.item()) != 0:
@@ -608,7 +611,8 @@ class GSNStackTrainFn(torch.autograd.Function):
         L_ = _lib.lib()
         dev = saved[0].device
         f32 = dict(dtype=torch.float32, device=dev)
-        Tc = T // K
+        Tc = -(-T // K)
+        clen = lambda ch: min(Tc, T - ch * Tc)
         sH = H * 4
         per = 1 + 9 * nl
         stk = []
@@ -660,7 +664,7 @@ class GSNStackTrainFn(torch.autograd.Function):
                 return
             sk = stk[i]
             d, t0, R, I0 = sk["lay"][l], ch * Tc, sk["R"], sk["I0"]
-            Tb = (min(ch + GB, K) - ch) * Tc
+            Tb = min((min(ch + GB, K) - ch) * Tc, T - t0)
             dz = d["dzs"][t0:t0 + Tb].reshape(Tb * R, GH)
             inp = sk["x"][t0:t0 + Tb].reshape(Tb * R, I0) if l == 0 else sk["lay"][l - 1]["spikes"][t0:t0 + Tb].reshape(Tb * R, H)
             d["dw_ih"].addmm_(dz.t(), inp)
@@ -680,11 +684,12 @@ class GSNStackTrainFn(torch.autograd.Function):
                     sk = stk[i]
                     d, t0, R = sk["lay"][l], ch * Tc, sk["R"]
                     sRH, s2H = R * H * 4, R * 2 * H * 4
+                    tn = clen(ch)
                     if l < nl - 1:  # dL/d(spikes of layer l), chunk ch = d_z of layer l + 1 (made by the previous stage) . W_ih of layer l + 1
                         up = sk["lay"][l + 1]
-                        torch.mm(up["dzs"][t0:t0 + Tc].reshape(Tc * R, GH), up["w_ih"], out=d["dh"][t0:t0 + Tc].view(Tc * R, H))
+                        torch.mm(up["dzs"][t0:t0 + tn].reshape(tn * R, GH), up["w_ih"], out=d["dh"][t0:t0 + tn].view(tn * R, H))
                         if d["dy"] is not None:
-                            d["dh"][t0:t0 + Tc].add_(d["dy"][t0:t0 + Tc])
+                            d["dh"][t0:t0 + tn].add_(d["dy"][t0:t0 + tn])
                     c.w_hh, c.dh_up, c.R = d["w_hh"].data_ptr(), d["dh"].data_ptr() + t0 * sRH, R
                     c.u, c.f, c.g = (d[k].data_ptr() + t0 * sRH for k in ("u", "f", "g"))
                     if use_bn:
@@ -694,9 +699,10 @@ class GSNStackTrainFn(torch.autograd.Function):
                     c.d_bn_w, c.d_bn_b, c.scratch = _dp(d["d_bn_w"]), _dp(d["d_bn_b"]), d["scr"][ch].data_ptr()
                     c.dc_in = d["dc"][(ch + 1) & 1].data_ptr() if ch < K - 1 else None
                     c.dc_out = d["dc"][ch & 1].data_ptr() if ch > 0 else None
-                    c.has_prev = int(ch > 0)
-                with _Logged("bwd", Tc, [(stk[i]["R"], H, GH) for i, _, _ in todo]):
-                    check(L_.sfsn_gsn_train_seq_bwd_multi(calls, len(todo), Tc, H, int(shared), st), "sfsn_gsn_train_seq_bwd_multi(stack)")
+                    c.has_prev, c.T = int(ch > 0), tn
+                tmax = max(clen(ch) for _, _, ch in todo)
+                with _Logged("bwd", tmax, [(stk[i]["R"], H, GH) for i, _, _ in todo]):
+                    check(L_.sfsn_gsn_train_seq_bwd_multi(calls, len(todo), tmax, H, int(shared), st), "sfsn_gsn_train_seq_bwd_multi(stack)")
                 if side is not None:
                     ev = torch.cuda.Event()
                     ev.record(main)
@@ -788,7 +794,8 @@ def _stack_chunks(xs, stacks, training: bool) -> int:
     """Chunks of frames for GSNStackTrainFn, or 1: stacks of one depth >= 2 and one cell shape (hidden size, gate sharing, BatchNorm
     use) in every layer of every stack, the one-launch layer calls (training-mode BatchNorm or none), two layers of every stack resident
     TOGETHER (sfsn_gsn_train_multi_check with one call per stack and layer in flight -- the library gives them larger row blocks when
-    it must), and T a multiple of the chunk count with chunks of at least STACK_MIN_FRAMES frames."""
+    it must), and chunks of at least STACK_MIN_FRAMES frames (the last chunk may be shorter: every call of a launch carries its own
+    frame count)."""
     K = STACK_CHUNKS
     nl = len(stacks[0].layers)
     if K < 2 or STEP_LAUNCHES or nl < 2 or any(len(st.layers) != nl for st in stacks) or len(stacks) * nl > _lib.TRAIN_MAX_CALLS:
@@ -802,7 +809,8 @@ def _stack_chunks(xs, stacks, training: bool) -> int:
     if any(layer.cell.weight_ih.shape[1] != H for st in stacks for layer in st.layers[1:]):
         return 1
     T = int(xs[0].shape[0])
-    while K > 1 and (T % K or T // K < STACK_MIN_FRAMES):
+    K = min(K, T // max(1, STACK_MIN_FRAMES))  # chunks of ceil(T / K) frames, the last one shorter
+    while K > 1 and -(-T // K) * (K - 1) >= T:  # (rounding up must not leave the last chunk empty)
         K -= 1
     if K < 2:
         return 1

@@ -51,14 +51,15 @@ def test_gsn_stack_pipelined_over_chunks_matches_the_reference(ci, chunked_stack
 
 @pytest.mark.parametrize("shared,bn,R,H", [(True, True, 64, 320), (True, True, 40, 48), (False, True, 24, 32), (True, False, 100, 64)])
 def test_pipelined_stack_equals_the_layer_calls_one_after_the_other(shared, bn, R, H):
-    """GSNStackTrainFn against GSNLayerTrainFn per layer on a longer sequence (T = 120 in 5 chunks; 3 layers in the small case): the
+    """GSNStackTrainFn against GSNLayerTrainFn per layer on a longer sequence (T = 123 in 5 chunks of 25, 25, 25, 25, 23 frames -- every
+    call of a launch carries its own frame count; 3 layers in the small case): the
     same spikes, BatchNorm buffers and gradients (the layer >= 1 input products are library GEMMs over a chunk instead of the whole
     sequence: gradients are compared to 1e-5 relative, everything the kernels produce bit for bit)."""
     import copy
     import spiking_fullsubnet_amd.modeling_spiking_fullsubnet as M
     from spiking_fullsubnet_amd import training
     torch.manual_seed(11)
-    T, I, L = 120, 20, (3 if H == 48 else 2)
+    T, I, L = 123, 20, (3 if H == 48 else 2)
     stack = M.StackedGSU(I, H, L, shared, bn).to(DEV).train()
     if bn:
         for layer in stack.layers:
