@@ -1021,7 +1021,14 @@ class Engine:
             if self._ov_streams is None:
                 self._ov_streams = {}
             if main.cuda_stream not in self._ov_streams:  # a pair per calling stream: forwards in flight stay independent
-                self._ov_streams[main.cuda_stream] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+                nx = int(os.environ.get("SFSN_OV_XCD_SPLIT", "0"))
+                if nx > 0:
+                    # experiment (round 5): the full-band stream on the first `nx` XCDs only, the sub-band stream on the others (a mask
+                    # word = one XCD, scripts/exp_cumask.py): the full-band stack's hand-offs then stay inside nx L2s
+                    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+                    self._ov_streams[main.cuda_stream] = (self._masked_stream(list(range(0, 32 * nx))), self._masked_stream(list(range(32 * nx, n_cu))))
+                else:
+                    self._ov_streams[main.cuda_stream] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
             sa, sb_ = self._ov_streams[main.cuda_stream]
             self._defer_err = []
             sstreams = gstreams = [sa] * nl_fb + [sb_] * nl_sb
