@@ -126,6 +126,52 @@ def _queue_final_check() -> None:
         check_pending()
 
 
+# The weight gradients are a^T . b over ALL (frame, row) pairs: a [M, N1], b [M, N2] with M = T R ~ 10^5 .. 10^6 and a result of a few
+# hundred squared.  As ONE library GEMM that is (N1 / 32) x (N2 / 64) ~ 30 workgroups walking the whole of M (hipBLASLt picks no split
+# over k here): 0.5 ms each, ~10 ms of a training step at B = 64.  Cut into WGRAD_SPLIT slices of M as a batched GEMM plus a sum of
+# the slices' results, every compute unit has a workgroup.
+WGRAD_SPLIT = int(os.environ.get("SFSN_TRAIN_WGRAD_SPLIT", "64"))
+
+
+def _tn_gemm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a^T . b for a [M, N1], b [M, N2] (contiguous views), M large."""
+    M = a.shape[0]
+    S = min(WGRAD_SPLIT, M // 2048)
+    if S < 2:
+        return torch.mm(a.t(), b)
+    m = M // S
+    out = torch.bmm(a[:S * m].view(S, m, a.shape[1]).transpose(1, 2), b[:S * m].view(S, m, b.shape[1])).sum(0)
+    if S * m < M:
+        out.addmm_(a[S * m:].t(), b[S * m:])
+    return out
+
+
+class _LinearTN(torch.autograd.Function):
+    """nn.Linear over [T, R, H] with the weight gradient through _tn_gemm (ATen's is one GEMM of ~30 workgroups over all T R rows)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = torch.mm(dy2, w).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = _tn_gemm(dy2 if dy2.is_contiguous() else dy2.contiguous(), x.reshape(-1, x.shape[-1])) if ctx.needs_input_grad[1] else None
+        db = dy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def _proj(lin, x):
+    """seq.proj(x) (MODEL:49-52,118): nn.Linear -> _LinearTN on contiguous HIP tensors; anything else (Identity, ...) as it is."""
+    if isinstance(lin, torch.nn.Linear) and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and lin.weight.dtype == torch.float32:
+        return _LinearTN.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
 class _Logged:
     """HIP events around a layer-call launch when ``launch_log`` is a list (bench.py's per-step figures); nothing otherwise."""
     def __init__(self, kind, T, shapes):
@@ -336,9 +382,9 @@ class GSNLayerTrainFn(torch.autograd.Function):
         _queue_final_check()
         dz = (d_z if shared else d_gates).reshape(T * R, GH)
         dx = torch.mm(dz, w_ih).view(T, R, I).add_(poison)
-        dw_ih = torch.mm(dz.t(), x.reshape(T * R, I)).add_(poison)
+        dw_ih = _tn_gemm(dz, x.reshape(T * R, I)).add_(poison)
         # dL/dW_hh = sum_t dz_t^T h_{t-1}: h_{-1} = 0, so steps 1 .. T-1 against spikes 0 .. T-2 (views: no shifted copy of the spikes)
-        dw_hh = (torch.mm(dz[R:].t(), spikes[:-1].reshape((T - 1) * R, H)) if T > 1 else torch.zeros((GH, H), **f32)).add_(poison)
+        dw_hh = (_tn_gemm(dz[R:], spikes[:-1].reshape((T - 1) * R, H)) if T > 1 else torch.zeros((GH, H), **f32)).add_(poison)
         dbias = d_gates.reshape(T * R, 2 * H).sum(0).add_(poison)
         if bn_kernel:
             d_bn_w.add_(poison)
@@ -479,8 +525,8 @@ class GSNLayersTrainFn(torch.autograd.Function):
             dy, d_gates, d_z, d_bn_w, d_bn_b, scr = work[i]
             dz = (d_z if shared else d_gates).reshape(T * R, GH)
             dx = torch.mm(dz, w_ih).view(T, R, I).add_(poison)
-            dw_ih = torch.mm(dz.t(), x.reshape(T * R, I)).add_(poison)
-            dw_hh = (torch.mm(dz[R:].t(), spikes[:-1].reshape((T - 1) * R, H)) if T > 1 else torch.zeros((GH, H), **f32)).add_(poison)
+            dw_ih = _tn_gemm(dz, x.reshape(T * R, I)).add_(poison)
+            dw_hh = (_tn_gemm(dz[R:], spikes[:-1].reshape((T - 1) * R, H)) if T > 1 else torch.zeros((GH, H), **f32)).add_(poison)
             dbias = d_gates.reshape(T * R, 2 * H).sum(0).add_(poison)
             if use_bn:
                 d_bn_w.add_(poison)
@@ -667,11 +713,11 @@ class GSNStackTrainFn(torch.autograd.Function):
             Tb = min((min(ch + GB, K) - ch) * Tc, T - t0)
             dz = d["dzs"][t0:t0 + Tb].reshape(Tb * R, GH)
             inp = sk["x"][t0:t0 + Tb].reshape(Tb * R, I0) if l == 0 else sk["lay"][l - 1]["spikes"][t0:t0 + Tb].reshape(Tb * R, H)
-            d["dw_ih"].addmm_(dz.t(), inp)
+            d["dw_ih"].add_(_tn_gemm(dz, inp))
             # dL/dW_hh = sum_t dz_t^T h_{t-1}, h_{-1} = 0: frames t0 .. t0 + Tb - 1 against spikes t0 - 1 .. (views: no shifted copy)
             a = 1 if t0 == 0 else 0
             if Tb - a > 0:
-                d["dw_hh"].addmm_(d["dzs"][t0 + a:t0 + Tb].reshape((Tb - a) * R, GH).t(), d["spikes"][t0 + a - 1:t0 + Tb - 1].reshape((Tb - a) * R, H))
+                d["dw_hh"].add_(_tn_gemm(d["dzs"][t0 + a:t0 + Tb].reshape((Tb - a) * R, GH), d["spikes"][t0 + a - 1:t0 + Tb - 1].reshape((Tb - a) * R, H)))
             d["dbias"].add_(d["d_gates"][t0:t0 + Tb].reshape(Tb * R, 2 * H).sum(0))
             if l == 0:
                 torch.mm(dz, d["w_ih"], out=sk["dx"][t0:t0 + Tb].view(Tb * R, I0))
@@ -875,7 +921,7 @@ def sequence_model(seq, x_bft: torch.Tensor, training: bool):
     if seq.use_pre_layer_norm:
         x = seq.pre_layer_norm(x)
     outs = gsn_stack(x.contiguous(), seq.sequence_model, training)
-    y = seq.proj(outs[-1])
+    y = _proj(seq.proj, outs[-1])
     outs = outs + [y]
     return seq.output_activate_function(y).permute(1, 2, 0), outs
 
@@ -893,7 +939,7 @@ def sequence_models(seqs, xs_bft, training: bool):
         xs.append(x.contiguous())
     res = []
     for seq, outs in zip(seqs, gsn_stacks(xs, [seq.sequence_model for seq in seqs], training)):
-        y = seq.proj(outs[-1])
+        y = _proj(seq.proj, outs[-1])
         res.append((seq.output_activate_function(y).permute(1, 2, 0), outs + [y]))
     return res
 
