@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--resident", action="store_true", help="with --host-io: one resident launch serves every hop (doorbell in pinned memory) instead of one launch per hop")
     ap.add_argument("--host-io", action="store_true", help="waveform streaming with the samples in host memory on both sides (pinned, read / written by the launch)")
     ap.add_argument("--training", action="store_true", help="SURVEY 8f-4: one training step (forward in train() mode + backward) of the live model, own JSON line")
+    ap.add_argument("--no-training-leg", action="store_true", help="skip the three training steps (config.training) behind the timed region")
     ap.add_argument("--no-streaming-leg", action="store_true", help="skip the 2,000-hop streaming measurement (config.streaming) behind the timed region")
     args = ap.parse_args()
 
@@ -377,6 +378,35 @@ def main():
         except Exception as e:  # the streaming leg is reported, never required for the headline
             streaming = dict(error=repr(e))
 
+    # ---- SURVEY 8f-4 behind the timed region too: three training steps (forward in train() mode + backward) of a COPY of the model at
+    #      this batch, so that the driver's record of the default command carries the figure (python bench.py --training prints the line)
+    training_leg = None
+    if rank == 0 and not args.no_training_leg and not args.no_phase_a:
+        try:
+            m2 = pkg.SpikingFullSubNet(**kw)  # (a fresh module with the same weights: the measured model's engine and buffers stay untouched)
+            m2.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+            m2 = m2.to(dev).train()
+            w2 = torch.from_numpy(rw.synth_wave(B, T, seed=7)).to(dev)
+
+            def tstep():
+                for p_ in m2.parameters():
+                    p_.grad = None
+                out = m2(w2)
+                (out[0].pow(2).mean() + out[1].mean()).backward()
+            tstep()
+            torch.cuda.synchronize()
+            t_tr = time.perf_counter()
+            for _ in range(3):
+                tstep()
+            torch.cuda.synchronize()
+            training_leg = dict(ms_per_step=round((time.perf_counter() - t_tr) / 3 * 1e3, 2), steps=3, clips=B, frames=T,
+                                what="forward in train() mode + backward of the whole live model (per-step batch-statistics BatchNorm, triangle "
+                                     "surrogate; no optimiser step); the layers of every stack pipelined over chunks of frames (training.GSNStackTrainFn)")
+            del m2, w2
+            torch.cuda.empty_cache()
+        except Exception as e:  # reported, never required for the headline
+            training_leg = dict(error=repr(e))
+
     if rank == 0:
         frames = world * B * T * args.steps
         ms_per_step = 1e3 * dt / args.steps
@@ -518,7 +548,7 @@ def main():
                                 clips_per_gpu=B, frames=T, bins=257,
                                 layer_outputs="api-faithful (fp32 spikes returned)" if want_layers else "skipped",
                                 in_flight=n_lanes, scan_rows_per_workgroup=list(eng.rows_per_wg),
-                                single_stream=single, streaming=streaming, no_layer_outputs=lean_obj,
+                                single_stream=single, streaming=streaming, training=training_leg, no_layer_outputs=lean_obj,
                                 visible_gpus=torch.cuda.device_count(),
                                 world_size=(dist.get_world_size() if dist is not None else 1), backend=(backend if dist is not None else None),
                                 library=dict(abi=_lib.ABI_VERSION, source_hash=_lib.source_hash(), stack_scan=str(eng.stack_scan)),
