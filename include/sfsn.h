@@ -131,6 +131,17 @@ int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs /* host array */, int n_se
  * membrane output); SFSN_EUNSUPPORTED otherwise -- the caller then uses sfsn_gsn_layer_scan.  BASELINE configs[2]'s 16-bit mode. */
 int sfsn_gsn_layer_scan_w16(const sfsn_scan_segment* segs /* host */, int n_segs, int T, int H, int shared, int rows_per_wg, void* stream);
 
+/* Separate gate weights that do not fit one compute unit (shared = 0, H > 256: baseline_xl's full-band model, 2 x 320 x 320 x 3 bytes):
+ * sfsn_gsn_layer_scan streams all of W_hh from the L2 every step (10 us per step); here the neuron tiles of a 16-row block are split
+ * over several workgroups that keep their share resident in LDS and exchange the new spikes every step through `scratch`
+ * (sfsn_scan_split_scratch_bytes(R, H) bytes, 16-byte aligned, ZEROED by the caller before every call; its first word is a sticky
+ * error word: non-zero = a bounded wait expired, the outputs are invalid).  Same results as sfsn_gsn_layer_scan, bit for bit.  One
+ * segment; ceil(R / 16) x splits workgroups must be co-resident (<= compute units): SFSN_EUNSUPPORTED otherwise, and for shapes
+ * sfsn_gsn_layer_scan serves from one compute unit.  (ABI 17) */
+size_t sfsn_scan_split_scratch_bytes(int R, int H);
+int sfsn_gsn_layer_scan_split(const sfsn_scan_segment* segs /* host */, int n_segs, int T, int H, int shared, void* scratch,
+                              size_t scratch_bytes, void* stream);
+
 /* ----------------------------------------------------------------------------------------------------
  * Training-mode cell steps -- replace one iteration of GSULayer.forward's loop (NEURON:78-80) around
  * GSUCell.forward (NEURON:132-153) with nn.BatchNorm1d in TRAINING mode (batch statistics of this step over all R rows, running

@@ -208,6 +208,10 @@ def lib() -> ctypes.CDLL:
     L.sfsn_input_proj_f32_multi.argtypes = [ctypes.POINTER(InProjJob), _I, _P]
     L.sfsn_features.restype = _I
     L.sfsn_features.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _I, _I, _P]
+    L.sfsn_scan_split_scratch_bytes.restype = ctypes.c_size_t
+    L.sfsn_scan_split_scratch_bytes.argtypes = [_I, _I]
+    L.sfsn_gsn_layer_scan_split.restype = _I
+    L.sfsn_gsn_layer_scan_split.argtypes = [ctypes.POINTER(ScanSegment), _I, _I, _I, _I, _P, ctypes.c_size_t, _P]
     L.sfsn_features_proj.restype = _I
     L.sfsn_features_proj.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatProjJob), _I, _I, _I, _P, ctypes.c_size_t, _P]
     L.sfsn_features_z.restype = _I
@@ -248,7 +252,8 @@ EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device
            "sfsn_laplace_means", "sfsn_cum_laplace_norm", "sfsn_deepfilter", "sfsn_hist_shift", "sfsn_hop_scratch_bytes", "sfsn_stream_hop", "sfsn_stream_hop_resident", "sfsn_hop_stages", "sfsn_spike_count", "sfsn_stft", "sfsn_istft", "sfsn_gsn_train_step_fwd", "sfsn_gsn_train_step_bwd", "sfsn_train_scratch_bytes",
            "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16", "sfsn_gsn_train_check", "sfsn_gsn_stack_scan_x", "sfsn_train_seq_scratch_bytes", "sfsn_gsn_train_multi_check",
            "sfsn_gsn_train_seq_fwd_multi", "sfsn_gsn_train_seq_bwd_multi", "sfsn_features_z", "sfsn_gaussian_stats", "sfsn_gsn_train_step_check",
-           "sfsn_spike_proj_multi", "sfsn_input_proj_f32_multi", "sfsn_features_proj")
+           "sfsn_spike_proj_multi", "sfsn_input_proj_f32_multi", "sfsn_features_proj",
+           "sfsn_scan_split_scratch_bytes", "sfsn_gsn_layer_scan_split")
 
 
 def check(rc: int, what: str = "") -> None:

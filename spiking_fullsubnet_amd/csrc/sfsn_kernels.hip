@@ -410,6 +410,159 @@ __global__ __launch_bounds__(512) void gsn_scan_stream_kernel(const ScanParams p
     if (!sg.spikes_f32) wave_count_add(sg.count, cnt);
 }
 
+// ---- separate gate weights that do not fit one CU, SPLIT over several (round 5: sfsn_gsn_layer_scan_split) ---------------------------
+// gsn_scan_stream_kernel fetches all 614 KB of W_hh from the L2 every step: 10 us per step on the FOUR compute units the 64 rows of
+// baseline_xl's full-band model occupy -- 20 of that model's 27 ms.  Here the neuron tiles of a 16-row block are dealt to NSPL
+// workgroups; each keeps the rows of BOTH gates of its TPS tiles resident in LDS (a wave per tile: 2 gates x 3 digit planes x KS KB)
+// and the workgroups of a row block exchange the new spikes through the L2 every step: one data-tagged 32-bit word per lane (four
+// spikes + the step's epoch, ONE write-through store: data and "ready" arrive together, the scheme of the training kernels'
+// tr_read_tagged), two slots by step parity; every workgroup polls the 16 x NT pieces of its rows (bounded: error word, all
+// workgroups give up).  Same digit MFMAs in the same order and the same epilogue as the streamed kernel: bit-identical.
+// The launch's workgroups must be co-resident (host: <= compute units).
+__device__ __forceinline__ v4i split_load16_sc1(const void* ptr) {
+    v4i v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned split_unpack4(unsigned w) { return (w & 1u) | ((w & 2u) << 7) | ((w & 4u) << 14) | ((w & 8u) << 21); }
+
+template <int G>
+__global__ __launch_bounds__(512) void gsn_scan_split_kernel(const ScanParams p, unsigned* __restrict__ scratch, const int TPS, const int NSPL) {
+    extern __shared__ __attribute__((aligned(16))) char scan_smem[];
+    const int H = p.H, NT = p.NT, T = p.T, KS = (H + 63) / 64, HP = KS * 64, LDH = HP + 32, H4 = H >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, nthr = TPS * 64;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const size_t wtile = (size_t)G * 3 * KS * 1024;                              // bytes of one tile's fragments (both gates, three planes)
+    int8_t* wl = reinterpret_cast<int8_t*>(scan_smem) + (size_t)wave * wtile;    // this wave's tile: [G][3][KS][64][16]
+    int8_t* hbuf = reinterpret_cast<int8_t*>(scan_smem) + (size_t)TPS * wtile;   // [2][16][LDH]
+    float* cst = reinterpret_cast<float*>(hbuf + 2 * 16 * LDH);                  // [3 + G][HP]
+    const ScanSegDev sg = p.seg[0];
+    const int R = sg.R, rb = (int)blockIdx.x / NSPL, sp = (int)blockIdx.x - rb * NSPL, row0 = rb * 16;
+    const int rowc = (row0 + n < R) ? row0 + n : R - 1;
+    const int ldz = G * H;
+    unsigned* err = scratch;                  // word 0: sticky error word (a wait expired)
+    unsigned* xch = scratch + 16;             // [2][R][H / 4] tagged words
+    const int ct = sp * TPS + wave;           // my neuron tile (wave-uniform)
+    const bool have = ct < NT;
+    for (int j = tid; j < HP; j += nthr) {
+        const bool in = j < H;
+        cst[0 * HP + j] = in ? sg.bias[H + j] - sg.bias[j] : 0.0f;
+        cst[1 * HP + j] = in ? sg.bn_alpha[j] : 0.0f;
+        cst[2 * HP + j] = in ? sg.bn_beta[j] : 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) cst[(3 + g) * HP + j] = in ? sg.w_dq[g * H + j] : 0.0f;
+    }
+    for (int i = tid; i < 2 * 16 * LDH / 4; i += nthr) reinterpret_cast<int*>(hbuf)[i] = 0;
+    const size_t plane = (size_t)G * NT * KS * 1024;
+    if (have) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            for (int pl = 0; pl < 3; ++pl)
+                for (int ks = 0; ks < KS; ++ks)
+                    *reinterpret_cast<v4i*>(wl + (((size_t)g * 3 + pl) * KS + ks) * 1024 + lane * 16) =
+                        *reinterpret_cast<const v4i*>(sg.w_hh + (size_t)pl * plane + ((((size_t)g * NT + ct) * KS + ks) * 64 + lane) * 16);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 16 * H4; idx += nthr) {
+        const int rr = idx / H4, j4 = (idx - rr * H4) * 4;
+        const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;
+        const v4f h = *reinterpret_cast<const v4f*>(sg.h_state + (size_t)rsrc * H + j4);
+        const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
+                            (h.w > 0.5f ? 0x1000000u : 0u);
+        *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
+    }
+    const int cc = ct * 16 + q * 4;
+    v4f c = have ? *reinterpret_cast<const v4f*>(sg.c_state + (size_t)rowc * H + cc) : v4f{0, 0, 0, 0};
+    __syncthreads();
+    unsigned cnt = 0, last_pk = 0;
+    for (int t = 0; t < T; ++t) {
+        const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
+        int8_t* hn = hbuf + ((t & 1) ^ 1) * 16 * LDH;
+        if (have) {
+            v4f z[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) z[g] = *reinterpret_cast<const v4f*>(sg.zin + ((size_t)t * R + rowc) * ldz + g * H + cc);
+            v4f pre[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+                const int8_t* wp = wl + (size_t)g * 3 * KS * 1024 + lane * 16;
+                for (int ks = 0; ks < KS; ++ks) {
+                    const v4i b = *reinterpret_cast<const v4i*>(hc + n * LDH + ks * 64 + q * 16);
+                    const v4i w0 = *reinterpret_cast<const v4i*>(wp + (size_t)ks * 1024);
+                    const v4i w1 = *reinterpret_cast<const v4i*>(wp + (size_t)(KS + ks) * 1024);
+                    const v4i w2 = *reinterpret_cast<const v4i*>(wp + (size_t)(2 * KS + ks) * 1024);
+                    a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, b, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, b, a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, b, a2, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre[g][r] = __builtin_fmaf(recombine3(a0[r], a1[r], a2[r]), cst[(3 + g) * HP + cc + r], z[g][r]);
+            }
+            v4f cy;
+            unsigned pk = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pre_g = (G == 2) ? pre[G - 1][r] : pre[0][r] + cst[cc + r];
+                const float f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre[0][r] * -1.44269504088896341f));
+                const float m = __builtin_fmaf(f, c[r] - pre_g, pre_g);
+                const float y = __builtin_fmaf(m, cst[1 * HP + cc + r], cst[2 * HP + cc + r]);
+                cy[r] = y;
+                pk |= (y >= 0.0f) ? (1u << (8 * r)) : 0u;
+            }
+            c = cy;
+            last_pk = pk;
+            if (row0 + n < R) {  // rows past R are computed (clamped duplicates) but neither published nor stored
+                if (t + 1 < T) {
+                    const unsigned bits = (pk & 1u) | ((pk >> 7) & 2u) | ((pk >> 14) & 4u) | ((pk >> 21) & 8u);
+                    __hip_atomic_store(xch + ((size_t)(t & 1) * R + rowc) * H4 + (cc >> 2), ((unsigned)(t + 1) << 4) | bits, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                *reinterpret_cast<unsigned*>(sg.spikes_i8 + ((size_t)t * R + rowc) * HP + cc) = pk;
+                cnt += (unsigned)__builtin_popcount(pk);
+                if (sg.spikes_f32) {
+                    const v4f sp4 = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)(pk >> 24)};
+                    *reinterpret_cast<v4f*>(sg.spikes_f32 + ((size_t)t * R + rowc) * H + cc) = sp4;
+                }
+                if (sg.membrane) *reinterpret_cast<v4f*>(sg.membrane + ((size_t)t * R + rowc) * H + cc) = cy;
+            }
+        }
+        if (t + 1 < T) {
+            // h_t of my 16 rows, every tile: a piece = the four tagged words of one (row, tile), written by one wave of one workgroup
+            int good = 1;
+            const unsigned epoch = (unsigned)(t + 1);
+            for (int pc = tid; pc < 16 * NT; pc += nthr) {
+                const int rr = pc / NT, tl = pc - rr * NT;
+                const int rsrc = (row0 + rr < R) ? row0 + rr : R - 1;
+                const unsigned* src = xch + ((size_t)(t & 1) * R + rsrc) * H4 + tl * 4;
+                v4i v;
+                for (unsigned spins = 0;; ++spins) {
+                    v = split_load16_sc1(src);
+                    if (((unsigned)v.x >> 4) == epoch && ((unsigned)v.y >> 4) == epoch && ((unsigned)v.z >> 4) == epoch && ((unsigned)v.w >> 4) == epoch) break;
+                    if (spins > 400000u) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        good = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                v4i o;
+                o.x = (int)split_unpack4((unsigned)v.x); o.y = (int)split_unpack4((unsigned)v.y);
+                o.z = (int)split_unpack4((unsigned)v.z); o.w = (int)split_unpack4((unsigned)v.w);
+                *reinterpret_cast<v4i*>(hn + rr * LDH + tl * 16) = o;
+            }
+            if (!__syncthreads_and(good)) return;  // (the error word is set: the host raises; nobody waits for this workgroup's words for long)
+        }
+    }
+    if (have && row0 + n < R) {
+        *reinterpret_cast<v4f*>(sg.c_state + (size_t)rowc * H + cc) = c;
+        const v4f h = {(float)(last_pk & 1u), (float)((last_pk >> 8) & 1u), (float)((last_pk >> 16) & 1u), (float)((last_pk >> 24) & 1u)};
+        *reinterpret_cast<v4f*>(sg.h_state + (size_t)rowc * H + cc) = h;
+    }
+    if (!sg.spikes_f32) wave_count_add(sg.count, cnt);
+}
+
 // =====================================================================================================
 // spike projection: y[m][n] = dq[n] * sum_k s[m][k] * Wq[n][k] (+ bias[n]);  s int8 0/1
 // Waves are dealt (column-tile group cg, row-tile lane mw); each wave keeps its W tiles in registers and
@@ -2082,6 +2235,50 @@ extern "C" int sfsn_gsn_layer_scan(const sfsn_scan_segment* segs, int n_segs, in
 extern "C" int sfsn_gsn_layer_scan_w16(const sfsn_scan_segment* segs, int n_segs, int T, int H, int shared, int rows_per_wg,
                                        void* stream) {
     return layer_scan_impl(segs, n_segs, T, H, shared, rows_per_wg, 1, stream);
+}
+
+// Separate gate weights too large for one compute unit (H > 256): the tiles of a 16-row block split over several workgroups that keep
+// their share of W_hh resident and exchange the spikes every step (gsn_scan_split_kernel).  One segment, co-resident workgroups.
+extern "C" size_t sfsn_scan_split_scratch_bytes(int R, int H) {
+    if (R <= 0 || H <= 0 || H % 16) return 0;
+    return 64 + (size_t)2 * R * (H / 4) * sizeof(unsigned);
+}
+extern "C" int sfsn_gsn_layer_scan_split(const sfsn_scan_segment* segs, int n_segs, int T, int H, int shared, void* scratch, size_t scratch_bytes,
+                                         void* stream) {
+    if (!segs || n_segs <= 0 || T < 0 || H <= 0 || !scratch) return SFSN_EINVAL;
+    if (H % 16 != 0 || H > SFSN_MAX_HIDDEN || n_segs != 1 || shared || H <= 256) return SFSN_EUNSUPPORTED;  // (what fits one CU has faster kernels)
+    const sfsn_scan_segment& s = segs[0];
+    const int out = 2 | (s.spikes_f32 ? 1 : 0) | (s.membrane ? 4 : 0);
+    if (out == 6) return SFSN_EUNSUPPORTED;
+    if (s.R <= 0 || !s.spikes_i8 || !s.zin || !s.w_hh || !s.w_dq || !s.bias || !s.bn_alpha || !s.bn_beta || !s.h_state || !s.c_state) return SFSN_EINVAL;
+    if (!aligned16(s.zin) || !aligned16(s.w_hh) || !aligned16(s.h_state) || !aligned16(s.c_state) || !aligned16(s.spikes_f32) ||
+        !aligned16(s.spikes_i8) || !aligned16(s.membrane) || !aligned16(scratch))
+        return SFSN_EINVAL;
+    if (scratch_bytes < sfsn_scan_split_scratch_bytes(s.R, H)) return SFSN_EINVAL;
+    if (T == 0) return SFSN_OK;
+    constexpr int G = 2;
+    const int NT = H / 16, KS = (H + 63) / 64, HP = KS * 64;
+    const size_t wtile = (size_t)G * 3 * KS * 1024, fixed = (size_t)2 * 16 * (HP + 32) + (size_t)(3 + G) * HP * 4;
+    int TPS = (int)((150 * 1024 - fixed) / wtile);
+    if (TPS > 8) TPS = 8;
+    if (TPS < 1) return SFSN_EUNSUPPORTED;
+    const int NSPL = (NT + TPS - 1) / TPS;
+    TPS = (NT + NSPL - 1) / NSPL;
+    const int blocks = ((s.R + 15) / 16) * NSPL;
+    if (blocks > cu_count()) return SFSN_EUNSUPPORTED;  // every workgroup needs a compute unit of its own for the whole launch (LDS)
+    const size_t lds = (size_t)TPS * wtile + fixed;
+    ScanParams p;
+    p.wg_times = nullptr; p.w16 = 0; p.lsplit = 0; p.rpw = 16;
+    ScanSegDev& d = p.seg[0];
+    d.zin = s.zin; d.w_hh = s.w_hh; d.w_dq = s.w_dq; d.bias = s.bias; d.bn_alpha = s.bn_alpha; d.bn_beta = s.bn_beta;
+    d.h_state = s.h_state; d.c_state = s.c_state; d.spikes_f32 = s.spikes_f32; d.spikes_i8 = s.spikes_i8; d.count = s.spike_count;
+    d.membrane = s.membrane; d.R = s.R; d.tile0 = 0;
+    p.nseg = 1; p.T = T; p.H = H; p.NT = NT;
+    auto kern = gsn_scan_split_kernel<G>;
+    static int lds_seen[SFSN_MAX_DEVICES] = {0};
+    if (raise_lds(reinterpret_cast<const void*>(kern), (int)lds, lds_seen) != SFSN_OK) return SFSN_EHIP;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(TPS * 64), lds, static_cast<hipStream_t>(stream), p, static_cast<unsigned*>(scratch), TPS, NSPL);
+    return hip_ok(hipGetLastError());
 }
 
 extern "C" int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, int n_segs, int T, int H,

@@ -262,6 +262,7 @@ class Engine:
         _ss = os.environ.get('SFSN_STACK_SCAN', 'auto')
         self.stack_scan = "auto" if _ss == "auto" else bool(int(_ss))
         self.stack_rows_fb_auto = int(os.environ.get("SFSN_FB_STACK_ROWS", "4"))  # rows per workgroup of the full-band stack under "auto"
+        self.split_scan = os.environ.get("SFSN_SPLIT_SCAN", "1") != "0"  # large separate gate weights: sfsn_gsn_layer_scan_split (see _stage_scan)
         self.merge_products = os.environ.get("SFSN_MERGE_PRODUCTS", "1") != "0"  # the independent products of a stage in one launch
         # features + layer-0 input products of a chunk in ONE launch (sfsn_features_proj): the rows never make the round trip through
         # HBM between the two, and are not written at all when nobody reads them (layer_outputs "counts" / "none").  OFF by default:
@@ -465,6 +466,28 @@ class Engine:
             sg.spike_count = None if cnts is None else _ptr(cnts[i])
         with self.timed("scan:" + tag, st):
             rc = _lib.SFSN_EUNSUPPORTED
+            if self.split_scan and not spec.shared and H > 256 and len(seqs) == 1:
+                # separate gate weights too large for one compute unit (baseline_xl's full-band model): the tiles of a row block split
+                # over workgroups with resident weights and a spike exchange per step, instead of streaming all of W_hh every step
+                # (10 us per step): same results; its scratch (tagged exchange words, error word first) is zeroed per call
+                R0 = s8s[0].shape[1]
+                scr = torch.empty((L.sfsn_scan_split_scratch_bytes(R0, H) // 4,), dtype=torch.int32, device=self.device)
+                stream = self._tstream(st)
+                scr.record_stream(stream)
+                with torch.cuda.stream(stream):
+                    scr.zero_()  # (on the launch's stream)
+                rc = L.sfsn_gsn_layer_scan_split(segs, 1, nt, H, 0, _ptr(scr), scr.numel() * 4, st)
+                if rc == 0:
+                    with torch.cuda.stream(stream):
+                        pin = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+                        pin.copy_(scr[:1], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(stream)
+                    self._stack_err_pending.append((ev, pin, f"split scan {tag} H={H}", scr))
+                    self.launches["split_scan"] = self.launches.get("split_scan", 0) + 1
+                    return
+                if rc != _lib.SFSN_EUNSUPPORTED:
+                    check(rc, "sfsn_gsn_layer_scan_split")
             if self.weight_bits == 16 and self.w16_fast:  # the two-plane scan where the library has it (same results)
                 rc = L.sfsn_gsn_layer_scan_w16(segs, len(seqs), nt, H, int(spec.shared), rpw, st)
                 if rc not in (0, _lib.SFSN_EUNSUPPORTED):

@@ -41,7 +41,7 @@ def hip():
     return L
 
 
-def run_scan(hip, zin, w_hh, bias, alpha, beta, shared, h0=None, c0=None, want_mem=True):
+def run_scan(hip, zin, w_hh, bias, alpha, beta, shared, h0=None, c0=None, want_mem=True, split=False, want_spk=True):
     """x.W_ih^T [T,R,G*H] numpy -> spikes, membrane, spikes_i8, hT, cT (numpy) through sfsn_gsn_layer_scan.
     The ABI's input term includes bias_ih (forget-gate bias when shared, both gate biases otherwise): added here."""
     from spiking_fullsubnet_amd._lib import ScanSegment, check
@@ -53,15 +53,21 @@ def run_scan(hip, zin, w_hh, bias, alpha, beta, shared, h0=None, c0=None, want_m
     pk, dq = pack_w3(w_hh)
     t = dict(zin=_t(zin), pk=_t(pk), dq=_t(dq), bias=_t(bias), alpha=_t(alpha), beta=_t(beta),
              h=_t(np.zeros((R, H), np.float32) if h0 is None else h0), c=_t(np.zeros((R, H), np.float32) if c0 is None else c0),
-             spk=torch.empty((T, R, H), device=DEV), s8=torch.zeros((T, R, HP), dtype=torch.int8, device=DEV),
+             spk=torch.empty((T, R, H), device=DEV) if want_spk else None, s8=torch.zeros((T, R, HP), dtype=torch.int8, device=DEV),
              mem=torch.empty((T, R, H), device=DEV) if want_mem else None)
     seg = (ScanSegment * 1)()
     s = seg[0]
     s.zin, s.w_hh, s.w_dq, s.bias, s.bn_alpha, s.bn_beta = _p(t["zin"]), _p(t["pk"]), _p(t["dq"]), _p(t["bias"]), _p(t["alpha"]), _p(t["beta"])
     s.h_state, s.c_state, s.spikes_f32, s.spikes_i8, s.membrane, s.R = _p(t["h"]), _p(t["c"]), _p(t["spk"]), _p(t["s8"]), _p(t["mem"]), R
-    check(hip.sfsn_gsn_layer_scan(seg, 1, T, H, int(shared), 0, None), "scan")
+    if split:  # the tiles of a row block split over several workgroups (sfsn_gsn_layer_scan_split)
+        scr = torch.zeros((hip.sfsn_scan_split_scratch_bytes(R, H) // 4,), dtype=torch.int32, device=DEV)
+        check(hip.sfsn_gsn_layer_scan_split(seg, 1, T, H, int(shared), _p(scr), scr.numel() * 4, None), "scan_split")
+        torch.cuda.synchronize()
+        assert int(scr[0]) == 0, "a wait of the split scan expired"
+    else:
+        check(hip.sfsn_gsn_layer_scan(seg, 1, T, H, int(shared), 0, None), "scan")
     torch.cuda.synchronize()
-    return (t["spk"].cpu().numpy(), t["mem"].cpu().numpy() if want_mem else None, t["s8"].cpu().numpy(), t["h"].cpu().numpy(),
+    return (t["spk"].cpu().numpy() if want_spk else None, t["mem"].cpu().numpy() if want_mem else None, t["s8"].cpu().numpy(), t["h"].cpu().numpy(),
             t["c"].cpu().numpy())
 
 
@@ -104,6 +110,48 @@ def test_scan_free_running_vs_oracle(hip, I, H, R, T, shared, bn):
     np.testing.assert_array_equal(hT[ok], ref_h[ok])
     np.testing.assert_array_equal(hT, spk[-1])
     np.testing.assert_allclose(cT[ok], ref_c[ok], atol=parity.MEM_ATOL, rtol=parity.MEM_RTOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,R,T", [(320, 64, 60), (320, 21, 33), (272, 40, 25), (320, 130, 17)])
+def test_split_scan_for_large_separate_gate_weights_equals_the_streamed_scan(hip, H, R, T):
+    """sfsn_gsn_layer_scan_split (round 5: separate gate weights that do not fit one CU -- baseline_xl's full-band model): the tiles
+    of a 16-row block over several workgroups with resident weights and a tagged spike exchange per step give the bits of
+    sfsn_gsn_layer_scan's streamed-weights kernel -- fp32 spikes, membranes, int8 spikes, final state -- for ragged row counts, a
+    hidden size that does not fill the last split, a sequence continued in a second call from the first call's state, and without the
+    fp32 outputs; shapes one compute unit serves are refused."""
+    from spiking_fullsubnet_amd import _lib
+    rng = np.random.default_rng(H + R)
+    I = 24
+    sd, alpha, beta, bnp = make_layer(rng, I, H, False, True)
+    x = rng.standard_normal((T, R, I)).astype(np.float32)
+    zin = Oracle("f32").linear(x, sd["weight_ih"])
+    h0 = (rng.random((R, H)) > 0.5).astype(np.float32)
+    c0 = rng.standard_normal((R, H)).astype(np.float32)
+    a = run_scan(hip, zin, sd["weight_hh"], sd["bias_ih"], alpha, beta, False, h0, c0)
+    b = run_scan(hip, zin, sd["weight_hh"], sd["bias_ih"], alpha, beta, False, h0, c0, split=True)
+    for u, v, nm in zip(a, b, ("spikes", "membrane", "spikes_i8", "h", "c")):
+        np.testing.assert_array_equal(u, v, err_msg=nm)
+    # two calls, the second from the first one's state; no fp32 outputs
+    t1 = T // 2
+    c1 = run_scan(hip, zin[:t1], sd["weight_hh"], sd["bias_ih"], alpha, beta, False, h0, c0, want_mem=False, split=True, want_spk=False)
+    c2 = run_scan(hip, zin[t1:], sd["weight_hh"], sd["bias_ih"], alpha, beta, False, c1[3], c1[4], want_mem=False, split=True, want_spk=False)
+    np.testing.assert_array_equal(np.concatenate([c1[2], c2[2]]), a[2])
+    np.testing.assert_array_equal(c2[3], a[3])
+    np.testing.assert_array_equal(c2[4], a[4])
+
+
+@pytest.mark.gpu
+def test_split_scan_refuses_what_one_compute_unit_serves(hip):
+    from spiking_fullsubnet_amd import _lib
+    from spiking_fullsubnet_amd._lib import ScanSegment
+    seg = (ScanSegment * 1)()
+    one = ctypes.c_void_p(256)
+    assert hip.sfsn_gsn_layer_scan_split(seg, 1, 5, 224, 0, one, 1 << 20, None) == _lib.SFSN_EUNSUPPORTED   # fits one CU
+    assert hip.sfsn_gsn_layer_scan_split(seg, 1, 5, 320, 1, one, 1 << 20, None) == _lib.SFSN_EUNSUPPORTED   # shared gates
+    assert hip.sfsn_gsn_layer_scan_split(seg, 2, 5, 320, 0, one, 1 << 20, None) == _lib.SFSN_EUNSUPPORTED   # one segment per launch
+    assert hip.sfsn_gsn_layer_scan_split(seg, 1, 5, 320, 0, one, 1 << 20, None) == _lib.SFSN_EINVAL         # empty descriptor
+    assert hip.sfsn_gsn_layer_scan_split(seg, 1, 5, 320, 0, None, 0, None) == _lib.SFSN_EINVAL
 
 
 def test_checkpoint_directory_loaded_on_the_device_passes_parity(tmp_path):

@@ -440,6 +440,10 @@ def test_training_entry_points_check_their_arguments_without_a_gpu():
         setattr(c[0], k, 64)
     c[0].R, c[0].h0 = 8, 64
     assert L.sfsn_gsn_train_seq_fwd_multi(c, 1, 5, 32, 1, None) == _lib.SFSN_EINVAL          # h0 without c0
+    assert L.sfsn_scan_split_scratch_bytes(0, 320) == 0 and L.sfsn_scan_split_scratch_bytes(64, 320) == 64 + 2 * 64 * 80 * 4
+    sg = (_lib.ScanSegment * 1)()
+    assert L.sfsn_gsn_layer_scan_split(sg, 1, 5, 320, 0, None, 0, None) == _lib.SFSN_EINVAL        # no scratch
+    assert L.sfsn_gsn_layer_scan_split(sg, 1, 5, 224, 0, one, 1 << 20, None) == _lib.SFSN_EUNSUPPORTED  # one compute unit serves it
     j = (_lib.FeatProjJob * 1)()
     j[0].feat.n_units, j[0].feat.ctr = 1, 32
     assert L.sfsn_features_proj(one, None, 1, 33, 8, 0, 0.5, j, 1, 0, 8, None, 0, None) == _lib.SFSN_EINVAL      # a job that produces nothing
