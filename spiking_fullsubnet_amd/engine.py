@@ -466,10 +466,13 @@ class Engine:
             sg.spike_count = None if cnts is None else _ptr(cnts[i])
         with self.timed("scan:" + tag, st):
             rc = _lib.SFSN_EUNSUPPORTED
-            if self.split_scan and not spec.shared and H > 256 and len(seqs) == 1:
+            if (self.split_scan and not spec.shared and H > 256 and len(seqs) == 1 and nt >= 16
+                    and not torch.cuda.is_current_stream_capturing()):
                 # separate gate weights too large for one compute unit (baseline_xl's full-band model): the tiles of a row block split
                 # over workgroups with resident weights and a spike exchange per step, instead of streaming all of W_hh every step
-                # (10 us per step): same results; its scratch (tagged exchange words, error word first) is zeroed per call
+                # (10 us per step): same results; its scratch (tagged exchange words, error word first) is zeroed per call.  Not for a
+                # few frames (a streaming hop: the workgroups' weights are loaded per call) and not under graph capture (the scratch
+                # buffer is this call's)
                 R0 = s8s[0].shape[1]
                 scr = torch.empty((L.sfsn_scan_split_scratch_bytes(R0, H) // 4,), dtype=torch.int32, device=self.device)
                 stream = self._tstream(st)
