@@ -623,7 +623,7 @@ def streaming_bench(args, model, dev, world, rank):
 def training_bench(args, model, dev, world, rank, rw, B, T):
     """a training step of the live baseline_m model -- forward in train() mode (BatchNorm on the batch statistics
     of every time step inside every cell, efficient_spiking_neuron.py:123,149-150) and backward through the triangle surrogate
-    (:94-101) -- on this package's differentiable path (training.py: one HIP launch per layer and direction for all T steps, library GEMMs for the
+    (:94-101) -- on this package's differentiable path (training.py: the layers of a model's stacks pipelined over chunks of frames in one grid per stage and direction, library GEMMs for the
     time-parallel products).  The recipe's batch is 64 clips (baseline_m.toml:72); the loss here is a stand-in of the same shape
     class (a mean over the enhanced waveform and magnitude).  Wall time per step, synchronised, no optimiser step (the optimiser,
     losses and trainer stay the reference's: out of scope)."""

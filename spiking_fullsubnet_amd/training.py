@@ -10,7 +10,10 @@ What the recipes' training step needs (recipes/intel_ndns/spiking_fullsubnet/tra
   16 neurons x a block of rows each -- stay resident for all T steps, recurrent products on the fp32 matrix pipe, carried state in
   LDS, what a step needs from other workgroups exchanged through the L2; layer l of all sub-band groups in one grid,
   ``_multi``); the time-parallel products around them (input product, weight gradients, input gradient) are library GEMMs
-  (``torch.mm``);
+  (``torch.mm``; the weight gradients as batched GEMMs over slices of the (frame, row) axis, ``_tn_gemm``).  Round 5: ``GSNStackTrainFn``
+  runs the layers of a model's stacks in ONE grid per stage, layer l + 1 a chunk of frames behind layer l (chunked layer calls carry
+  their state through ``SfsnTrainSeqFwd.h0 / c0`` and ``SfsnTrainSeqBwd.dc_in / dc_out``) -- ``gsn_stack`` / ``gsn_stacks`` take it
+  wherever the library can hold the calls resident together;
 * everything between ``stft`` and ``istft`` that is time-parallel (band selection, reflect-gathered sub-band features, LayerNorm,
   projections, deep filter) as differentiable ATen operations on index tensors built once per module -- the kernels of the
   inference engine have no backward.
