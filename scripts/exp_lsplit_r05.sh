@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 for v in ${LSPLITS:-0,0 2,2 2,0 2,1 3,0 3,1 7,0 7,1 7,2 1,1}; do
   a=${v%,*}; b=${v#*,}
-  SFSN_S3_LSPLIT=$a SFSN_S3X_LSPLIT=$b timeout 240 python bench.py --no-cpu-baseline --no-streaming-leg --sequential --steps 10 --warmup 3 2>/dev/null | tail -1 | python -c "
+  SFSN_S3_LSPLIT=$a SFSN_S3X_LSPLIT=$b timeout 240 python bench.py --no-cpu-baseline --no-streaming-leg --no-training-leg --sequential --steps 10 --warmup 3 2>/dev/null | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
 s=d['config']['single_stream']; r=(d['roofline'] or {}).get('sub_band_scan_single_forward') or {}

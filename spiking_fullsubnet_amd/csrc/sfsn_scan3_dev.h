@@ -55,11 +55,15 @@
 // launch; run-to-run noise ~2 %): loader share 0 / 1 / 2 / 3 / 7 of the scan3 roles x 0 / 1 / 2 of the FUSEDX3 role: 1.08-1.09 ms at
 // (0, 0), 1.03-1.05 at (2, 1), (2, 2), (1, 1), 1.08-1.12 at (3, 0), (3, 1), 1.05-1.09 at (7, *) -- four per cent, not the forty
 // the issue arithmetic promised: with the IO waves relieved the pair runs at its FUSED3 roles' compute floor (0.9-0.93 us per step
-// alone).  Defaults: 2 for the scan3 roles, 1 for FUSEDX3 (whose loader wave also converts the feature rows).
-#define SFSN_S3_LSPLIT 2
+// alone).  That held while every counted wait of an IO wave cost ~400 clk (the 64-case switch behind wait_vmcnt_n); with
+// the wait as a computed jump (~80 clk) the storer wave has the time for all of a frame's stores and the split only
+// lengthens the loader's path: measured again at the end of round 5 (three interleaved rounds, scripts/exp_lsplit_r05.sh): (0, 0)
+// 0.971-0.983 ms = 0.237-0.241 of the HBM roofline, (1, 0) 0.988-1.000, (1, 1) 0.994-1.004, (2, 1) 1.005-1.015; strict forward 2.49-2.53
+// against 2.53-2.58; the timed region and B = 16 / 32 unchanged (scripts/exp_lsplit_ab2_r05.sh).  Defaults: 0 / 0 (no split).
+#define SFSN_S3_LSPLIT 0
 #endif
 #ifndef SFSN_S3X_LSPLIT
-#define SFSN_S3X_LSPLIT 1
+#define SFSN_S3X_LSPLIT 0
 #endif
 #ifndef SFSN_S3_PFMAX
 #define SFSN_S3_PFMAX 8   // frames of a publishing storer's stores that may be in flight (24 measured the same: the limit is elsewhere)
