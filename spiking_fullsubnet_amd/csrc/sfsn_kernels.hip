@@ -2032,6 +2032,27 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 extern "C" int sfsn_abi_version(void) { return SFSN_ABI_VERSION; }
 
+// Test hook (not part of include/sfsn.h): wave n of a 64-wave launch runs wait_vmcnt_n's computed jump with n in its probe form (every
+// table entry records its own index instead of waiting) -> out[n] must be n for all 64 entries (tests/test_hip_parity.py).
+__global__ __launch_bounds__(64) void vmcnt_table_probe_kernel(int* __restrict__ out) {
+    const int landed = wait_vmcnt_n<true>((int)blockIdx.x);
+    wait_vmcnt_n((int)blockIdx.x);  // (the product form on an empty queue: must fall through)
+    if (threadIdx.x == 0) out[blockIdx.x] = landed;
+}
+extern "C" int sfsn_debug_vmcnt_table(int* out_host /* [64] */) {
+    int* d = nullptr;
+    if (!out_host) return SFSN_EINVAL;
+    if (hipMalloc(&d, 64 * sizeof(int)) != hipSuccess) return SFSN_EHIP;
+    int rc = SFSN_OK;
+    if (hipMemset(d, 0xff, 64 * sizeof(int)) != hipSuccess) rc = SFSN_EHIP;
+    if (rc == SFSN_OK) {
+        hipLaunchKernelGGL(vmcnt_table_probe_kernel, dim3(64), dim3(64), 0, 0, d);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out_host, d, 64 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = SFSN_EHIP;
+    }
+    hipFree(d);
+    return rc;
+}
+
 #ifdef SFSN_EXPERIMENTS
 // the workgroup-stamp probe (sfsn_scan_dev.h): a caller-owned device buffer of 2 x capacity stamps, handed out launch by launch;
 // kind 1 = gsn_scan_kernel, 2 = the fused scan, 3 = the fused-x scan, 4 = the narrow stack launch, 5 = the IO-wave full-band launch

@@ -395,24 +395,67 @@ __device__ __forceinline__ void scan_prologue(const ScanSegDev& sg, char* smem, 
 // compares and branches -- ~400 clk per call on a SIMD shared with three compute waves (the per-wave stall counters of an EXPERIMENTS
 // build showed the same 400-420 clk of "waiting" whether or not anything was in flight), once per step in every loader and storer
 // wave: a fifth of a 2,200-clk step, on the wave the layer-1 roles' step ends with.  s96-s98 are scratch for the address.
-__device__ __forceinline__ void wait_vmcnt_n(int n) {
+// Round 6 (advisor): the distance from s_getpc's result to the table is the ASSEMBLER's label difference, not a literal byte count, and
+// the assembler itself refuses a table whose entries are not 8 bytes (.if / .error below); the s_waitcnt immediate is gfx9's layout
+// (vmcnt[3:0] at bits 3:0, vmcnt[5:4] at bits 15:14), hence the #error for any other target.  PROBE = true (tests only,
+// sfsn_debug_vmcnt_table): every entry is {s_movk_i32 s99, i; s_branch end} instead -- the same sizes and the same jump arithmetic --
+// and the function returns the index of the entry that ran.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "wait_vmcnt_n encodes s_waitcnt with the gfx9 vmcnt field layout: gfx950 (gfx9 family) only"
+#endif
+template <bool PROBE = false>
+__device__ __forceinline__ int wait_vmcnt_n(int n) {
     n = n < 0 ? 0 : (n > 63 ? 63 : n);
-    asm volatile(
-        "s_getpc_b64 s[96:97]\n\t"            // = the address of the next instruction; the table starts 20 bytes behind it
-        "s_lshl_b32 s98, %0, 3\n\t"
-        "s_add_u32 s98, s98, 20\n\t"
-        "s_add_u32 s96, s96, s98\n\t"
-        "s_addc_u32 s97, s97, 0\n\t"
-        "s_setpc_b64 s[96:97]\n\t"
-        ".set sfsn_wv_i, 0\n\t"
-        ".rept 64\n\t"
-        "s_waitcnt ((sfsn_wv_i & 15) | 0x0F70 | ((sfsn_wv_i >> 4) << 14))\n\t"  // vmcnt(i), expcnt / lgkmcnt not waited for
-        "s_branch sfsn_wv_end_%=\n\t"
-        ".set sfsn_wv_i, sfsn_wv_i + 1\n\t"
-        ".endr\n"
-        "sfsn_wv_end_%=:"
-        ::"s"(__builtin_amdgcn_readfirstlane(n))
-        : "s96", "s97", "s98", "scc", "memory");
+    int landed = 0;
+    if constexpr (PROBE) {
+        asm volatile(
+            "s_getpc_b64 s[96:97]\n"
+            "sfsn_wp_pc_%=:\n\t"
+            "s_lshl_b32 s98, %1, 3\n\t"
+            "s_add_u32 s98, s98, sfsn_wp_tab_%=-sfsn_wp_pc_%=\n\t"
+            "s_add_u32 s96, s96, s98\n\t"
+            "s_addc_u32 s97, s97, 0\n\t"
+            "s_setpc_b64 s[96:97]\n"
+            "sfsn_wp_tab_%=:\n\t"
+            ".set sfsn_wp_i, 0\n\t"
+            ".rept 64\n\t"
+            "s_movk_i32 s99, sfsn_wp_i\n\t"
+            "s_branch sfsn_wp_end_%=\n\t"
+            ".set sfsn_wp_i, sfsn_wp_i + 1\n\t"
+            ".endr\n"
+            "sfsn_wp_end_%=:\n\t"
+            ".if (sfsn_wp_end_%=-sfsn_wp_tab_%=) != 512\n\t"
+            ".error \"wait_vmcnt_n: a table entry is not 8 bytes\"\n\t"
+            ".endif\n\t"
+            "s_mov_b32 %0, s99"
+            : "=s"(landed)
+            : "s"(__builtin_amdgcn_readfirstlane(n))
+            : "s96", "s97", "s98", "s99", "scc", "memory");
+        return landed;
+    } else {
+        asm volatile(
+            "s_getpc_b64 s[96:97]\n"             // = the address of the next instruction = label sfsn_wv_pc
+            "sfsn_wv_pc_%=:\n\t"
+            "s_lshl_b32 s98, %0, 3\n\t"
+            "s_add_u32 s98, s98, sfsn_wv_tab_%=-sfsn_wv_pc_%=\n\t"
+            "s_add_u32 s96, s96, s98\n\t"
+            "s_addc_u32 s97, s97, 0\n\t"
+            "s_setpc_b64 s[96:97]\n"
+            "sfsn_wv_tab_%=:\n\t"
+            ".set sfsn_wv_i, 0\n\t"
+            ".rept 64\n\t"
+            "s_waitcnt ((sfsn_wv_i & 15) | 0x0F70 | ((sfsn_wv_i >> 4) << 14))\n\t"  // vmcnt(i), expcnt / lgkmcnt not waited for
+            "s_branch sfsn_wv_end_%=\n\t"
+            ".set sfsn_wv_i, sfsn_wv_i + 1\n\t"
+            ".endr\n"
+            "sfsn_wv_end_%=:\n\t"
+            ".if (sfsn_wv_end_%=-sfsn_wv_tab_%=) != 512\n\t"
+            ".error \"wait_vmcnt_n: a table entry is not 8 bytes\"\n\t"
+            ".endif"
+            ::"s"(__builtin_amdgcn_readfirstlane(n))
+            : "s96", "s97", "s98", "scc", "memory");
+        return n;
+    }
 }
 
 // ---- the scan body for a wave that owns NTL (compile-time) output tiles -------------------------------------

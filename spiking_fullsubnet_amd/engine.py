@@ -474,11 +474,12 @@ class Engine:
                 # few frames (a streaming hop: the workgroups' weights are loaded per call) and not under graph capture (the scratch
                 # buffer is this call's)
                 R0 = s8s[0].shape[1]
-                scr = torch.empty((L.sfsn_scan_split_scratch_bytes(R0, H) // 4,), dtype=torch.int32, device=self.device)
                 stream = self._tstream(st)
-                scr.record_stream(stream)
                 with torch.cuda.stream(stream):
-                    scr.zero_()  # (on the launch's stream)
+                    # allocated AND zeroed under the launch's stream: the block then comes from that stream's pool, so its previous use
+                    # is ordered before the fill (round-5 advisor finding: a block freed on the caller's stream could still be in use
+                    # there when the stage stream zeroed it -- a corrupted epoch tag ends in a bounded-spin error)
+                    scr = torch.zeros((L.sfsn_scan_split_scratch_bytes(R0, H) // 4,), dtype=torch.int32, device=self.device)
                 rc = L.sfsn_gsn_layer_scan_split(segs, 1, nt, H, 0, _ptr(scr), scr.numel() * 4, st)
                 if rc == 0:
                     with torch.cuda.stream(stream):

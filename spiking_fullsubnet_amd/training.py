@@ -76,10 +76,17 @@ def check_pending() -> None:
     _poll_pending(block=True)
 
 
-def _poll_pending(block: bool = False) -> None:
+def _poll_pending(block: bool = False, new_forward: bool = False) -> None:
     """Raise if an earlier layer call reported a failed row-block exchange (a forward nobody followed with a backward, or a
-    backward: its gradients are NaN)."""
+    backward: its gradients are NaN).  new_forward (the layer calls' forward()): a backward pass that queued its end-of-pass check and
+    then ABORTED in another node (out of memory, a user exception) never ran the callback -- autograd drops the graph task's callbacks
+    -- and would leave the "queued" flag set for the rest of the process, so that no later loss.backward() checked anything (round-5
+    advisor finding).  A forward is outside any pass that could still run that callback: the flag is cleared here, the next backward
+    queues afresh (a forward recomputed INSIDE a backward pass -- activation checkpointing -- merely queues a second, idempotent check)."""
+    global _final_check_queued
     with _lock:
+        if new_forward:
+            _final_check_queued = False
         items, _pending[:] = list(_pending), []
     keep, failed = [], False
     for ev, pin in items:
@@ -205,7 +212,7 @@ class GSNLayerTrainFn(torch.autograd.Function):
         if not x.is_cuda:
             raise RuntimeError("spiking_fullsubnet_amd has no CPU path: move the module and its input to a HIP device")
         L = _lib.lib()
-        _poll_pending()
+        _poll_pending(new_forward=True)
         T, R, I = x.shape
         GH, H = w_hh.shape
         dev = x.device
@@ -410,7 +417,7 @@ class GSNLayersTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, *flat):
         L = _lib.lib()
-        _poll_pending()
+        _poll_pending(new_forward=True)
         n = len(flat) // 6
         shared = bool(meta["shared"])
         xs = [flat[6 * i].contiguous().float() for i in range(n)]
@@ -556,7 +563,7 @@ class GSNStackTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, *args):
         L_ = _lib.lib()
-        _poll_pending()
+        _poll_pending(new_forward=True)
         n, K, shared = int(meta["n"]), int(meta["chunks"]), bool(meta["shared"])
         xs, flat = [a.contiguous().float() for a in args[:n]], args[n:]
         nl = len(flat) // (5 * n)
@@ -650,6 +657,9 @@ class GSNStackTrainFn(torch.autograd.Function):
                           d["bw"] if use_bn else zero]
         ctx.save_for_backward(*saved)
         ctx.fwd_err = errs
+        # unused outputs arrive as None in backward() instead of materialised zero tensors (only the last layer's spikes are consumed in
+        # the live recipe: without this every other layer paid a [T, R, H] buffer of zeros and a dh.add_(zeros) per chunk)
+        ctx.set_materialize_grads(False)
         ctx.meta = (shared, use_bn, n, nl, K, T, H, GH, [(sk["R"], sk["I0"]) for sk in stk])
         return tuple(d["spikes"] for sk in stk for d in sk["lay"])
 

@@ -147,6 +147,35 @@ def test_full_band_stack_with_io_waves_equals_round_2_bodies(hip, H, nl, Rs, T, 
             assert res["1"][l][i][1].any()
 
 
+@pytest.mark.parametrize("Rs,T,rpw,force", [([64], 150, 8, None), ([64], 40, 8, "1"), ([35, 6], 33, 8, "1"), ([64], 136, 4, None)])
+def test_full_band_stack_with_io_waves_vs_oracle(hip, Rs, T, rpw, force):
+    """gsn_stack_fb_kernel (scan3w_role + the column-split PROJ role) held to the ORACLE directly, outside the full-size case (round-5
+    review): H = 320, two layers, 8 rows per workgroup at 64 rows = the full-band stack's geometry in bench.py's timed region; once as
+    the library selects it by itself (>= 128 frames) and once forced on a short launch; the causal parity rule per layer on the
+    oracle's own spikes (NEURON:56-61), int8 copies equal to the fp32 spikes."""
+    H, nl, I = 320, 2, 64
+    rng = np.random.default_rng(4200 + T + len(Rs))
+    cells = _cells(rng, I, H, nl)
+    o = Oracle("f32")
+    xs = [rng.standard_normal((T, R, I)).astype(np.float32) for R in Rs]
+    zin0 = [o.linear(x, cells[0][0]["weight_ih"]) for x in xs]
+    if force is not None:
+        os.environ["SFSN_STACK_FB3"] = force
+    try:
+        got = run_stack(hip, zin0, cells, T, H, rpw)
+    finally:
+        os.environ.pop("SFSN_STACK_FB3", None)
+    for i, x in enumerate(xs):
+        inp, valid = x, np.full(x.shape[1], T)
+        for l, (sd, alpha, beta, bnp) in enumerate(cells):
+            ref_spk, ref_mem, _, _ = o.gsn_layer(inp, sd["weight_ih"], sd["weight_hh"], sd["bias_ih"], bn=bnp, shared=True)
+            valid, st = parity.check_chain(got[l][i][0], ref_spk, np.abs(ref_mem) < parity.TAU, valid, f"fb stack layer {l}")
+            assert st["spike_agreement"] > 0.999, st
+            np.testing.assert_array_equal(got[l][i][1][:, :, :H], got[l][i][0].astype(np.int8))
+            inp = ref_spk
+        assert (valid > 0).all()
+
+
 @pytest.mark.parametrize("wide", [True, False], ids=["wide", "narrow"])
 @pytest.mark.parametrize("I,H,nl,Rs,T,rpw", STACKS)
 def test_stack_scan_vs_oracle_and_per_layer_calls(hip, I, H, nl, Rs, T, rpw, wide):
