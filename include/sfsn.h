@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 17 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 18 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -418,6 +418,27 @@ typedef struct sfsn_df_group {
 int sfsn_deepfilter(const float* stft_ri /* [B][F][T][2] */, int B, int F, int T, int S,
                     const sfsn_df_group* groups /* host */, int n_groups, float* enh_ri /* [B][S][F][T][2] */,
                     float* enh_mag /* [B][S][F][T], nullable */, int t0, int nt /* frames [t0, t0+nt) */, void* stream);
+
+/* ----------------------------------------------------------------------------------------------------
+ * Round 6: the sub-band epilogue in ONE launch -- per group the projection of the last layer's spikes (MODEL:118 `self.proj`,
+ * FROZEN:125 `fc_output_layer`: sfsn_spike_proj's product) AND everything sfsn_deepfilter does with its result (MODEL:160-167,
+ * 315-346, 450-474).  The coefficient tile of a (clip, 16-frame block, unit range) is formed on the int8 matrix cores, stays in LDS,
+ * is written to `proj` once (the module API's last all_layer_outputs entry; NULL: not written at all) and is applied to the noisy
+ * spectrum from LDS: the coefficients are never re-read from memory.  Same results, bit for bit, as sfsn_spike_proj_multi followed
+ * by sfsn_deepfilter on the same arguments.  H <= 256 (spike rows of pad64(H) bytes), every P = 2*fc*df*S a multiple of 4 and <= 256;
+ * SFSN_EUNSUPPORTED otherwise (issue the two calls).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct sfsn_projdf_group {
+    const int8_t* spikes_i8; /* [T][B*n_units][pad64(H)] int8 spikes of the group's last layer (frame 0 of the sequence) */
+    const int8_t* w_packed;  /* sfsn_w3_pack(W_p [P][H]) */
+    const float* w_dq;
+    const float* bias;       /* [P], nullable */
+    float* proj;             /* [T][B*n_units][P] coefficient rows, 16-byte aligned; NULL = not written */
+    int n_units, fc, df;
+} sfsn_projdf_group;
+int sfsn_proj_deepfilter(const float* stft_ri /* [B][F][T][2] */, int B, int F, int T, int S, int H,
+                         const sfsn_projdf_group* groups /* host */, int n_groups, float* enh_ri /* [B][S][F][T][2] */,
+                         float* enh_mag /* [B][S][F][T], nullable */, int t0, int nt /* frames [t0, t0+nt) */, void* stream);
 
 /* ----------------------------------------------------------------------------------------------------
  * Streaming sessions (BASELINE configs[4]): the input history the deep filter reaches back into (MODEL:331-333: df - 1 frames

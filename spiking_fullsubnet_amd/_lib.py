@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
 NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE, NORM_CUMLAPLACE, NORM_GAUSSIAN = 0, 1, 2, 3, 4
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
-ABI_VERSION = 17  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
+ABI_VERSION = 18  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -44,6 +44,10 @@ class FeatureGroup(ctypes.Structure):
 
 class DfGroup(ctypes.Structure):
     _fields_ = [("proj", _P), ("n_units", _I), ("fc", _I), ("df", _I)]
+
+
+class ProjDfGroup(ctypes.Structure):  # sfsn_projdf_group
+    _fields_ = [("spikes_i8", _P), ("w_packed", _P), ("w_dq", _P), ("bias", _P), ("proj", _P), ("n_units", _I), ("fc", _I), ("df", _I)]
 
 
 class ProjJob(ctypes.Structure):
@@ -100,7 +104,7 @@ def _sources():
     """The files the library is made of, in the order the Makefile hashes them (SRCS)."""
     return [os.path.join(_HERE, "..", "include", "sfsn.h")] + [
         os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_scan3_dev.h", "sfsn_scan3i_dev.h", "sfsn_scan3x_dev.h", "sfsn_scan3w_dev.h", "sfsn_feat_dev.h", "sfsn_fft_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_hop.hip", "sfsn_fft.hip", "sfsn_train.hip",
-                                  "sfsn_featproj.hip", "sfsn_pack.cpp")]
+                                  "sfsn_featproj.hip", "sfsn_projdf.hip", "sfsn_pack.cpp")]
 
 
 def source_hash() -> str:
@@ -222,6 +226,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_gaussian_stats.argtypes = [_P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(FeatureGroup), _I, _P, _P, _P, _P]
     L.sfsn_deepfilter.restype = _I
     L.sfsn_deepfilter.argtypes = [_P, _I, _I, _I, _I, ctypes.POINTER(DfGroup), _I, _P, _P, _I, _I, _P]
+    L.sfsn_proj_deepfilter.restype = _I
+    L.sfsn_proj_deepfilter.argtypes = [_P, _I, _I, _I, _I, _I, ctypes.POINTER(ProjDfGroup), _I, _P, _P, _I, _I, _P]
     L.sfsn_hist_shift.restype = _I
     L.sfsn_hist_shift.argtypes = [_P, _P, _I, _I, _I, _P]
     L.sfsn_cum_laplace_norm.restype = _I
@@ -253,7 +259,7 @@ EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device
            "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16", "sfsn_gsn_train_check", "sfsn_gsn_stack_scan_x", "sfsn_train_seq_scratch_bytes", "sfsn_gsn_train_multi_check",
            "sfsn_gsn_train_seq_fwd_multi", "sfsn_gsn_train_seq_bwd_multi", "sfsn_features_z", "sfsn_gaussian_stats", "sfsn_gsn_train_step_check",
            "sfsn_spike_proj_multi", "sfsn_input_proj_f32_multi", "sfsn_features_proj",
-           "sfsn_scan_split_scratch_bytes", "sfsn_gsn_layer_scan_split")
+           "sfsn_scan_split_scratch_bytes", "sfsn_gsn_layer_scan_split", "sfsn_proj_deepfilter")
 
 
 def check(rc: int, what: str = "") -> None:

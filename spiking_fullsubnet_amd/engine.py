@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CountTensor, DfGroup, FeatProjJob, FeatureGroup, FusedInput, FusedX, InProjJob, ProjJob, ScanSegment, check
+from ._lib import CountTensor, DfGroup, FeatProjJob, FeatureGroup, FusedInput, FusedX, InProjJob, ProjDfGroup, ProjJob, ScanSegment, check
 
 
 @dataclass
@@ -270,6 +270,12 @@ class Engine:
         # instructions per row) and the product's W pieces (120 registers per wave) leave two waves per SIMD where the feature kernel
         # has three: 316 us per sub-band chunk against 67 + 72 (profiles/EXPERIMENTS.md).  SFSN_FEATPROJ=1 switches it on.
         self.fuse_featproj = os.environ.get("SFSN_FEATPROJ", "0") == "1"
+        # round 6: the sub-band projection, the output re-index, the deep filter and |.| in ONE launch (sfsn_proj_deepfilter): the
+        # coefficient rows are written once and never re-read (0.3 GB per forward at B = 64, T = 1000).  SFSN_PROJDF=0: the two launches.
+        self.fuse_projdf = os.environ.get("SFSN_PROJDF", "1") != "0"
+        # layer_outputs "counts" / "none": the coefficient rows (`all_layer_outputs[-1]`) are not written either -- nobody reads them
+        # there (metric.compute_neuronops reads size(-1) only); the entry keeps its shape as a meta tensor like the skipped feature rows
+        self.lean_skips_proj = os.environ.get("SFSN_LEAN_PROJ", "0") == "0"
         self.count_in_scan = os.environ.get("SFSN_COUNT_IN_SCAN", "1") != "0"  # layer_outputs="counts": counted by the scans themselves
         self.pair_scan = os.environ.get("SFSN_PAIR_SCAN", "1") != "0"  # H <= 224 stacks as one launch of FUSED3 roles (see _stack_choice)
         self.stack_rows_per_wg = {"fb": 4, "sb": 8}  # rows per workgroup of every layer of a stack: sum of workgroups <= CUs
@@ -740,6 +746,26 @@ class Engine:
                                         _ptr(seq.proj_b), ctypes.c_void_p(y.data_ptr() + t0 * R * seq.P * 4), nt * R, seq.H, seq.P, seq.P,
                                         st), "sfsn_spike_proj(proj)")
 
+    def _stage_projdf(self, seqs, s8s, projs, ri, enh_ri, enh_mag, dims, t0, nt, st, write_proj=True) -> bool:
+        """Projection of every group's last-layer spikes + deep filter + pass-through + |.| in one launch (sfsn_proj_deepfilter).
+        False (nothing launched): the library does not cover the shapes, the caller issues _stage_proj and sfsn_deepfilter."""
+        if not self.fuse_projdf:
+            return False
+        B, F, T, S = dims
+        spec = self.spec
+        arr = (ProjDfGroup * len(seqs))()
+        for g, (a, seq, s8, y) in enumerate(zip(arr, seqs, s8s, projs)):
+            a.spikes_i8, a.w_packed, a.w_dq, a.bias = s8.data_ptr(), seq.proj_q.data_ptr(), seq.proj_dq.data_ptr(), seq.proj_b.data_ptr()
+            a.proj = y.data_ptr() if write_proj else None
+            a.n_units, a.fc, a.df = spec.units(g), spec.ctr[g], spec.df[g]
+        with self.timed("projdf", st):
+            rc = self.lib.sfsn_proj_deepfilter(_ptr(ri), B, F, T, S, seqs[0].H, arr, len(seqs), _ptr(enh_ri), _ptr(enh_mag), t0, nt, st)
+        if rc == _lib.SFSN_EUNSUPPORTED:
+            return False
+        check(rc, "sfsn_proj_deepfilter")
+        self.launches["projdf"] = self.launches.get("projdf", 0) + 1
+        return True
+
     def _zero_states(self, Rs, H, nl, flat=None):
         """(h, c) state pairs of a stack as views of one flat buffer; ``flat`` given = a slice of the forward's state buffer, which the
         forward's first feature launch zeroes (sfsn_features_z) -- otherwise a fill of its own."""
@@ -1094,7 +1120,7 @@ class Engine:
                 dst.wait_event(ev)
 
         # per-chunk completion events of the producers the next model / layer gates on
-        def run_model(seqs, d, xs_, first, feat_fn, tag, rpw, post_fn, gate_events):
+        def run_model(seqs, d, xs_, first, feat_fn, tag, rpw, post_fn, gate_events, fused_post=None):
             nl = len(seqs[0].cells)
             fused = self._fusable(seqs, rpw, want_membrane)
             done = []
@@ -1127,9 +1153,10 @@ class Engine:
                             gstreams[first].wait_event(gate_events[c])
                         xg = prep(t0, nt, dv, hG[first])
                     self._stage_stack(seqs, dv, t0, nt, hS[first], tag, wide, rpw_stack, xs_=xs_, xg=xg)
-                    self._stage_proj(seqs, d["s8"][nl - 1], d["proj"], t0, nt, hG[first], tag)
-                    if post_fn is not None:
-                        post_fn(t0, nt, hG[first])
+                    if fused_post is None or not fused_post(t0, nt, hG[first]):
+                        self._stage_proj(seqs, d["s8"][nl - 1], d["proj"], t0, nt, hG[first], tag)
+                        if post_fn is not None:
+                            post_fn(t0, nt, hG[first])
                     if staged:
                         ev = torch.cuda.Event()
                         ev.record(gstreams[first])
@@ -1171,10 +1198,11 @@ class Engine:
                     if staged:
                         link(sc, g)  # the chunk-local zin buffer is reused by the next chunk's input product
                     # ---- after the last layer: projection and whatever follows the model
-                    if l == nl - 1:
+                    if l == nl - 1 and (fused_post is None or not fused_post(t0, nt, hG[si])):
                         self._stage_proj(seqs, d["s8"][l], d["proj"], t0, nt, hG[si], tag)
                         if post_fn is not None:
                             post_fn(t0, nt, hG[si])
+                    if l == nl - 1:
                         if staged:
                             ev = torch.cuda.Event()
                             ev.record(g)
@@ -1228,6 +1256,16 @@ class Engine:
             with self.timed("deepfilter", st):
                 check(L.sfsn_deepfilter(_ptr(ri), B, F, T, S, dfg, ng, _ptr(enh_ri), _ptr(enh_mag), t0, nt, st), "sfsn_deepfilter")
 
+        # round 6: projection + deep filter of a chunk in one launch; in the lean modes the coefficient rows are not written at all
+        write_proj = bool(want_layers or want_membrane or not self.lean_skips_proj)
+        proj_skipped = [False]
+
+        def fused_post_sb(t0, nt, st):
+            if not self._stage_projdf(self.sb, sb["s8"][nl_sb - 1], sb["proj"], ri, enh_ri, enh_mag, (B, F, T, S), t0, nt, st, write_proj):
+                return False
+            proj_skipped[0] = not write_proj
+            return True
+
         if spec.laplace and spec.gaussian:
             check(L.sfsn_gaussian_stats(_ptr(ri), None, B, F, T, 0, spec.fdrc, fg_fb, 1, _ptr(mu_fb), _ptr(sd_fb), _ptr(scratch), hG[0]),
                   "sfsn_gaussian_stats(fb)")
@@ -1244,13 +1282,13 @@ class Engine:
             else:
                 check(L.sfsn_laplace_means(_ptr(ri), _ptr(fb_proj), B, F, T, spec.fb_proj, spec.fdrc, fg_sb, ng, _ptr(mu_sb), _ptr(scratch),
                                            hG[nl_fb]), "sfsn_laplace_means(sb)")
-            sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, None)
+            sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, None, fused_post_sb)
         elif pipeline and self.pipeline_two_phase:
             # full-band model first (its two layers overlapped), then the sub-band models (their two layers overlapped)
             gstreams[nl_fb].wait_event(fb_done[-1])
-            sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, None)
+            sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, None, fused_post_sb)
         else:
-            sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, fb_done if staged else None)
+            sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, fb_done if staged else None, fused_post_sb)
         if staged:
             for s_ in {id(x): x for x in sstreams + gstreams + ([aux_stream] if prep_ahead else [])}.values():
                 link(s_, main)
@@ -1292,11 +1330,14 @@ class Engine:
                 for l in range(nl_sb):
                     sb["spk"][l][g] = summ[nl_fb + g * nl_sb + l]
 
-        def outs(x, d, i, skipped):
+        def outs(x, d, i, skipped, no_proj=False):
             if i in skipped:  # never written: the entry keeps its shape (compute_neuronops reads size(-1)) and nothing else
                 x = torch.empty(x.shape, dtype=x.dtype, device="meta")
-            return [x] + [d["spk"][l][i] for l in range(len(d["spk"]))] + [d["proj"][i]]
+            pr = d["proj"][i]
+            if no_proj:  # (lean modes through sfsn_proj_deepfilter: the coefficient rows stayed in LDS)
+                pr = torch.empty(pr.shape, dtype=pr.dtype, device="meta")
+            return [x] + [d["spk"][l][i] for l in range(len(d["spk"]))] + [pr]
         return dict(enh_stft=enh, enh_mag=enh_mag, fb_all=outs(x_fb, fb, 0, x_skipped["fb"]),
-                    sb_all=[outs(xs[g], sb, g, x_skipped["sb"]) for g in range(ng)],
+                    sb_all=[outs(xs[g], sb, g, x_skipped["sb"], proj_skipped[0]) for g in range(ng)],
                     fb_mem=[fb["mem"][l][0] for l in range(nl_fb)], sb_mem=[[sb["mem"][l][g] for l in range(nl_sb)] for g in range(ng)],
                     mu_fb=mu_fb, mu_sb=mu_sb, pipelined=bool(pipeline), overlapped=overlap, n_chunks=len(bounds))

@@ -1619,6 +1619,124 @@ def test_forward_with_the_fused_feature_product_launch_is_bit_identical(front, k
     eng.check_stack_errors()
 
 
+def _projdf_case(hip, rng, B, F, T, S, H, groups, t0, nt, write_proj=True):
+    """groups: [(n_units, fc, df)].  Runs sfsn_spike_proj (per group) + sfsn_deepfilter and sfsn_proj_deepfilter on the same random
+    spikes / weights / spectrum; returns both result sets (torch tensors; rows / frames outside [t0, t0 + nt) carry NaN canaries)."""
+    from spiking_fullsubnet_amd._lib import DfGroup, ProjDfGroup, check
+    from spiking_fullsubnet_amd.engine import pack_w3
+    HP = (H + 63) // 64 * 64
+    stft = _t(rng.standard_normal((B, F, T, 2)).astype(np.float32))
+    keep, per = [], []
+    for (N, fc, df) in groups:
+        P = 2 * fc * df * S
+        s8 = np.zeros((T, B * N, HP), np.int8)
+        s8[:, :, :H] = rng.random((T, B * N, H)) < 0.3
+        w = (rng.standard_normal((P, H)) * 0.2).astype(np.float32)
+        pk, dq = pack_w3(w)
+        per.append(dict(N=N, fc=fc, df=df, P=P, s8=_t(s8), pk=_t(pk), dq=_t(dq), bias=_t(rng.standard_normal(P).astype(np.float32))))
+    out = {}
+    for how in ("two", "one"):
+        enh = torch.full((B, S, F, T, 2), float("nan"), device=DEV)
+        mag = torch.full((B, S, F, T), float("nan"), device=DEV)
+        projs = [torch.full((T, B * g["N"], g["P"]), float("nan"), device=DEV) for g in per]
+        if how == "two":
+            dfg = (DfGroup * len(per))()
+            for a, g, y in zip(dfg, per, projs):
+                R = B * g["N"]
+                check(hip.sfsn_spike_proj(ctypes.c_void_p(g["s8"].data_ptr() + t0 * R * HP), _p(g["pk"]), _p(g["dq"]), _p(g["bias"]),
+                                          ctypes.c_void_p(y.data_ptr() + t0 * R * g["P"] * 4), nt * R, H, g["P"], g["P"], None), "spike_proj")
+                a.proj, a.n_units, a.fc, a.df = y.data_ptr(), g["N"], g["fc"], g["df"]
+            check(hip.sfsn_deepfilter(_p(stft), B, F, T, S, dfg, len(per), _p(enh), _p(mag), t0, nt, None), "deepfilter")
+        else:
+            arr = (ProjDfGroup * len(per))()
+            for a, g, y in zip(arr, per, projs):
+                a.spikes_i8, a.w_packed, a.w_dq, a.bias = g["s8"].data_ptr(), g["pk"].data_ptr(), g["dq"].data_ptr(), g["bias"].data_ptr()
+                a.proj = y.data_ptr() if write_proj else None
+                a.n_units, a.fc, a.df = g["N"], g["fc"], g["df"]
+            rc = hip.sfsn_proj_deepfilter(_p(stft), B, F, T, S, H, arr, len(per), _p(enh), _p(mag), t0, nt, None)
+            if rc != 0:
+                return rc, None
+        torch.cuda.synchronize()
+        out[how] = (enh, mag, projs)
+    return 0, out
+
+
+def _same_nan(a, b):
+    return torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+@pytest.mark.parametrize("B,F,T,S,H,groups,t0,nt", [
+    (3, 257, 50, 1, 224, [(8, 4, 5), (3, 32, 3), (2, 64, 1)], 0, 50),      # baseline_m's groups, a ragged last tile
+    (2, 257, 77, 1, 224, [(8, 4, 5), (3, 32, 3), (2, 64, 1)], 19, 41),     # a chunk in the middle: history from before t0
+    (2, 129, 40, 2, 64, [(4, 8, 2), (2, 16, 1), (1, 32, 1)], 0, 40),       # two speakers (wsj0-mix shape class), 129 bins
+    (1, 257, 16, 1, 32, [(8, 4, 2), (3, 32, 3), (2, 64, 1)], 0, 16),       # tiny hidden size, exactly one tile
+    (2, 257, 33, 1, 256, [(16, 2, 3), (7, 32, 1)], 5, 28),                 # many units in a group (several unit passes), bins left over
+    (5, 257, 9, 1, 160, [(8, 4, 5), (3, 32, 3), (2, 64, 1)], 0, 9),        # fewer frames than one tile
+])
+def test_projection_and_deep_filter_in_one_launch_equal_the_two_calls(hip, B, F, T, S, H, groups, t0, nt):
+    """sfsn_proj_deepfilter (round 6) == sfsn_spike_proj + sfsn_deepfilter, bit for bit: coefficient rows, enhanced spectrum incl. the
+    pass-through bins, magnitude; frames outside [t0, t0 + nt) untouched; with proj = NULL the rows are not written and the spectrum is
+    the same."""
+    rng = np.random.default_rng(B * 1000 + T)
+    rc, out = _projdf_case(hip, rng, B, F, T, S, H, groups, t0, nt)
+    assert rc == 0
+    (e2, m2, p2), (e1, m1, p1) = out["two"], out["one"]
+    assert _same_nan(e1, e2) and _same_nan(m1, m2)
+    for a, b in zip(p1, p2):
+        assert _same_nan(a, b)
+    assert not torch.isnan(e1[:, :, :, t0:t0 + nt]).any() and (t0 == 0 or torch.isnan(e1[:, :, :, :t0]).all())
+    rng = np.random.default_rng(B * 1000 + T)
+    rc, out = _projdf_case(hip, rng, B, F, T, S, H, groups, t0, nt, write_proj=False)
+    assert rc == 0 and _same_nan(out["one"][0], e2) and _same_nan(out["one"][1], m2)
+    assert all(torch.isnan(y).all() for y in out["one"][2])
+
+
+def test_proj_deepfilter_argument_checks(hip):
+    from spiking_fullsubnet_amd import _lib
+    from spiking_fullsubnet_amd._lib import ProjDfGroup
+    arr = (ProjDfGroup * 1)()
+    one = ctypes.c_void_p(256)
+    assert hip.sfsn_proj_deepfilter(one, 1, 257, 8, 1, 224, arr, 1, one, one, 0, 8, None) == _lib.SFSN_EINVAL       # empty descriptor
+    a = arr[0]
+    a.spikes_i8, a.w_packed, a.w_dq, a.n_units, a.fc, a.df = 256, 256, 256, 2, 3, 1                                    # P = 6: not a multiple of 4
+    assert hip.sfsn_proj_deepfilter(one, 1, 257, 8, 1, 224, arr, 1, one, one, 0, 8, None) == _lib.SFSN_EUNSUPPORTED
+    a.fc = 4
+    assert hip.sfsn_proj_deepfilter(one, 1, 257, 8, 1, 320, arr, 1, one, one, 0, 8, None) == _lib.SFSN_EUNSUPPORTED  # H > 256
+    assert hip.sfsn_proj_deepfilter(one, 1, 257, 8, 1, 224, arr, 1, one, one, 4, 8, None) == _lib.SFSN_EINVAL        # frames past T
+    assert hip.sfsn_proj_deepfilter(one, 1, 5, 8, 1, 224, arr, 1, one, one, 0, 8, None) == _lib.SFSN_EINVAL          # more bins than F
+
+
+@pytest.mark.parametrize("front,kw,seed,covered", [("live", rw.LIVE_TINY, 11, True), ("live", rw.LIVE_TINY_2SPK, 12, True), ("live", rw.LIVE_M, 21, True),
+                                                   ("frozen", rw.FROZEN_S, 32, True), ("live", rw.LIVE_TINY_UNSHARED, 13, True),
+                                                   ("frozen", rw.FROZEN_TINY, 31, False)])  # (P = 384 coefficients per row: the two launches)
+def test_forward_with_the_fused_projection_filter_launch_is_bit_identical(front, kw, seed, covered):
+    """A whole forward with the sub-band epilogue in one launch per chunk (Engine.fuse_projdf, the default) against the two launches:
+    every tensor of the module API, in the overlapped three-chunk schedule and as one whole-sequence chunk; layer_outputs "counts":
+    the same spectrum, the coefficient rows not written (a meta tensor of the same shape)."""
+    sd = rw.live_state_dict(kw, seed) if front == "live" else rw.frozen_state_dict(kw, seed)
+    model = build_module(front, kw, sd)
+    eng = model.engine()
+    stft = model._stft(_t(rw.synth_wave(3, 128 * 330, 5)))
+    for chunks in (3, 0):
+        eng.overlap_chunks = chunks
+        eng.fuse_projdf = True
+        n0 = eng.launches.get("projdf", 0)
+        a = eng.forward_stft(stft)
+        assert (eng.launches.get("projdf", 0) > n0) == covered
+        eng.fuse_projdf = False
+        n1 = eng.launches.get("projdf", 0)
+        b = eng.forward_stft(stft)
+        assert eng.launches.get("projdf", 0) == n1
+        assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(b["enh_stft"])) and torch.equal(a["enh_mag"], b["enh_mag"])
+        assert all(torch.equal(u, v) for u, v in zip(a["fb_all"] + sum(a["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])))
+        eng.fuse_projdf = True
+        c = eng.forward_stft(stft, want_layers=False, want_counts=True)
+        assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(c["enh_stft"])) and torch.equal(a["enh_mag"], c["enh_mag"])
+        for la, lc in zip(a["sb_all"], c["sb_all"]):
+            assert lc[-1].shape == la[-1].shape and (lc[-1].device.type == "meta") == covered
+    eng.check_stack_errors()
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (one rank per GPU; with
     SFSN_BENCH_BACKEND=gloo the two ranks share this box's GPU -- a plumbing check of the N > 1 path): one JSON line, n_gpus 2,
