@@ -9,9 +9,9 @@
 //
 // Round 3 built this fusion with serial phases behind __syncthreads() in small non-persistent workgroups and measured it slower than the
 // two launches (profiles/EXPERIMENTS.md).  What is different: persistent workgroups (the W_p tiles of a job stay in registers for the
-// launch, as in spike_proj_fast_body), the NEXT tile's spikes and spectrum are requested before the current tile's matrix phase and
-// parked before any of its stores is issued (vmcnt retires in order), raw barriers that do not drain stores, and a tile order that
-// puts the two 16-frame halves of a 256-byte output run back to back in the same workgroup (the L2 merges them).
+// launch, as in spike_proj_fast_body), two LOADER waves per workgroup that keep the tile after next in flight for a whole tile's time
+// (see projdf_body), raw barriers that do not drain stores, and a tile order that puts the two 16-frame halves of a 256-byte output
+// run back to back in the same workgroup (the L2 merges them).
 //
 // Arithmetic: the projection is spike_proj_fast_body's instruction for instruction (three exact int8 digit products, recombine3,
 // `* dq + bias`), the filter deepfilter_pass_kernel's expression for expression on the same fp32 coefficients: bit-identical to the
@@ -24,8 +24,10 @@
 
 #define PDF_MAX_JOBS 16
 #define PDF_THREADS 512
-#define PDF_NV 4   // 16-byte spike vectors per thread and tile (<= 2048 per tile)
-#define PDF_NX 8   // spectrum elements per thread and tile (<= 4096 per tile)
+#define PDF_CW 6     // compute waves (matrix phase, coefficient write-out, filter); waves 6 and 7 are the two loader waves
+#define PDF_NV 16    // 16-byte spike vectors per LOADER lane and tile (two loaders: <= 2048 per tile)
+#define PDF_NX 16    // spectrum elements per loader lane and tile (<= 2048 per tile)
+#define PDF_RING 3   // LDS slots of (spike tile, spectrum tile): tile j + 2 is written while tile j is multiplied and filtered
 
 struct PdfJobDev {
     const int8_t* s;   // [T][R][KP] int8 spikes of the group's last layer (frame 0 of the sequence)
@@ -37,7 +39,7 @@ struct PdfJobDev {
     int k0, U;         // this job's units [k0, k0 + U) of every clip
     int fc, df, lo;    // bins per unit, filter order, first bin of the GROUP
     int P, NT, NWN, tpw;
-    int FT;            // frames per tile: 16 or 32
+    int FT;            // frames per tile (16)
     int block0, nblocks;
     int kind;          // 0: projection + filter, 1: pass-through bins [fcov, F)
 };
@@ -49,6 +51,13 @@ struct PdfParams {
     float* mag;
 };
 
+// Workgroup = six compute waves + two LOADER waves.  What the first form of this kernel measured (round 6, B = 64, T = 1000: 324 us per
+// forward, the same as the two launches it replaces although it moves 0.3 GB less): every wave requested the next tile's operands at
+// the top of a tile and parked them behind its matrix phase -- ~1 us later, against 2-3 us of HBM latency under load: 15 k clk per tile
+// for ~5 k clk of work.  A wave that does nothing but load has a vmcnt queue of loads only (whatever the compiler's waits look like,
+// they never wait for a store) and 200 registers to hold half a tile in flight for a whole tile's time: loader k requests its half of
+// tile j + 2 at the top of tile j, crosses the tile's first barrier with the loads in flight, and writes them into ring slot (j + 2) % 3
+// (free since tile j - 1's last barrier) before the tile's second barrier.
 template <int TPW, int KS>
 __device__ __forceinline__ void projdf_body(const PdfParams& p, const PdfJobDev& jb, int blk, char* smem) {
     constexpr int KP = KS * 64, SROW = KP + 16, C16 = KP / 16;
@@ -58,18 +67,109 @@ __device__ __forceinline__ void projdf_body(const PdfParams& p, const PdfJobDev&
     const int FT = jb.FT, U = jb.U, P = jb.P, N = P, NT = jb.NT, NWN = jb.NWN;
     const int B = p.B, F = p.F, T = p.T, S = p.S, t1 = p.t1;
     const int MR = FT * U, MRT = (MR + 15) >> 4;
-    const int LDF = U * P + 1;                       // odd: the 16 / 32 frames of a filter wave hit distinct banks
+    const int LDF = U * P + 1;                       // odd: the 16 frames of a filter wave hit distinct banks
     const int nb = U * jb.fc, XW = FT + jb.df - 1, NXT = nb * XW, NVT = MR * C16;
-    const int SBUF = MRT * 16 * SROW;
-    int8_t* sbuf = reinterpret_cast<int8_t*>(smem);                                    // [2][MRT*16][SROW]
-    float* obuf = reinterpret_cast<float*>(smem + 2 * SBUF);                           // [FT][LDF]
+    const int SBUF = MRT * 16 * SROW, XB = (NXT * 8 + 15) & ~15, SLOTB = SBUF + XB;
+    float* obuf = reinterpret_cast<float*>(smem + PDF_RING * SLOTB);                   // [FT][LDF]
     int* rowoff = reinterpret_cast<int*>(obuf + ((FT * LDF + 3) & ~3));                // [MRT*16]: obuf offset of tile row m (or -1)
-    float2* xt = reinterpret_cast<float2*>(rowoff + MRT * 16);                         // [2][NXT]
-    const int MW = 8 / NWN;
+
+    const int ntile = (t1 - p.t0 + FT - 1) / FT;     // frame tiles per clip
+    const int tiles = B * ntile;
+    // a contiguous range of tiles per workgroup: consecutive frame tiles of one clip follow each other in the same workgroup (the two
+    // 16-frame halves of a 256-byte run of the enhanced spectrum are written within microseconds of each other: the L2 merges them)
+    const int tl0 = (int)((long long)tiles * blk / jb.nblocks), tl1 = (int)((long long)tiles * (blk + 1) / jb.nblocks);
+    const size_t frame_s = (size_t)jb.R * KP;
+    const int fbin0 = jb.lo + jb.k0 * jb.fc;
+
+    for (int m = tid; m < MRT * 16; m += PDF_THREADS) {
+        const int fl = m / U, u = m - fl * U;
+        rowoff[m] = m < MR ? fl * LDF + u * P : -1;
+    }
+
+    if (wave >= PDF_CW) {
+        // ================================================= loader wave k =================================================
+        const int k = wave - PDF_CW;
+        // my vectors of a tile: piece index 2 i + k (a piece = 64 consecutive 16-byte vectors / spectrum elements)
+        int s_fl[PDF_NV], s_in[PDF_NV], s_lds[PDF_NV];
+#pragma unroll
+        for (int i = 0; i < PDF_NV; ++i) {
+            int v = (2 * i + k) * 64 + lane;
+            const bool have = v < NVT;
+            if (v > NVT - 1) v = NVT - 1;
+            const int r = v / C16, c16 = v - r * C16;
+            const int fl = r / U, u = r - fl * U;
+            s_fl[i] = fl;
+            s_in[i] = u * KP + c16 * 16;
+            s_lds[i] = have ? r * SROW + c16 * 16 : -1;
+        }
+        int x_jc[PDF_NX];                            // (bin row << 8) | column, or -1: no element
+#pragma unroll
+        for (int i = 0; i < PDF_NX; ++i) {
+            const int e = (2 * i + k) * 64 + lane;
+            const int ec = e < NXT ? e : NXT - 1;
+            const int j = ec / XW, c = ec - j * XW;
+            x_jc[i] = e < NXT ? (j << 8) | c : -1;
+        }
+        v4i pre[PDF_NV];
+        float2 xpre[PDF_NX];
+        bool x_ok[PDF_NX];
+        auto fetch = [&](int tl) __attribute__((always_inline)) {
+            const int b = tl / ntile, tb = p.t0 + (tl - b * ntile) * FT;
+            const int flmax = t1 - 1 - tb;           // frames past the chunk re-read its last frame (their rows are never stored)
+            const int8_t* sb = jb.s + (size_t)tb * frame_s + ((size_t)b * jb.N + jb.k0) * KP;
+#pragma unroll
+            for (int i = 0; i < PDF_NV; ++i) {
+                // (no branch around a load: hipcc drains vmcnt(0) at every control-flow merge, which would leave ONE load in flight at a
+                //  time -- slots beyond the tile re-read its last vector: same line for all 64 lanes, an issue slot and nothing else)
+                const int fl = s_fl[i] < flmax ? s_fl[i] : flmax;
+                pre[i] = *reinterpret_cast<const v4i*>(sb + (size_t)fl * frame_s + s_in[i]);
+            }
+            const float* xb = p.stft + ((size_t)b * F + fbin0) * T * 2;
+            const int ts0 = tb - (jb.df - 1);
+#pragma unroll
+            for (int i = 0; i < PDF_NX; ++i) {
+                const int jc = x_jc[i] < 0 ? 0 : x_jc[i];
+                const int ts = ts0 + (jc & 255);
+                const int tsc = ts < 0 ? 0 : (ts > T - 1 ? T - 1 : ts);
+                xpre[i] = *reinterpret_cast<const float2*>(xb + ((size_t)(jc >> 8) * T + tsc) * 2);
+                x_ok[i] = ts >= 0 && ts < T;
+            }
+        };
+        auto park = [&](int slot) __attribute__((always_inline)) {
+            char* sl = smem + slot * SLOTB;
+#pragma unroll
+            for (int i = 0; i < PDF_NV; ++i)
+                if (s_lds[i] >= 0) *reinterpret_cast<v4i*>(sl + s_lds[i]) = pre[i];
+            float2* xt = reinterpret_cast<float2*>(sl + SBUF);
+#pragma unroll
+            for (int i = 0; i < PDF_NX; ++i)
+                if (x_jc[i] >= 0) xt[(2 * i + k) * 64 + lane] = x_ok[i] ? xpre[i] : make_float2(0.0f, 0.0f);
+        };
+        // prologue: the first two tiles
+        for (int d = 0; d < 2; ++d)
+            if (tl0 + d < tl1) {
+                fetch(tl0 + d);
+                park(d);
+            }
+        __syncthreads();
+        int slot = 0;
+        for (int tl = tl0; tl < tl1; ++tl) {
+            const bool more = tl + 2 < tl1;
+            if (more) fetch(tl + 2);
+            __builtin_amdgcn_s_barrier();            // (the tile's first barrier: my loads stay in flight across it)
+            if (more) park(slot == 0 ? 2 : slot - 1);  // = (slot + 2) % 3: free since the last barrier of tile tl - 1
+            slot = slot == 2 ? 0 : slot + 1;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ================================================= compute waves =================================================
+    const int MW = PDF_CW / NWN;
     const int cg = wave % NWN, mw = wave / NWN;
     const bool worker = mw < MW;
-
-    // ---- W_p tiles of this wave -> registers, once (spike_proj_fast_body's deal)
+    // ---- W_p tiles of this wave -> registers, once (spike_proj_fast_body's deal over six waves)
     v4i W[TPW][KS][3];
     v4f dqv[TPW], bv[TPW];
     int col[TPW];
@@ -89,92 +189,20 @@ __device__ __forceinline__ void projdf_body(const PdfParams& p, const PdfJobDev&
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[i][r] = (jb.bias && have && col[i] + r < N) ? jb.bias[col[i] + r] : 0.0f;
     }
-    for (int m = tid; m < MRT * 16; m += PDF_THREADS) {
-        const int fl = m / U, u = m - fl * U;
-        rowoff[m] = m < MR ? fl * LDF + u * P : -1;
-    }
-
-    // ---- tile-invariant addressing of the two prefetches
-    int s_fl[PDF_NV], s_in[PDF_NV], s_lds[PDF_NV];   // frame within the tile, byte offset within a frame's rows, LDS byte offset
-#pragma unroll
-    for (int j = 0; j < PDF_NV; ++j) {
-        int v = tid + j * PDF_THREADS;
-        s_lds[j] = v < NVT ? 0 : -1;
-        if (v > NVT - 1) v = NVT - 1;
-        const int r = v / C16, c16 = v - r * C16;
-        const int fl = r / U, u = r - fl * U;
-        s_fl[j] = fl;
-        s_in[j] = u * KP + c16 * 16;
-        if (s_lds[j] == 0) s_lds[j] = r * SROW + c16 * 16;
-    }
-    int x_c[PDF_NX], x_row[PDF_NX];                  // column within the spectrum tile, bin row offset (floats / 2) ; x_c < 0: no element
-#pragma unroll
-    for (int i = 0; i < PDF_NX; ++i) {
-        int e = tid + i * PDF_THREADS;
-        const bool have = e < NXT;
-        if (e > NXT - 1) e = NXT - 1;
-        const int j = e / XW, c = e - j * XW;
-        x_c[i] = have ? c : -1 - c;
-        x_row[i] = j;
-    }
-
-    const int ntile = (t1 - p.t0 + FT - 1) / FT;     // frame tiles per clip
-    const int tiles = B * ntile;
-    // a contiguous range of tiles per workgroup: consecutive frame tiles of one clip follow each other in the same workgroup
-    const int tl0 = (int)((long long)tiles * blk / jb.nblocks), tl1 = (int)((long long)tiles * (blk + 1) / jb.nblocks);
-    const size_t frame_s = (size_t)jb.R * KP;
-    const int fbin0 = jb.lo + jb.k0 * jb.fc;
-
-    v4i pre[PDF_NV];
-    float2 xpre[PDF_NX];
-    auto fetch = [&](int tl) __attribute__((always_inline)) {
-        const int b = tl / ntile, tb = p.t0 + (tl - b * ntile) * FT;
-        const int flmax = t1 - 1 - tb;               // frames past the chunk re-read its last frame (their rows are never stored)
-        const int8_t* sb = jb.s + (size_t)tb * frame_s + ((size_t)b * jb.N + jb.k0) * KP;
-#pragma unroll
-        for (int j = 0; j < PDF_NV; ++j) {
-            if (j * PDF_THREADS < NVT) {             // (uniform)
-                const int fl = s_fl[j] < flmax ? s_fl[j] : flmax;
-                pre[j] = *reinterpret_cast<const v4i*>(sb + (size_t)fl * frame_s + s_in[j]);
-            }
-        }
-        const float* xb = p.stft + ((size_t)b * F + fbin0) * T * 2;
-        const int ts0 = tb - (jb.df - 1);
-#pragma unroll
-        for (int i = 0; i < PDF_NX; ++i) {
-            if (i * PDF_THREADS < NXT) {             // (uniform)
-                const int c = x_c[i] < 0 ? -1 - x_c[i] : x_c[i];
-                const int ts = ts0 + c;
-                const int tsc = ts < 0 ? 0 : (ts > T - 1 ? T - 1 : ts);
-                const float2 v = *reinterpret_cast<const float2*>(xb + ((size_t)x_row[i] * T + tsc) * 2);
-                xpre[i] = (ts >= 0 && ts < T) ? v : make_float2(0.0f, 0.0f);
-            }
-        }
-    };
-    auto park = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < PDF_NV; ++j)
-            if (j * PDF_THREADS < NVT && s_lds[j] >= 0) *reinterpret_cast<v4i*>(sbuf + buf * SBUF + s_lds[j]) = pre[j];
-#pragma unroll
-        for (int i = 0; i < PDF_NX; ++i)
-            if (i * PDF_THREADS < NXT && x_c[i] >= 0) xt[buf * NXT + tid + i * PDF_THREADS] = xpre[i];
-    };
-
-    int cur = 0;
-    if (tl0 < tl1) {
-        fetch(tl0);
-        park(0);
-    }
     __syncthreads();
-    const int tt = tid & (FT - 1), slot0 = tid / FT, nslot = PDF_THREADS / FT;
+    constexpr int CT = PDF_CW * 64;                  // compute threads
+    const int tt = tid & (FT - 1), slot0 = tid / FT, nslot = CT / FT;
     const int Q = (U * P) >> 2;                      // 16-byte units of a frame's coefficient rows
+    int slot = 0;
     for (int tl = tl0; tl < tl1; ++tl) {
         const int b = tl / ntile, tb = p.t0 + (tl - b * ntile) * FT;
-        if (tl + 1 < tl1) fetch(tl + 1);
+        const char* sl = smem + slot * SLOTB;
+        const int8_t* sbuf = reinterpret_cast<const int8_t*>(sl);
+        const float2* xc = reinterpret_cast<const float2*>(sl + SBUF);
         // ---- matrix phase: coefficient tile -> obuf
         if (worker) {
             for (int mi = mw; mi < MRT; mi += MW) {
-                const int8_t* sr = sbuf + cur * SBUF + (mi * 16 + n) * SROW + q * 16;
+                const int8_t* sr = sbuf + (mi * 16 + n) * SROW + q * 16;
                 v4i bfr[KS];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) bfr[ks] = *reinterpret_cast<const v4i*>(sr + ks * 64);
@@ -197,16 +225,13 @@ __device__ __forceinline__ void projdf_body(const PdfParams& p, const PdfJobDev&
                 }
             }
         }
-        // the next tile's operands are parked BEFORE any store of this tile is issued: the wait for them covers loads (and the
-        // previous tile's stores, which have had the matrix phase to retire) only
-        if (tl + 1 < tl1) park(cur ^ 1);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
         // ---- the coefficient rows leave once (the module API's last `all_layer_outputs` entry): a wave per frame, whole rows
         if (jb.y) {
-            for (int fl = wave; fl < FT; fl += PDF_THREADS / 64) {
+            for (int fl = wave; fl < FT; fl += PDF_CW) {
                 const int t = tb + fl;
-                if (t >= t1) break;
+                if (t >= t1) continue;
                 float* yp = jb.y + (((size_t)t * jb.R) + (size_t)b * jb.N + jb.k0) * P;
                 const float* op = obuf + fl * LDF;
                 for (int c4 = lane; c4 < Q; c4 += 64) {
@@ -220,7 +245,6 @@ __device__ __forceinline__ void projdf_body(const PdfParams& p, const PdfJobDev&
             const int t = tb + tt;
             if (t < t1) {
                 const float* pr = obuf + tt * LDF;
-                const float2* xc = xt + cur * NXT;
                 int u = 0, fci = slot0;
                 while (fci >= jb.fc) { fci -= jb.fc; ++u; }
                 for (int j = slot0; j < nb; j += nslot) {
@@ -245,8 +269,8 @@ __device__ __forceinline__ void projdf_body(const PdfParams& p, const PdfJobDev&
                 }
             }
         }
-        cur ^= 1;
-        // obuf / xt are rewritten by the next tile: LDS reads done, stores stay in flight (raw barrier)
+        slot = slot == 2 ? 0 : slot + 1;
+        // obuf and this tile's ring slot are rewritten next: LDS reads done, stores stay in flight (raw barrier)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
     }
@@ -280,7 +304,8 @@ __global__ __launch_bounds__(PDF_THREADS) void projdf_kernel(const PdfParams p) 
     const int blk = (int)blockIdx.x - jb.block0;
     if (jb.kind == 1) passthrough_body(p, jb, blk);
     else if (jb.tpw == 1) projdf_body<1, KS>(p, jb, blk, pdf_smem);
-    else projdf_body<2, KS>(p, jb, blk, pdf_smem);
+    else if (jb.tpw == 2) projdf_body<2, KS>(p, jb, blk, pdf_smem);
+    else projdf_body<3, KS>(p, jb, blk, pdf_smem);
 }
 
 // =====================================================================================================
@@ -295,11 +320,10 @@ static int pdf_cu_count() {
 
 static size_t pdf_lds_bytes(int KS, int FT, int U, int P, int fc, int df) {
     const int KP = KS * 64, SROW = KP + 16, MRT = (FT * U + 15) / 16;
-    const size_t sbuf = (size_t)2 * MRT * 16 * SROW;
+    const size_t slot = (size_t)MRT * 16 * SROW + (((size_t)U * fc * (FT + df - 1) * 8 + 15) & ~(size_t)15);
     const size_t obuf = (size_t)((FT * (U * P + 1) + 3) & ~3) * 4;
     const size_t rows = (size_t)MRT * 16 * 4;
-    const size_t xt = (size_t)2 * U * fc * (FT + df - 1) * 8;
-    return sbuf + obuf + rows + xt;
+    return PDF_RING * slot + obuf + rows;
 }
 
 extern "C" int sfsn_proj_deepfilter(const float* stft_ri, int B, int F, int T, int S, int H, const sfsn_projdf_group* groups, int n_groups,
@@ -324,24 +348,21 @@ extern "C" int sfsn_proj_deepfilter(const float* stft_ri, int B, int F, int T, i
         if (!pdf_aligned16(g.spikes_i8) || !pdf_aligned16(g.w_packed) || !pdf_aligned16(g.w_dq) || !pdf_aligned16(g.proj)) return SFSN_EINVAL;
         const int P = 2 * g.fc * g.df * S, NT = (P + 15) / 16;
         if (P % 4) return SFSN_EUNSUPPORTED;
-        int TPW = (NT + 7) / 8;
-        if (TPW > 2) return SFSN_EUNSUPPORTED;
+        int TPW = (NT + PDF_CW - 1) / PDF_CW;
+        if (TPW > 3) return SFSN_EUNSUPPORTED;  // (P <= 288)
         const int NWN = (NT + TPW - 1) / TPW;
         // units per job and frames per tile: the largest that fit the per-thread prefetch slots and the LDS budget
-        int FT = ft_env == 32 ? 32 : 16, U = g.n_units;
+        int FT = 16, U = g.n_units;
+        (void)ft_env;
         auto fits = [&](int ft, int u) {
-            return ft * u * (KS * 4) <= PDF_NV * PDF_THREADS && u * g.fc * (ft + g.df - 1) <= PDF_NX * PDF_THREADS &&
+            return ft * u * (KS * 4) <= PDF_NV * 128 && u * g.fc * (ft + g.df - 1) <= PDF_NX * 128 && g.df <= 200 &&
                    pdf_lds_bytes(KS, ft, u, P, g.fc, g.df) <= lds_cap_env;
         };
-        if (FT == 32 && !fits(32, 1)) FT = 16;
         while (U > 1 && !fits(FT, U)) {
             const int np = (g.n_units + U - 1) / U + 1;  // one more pass
             U = (g.n_units + np - 1) / np;
         }
-        if (!fits(FT, U)) {
-            if (FT == 32) { FT = 16; U = g.n_units; while (U > 1 && !fits(FT, U)) { const int np = (g.n_units + U - 1) / U + 1; U = (g.n_units + np - 1) / np; } }
-            if (!fits(FT, U)) return SFSN_EUNSUPPORTED;
-        }
+        if (!fits(FT, U)) return SFSN_EUNSUPPORTED;
         for (int k0 = 0; k0 < g.n_units; k0 += U) {
             if (p.n >= PDF_MAX_JOBS - 1) return SFSN_EUNSUPPORTED;
             PdfJobDev& d = p.job[p.n];
@@ -360,6 +381,8 @@ extern "C" int sfsn_proj_deepfilter(const float* stft_ri, int B, int F, int T, i
     if (lo > F) return SFSN_EINVAL;
     p.fcov = lo;
     const int n_cu = pdf_cu_count();
+    // one persistent workgroup per compute unit (the ring and the coefficient tile take most of a unit's LDS).  Measured with the loader
+    // waves, B = 64, T = 1000: 256 / 512 / 1024 workgroups 238 / 246 / 296 us per forward (every workgroup reloads its W_p tiles)
     int total = wgs_env > 0 ? wgs_env : n_cu;
     int n_pass = 0;
     if (lo < F) {  // the pass-through bins: a few workgroups of their own
