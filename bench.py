@@ -347,6 +347,8 @@ def main():
     #      launch alone, and the region with the same lanes.  -> config.no_layer_outputs
     lean = None
     if want_layers and not args.no_phase_a and not args.sequential:
+        eng.lean_skips_proj = True  # (this leg only: the coefficient rows stay in LDS -- sfsn_proj_deepfilter with proj = NULL)
+
         def forward_lean(x=None):
             res = eng.forward_stft(stft if x is None else x, want_layers=False, want_counts=True, pipeline=False)
             if dist is not None:
@@ -380,6 +382,7 @@ def main():
             lean["timed_region"] = dict(ms_per_step=round(1e3 * dt_lr / args.steps, 4), value=round(world * B * T * args.steps / dt_lr, 1),
                                         steps=args.steps, warmup=args.warmup, in_flight=n_lanes, scan_rows_per_workgroup=list(geom_b))
         eng.overlap_chunks = ov_default
+        eng.lean_skips_proj = False
 
     # ---- BASELINE configs[2] words its mode "bf16": the 16-bit-weight mode (module.weight_bits = 16: recurrent, spike-input and projection
     #      weights rounded to 16 significant bits of their row grid = two int8 digit planes instead of three; activations are spikes and
@@ -598,7 +601,8 @@ def main():
             lp = lean["scan_groups_whole_launch_ms"].get("stack:sb")
             lean_obj = dict(
                 mode='layer_outputs="counts": no fp32 spike tensors; SpikeSummary (exact spike count + shape) per layer, counted inside the scans '
-                     '(sfsn_scan_segment.spike_count) -- what recipes/intel_ndns/spiking_fullsubnet/trainer.py:31,52 needs (it discards the lists) '
+                     '(sfsn_scan_segment.spike_count); since round 6 the sub-band coefficient rows are not written either (Engine.lean_skips_proj: they '
+                     'stay in LDS inside sfsn_proj_deepfilter) -- what recipes/intel_ndns/spiking_fullsubnet/trainer.py:31,52 needs (it discards the lists) '
                      'and what audiozen/metric.py:303-340 reads',
                 single_stream=lean["single_stream"], timed_region=lean.get("timed_region"),
                 scan_groups_whole_launch_ms=lean["scan_groups_whole_launch_ms"],

@@ -24,6 +24,7 @@
 
 #include "sfsn_scan_dev.h"
 #include "sfsn_scan3_dev.h"
+#include "sfsn_scan3j_dev.h"
 #include "sfsn_feat_dev.h"
 
 // G = 1: shared gate weights (W [H][*] used for both gates); G = 2: separate forget / cell weights.
@@ -289,6 +290,25 @@ __global__ __launch_bounds__(512) void gsn_scan_fused_kernel(const ScanParams p)
         fused_body<KS, OUT, 2>(sg, smem, T, H, NT, R, row0, rowc, n, q, tid, wave);
     else
         fused_body<KS, OUT, 1>(sg, smem, T, H, NT, R, row0, rowc, n, q, tid, wave);
+    SFSN_WG_STAMP(p.wg_times, 1);
+}
+
+// Round 6: the fused-input scan at 16 rows per workgroup with IO-specialised waves (sfsn_scan3j_dev.h): what sfsn_gsn_layer_scan_fused
+// launches for H <= 224 (at most 14 tiles: one per compute wave + loader + storer); bit-identical to gsn_scan_fused_kernel.
+template <int KS, int TL, int OUT>
+__global__ __launch_bounds__(1024) void gsn_scan_fused3_kernel(const ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char scan_smem[];
+    int s = 0;
+    for (int i = 1; i < p.nseg; ++i)
+        if ((int)blockIdx.x >= p.seg[i].tile0) s = i;
+    const ScanSegDev& sg = p.seg[s];
+    Scan3jRole rl;
+    rl.spikes_in = sg.spikes_in; rl.w_ih = sg.w_ih; rl.w_ih_dq = sg.w_ih_dq; rl.w_hh = sg.w_hh; rl.w_dq = sg.w_dq; rl.bias = sg.bias;
+    rl.bn_alpha = sg.bn_alpha; rl.bn_beta = sg.bn_beta; rl.h_state = sg.h_state; rl.c_state = sg.c_state;
+    rl.spikes_f32 = sg.spikes_f32; rl.spikes_i8 = sg.spikes_i8; rl.R = sg.R; rl.row0 = ((int)blockIdx.x - sg.tile0) * 16;
+    rl.count = sg.count; rl.lsplit = p.lsplit;
+    SFSN_WG_STAMP(p.wg_times, 0);
+    scan3j_role<KS, TL, OUT>(rl, scan_smem, p.T, p.H, p.NT);
     SFSN_WG_STAMP(p.wg_times, 1);
 }
 
@@ -2331,9 +2351,30 @@ extern "C" int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs, const sf
     }
     p.nseg = n_segs; p.T = T; p.H = H; p.NT = H / 16;
     const int KS = (H + 63) / 64, HP = KS * 64;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // round 6: at most 14 tiles -> the IO-wave form (sfsn_scan3j_dev.h; SFSN_FUSED_V2=1 / SFSN_SCAN_V2=1 keep round 2's body: A/B runs, tests)
+    if (p.NT <= 14 && !getenv("SFSN_FUSED_V2") && !getenv("SFSN_SCAN_V2")) {
+        const bool tl = (H & 63) != 0 && (H & 63) <= 32;
+        const int lds3 = KS == 3 ? Scan3jCfg<3>::lds_bytes(p.NT) : Scan3jCfg<4>::lds_bytes(p.NT);
+        {
+            const char* e = getenv("SFSN_S3J_LSPLIT");  // fp32 store instructions per frame the loader wave takes (A/B runs)
+            const int x = e ? atoi(e) : SFSN_S3J_LSPLIT;
+            p.lsplit = x < 0 ? 0 : (x > 14 ? 14 : x);
+        }
+#define FUSED3_CASE(KS_, TL_, OUT_)                                                                                        \
+    if (KS == KS_ && (int)tl == TL_ && out == OUT_ && lds3 <= 160 * 1024 - 64) {                                           \
+        auto kern = gsn_scan_fused3_kernel<KS_, TL_, OUT_>;                                                                \
+        static int seen[SFSN_MAX_DEVICES] = {0};                                                                           \
+        if (raise_lds(reinterpret_cast<const void*>(kern), lds3, seen) != SFSN_OK) return SFSN_EHIP;                       \
+        p.wg_times = sfsn_wgprobe_take(2, tiles);                                                                          \
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(1024), lds3, st, p);                                                    \
+        return hip_ok(hipGetLastError());                                                                                  \
+    }
+        FUSED3_CASE(3, 0, 2) FUSED3_CASE(3, 0, 3) FUSED3_CASE(3, 1, 2) FUSED3_CASE(3, 1, 3) FUSED3_CASE(4, 1, 2) FUSED3_CASE(4, 1, 3)
+#undef FUSED3_CASE
+    }
     const int lds = 3 * 16 * HP + 2 * 16 * (HP + 32) + 6 * HP * 4 + 2 * p.NT * KS * 1024;
     if (lds > 160 * 1024) return SFSN_EUNSUPPORTED;
-    hipStream_t st = static_cast<hipStream_t>(stream);
 #define FUSED_CASE(KS_, OUT_)                                                                                              \
     if (KS == KS_ && out == OUT_) {                                                                                        \
         auto kern = gsn_scan_fused_kernel<KS_, OUT_>;                                                                      \

@@ -1444,6 +1444,69 @@ def test_fused_scan_entry_points_reject_what_they_do_not_cover(hip):
     torch.cuda.synchronize()
 
 
+def _run_fused(hip, s_in, sd, alpha, beta, h0, c0, want_f32=True, segs_split=None):
+    """sfsn_gsn_layer_scan_fused on int8 input spikes s_in [T, R, HP] (a layer >= 1): fp32 spikes (or None), int8 spikes, h, c, count."""
+    from spiking_fullsubnet_amd._lib import FusedInput, ScanSegment, check
+    from spiking_fullsubnet_amd.engine import pack_w3
+    T, R, HP = s_in.shape
+    H = sd["weight_hh"].shape[1]
+    pk, dq = pack_w3(sd["weight_hh"])
+    pki, dqi = pack_w3(sd["weight_ih"])
+    cuts = [0, R] if segs_split is None else [0, segs_split, R]
+    ns = len(cuts) - 1
+    keep = [_t(pk), _t(dq), _t(pki), _t(dqi), _t(sd["bias_ih"]), _t(alpha), _t(beta)]
+    seg, fin, outs = (ScanSegment * ns)(), (FusedInput * ns)(), []
+    for i in range(ns):
+        r0, r1 = cuts[i], cuts[i + 1]
+        t = dict(sin=_t(np.ascontiguousarray(s_in[:, r0:r1])), h=_t(h0[r0:r1]), c=_t(c0[r0:r1]),
+                 spk=torch.empty((T, r1 - r0, H), device=DEV) if want_f32 else None,
+                 s8=torch.zeros((T, r1 - r0, HP), dtype=torch.int8, device=DEV), cnt=torch.zeros((1,), dtype=torch.int64, device=DEV))
+        s = seg[i]
+        s.zin, s.w_hh, s.w_dq, s.bias, s.bn_alpha, s.bn_beta = None, _p(keep[0]), _p(keep[1]), _p(keep[4]), _p(keep[5]), _p(keep[6])
+        s.h_state, s.c_state, s.spikes_f32, s.spikes_i8, s.membrane, s.R = _p(t["h"]), _p(t["c"]), _p(t["spk"]), _p(t["s8"]), None, r1 - r0
+        s.spike_count = None if want_f32 else _p(t["cnt"])
+        fin[i].spikes_in, fin[i].w_ih, fin[i].w_ih_dq = t["sin"].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr()
+        outs.append(t)
+    check(hip.sfsn_gsn_layer_scan_fused(seg, fin, ns, T, H, None), "sfsn_gsn_layer_scan_fused")
+    torch.cuda.synchronize()
+    cat = lambda k: None if outs[0][k] is None else torch.cat([o[k] for o in outs], dim=1 if k in ("spk", "s8") else 0).cpu().numpy()
+    return cat("spk"), cat("s8"), cat("h"), cat("c"), sum(int(o["cnt"][0]) for o in outs)
+
+
+@pytest.mark.parametrize("H,R,T,split", [(224, 37, 33, None), (224, 16, 1, None), (224, 5, 2, None), (160, 21, 19, None), (192, 40, 17, 16),
+                                         (144, 9, 12, None), (208, 33, 11, 8), (176, 18, 9, None), (224, 64, 90, 32)])
+def test_fused_scan_with_io_waves_equals_round_2_body_and_the_two_calls(hip, H, R, T, split, monkeypatch):
+    """Round 6: sfsn_gsn_layer_scan_fused runs scan3j_role (16 rows per workgroup, IO-specialised waves) for H <= 224.  Bit for bit
+    equal to round 2's body (SFSN_FUSED_V2=1, read per call) and to sfsn_spike_proj + sfsn_gsn_layer_scan -- fp32 / int8 spikes,
+    final h and c -- for every k-step form (H mod 64 in (0, 32]: the 32-wide tail; full steps), ragged row blocks, one / two / odd
+    frame counts, two segments in one launch, non-zero initial state; without fp32 spikes the launch's count equals their sum."""
+    from test_stack_scan import _spike_proj
+    rng = np.random.default_rng(H * 7 + R)
+    sd, alpha, beta, bnp = make_layer(rng, H, H, True, True)
+    HP = (H + 63) // 64 * 64
+    s_in = np.zeros((T, R, HP), np.int8)
+    s_in[:, :, :H] = rng.random((T, R, H)) < 0.25
+    h0 = (rng.random((R, H)) > 0.5).astype(np.float32)
+    c0 = rng.standard_normal((R, H)).astype(np.float32)
+    new = _run_fused(hip, s_in, sd, alpha, beta, h0, c0, segs_split=split)
+    monkeypatch.setenv("SFSN_FUSED_V2", "1")
+    old = _run_fused(hip, s_in, sd, alpha, beta, h0, c0, segs_split=split)
+    monkeypatch.delenv("SFSN_FUSED_V2")
+    for a, b, nm in zip(new[:4], old[:4], ("fp32 spikes", "int8 spikes", "h", "c")):
+        np.testing.assert_array_equal(a, b, err_msg=nm)
+    assert new[1].any() and not new[1][:, :, H:].any()
+    zin = _spike_proj(hip, s_in, sd["weight_ih"], H)
+    spk, _, s8, hT, cT = run_scan(hip, zin, sd["weight_hh"], sd["bias_ih"], alpha, beta, True, h0, c0, want_mem=False)
+    np.testing.assert_array_equal(new[0], spk)
+    np.testing.assert_array_equal(new[1], s8)
+    np.testing.assert_array_equal(new[2], hT)
+    np.testing.assert_array_equal(new[3], cT)
+    lean = _run_fused(hip, s_in, sd, alpha, beta, h0, c0, want_f32=False, segs_split=split)
+    assert lean[0] is None and lean[4] == int(new[0].sum())
+    np.testing.assert_array_equal(lean[1], new[1])
+    np.testing.assert_array_equal(lean[3], new[3])
+
+
 def test_feature_launch_zeroes_the_scan_states_and_nothing_else(hip, monkeypatch):
     """sfsn_features_z: extra workgroups of the feature launch write the zero initial state of the forward's scans (MODEL:100-106)
     -- exactly the bytes asked for, the features themselves unchanged -- and the engine's forward gives the same bits with the
@@ -1730,10 +1793,15 @@ def test_forward_with_the_fused_projection_filter_launch_is_bit_identical(front,
         assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(b["enh_stft"])) and torch.equal(a["enh_mag"], b["enh_mag"])
         assert all(torch.equal(u, v) for u, v in zip(a["fb_all"] + sum(a["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])))
         eng.fuse_projdf = True
-        c = eng.forward_stft(stft, want_layers=False, want_counts=True)
-        assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(c["enh_stft"])) and torch.equal(a["enh_mag"], c["enh_mag"])
-        for la, lc in zip(a["sb_all"], c["sb_all"]):
-            assert lc[-1].shape == la[-1].shape and (lc[-1].device.type == "meta") == covered
+        for skip in (False, True):
+            eng.lean_skips_proj = skip
+            c = eng.forward_stft(stft, want_layers=False, want_counts=True)
+            assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(c["enh_stft"])) and torch.equal(a["enh_mag"], c["enh_mag"])
+            for la, lc in zip(a["sb_all"], c["sb_all"]):
+                assert lc[-1].shape == la[-1].shape and (lc[-1].device.type == "meta") == (covered and skip)
+                if not (covered and skip):
+                    assert torch.equal(la[-1], lc[-1])
+        eng.lean_skips_proj = False
     eng.check_stack_errors()
 
 
