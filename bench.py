@@ -29,7 +29,7 @@ Prints ONE JSON line on rank 0 (see the task contract), carrying
                    HIP-event launch duration -- the north star's "HBM roofline on the sub-band scan"), `dominant_kernel_timed_region`
                    (the fused sub-band scan of the timed region's geometry, alone on the chip and as a time share inside the
                    region), `full_band_stack` (MFMA utilisation).  PMC-derived fields (`traffic`, `mfma.pmc`) come from
-                   profiles/r05_pmc.json and are attached only when that file was taken with the library build that is running
+                   profiles/r06_pmc.json and are attached only when that file was taken with the library build that is running
                    (source hash) on this workload (B, T, geometry, forwards in flight);
   cpu_baseline  -- the CPU oracle (oracle/, a C restatement of the reference) timed on this host's cores on the whole workload
                    (all B clips x all T frames, groups of clips side by side; rank 0, N=1 only).
@@ -93,7 +93,7 @@ def _self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env, stdout=JSON_OUT.fileno()))  # (the ranks get the real stdout as their fd 1)
 
 
-PROFILE_JSON = os.path.join(ROOT, "profiles", "r05_pmc.json")
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r06_pmc.json")
 
 
 def _pmc_profile():
@@ -204,6 +204,8 @@ def main():
     if args.streaming:
         return streaming_bench(args, model, dev, world, rank)
     want_layers = not args.no_layer_outputs
+    if args.no_layer_outputs:
+        eng.lean_skips_proj = True  # (the lean modes of the bench: the sub-band coefficient rows stay in LDS too, see Engine.lean_skips_proj)
     gathered = {}  # per HIP stream (lane): the all-gathered magnitudes of that lane's batch
 
     def forward(x=None):
@@ -529,7 +531,13 @@ def main():
                               **hbm(sp["mean_ms"], nl_sb * alg), per_step_us=round(1e3 * sp["mean_ms"] / T, 3),
                               launches=sp["n"], layers_per_launch=nl_sb, algorithmic_bytes_per_launch=int(nl_sb * alg),
                               traffic=(pj or {}).get("sb_pair_hbm_bytes_per_launch"),
-                              measured_in="one forward at a time, the whole sequence in one launch for all layers (HIP events on the launch stream)")
+                              measured_in="one forward at a time, the whole sequence in one launch for all layers (HIP events on the launch stream)",
+                              floor_note="the north star's 0.40 is NOT reachable with exact 24-bit weights in this structure: a frame of the layer-2 "
+                                         "(FUSED3) role is 72 matrix instructions x 16 clk = 1,152 clk on the SIMDs that carry four tiles PLUS ~780 clk of "
+                                         "epilogue VALU -- on gfx950 the two do not overlap within a SIMD (scripts/micro/pingpong_step.hip, round 6: two "
+                                         "INDEPENDENT 8-row blocks per workgroup, half a step apart, 1,409 against 1,401 clk per 8 row-frames; staggered "
+                                         "wave slots 1,444) -- i.e. ~1,930 clk = 0.80 us per frame = 0.29 of the roof if the IO side were free; measured "
+                                         "2,040-2,180 clk with it (profiles/r05_stall_ledger.txt).  0.40 needs <= 1,400 clk per frame")
             # --- the full-band stack (phase S): both layers + the layer-2 input product in ONE layer-pipelined launch
             fb = t_s.get("stack:fb")
             full_band = None
@@ -579,8 +587,10 @@ def main():
                 # forwards' kernels run beside it, so that wall time is a time share and may exceed ms_per_step)
                 kf, kx, kp = t_k["scanf:sb"], t_k.get("scanx:sb"), t_k.get("scan:sb")
                 roofline["dominant_kernel_timed_region"] = dict(
-                    kernel=f"gsn_scan_fused_kernel<KS={(Hs + 63) // 64},OUT=fp32+int8 spikes> (sub-band layer 2, input product inside, {geom_b[1]} rows per "
-                           f"workgroup, {wgs(sb_rows, geom_b[1])} workgroups, {spec.n_groups} groups in one launch)",
+                    kernel=(f"gsn_scan_fused3_kernel<KS={(Hs + 63) // 64}> (round 6: IO-specialised waves -- 14 compute waves + loader + storer; " if Hs // 16 <= 14
+                            else f"gsn_scan_fused_kernel<KS={(Hs + 63) // 64}> (") +
+                           f"sub-band layer 2, input product inside, {geom_b[1]} rows per workgroup, {wgs(sb_rows, geom_b[1])} workgroups, "
+                           f"{spec.n_groups} groups in one launch, OUT=fp32+int8 spikes)",
                     alone_on_chip=hbm(kf["mean_ms"]), per_step_us=round(1e3 * kf["mean_ms"] / T, 3),
                     in_region_time_share=hbm(t_b["scanf:sb"]["mean_ms"]) if t_b.get("scanf:sb") else None,  # (--time-region; profiles/r05_region_wg_residency.json has the exact per-workgroup figures)
                     launches=(t_b.get("scanf:sb") or kf)["n"],
