@@ -312,6 +312,26 @@ __global__ __launch_bounds__(1024) void gsn_scan_fused3_kernel(const ScanParams 
     SFSN_WG_STAMP(p.wg_times, 1);
 }
 
+// ... and its layer-0 twin (scan3y_role): what sfsn_gsn_layer_scan_fused_x launches for H <= 224; bit-identical to gsn_scan_fusedx_kernel.
+template <int KS, int TL, int OUT>
+__global__ __launch_bounds__(1024) void gsn_scan_fusedx3_kernel(const ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char scan_smem[];
+    int s = 0;
+    for (int i = 1; i < p.nseg; ++i)
+        if ((int)blockIdx.x >= p.seg[i].tile0) s = i;
+    const ScanSegDev& sg = p.seg[s];
+    Scan3yRole rl;
+    rl.x = sg.x_in; rl.w_ih = sg.w_ih_f32; rl.I = sg.I; rl.w_hh = sg.w_hh; rl.w_dq = sg.w_dq; rl.bias = sg.bias;
+    rl.bn_alpha = sg.bn_alpha; rl.bn_beta = sg.bn_beta; rl.h_state = sg.h_state; rl.c_state = sg.c_state;
+    rl.spikes_f32 = sg.spikes_f32; rl.spikes_i8 = sg.spikes_i8; rl.R = sg.R; rl.row0 = ((int)blockIdx.x - sg.tile0) * 16;
+    rl.count = sg.count; rl.lsplit = p.lsplit;
+    SFSN_WG_STAMP(p.wg_times, 0);
+    // (the k-chunk count is compile time: a wave-uniform `if` around operand loads makes hipcc drain lgkmcnt at every merge)
+    if (sg.I > 32) scan3y_role<KS, TL, OUT, 2>(rl, scan_smem, p.T, p.H, p.NT);
+    else scan3y_role<KS, TL, OUT, 1>(rl, scan_smem, p.T, p.H, p.NT);
+    SFSN_WG_STAMP(p.wg_times, 1);
+}
+
 // ---- streamed-weights scan: the shapes whose W_hh cannot live in one CU (unshared gates with H > 256: baseline_xl's
 // full-band layers, 2 x 320 x 320 x 3 B = 614 KB against 512 KB of registers + 160 KB of LDS) -------------------------
 // Same arithmetic as gsn_scan_kernel, bit for bit (same digit MFMAs, same epilogue), but every A fragment is fetched
@@ -2421,10 +2441,31 @@ extern "C" int sfsn_gsn_layer_scan_fused_x(const sfsn_scan_segment* segs, const 
     }
     p.nseg = n_segs; p.T = T; p.H = H; p.NT = H / 16;
     const int KS = (H + 63) / 64, HP = KS * 64;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // round 6: at most 14 tiles -> the IO-wave form (scan3y_role; SFSN_FUSED_V2=1 / SFSN_SCAN_V2=1 keep round 2's body: A/B runs, tests)
+    if (p.NT <= 14 && !getenv("SFSN_FUSED_V2") && !getenv("SFSN_SCAN_V2")) {
+        const bool tl = (H & 63) != 0 && (H & 63) <= 32;
+        const int lds3 = KS == 3 ? Scan3yCfg<3, 2>::lds_bytes(p.NT) : Scan3yCfg<4, 2>::lds_bytes(p.NT);
+        {
+            const char* e = getenv("SFSN_S3Y_LSPLIT");
+            const int x = e ? atoi(e) : SFSN_S3Y_LSPLIT;
+            p.lsplit = x < 0 ? 0 : (x > 14 ? 14 : x);
+        }
+#define FUSEDX3_CASE(KS_, TL_, OUT_)                                                                                       \
+    if (KS == KS_ && (int)tl == TL_ && out == OUT_ && lds3 <= 160 * 1024 - 64) {                                           \
+        auto kern = gsn_scan_fusedx3_kernel<KS_, TL_, OUT_>;                                                               \
+        static int seen[SFSN_MAX_DEVICES] = {0};                                                                           \
+        if (raise_lds(reinterpret_cast<const void*>(kern), lds3, seen) != SFSN_OK) return SFSN_EHIP;                       \
+        p.wg_times = sfsn_wgprobe_take(3, tiles);                                                                          \
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(1024), lds3, st, p);                                                    \
+        return hip_ok(hipGetLastError());                                                                                  \
+    }
+        FUSEDX3_CASE(3, 0, 2) FUSEDX3_CASE(3, 0, 3) FUSEDX3_CASE(3, 1, 2) FUSEDX3_CASE(3, 1, 3) FUSEDX3_CASE(4, 1, 2) FUSEDX3_CASE(4, 1, 3)
+#undef FUSEDX3_CASE
+    }
     const int xslot = (16 * imax * 4 + 1023) & ~1023;
     const int lds = 3 * xslot + 2 * 3 * 16 * 72 * 2 + 2 * 16 * (HP + 32) + 5 * HP * 4 + p.NT * KS * 1024;
     if (lds > 160 * 1024) return SFSN_EUNSUPPORTED;
-    hipStream_t st = static_cast<hipStream_t>(stream);
 #define FUSEDX_CASE(KS_, OUT_)                                                                                             \
     if (KS == KS_ && out == OUT_) {                                                                                        \
         auto kern = gsn_scan_fusedx_kernel<KS_, OUT_>;                                                                     \

@@ -321,4 +321,334 @@ __device__ __forceinline__ void scan3j_role(const Scan3jRole& rl, char* smem, in
     }
 }
 
+// =====================================================================================================================
+// scan3y_role -- the layer-0 twin at 16 rows: the real-valued input product x . W_ih^T + b of a group with narrow feature rows (even
+// I <= 64, rows a multiple of 16) inside the 16-row IO-wave scan, on the bf16 matrix cores with input_proj_bf3_kernel's 3-way split
+// (the six products per 32 k of fusedx_body / scan3x_role in their order into the same two accumulators, the same (hi + lo) + b):
+// what sfsn_gsn_layer_scan_fused_x launches for H <= 224 since round 6 (gsn_scan_fusedx3_kernel), bit-identical to round 2's body.
+//   compute waves: as scan3j_role; W_ih piece 1 in registers, pieces 2 / 3 in LDS as A fragments (written by the wave at set-up); the
+//       product of frame t + 1 behind the epilogue of frame t, finished to (hi + lo) + b_f in four registers.
+//   loader wave: a frame's 16 feature rows are one contiguous block (16 x I floats <= 4 KiB): LDS-DMA into a ring and, three frames
+//       ahead of their use, split by the same wave into three bf16 planes (row stride 72 elements).
+//   storer wave / spare waves: scan3j_role's.
+// =====================================================================================================================
+#ifndef SFSN_S3Y_LSPLIT
+// fp32 store instructions per frame issued by the loader wave (it also converts the features).  Measured (B = 64, T = 1000, 32 workgroups,
+// ms per launch): 0 / 1-3 / 4 / 7 -> 1.49 / 1.47 / 1.52 / 1.66 (round 2's body 1.64); without fp32 spikes 1.37 (1.64)
+#define SFSN_S3Y_LSPLIT 2
+#endif
+
+template <int KS, int KSB>
+struct Scan3yCfg {
+    static constexpr int RPW = 16, HP = KS * 64, LDH = HP + 32;
+    static constexpr int NPX = 4, XSLOT = NPX * 1024;      // a frame's features: 16 rows x I floats <= 4 KiB
+    static constexpr int A = 6, DX = 7;                    // frame t + A is requested during step t into the slot of frame t - 1 (converted at step t - 4)
+    static constexpr int LDX = 72, PLANE = 16 * LDX * 2;   // one bf16 plane of a frame's 16 rows
+    static constexpr int DP = 5;                           // plane slots: step t converts frame t + 3 into the slot of frame t - 2 (read during step t - 3)
+    static constexpr int PL_OFF = DX * XSLOT;
+    static constexpr int HBUF_OFF = PL_OFF + DP * 3 * PLANE;
+    static constexpr int CST_OFF = HBUF_OFF + 2 * 16 * LDH;  // [5][HP] floats: dq_hh, b_g - b_f, alpha, beta, b_f
+    static constexpr int WX_OFF = CST_OFF + 5 * HP * 4;
+    __host__ __device__ static constexpr int wx_bytes(int NT) { return 2 * NT * KSB * 1024; }  // pieces 2, 3 x tiles x k-chunks x 1 KiB
+    __host__ __device__ static constexpr int lds_bytes(int NT) { return WX_OFF + wx_bytes(NT); }
+};
+
+struct Scan3yRole {
+    const float* x;       // [T][R][I] the layer input (sfsn_features' output), R a multiple of 16
+    const float* w_ih;    // [H][I] fp32, row-major
+    int I;
+    const int8_t* w_hh;
+    const float* w_dq;
+    const float* bias;    // [2 H]: b_f, b_g
+    const float* bn_alpha;
+    const float* bn_beta;
+    float* h_state;
+    float* c_state;
+    float* spikes_f32;
+    int8_t* spikes_i8;
+    int R, row0;
+    unsigned long long* count;
+    int lsplit;
+};
+
+template <int KS, int TL, int OUT, int KSB>
+__device__ __forceinline__ void scan3y_role(const Scan3yRole& rl, char* smem, int T, int H, int NT) {
+    using C = Scan3yCfg<KS, KSB>;
+    constexpr int RPW = 16, LDH = C::LDH, HP = C::HP, A = C::A, DX = C::DX, XSLOT = C::XSLOT, NPX = C::NPX, LDX = C::LDX, PLANE = C::PLANE, DP = C::DP;
+    constexpr int KSF = TL ? KS - 1 : KS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int R = rl.R, row0 = rl.row0, I = rl.I;
+    int8_t* hbuf = reinterpret_cast<int8_t*>(smem + C::HBUF_OFF);
+    float(*cst)[HP] = reinterpret_cast<float(*)[HP]>(smem + C::CST_OFF);
+
+    // ---- set-up by all threads: state buffers and bf16 planes zeroed (k >= I must read as 0), constants, h_{-1} -> hbuf[0]
+    for (int i = tid; i < 2 * 16 * LDH / 4; i += 1024) reinterpret_cast<int*>(hbuf)[i] = 0;
+    for (int i = tid; i < DP * 3 * PLANE / 4; i += 1024) reinterpret_cast<int*>(smem + C::PL_OFF)[i] = 0;
+    for (int j = tid; j < HP; j += 1024) {
+        const bool in = j < H;
+        cst[0][j] = in ? rl.w_dq[j] : 0.0f;
+        cst[1][j] = in ? rl.bias[H + j] - rl.bias[j] : 0.0f;
+        cst[2][j] = in ? rl.bn_alpha[j] : 0.0f;
+        cst[3][j] = in ? rl.bn_beta[j] : 0.0f;
+        cst[4][j] = in ? rl.bias[j] : 0.0f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < RPW * (H / 4); idx += 1024) {
+        const int rr = idx / (H / 4), j4 = (idx - rr * (H / 4)) * 4;
+        const int rsrc = row0 + rr < R ? row0 + rr : R - 1;
+        const v4f h = *reinterpret_cast<const v4f*>(rl.h_state + (size_t)rsrc * H + j4);
+        const unsigned pk = (h.x > 0.5f ? 1u : 0u) | (h.y > 0.5f ? 0x100u : 0u) | (h.z > 0.5f ? 0x10000u : 0u) |
+                            (h.w > 0.5f ? 0x1000000u : 0u);
+        *reinterpret_cast<unsigned*>(hbuf + rr * LDH + j4) = pk;
+    }
+
+    if (wave < NT) {
+        // ================================================= compute wave: output tile `wave` =================================================
+        const int ct = wave;
+        const int cj = ct * 16 + q * 4;
+        const bool live = row0 + n < R;
+        const int grow = live ? row0 + n : R - 1;
+        const unsigned toff = (unsigned)((((q >> 1) * 16 + n) * 16) + (q & 1) * 8);
+        v4i Whh[KSF > 0 ? KSF : 1][3];
+        long Wht[3] = {0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks)
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                Whh[ks][d] = *reinterpret_cast<const v4i*>(rl.w_hh + ((((size_t)d * NT + ct) * KS + ks) * 64 + lane) * 16);
+        if constexpr (TL) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) Wht[d] = *reinterpret_cast<const long*>(rl.w_hh + (((size_t)d * NT + ct) * KS + KS - 1) * 1024 + toff);
+        }
+        // W_ih: A fragment = 8 consecutive k of weight row ct * 16 + n (as input_proj_bf3_kernel); piece 1 in registers, 2 / 3 -> LDS
+        bf8 Wx1[KSB];
+        const unsigned wxoff = (unsigned)(C::WX_OFF + (ct * KSB) * 1024 + lane * 16);
+        const int wxplane = NT * KSB * 1024;
+        {
+            const int wr = ct * 16 + n;
+#pragma unroll
+            for (int ks = 0; ks < KSB; ++ks) {
+                unsigned pw[3][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = ks * 32 + q * 8 + 2 * e;
+                    const float a = (wr < H && k < I) ? rl.w_ih[(size_t)wr * I + k] : 0.0f;
+                    const float b = (wr < H && k + 1 < I) ? rl.w_ih[(size_t)wr * I + k + 1] : 0.0f;
+                    split3(a, b, pw[0][e], pw[1][e], pw[2][e]);
+                }
+                Wx1[ks] = *reinterpret_cast<const bf8*>(pw[0]);
+                *reinterpret_cast<v4i*>(smem + wxoff + ks * 1024) = *reinterpret_cast<const v4i*>(pw[1]);
+                *reinterpret_cast<v4i*>(smem + wxoff + wxplane + ks * 1024) = *reinterpret_cast<const v4i*>(pw[2]);
+            }
+        }
+        v4f c = *reinterpret_cast<const v4f*>(rl.c_state + (size_t)grow * H + cj);
+        const unsigned boff = (unsigned)(n * LDH + q * 16);
+        const unsigned boft = (unsigned)(n * LDH + (KS - 1) * 64 + q * 8);
+        const unsigned hoff = (unsigned)(n * LDH + cj);
+        const unsigned xoff = (unsigned)(C::PL_OFF + (n * LDX + q * 8) * 2);  // my B fragment: row n, k = 32 ks + 8 q .. + 7 of a plane
+        const char* cq = smem + C::CST_OFF + cj * 4;
+        v4f z = {0.f, 0.f, 0.f, 0.f};
+        // the input term of frame f (plane slot f % DP) -> z: the product sequence of input_proj_bf3_kernel, instruction for instruction
+        auto in_product = [&](int f) __attribute__((always_inline)) {
+            const char* pl = smem + xoff + (f % DP) * 3 * PLANE;
+            v4f hi = {0.f, 0.f, 0.f, 0.f}, lo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSB; ++ks) {
+                const bf8 x1 = *reinterpret_cast<const bf8*>(pl + ks * 64);
+                const bf8 x2 = *reinterpret_cast<const bf8*>(pl + PLANE + ks * 64);
+                const bf8 x3 = *reinterpret_cast<const bf8*>(pl + 2 * PLANE + ks * 64);
+                const bf8 w2 = *reinterpret_cast<const bf8*>(smem + wxoff + ks * 1024);
+                const bf8 w3 = *reinterpret_cast<const bf8*>(smem + wxoff + wxplane + ks * 1024);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3, x1, lo, 0, 0, 0);
+                hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wx1[ks], x1, hi, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, x2, lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wx1[ks], x3, lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, x1, lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wx1[ks], x2, lo, 0, 0, 0);
+            }
+            const v4f bf = *reinterpret_cast<const v4f*>(cq + 4 * HP * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = (hi[r] + lo[r]) + bf[r];  // = input_proj_bf3_kernel's epilogue
+        };
+
+        __syncthreads();                       // initial state, W_ih pieces 2 / 3 and constants in LDS
+        __builtin_amdgcn_s_barrier();          // the loader's planes of frames 0 .. 2
+        in_product(0);
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
+            int8_t* hn = hbuf + ((t & 1) ^ 1) * 16 * LDH;
+            v4i b[KSF > 0 ? KSF : 1];
+#pragma unroll
+            for (int ks = 0; ks < KSF; ++ks) b[ks] = *reinterpret_cast<const v4i*>(hc + boff + ks * 64);
+            long bt = 0;
+            if constexpr (TL) bt = *reinterpret_cast<const long*>(hc + boft);
+            const v4f dq = *reinterpret_cast<const v4f*>(cq);
+            const v4f db = *reinterpret_cast<const v4f*>(cq + 1 * HP * 4);
+            const v4f al = *reinterpret_cast<const v4f*>(cq + 2 * HP * 4);
+            const v4f be = *reinterpret_cast<const v4f*>(cq + 3 * HP * 4);
+            v4i a[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
+            if constexpr (TL) {  // (the 32-wide tail step first, with its wait states: see scan3i_role)
+                asm volatile(
+                    "v_mfma_i32_16x16x32_i8 %0, %3, %6, 0\n\t"
+                    "v_mfma_i32_16x16x32_i8 %1, %4, %6, 0\n\t"
+                    "v_mfma_i32_16x16x32_i8 %2, %5, %6, 0\n\t"
+                    "s_nop 5"
+                    : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2])
+                    : "v"(Wht[0]), "v"(Wht[1]), "v"(Wht[2]), "v"(bt));
+                if constexpr (KSF == 0) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSF; ++ks)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) a[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[ks][d], b[ks], a[d], 0, 0, 0);
+            unsigned pk = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rec = (float)((a[2][r] << 16) + (a[1][r] << 8) + a[0][r]);
+                const float pre_f = __builtin_fmaf(rec, dq[r], z[r]);
+                const float pre_g = pre_f + db[r];
+                const float f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre_f * -1.44269504088896341f));
+                const float m = __builtin_fmaf(f, c[r] - pre_g, pre_g);
+                const float y = __builtin_fmaf(m, al[r], be[r]);
+                c[r] = y;
+                pk |= (y >= 0.0f) ? (1u << (8 * r)) : 0u;
+            }
+            *reinterpret_cast<unsigned*>(hn + hoff) = pk;
+            __builtin_amdgcn_sched_barrier(0);
+            in_product(t + 1);                   // off the chain (frames past the end: the loader converts clamped copies of the last one)
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
+        const int8_t* hl = hbuf + (T & 1) * 16 * LDH;
+        if (live) {
+            *reinterpret_cast<v4f*>(rl.c_state + (size_t)grow * H + cj) = c;
+            const unsigned pk = *reinterpret_cast<const unsigned*>(hl + hoff);
+            const v4f h = {(float)(pk & 1u), (float)((pk >> 8) & 1u), (float)((pk >> 16) & 1u), (float)((pk >> 24) & 1u)};
+            *reinterpret_cast<v4f*>(rl.h_state + (size_t)grow * H + cj) = h;
+        }
+        return;
+    }
+
+    if (wave == NT) {
+        // ================================================= loader wave: features -> ring -> bf16 planes =================================================
+        const int nchunk = 4 * I;  // 16 * I floats / 4
+        unsigned goff[NPX];
+        int po[NPX][4];            // my four floats of piece p: element offset within a bf16 plane (clamped lanes repeat the last chunk)
+#pragma unroll
+        for (int p = 0; p < NPX; ++p) {
+            int e = 64 * p + lane;
+            if (e > nchunk - 1) e = nchunk - 1;
+            goff[p] = (unsigned)e * 16u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = 4 * e + j, rr = f / I, k = f - rr * I;
+                po[p][j] = rr * LDX + k;
+            }
+        }
+        const size_t frame = (size_t)R * I;
+        const float* xbase = rl.x + (size_t)row0 * I;
+        S3FlushF<RPW, LDH> ffl;
+        if constexpr (OUT & 1) ffl.init(lane, row0, R, H, 0, rl.lsplit);
+        const int lst = (OUT & 1) ? ffl.nsf : 0;
+        int allow = (A - 3) * (NPX + lst) + lst;  // behind the DMA of frame t + 3: the DMAs and stores of the steps since, and this step's stores
+        if (allow > 62) allow = 62;
+        auto issue = [&](int slot, int td) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = 0; p < NPX; ++p)
+                dma16_to_lds(__builtin_amdgcn_readfirstlane((unsigned)(slot * XSLOT + p * 1024)), xbase + (size_t)td * frame, goff[p]);
+        };
+        auto convert = [&](int fr) __attribute__((always_inline)) {
+            const char* src = smem + (fr % DX) * XSLOT;
+            unsigned short* pl = reinterpret_cast<unsigned short*>(smem + C::PL_OFF + (fr % DP) * 3 * PLANE);
+#pragma unroll
+            for (int p = 0; p < NPX; ++p) {
+                const v4f v = *reinterpret_cast<const v4f*>(src + p * 1024 + lane * 16);  // (a clamped lane's DMA landed at its OWN lds position)
+                unsigned p1[2], p2[2], p3[2];
+                split3(v[0], v[1], p1[0], p2[0], p3[0]);
+                split3(v[2], v[3], p1[1], p2[1], p3[1]);
+                // (I is even and a chunk starts at an even float: the two values of a pair sit side by side in one row -> one 32-bit store
+                //  per pair and plane instead of two 16-bit ones)
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) {
+                    *reinterpret_cast<unsigned*>(pl + po[p][2 * j2]) = p1[j2];
+                    *reinterpret_cast<unsigned*>(pl + PLANE / 2 + po[p][2 * j2]) = p2[j2];
+                    *reinterpret_cast<unsigned*>(pl + PLANE + po[p][2 * j2]) = p3[j2];
+                }
+            }
+        };
+        __syncthreads();
+        if (T > 0)
+            for (int s0 = 0; s0 < A; ++s0) issue(s0, s0 < T ? s0 : T - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int fr = 0; fr < 3; ++fr) convert(fr);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            issue((t + A) % DX, (t + A < T) ? t + A : T - 1);
+            if constexpr (OUT & 1) if (t > 0 && lst > 0) ffl.run(hbuf + (t & 1) * 16 * LDH, rl.spikes_f32 + ((size_t)(t - 1) * R + row0) * H, lane);
+            wait_vmcnt_n(allow);    // frame t + 3 has landed
+            convert(t + 3);         // its planes are read during step t + 2; the slot held frame t - 2 (read during step t - 3)
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (OUT & 1) if (T > 0 && lst > 0) ffl.run(hbuf + (T & 1) * 16 * LDH, rl.spikes_f32 + ((size_t)(T - 1) * R + row0) * H, lane);
+        return;
+    }
+
+    if (wave == NT + 1) {
+        // ================================================= storer wave (scan3j_role's) =================================================
+        constexpr int MAX8 = (RPW * KS * 4 + 63) / 64;
+        constexpr int nu8 = RPW * (HP / 16), ns8 = (nu8 + 63) / 64;
+        constexpr bool F32 = (OUT & 1) != 0;
+        S3FlushF<RPW, LDH> ff;
+        if constexpr (F32) ff.init(lane, row0, R, H, rl.lsplit);
+        int l8[MAX8];
+        unsigned ok8 = 0;
+        unsigned cnt = 0;
+#pragma unroll
+        for (int k = 0; k < MAX8; ++k) {
+            const int u = 64 * k + lane, rr = u / (HP / 16), c16 = u - rr * (HP / 16);
+            l8[k] = rr * LDH + c16 * 16;
+            if (k < ns8 && u < nu8 && row0 + rr < R) ok8 |= 1u << k;
+        }
+        auto flush = [&](const int8_t* hsrc, int ts) __attribute__((always_inline)) {
+            int8_t* p8 = rl.spikes_i8 + ((size_t)ts * R + row0) * HP;
+#pragma unroll
+            for (int k = 0; k < MAX8; ++k) {
+                if ((ok8 >> k) & 1u) {
+                    const v4i d = *reinterpret_cast<const v4i*>(hsrc + l8[k]);
+                    *reinterpret_cast<v4i*>(p8 + (size_t)(64 * k + lane) * 16) = d;
+                    if constexpr (!(OUT & 1)) cnt += popc16(d);
+                }
+            }
+            if constexpr (F32) ff.run(hsrc, rl.spikes_f32 + ((size_t)ts * R + row0) * H, lane);
+        };
+        __syncthreads();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            if (t > 0) flush(hbuf + (t & 1) * 16 * LDH, t - 1);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (T > 0) flush(hbuf + (T & 1) * 16 * LDH, T - 1);
+        if constexpr (!(OUT & 1)) wave_count_add(rl.count, cnt);
+        return;
+    }
+
+    // ================================================= spare waves =================================================
+    __syncthreads();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 #endif

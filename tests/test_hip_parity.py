@@ -1507,6 +1507,68 @@ def test_fused_scan_with_io_waves_equals_round_2_body_and_the_two_calls(hip, H, 
     np.testing.assert_array_equal(lean[3], new[3])
 
 
+def _run_fused_x(hip, x, sd, alpha, beta, h0, c0, want_f32=True, segs_split=None):
+    """sfsn_gsn_layer_scan_fused_x on fp32 feature rows x [T, R, I] (a layer 0): fp32 spikes (or None), int8 spikes, h, c, count."""
+    from spiking_fullsubnet_amd._lib import FusedX, ScanSegment, check
+    from spiking_fullsubnet_amd.engine import pack_w3
+    T, R, I = x.shape
+    H = sd["weight_hh"].shape[1]
+    HP = (H + 63) // 64 * 64
+    pk, dq = pack_w3(sd["weight_hh"])
+    cuts = [0, R] if segs_split is None else [0, segs_split, R]
+    ns = len(cuts) - 1
+    keep = [_t(pk), _t(dq), _t(sd["weight_ih"].astype(np.float32)), _t(sd["bias_ih"]), _t(alpha), _t(beta)]
+    seg, fin, outs = (ScanSegment * ns)(), (FusedX * ns)(), []
+    for i in range(ns):
+        r0, r1 = cuts[i], cuts[i + 1]
+        t = dict(x=_t(np.ascontiguousarray(x[:, r0:r1])), h=_t(h0[r0:r1]), c=_t(c0[r0:r1]),
+                 spk=torch.empty((T, r1 - r0, H), device=DEV) if want_f32 else None,
+                 s8=torch.zeros((T, r1 - r0, HP), dtype=torch.int8, device=DEV), cnt=torch.zeros((1,), dtype=torch.int64, device=DEV))
+        s = seg[i]
+        s.zin, s.w_hh, s.w_dq, s.bias, s.bn_alpha, s.bn_beta = None, _p(keep[0]), _p(keep[1]), _p(keep[3]), _p(keep[4]), _p(keep[5])
+        s.h_state, s.c_state, s.spikes_f32, s.spikes_i8, s.membrane, s.R = _p(t["h"]), _p(t["c"]), _p(t["spk"]), _p(t["s8"]), None, r1 - r0
+        s.spike_count = None if want_f32 else _p(t["cnt"])
+        fin[i].x, fin[i].w_ih, fin[i].I = t["x"].data_ptr(), keep[2].data_ptr(), I
+        outs.append(t)
+    check(hip.sfsn_gsn_layer_scan_fused_x(seg, fin, ns, T, H, None), "sfsn_gsn_layer_scan_fused_x")
+    torch.cuda.synchronize()
+    cat = lambda k: None if outs[0][k] is None else torch.cat([o[k] for o in outs], dim=1 if k in ("spk", "s8") else 0).cpu().numpy()
+    return cat("spk"), cat("s8"), cat("h"), cat("c"), sum(int(o["cnt"][0]) for o in outs)
+
+
+@pytest.mark.parametrize("I,H,R,T,split", [(38, 224, 32, 33, None), (38, 224, 16, 1, None), (64, 224, 48, 2, 16), (20, 160, 32, 19, None),
+                                           (32, 192, 64, 17, 32), (34, 144, 16, 12, None), (62, 208, 32, 11, None), (6, 176, 16, 9, None),
+                                           (38, 224, 512, 60, None)])
+def test_fused_x_scan_with_io_waves_equals_round_2_body_and_the_two_calls(hip, I, H, R, T, split, monkeypatch):
+    """Round 6: sfsn_gsn_layer_scan_fused_x runs scan3y_role (16 rows per workgroup, IO-specialised waves, the bf16 three-way split of
+    the real-valued input product inside) for H <= 224.  Bit for bit equal to round 2's body (SFSN_FUSED_V2=1) and to
+    sfsn_input_proj_f32 + sfsn_gsn_layer_scan: one and two 32-wide k-chunks, every k-step form of the recurrent product, one / two /
+    odd frame counts, two segments, non-zero initial state, the spike count without fp32 spikes."""
+    from test_stack_scan import _input_proj
+    rng = np.random.default_rng(H * 5 + I)
+    sd, alpha, beta, bnp = make_layer(rng, I, H, True, True)
+    x = rng.standard_normal((T, R, I)).astype(np.float32)
+    h0 = (rng.random((R, H)) > 0.5).astype(np.float32)
+    c0 = rng.standard_normal((R, H)).astype(np.float32)
+    new = _run_fused_x(hip, x, sd, alpha, beta, h0, c0, segs_split=split)
+    monkeypatch.setenv("SFSN_FUSED_V2", "1")
+    old = _run_fused_x(hip, x, sd, alpha, beta, h0, c0, segs_split=split)
+    monkeypatch.delenv("SFSN_FUSED_V2")
+    for a, b, nm in zip(new[:4], old[:4], ("fp32 spikes", "int8 spikes", "h", "c")):
+        np.testing.assert_array_equal(a, b, err_msg=nm)
+    assert new[1].any() and not new[1][:, :, H:].any()
+    if T * R >= 64:  # (below that sfsn_input_proj_f32 takes its fp32-MFMA form: another summation order)
+        zin = _input_proj(hip, x, sd["weight_ih"]).reshape(T, R, H)
+        spk, _, s8, hT, cT = run_scan(hip, zin, sd["weight_hh"], sd["bias_ih"], alpha, beta, True, h0, c0, want_mem=False)
+        np.testing.assert_array_equal(new[0], spk)
+        np.testing.assert_array_equal(new[2], hT)
+        np.testing.assert_array_equal(new[3], cT)
+    lean = _run_fused_x(hip, x, sd, alpha, beta, h0, c0, want_f32=False, segs_split=split)
+    assert lean[0] is None and lean[4] == int(new[0].sum())
+    np.testing.assert_array_equal(lean[1], new[1])
+    np.testing.assert_array_equal(lean[3], new[3])
+
+
 def test_feature_launch_zeroes_the_scan_states_and_nothing_else(hip, monkeypatch):
     """sfsn_features_z: extra workgroups of the feature launch write the zero initial state of the forward's scans (MODEL:100-106)
     -- exactly the bytes asked for, the features themselves unchanged -- and the engine's forward gives the same bits with the
