@@ -65,6 +65,13 @@
 #ifndef SFSN_S3X_LSPLIT
 #define SFSN_S3X_LSPLIT 0
 #endif
+#ifndef SFSN_S3_NT
+// 1: the fp32 spike tensors (the module API's all_layer_outputs: written once, never read again on the device) leave as NON-TEMPORAL
+// stores: 1.5 GB of write-once lines per forward need not displace what the L2 holds for the full-band stack's hand-offs and the
+// time-parallel kernels.  Measured (round 6, interleaved A/B, scripts/ab_lib_r06.sh): strict forward 2.44-2.45 against 2.49-2.56 ms, pair
+// launch 0.956-0.965 against 0.973 ms, timed region unchanged.
+#define SFSN_S3_NT 1
+#endif
 #ifndef SFSN_S3_PFMAX
 #define SFSN_S3_PFMAX 8   // frames of a publishing storer's stores that may be in flight (24 measured the same: the limit is elsewhere)
 #endif
@@ -188,7 +195,11 @@ struct S3FlushF {
             if ((okf >> k) & 1u) {
                 const unsigned pk = *reinterpret_cast<const unsigned*>(hsrc + lf[k]);
                 const v4f sp = {(float)(pk & 0xffu), (float)((pk >> 8) & 0xffu), (float)((pk >> 16) & 0xffu), (float)(pk >> 24)};
+#if SFSN_S3_NT
+                __builtin_nontemporal_store(sp, reinterpret_cast<v4f*>(pf + (size_t)(64 * k + lane) * 4));
+#else
                 *reinterpret_cast<v4f*>(pf + (size_t)(64 * k + lane) * 4) = sp;
+#endif
             }
         }
     }

@@ -91,7 +91,11 @@ struct S3wFlushF {
             if ((okf >> k) & 1u) {
                 const unsigned pk = *reinterpret_cast<const unsigned*>(hsrc + lf[k]);
                 const v4f sp = {(float)(pk & 0xffu), (float)((pk >> 8) & 0xffu), (float)((pk >> 16) & 0xffu), (float)(pk >> 24)};
+#if SFSN_S3_NT
+                __builtin_nontemporal_store(sp, reinterpret_cast<v4f*>(pf + (size_t)(64 * k + lane) * 4));
+#else
                 *reinterpret_cast<v4f*>(pf + (size_t)(64 * k + lane) * 4) = sp;
+#endif
             }
         }
     }

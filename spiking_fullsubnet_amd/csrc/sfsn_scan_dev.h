@@ -12,6 +12,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define SFSN_WAVE 64
+#ifndef SFSN_NT_OUT
+#define SFSN_NT_OUT 1  // write-once API tensors (fp32 spikes of round 2's bodies, coefficient rows, enhanced spectrum / magnitude) as non-temporal stores (see SFSN_S3_NT)
+#endif
 
 // =====================================================================================================
 // GSN layer scan
@@ -332,7 +335,11 @@ struct ScanFlush {
                 if ((OUT & 2) && !SC1) *reinterpret_cast<unsigned*>(p8 + off_i8[k]) = pk;
                 if (OUT & 1) {
                     const v4f sp = {(float)(pk & 0xffu), (float)((pk >> 8) & 0xffu), (float)((pk >> 16) & 0xffu), (float)(pk >> 24)};
+#if SFSN_NT_OUT
+                    __builtin_nontemporal_store(sp, reinterpret_cast<v4f*>(pf + off_f32[k]));  // (API tensor: written once, never read again here)
+#else
                     *reinterpret_cast<v4f*>(pf + off_f32[k]) = sp;
+#endif
                 }
             }
         }
