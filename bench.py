@@ -400,6 +400,9 @@ def main():
             m16.weight_bits = 16
             e16 = m16.engine()
             e16.stack_scan = eng.stack_scan
+            # (the second engine shares the first one's side streams: streams created THIS late in the process -- behind the twelve lanes'
+            #  and the sessions' -- landed on one hardware queue and the full-band / sub-band overlap of a forward was gone: 2.77 ms against 2.36)
+            e16._ov_streams, e16._err_stream = eng._ov_streams, eng._err_stream
             set_geometry((0, 0))
             e16.rows_per_wg, e16.stack_rows_fb_auto = eng.rows_per_wg, eng.stack_rows_fb_auto
             eng.overlap_chunks = e16.overlap_chunks = ov_default

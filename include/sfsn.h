@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFSN_ABI_VERSION 18 /* bumped on every struct / signature change: a stale .so must not load */
+#define SFSN_ABI_VERSION 19 /* bumped on every struct / signature change: a stale .so must not load */
 
 #define SFSN_OK 0
 #define SFSN_EINVAL (-1)       /* malformed argument (NULL where required, size <= 0, misaligned pointer)      */
@@ -288,6 +288,14 @@ int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs /* host [n_layers][n_segs]
  * layout this entry point gives stacks of H <= 224 without input-term buffers (or a single layer): 8 rows per workgroup in every
  * layer, even I <= 64, R a multiple of 8, x 16-byte aligned; SFSN_EUNSUPPORTED otherwise (use `zin`). */
 int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, const sfsn_fused_x* fx /* host [n_segs], nullable */,
+                          int n_layers, int n_segs, int T, int H, const int* rows_per_wg, int lag, void* scratch, size_t scratch_bytes,
+                          void* stream);
+/* Round 6 (ABI 19): the same launch for weights packed with 16 bits (sfsn_w3_pack_bits(w, n, k, 16, ..): the least significant digit plane
+ * of every recurrent / spike-input matrix is zero): the zero plane's matrix instructions are skipped in the IO-wave scan, FUSEDX3 and FUSED3
+ * roles of the sub-band pair layout (8 rows per workgroup, no input-term buffers for the layers >= 1, H <= 224) -- the same sums, hence the
+ * same results as sfsn_gsn_stack_scan_x on such weights.  SFSN_EUNSUPPORTED for every other layout.  BASELINE configs[2]'s 16-bit mode
+ * (module.weight_bits = 16): a report mode, not the fp32 parity mode. */
+int sfsn_gsn_stack_scan_x_w16(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, const sfsn_fused_x* fx /* host [n_segs], nullable */,
                           int n_layers, int n_segs, int T, int H, const int* rows_per_wg, int lag, void* scratch, size_t scratch_bytes,
                           void* stream);
 

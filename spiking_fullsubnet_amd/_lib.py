@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libsfsn_hip.so")
 SFSN_OK, SFSN_EINVAL, SFSN_EUNSUPPORTED, SFSN_EHIP, SFSN_EDIVISIBLE = 0, -1, -2, -3, -4
 NORM_NONE, NORM_LAYERNORM, NORM_LAPLACE, NORM_CUMLAPLACE, NORM_GAUSSIAN = 0, 1, 2, 3, 4
 MAX_SEGMENTS, MAX_GROUPS, MAX_HIDDEN = 8, 8, 320
-ABI_VERSION = 18  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
+ABI_VERSION = 19  # = SFSN_ABI_VERSION of include/sfsn.h; bumped with every struct / signature change
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -202,6 +202,8 @@ def lib() -> ctypes.CDLL:
     L.sfsn_gsn_stack_scan_x.restype = _I
     L.sfsn_gsn_stack_scan_x.argtypes = [ctypes.POINTER(ScanSegment), ctypes.POINTER(FusedInput), ctypes.POINTER(FusedX), _I, _I, _I, _I,
                                         ctypes.POINTER(_I), _I, _P, ctypes.c_size_t, _P]
+    L.sfsn_gsn_stack_scan_x_w16.restype = _I
+    L.sfsn_gsn_stack_scan_x_w16.argtypes = L.sfsn_gsn_stack_scan_x.argtypes
     L.sfsn_input_proj_f32.restype = _I
     L.sfsn_input_proj_f32.argtypes = [_P, _P, _P, _P, _I, _I, _I, _I, _P]
     L.sfsn_spike_proj.restype = _I
@@ -259,7 +261,7 @@ EXPORTS = ("sfsn_abi_version", "sfsn_source_hash", "sfsn_strerror", "sfsn_device
            "sfsn_gsn_train_seq_fwd", "sfsn_gsn_train_seq_bwd", "sfsn_gsn_layer_scan_w16", "sfsn_gsn_train_check", "sfsn_gsn_stack_scan_x", "sfsn_train_seq_scratch_bytes", "sfsn_gsn_train_multi_check",
            "sfsn_gsn_train_seq_fwd_multi", "sfsn_gsn_train_seq_bwd_multi", "sfsn_features_z", "sfsn_gaussian_stats", "sfsn_gsn_train_step_check",
            "sfsn_spike_proj_multi", "sfsn_input_proj_f32_multi", "sfsn_features_proj",
-           "sfsn_scan_split_scratch_bytes", "sfsn_gsn_layer_scan_split", "sfsn_proj_deepfilter")
+           "sfsn_scan_split_scratch_bytes", "sfsn_gsn_layer_scan_split", "sfsn_proj_deepfilter", "sfsn_gsn_stack_scan_x_w16")
 
 
 def check(rc: int, what: str = "") -> None:

@@ -69,7 +69,9 @@ struct Scan3iRole {
 // are cut out of the 16x16x64 fragment layout (lane (n, q) of the 32-wide step holds k = 8 q + j = bytes [(q & 1) * 8, +8) of lane
 // (n, q >> 1)): six registers less of W_hh.
 // FLG / OUT as in scan3_role.  8 rows per workgroup.
-template <int KS, int TL, int OUT, int FLG>
+// D0 = 1 (round 6): the weights were packed with 16 bits (sfsn_w3_pack_bits): digit plane 0 of BOTH matrices is zero and its matrix
+// instructions are skipped -- 12 instead of 18 per tile and step, the same sums (the 16-bit report mode, sfsn_gsn_stack_scan_x_w16).
+template <int KS, int TL, int OUT, int FLG, int D0 = 0>
 __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLink& lk, char* smem, int T, int H, int NT, int exp_flags = 0) {
     using C = Scan3iCfg<KS, FLG>;
     constexpr int RPW = 8, LDH = C::LDH, HP = C::HP, D = C::D, A = C::A, SLOT = C::SLOT, NP = C::NP, NCH = C::NCH;
@@ -172,7 +174,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
                 if (ks >= NK) continue;
                 if (part == 0) {
                     pfb[i] = *reinterpret_cast<const v4i*>(ring + soff[ks]);
-                    pfw0[i] = *reinterpret_cast<const v4i*>(smem + woff + ks * 1024);
+                    if constexpr (!D0) pfw0[i] = *reinterpret_cast<const v4i*>(smem + woff + ks * 1024);
                 } else {
                     pfw1[i] = *reinterpret_cast<const v4i*>(smem + woff + PLANE + ks * 1024);
                 }
@@ -187,7 +189,7 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
                     const int ks = k0 + i;
                     if (ks >= NK) continue;
                     if (pass == 0) {
-                        e[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(pfw0[i], pfb[i], e[0], 0, 0, 0);
+                        if constexpr (!D0) e[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(pfw0[i], pfb[i], e[0], 0, 0, 0);
                         e[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wi2[ks], pfb[i], e[2], 0, 0, 0);
                     } else {
                         e[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(pfw1[i], pfb[i], e[1], 0, 0, 0);
@@ -245,19 +247,28 @@ __device__ __forceinline__ void scan3i_role(const Scan3iRole& rl, const StackLin
                     // shapes as back-to-back compatible (no wait states), the hardware does not forward between them -- sums came
                     // out wrong whenever the two met within two matrix instructions (scripts/micro/pair_role.hip; in a kernel
                     // where the scheduler happened to move them together: H = 96 in tests/test_stack_scan.py).
-                    asm volatile(
-                        "v_mfma_i32_16x16x32_i8 %0, %3, %6, 0\n\t"
-                        "v_mfma_i32_16x16x32_i8 %1, %4, %6, 0\n\t"
-                        "v_mfma_i32_16x16x32_i8 %2, %5, %6, 0\n\t"
-                        "s_nop 5"
-                        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2])
-                        : "v"(Wht[0]), "v"(Wht[1]), "v"(Wht[2]), "v"(bt));
+                    if constexpr (D0) {
+                        asm volatile(
+                            "v_mfma_i32_16x16x32_i8 %0, %2, %4, 0\n\t"
+                            "v_mfma_i32_16x16x32_i8 %1, %3, %4, 0\n\t"
+                            "s_nop 7"
+                            : "=&v"(a[1]), "=&v"(a[2])
+                            : "v"(Wht[1]), "v"(Wht[2]), "v"(bt));
+                    } else {
+                        asm volatile(
+                            "v_mfma_i32_16x16x32_i8 %0, %3, %6, 0\n\t"
+                            "v_mfma_i32_16x16x32_i8 %1, %4, %6, 0\n\t"
+                            "v_mfma_i32_16x16x32_i8 %2, %5, %6, 0\n\t"
+                            "s_nop 5"
+                            : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2])
+                            : "v"(Wht[0]), "v"(Wht[1]), "v"(Wht[2]), "v"(bt));
+                    }
                     if constexpr (KSF == 0) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // (the epilogue reads them next)
                 }
 #pragma unroll
                 for (int ks = 0; ks < KSF; ++ks)
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) a[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[ks][d], b[ks], a[d], 0, 0, 0);
+                    for (int d = D0; d < 3; ++d) a[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[ks][d], b[ks], a[d], 0, 0, 0);
                 // columns 0..7 are live: lanes 8..15 of a row of 16 take elements 2, 3 of the lane 8 below them; exact sum (= recombine3)
                 int ri[2];
                 {

@@ -60,7 +60,7 @@ struct Scan3xRole {
 
 // KSB: 32-wide k-chunks of the input product (2: 32 < I <= 64, 1: I <= 32) -- compile time, so that a step is straight-line code (a
 // wave-uniform `if` around the operand loads made hipcc drain lgkmcnt at every merge: 2.0 us per step instead of 0.9)
-template <int KS, int TL, int OUT, int FLG, int KSB>
+template <int KS, int TL, int OUT, int FLG, int KSB, int D0 = 0>  // (D0 = 1: 16-bit recurrent weights, digit plane 0 skipped -- see scan3i_role)
 __device__ __forceinline__ void scan3x_role(const Scan3xRole& rl, const StackLink& lk, char* smem, int T, int H, int NT) {
     using C = Scan3xCfg<KS, FLG>;
     constexpr int RPW = 8, LDH = C::LDH, HP = C::HP, A = C::A, DX = C::DX, XSLOT = C::XSLOT, NPX = C::NPX, LDX = C::LDX, PLANE = C::PLANE, DP = C::DP;
@@ -206,19 +206,28 @@ __device__ __forceinline__ void scan3x_role(const Scan3xRole& rl, const StackLin
                 if constexpr (TL) bt = *reinterpret_cast<const long*>(hc + boft);
                 v4i a[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
                 if constexpr (TL) {  // (the 32-wide tail step first, with its wait states: see scan3i_role)
-                    asm volatile(
-                        "v_mfma_i32_16x16x32_i8 %0, %3, %6, 0\n\t"
-                        "v_mfma_i32_16x16x32_i8 %1, %4, %6, 0\n\t"
-                        "v_mfma_i32_16x16x32_i8 %2, %5, %6, 0\n\t"
-                        "s_nop 5"
-                        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2])
-                        : "v"(Wht[0]), "v"(Wht[1]), "v"(Wht[2]), "v"(bt));
+                    if constexpr (D0) {
+                        asm volatile(
+                            "v_mfma_i32_16x16x32_i8 %0, %2, %4, 0\n\t"
+                            "v_mfma_i32_16x16x32_i8 %1, %3, %4, 0\n\t"
+                            "s_nop 7"
+                            : "=&v"(a[1]), "=&v"(a[2])
+                            : "v"(Wht[1]), "v"(Wht[2]), "v"(bt));
+                    } else {
+                        asm volatile(
+                            "v_mfma_i32_16x16x32_i8 %0, %3, %6, 0\n\t"
+                            "v_mfma_i32_16x16x32_i8 %1, %4, %6, 0\n\t"
+                            "v_mfma_i32_16x16x32_i8 %2, %5, %6, 0\n\t"
+                            "s_nop 5"
+                            : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2])
+                            : "v"(Wht[0]), "v"(Wht[1]), "v"(Wht[2]), "v"(bt));
+                    }
                     if constexpr (KSF == 0) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
                 }
 #pragma unroll
                 for (int ks = 0; ks < KSF; ++ks)
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) a[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[ks][d], b[ks], a[d], 0, 0, 0);
+                    for (int d = D0; d < 3; ++d) a[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Whh[ks][d], b[ks], a[d], 0, 0, 0);
                 int ri[2];
                 {
                     int v[3][2];

@@ -685,7 +685,8 @@ __device__ __forceinline__ void stack_zin16_role(const StackRoleDev& rl, const S
                                                 rowc, n, q, tid, wave, rpw, &lk, gate_word, rl.count);
 }
 
-template <int KS, int OUT>
+// D0 = 1 (round 6, sfsn_gsn_stack_scan_x_w16): 16-bit weights, the zero digit plane's matrix instructions skipped in every scan role
+template <int KS, int OUT, int D0 = 0>
 __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams p) {
     extern __shared__ __attribute__((aligned(16))) char scan_smem[];
     int* gate_word_p = reinterpret_cast<int*>(scan_smem + p.gate_off);
@@ -729,8 +730,8 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         const bool tl = (H & 63) != 0 && (H & 63) <= 32;
 #define X3_CASE(TL_, F_)                                                                    \
     {                                                                                       \
-        if (rl.I > 32) scan3x_role<KS, TL_, OUT, F_, 2>(rx, lk, scan_smem, T, H, NT);       \
-        else scan3x_role<KS, TL_, OUT, F_, 1>(rx, lk, scan_smem, T, H, NT);                 \
+        if (rl.I > 32) scan3x_role<KS, TL_, OUT, F_, 2, D0>(rx, lk, scan_smem, T, H, NT);   \
+        else scan3x_role<KS, TL_, OUT, F_, 1, D0>(rx, lk, scan_smem, T, H, NT);             \
     }
         if (rl.pub) {
             if (tl) X3_CASE(1, 2)
@@ -751,11 +752,11 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
         const bool tl = (H & 63) != 0 && (H & 63) <= 32;  // the k tail as one 16x16x32 step
         // (KS = 4 with at most 14 tiles is H = 208 or 224: always the tail form -- four full k-steps of both matrices do not fit)
         if (rl.pub) {
-            if (tl) scan3i_role<KS, 1, OUT, 3>(ri, lk, scan_smem, T, H, NT, p.exp_flags);
-            else if constexpr (KS < 4) scan3i_role<KS, 0, OUT, 3>(ri, lk, scan_smem, T, H, NT, p.exp_flags);
+            if (tl) scan3i_role<KS, 1, OUT, 3, D0>(ri, lk, scan_smem, T, H, NT, p.exp_flags);
+            else if constexpr (KS < 4) scan3i_role<KS, 0, OUT, 3, D0>(ri, lk, scan_smem, T, H, NT, p.exp_flags);
         } else {
-            if (tl) scan3i_role<KS, 1, OUT, 1>(ri, lk, scan_smem, T, H, NT, p.exp_flags);
-            else if constexpr (KS < 4) scan3i_role<KS, 0, OUT, 1>(ri, lk, scan_smem, T, H, NT, p.exp_flags);
+            if (tl) scan3i_role<KS, 1, OUT, 1, D0>(ri, lk, scan_smem, T, H, NT, p.exp_flags);
+            else if constexpr (KS < 4) scan3i_role<KS, 0, OUT, 1, D0>(ri, lk, scan_smem, T, H, NT, p.exp_flags);
         }
     } else if (rl.kind == STACK_PROJ) {
         if (NT <= 14 && !p.v2) {
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(1024) void gsn_stack_wide_kernel(const StackParams 
             r3.probe = lk.probe;
 #endif
 #define S3_CASE(RPW_, F) \
-    if (rl.rpw == RPW_ && flg == F) scan3_role<KS, RPW_, OUT, F>(r3, lk, scan_smem, T, H, NT, p.exp_flags);
+    if (rl.rpw == RPW_ && flg == F) scan3_role<KS, RPW_, OUT, F, D0>(r3, lk, scan_smem, T, H, NT, p.exp_flags);
             S3_CASE(4, 0) S3_CASE(4, 1) S3_CASE(4, 2) S3_CASE(4, 3)
             S3_CASE(8, 0) S3_CASE(8, 1) S3_CASE(8, 2) S3_CASE(8, 3)
             S3_CASE(16, 0) S3_CASE(16, 1) S3_CASE(16, 2) S3_CASE(16, 3)
@@ -972,9 +973,27 @@ extern "C" int sfsn_gsn_stack_scan(const sfsn_scan_segment* segs, const sfsn_fus
     return sfsn_gsn_stack_scan_x(segs, fin, nullptr, n_layers, n_segs, T, H, rows_per_wg, lag, scratch, scratch_bytes, stream);
 }
 
+static int stack_scan_impl(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, const sfsn_fused_x* fx, int n_layers, int n_segs, int T,
+                           int H, const int* rows_per_wg, int lag, void* scratch, size_t scratch_bytes, void* stream, int w16);
+
 extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, const sfsn_fused_x* fx, int n_layers,
                                      int n_segs, int T, int H, const int* rows_per_wg, int lag, void* scratch, size_t scratch_bytes,
                                      void* stream) {
+    return stack_scan_impl(segs, fin, fx, n_layers, n_segs, T, H, rows_per_wg, lag, scratch, scratch_bytes, stream, 0);
+}
+
+// The same launch for weights packed with 16 bits (sfsn_w3_pack_bits(.., 16, ..): digit plane 0 of every recurrent / spike-input matrix
+// is zero): the sub-band pair layout (IO-wave scan roles, FUSEDX3, FUSED3) with the zero plane's matrix instructions skipped -- the same
+// sums, 12 instead of 18 per tile and frame in the FUSED3 role.  SFSN_EUNSUPPORTED for any other layout (call sfsn_gsn_stack_scan_x:
+// same results).  The 16-bit report mode of BASELINE configs[2] (module.weight_bits = 16), not the parity mode.
+extern "C" int sfsn_gsn_stack_scan_x_w16(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, const sfsn_fused_x* fx, int n_layers,
+                                         int n_segs, int T, int H, const int* rows_per_wg, int lag, void* scratch, size_t scratch_bytes,
+                                         void* stream) {
+    return stack_scan_impl(segs, fin, fx, n_layers, n_segs, T, H, rows_per_wg, lag, scratch, scratch_bytes, stream, 1);
+}
+
+static int stack_scan_impl(const sfsn_scan_segment* segs, const sfsn_fused_input* fin, const sfsn_fused_x* fx, int n_layers, int n_segs, int T,
+                           int H, const int* rows_per_wg, int lag, void* scratch, size_t scratch_bytes, void* stream, int w16) {
     if (!segs || !fin || n_layers <= 0 || n_segs <= 0 || n_segs > SFSN_MAX_SEGMENTS || T < 0 || H <= 0 || !scratch) return SFSN_EINVAL;
     if (H % 16 != 0 || H > SFSN_MAX_HIDDEN) return SFSN_EUNSUPPORTED;
     const int KS = (H + 63) / 64, NT = H / 16, HP = KS * 64;
@@ -994,6 +1013,7 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
         if ((rows_per_wg ? rows_per_wg[l] : 8) != 8) inscan = false;
     if (inscan) wide = true;
     if (wide) fused = false;
+    if (w16 && !(inscan && (KS == 3 || KS == 4))) return SFSN_EUNSUPPORTED;  // the two-plane form exists for the pair layout only
     // round 5: 256 < H <= 320 at 4 / 8 rows per workgroup: the 768-thread kernel with IO-specialised scan roles (SFSN_SCAN_V2=1 keeps
     // round 2's bodies: A/B runs)
     // Where it is used -- measured (scripts/exp_fb3_r05.py, exp_fb3_chunks_r05.sh; B = 64): the stack ALONE on the chip 1.09 / 1.34 ms
@@ -1172,6 +1192,18 @@ extern "C" int sfsn_gsn_stack_scan_x(const sfsn_scan_segment* segs, const sfsn_f
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, st, q);                                                       \
         return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;                                                         \
     }
+#define WIDE16_CASE(KS_, OUT_)                                                                                                \
+    if (w16 && wide && !p.v2 && KS == KS_ && out == OUT_) {                                                                   \
+        auto kern = gsn_stack_wide_kernel<KS_, OUT_, 1>;                                                                      \
+        if (lds > 64 * 1024 &&                                                                                                \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
+            return SFSN_EHIP;                                                                                                 \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, st, p);                                                       \
+        return hipGetLastError() == hipSuccess ? SFSN_OK : SFSN_EHIP;                                                         \
+    }
+    WIDE16_CASE(3, 2) WIDE16_CASE(3, 3) WIDE16_CASE(4, 2) WIDE16_CASE(4, 3)
+#undef WIDE16_CASE
+    if (w16) return SFSN_EUNSUPPORTED;
     WIDE_CASE(1, 2) WIDE_CASE(1, 3) WIDE_CASE(2, 2) WIDE_CASE(2, 3) WIDE_CASE(3, 2) WIDE_CASE(3, 3) WIDE_CASE(4, 2) WIDE_CASE(4, 3)
 #undef WIDE_CASE
     if (fb3 && out == 2) return launch_stack_fb<2>(p, blocks, lds, st);

@@ -670,7 +670,16 @@ class Engine:
         rpw = (ctypes.c_int * nl)(*([rp] * nl))
         self.launches["stack"] = self.launches.get("stack", 0) + 1
         with self.timed("stack:" + tag, st):
-            if xg:
+            rc16 = _lib.SFSN_EUNSUPPORTED
+            if self.weight_bits == 16 and self.w16_fast:  # the two-plane roles where the library has them (the pair layout): same results
+                rc16 = L.sfsn_gsn_stack_scan_x_w16(segs, fin, fx, nl, ns, nt, H, rpw, self.stack_lag if lag is None else lag, _ptr(scratch), nbytes, st)
+                if rc16 not in (0, _lib.SFSN_EUNSUPPORTED):
+                    check(rc16, "sfsn_gsn_stack_scan_x_w16")
+                if rc16 == 0:
+                    self.launches["stack_w16"] = self.launches.get("stack_w16", 0) + 1
+            if rc16 == 0:
+                pass
+            elif xg:
                 check(L.sfsn_gsn_stack_scan_x(segs, fin, fx, nl, ns, nt, H, rpw, self.stack_lag if lag is None else lag, _ptr(scratch), nbytes, st),
                       "sfsn_gsn_stack_scan_x")
             else:

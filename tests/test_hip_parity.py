@@ -1387,17 +1387,25 @@ def test_sixteen_bit_weights_take_the_two_plane_scan_with_the_same_results():
     stft = torch.stft(wave, 512, 128, 512, window=torch.hann_window(512, device=DEV), return_complex=True, pad_mode="constant")[..., :T].contiguous()
     eng = model.engine()
     assert eng.weight_bits == 16
-    eng.stack_scan = False  # per-layer launches: the path that has the two-plane form
-    res = {}
-    for fast in (False, True):
-        eng.w16_fast = fast
-        eng.launches = {}
-        res[fast] = eng.forward_stft(stft)
-        torch.cuda.synchronize()
-    a, b = res[False], res[True]
-    assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(b["enh_stft"]))
-    for x, y in zip(a["fb_all"] + sum(a["sb_all"], []), b["fb_all"] + sum(b["sb_all"], [])):
-        assert torch.equal(x, y)
+    ref = None
+    # per-layer launches (sfsn_gsn_layer_scan_w16) and -- round 6 -- the pair launch of the sub-band layers (sfsn_gsn_stack_scan_x_w16:
+    # two-plane scan3 / FUSEDX3 / FUSED3 roles), as one whole-sequence launch and in the overlapped three-chunk schedule
+    for stack, chunks in ((False, 0), ("auto", 0), ("auto", 3)):
+        eng.stack_scan, eng.overlap_chunks = stack, chunks
+        res = {}
+        for fast in (False, True):
+            eng.w16_fast = fast
+            eng.launches = {}
+            res[fast] = eng.forward_stft(stft)
+            torch.cuda.synchronize()
+            assert (eng.launches.get("stack_w16", 0) > 0) == (fast and stack == "auto"), eng.launches
+        a, b = res[False], res[True]
+        ref = ref or a
+        for c in (b, ref):
+            assert torch.equal(torch.view_as_real(a["enh_stft"]), torch.view_as_real(c["enh_stft"]))
+            for x, y in zip(a["fb_all"] + sum(a["sb_all"], []), c["fb_all"] + sum(c["sb_all"], [])):
+                assert torch.equal(x, y)
+    eng.check_stack_errors()
     assert float(b["sb_all"][0][2].mean()) > 0.01  # (the cells do spike)
 
 
