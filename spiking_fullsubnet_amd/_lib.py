@@ -103,7 +103,7 @@ class HopDesc(ctypes.Structure):
 def _sources():
     """The files the library is made of, in the order the Makefile hashes them (SRCS)."""
     return [os.path.join(_HERE, "..", "include", "sfsn.h")] + [
-        os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_scan3_dev.h", "sfsn_scan3i_dev.h", "sfsn_scan3x_dev.h", "sfsn_scan3w_dev.h", "sfsn_scan3j_dev.h", "sfsn_feat_dev.h", "sfsn_fft_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_hop.hip", "sfsn_fft.hip", "sfsn_train.hip",
+        os.path.join(CSRC, f) for f in ("sfsn_scan_dev.h", "sfsn_scan3_dev.h", "sfsn_scan3i_dev.h", "sfsn_scan3x_dev.h", "sfsn_scan3w_dev.h", "sfsn_scan3j_dev.h", "sfsn_scan3g_dev.h", "sfsn_feat_dev.h", "sfsn_fft_dev.h", "sfsn_kernels.hip", "sfsn_stack.hip", "sfsn_hop.hip", "sfsn_fft.hip", "sfsn_train.hip",
                                   "sfsn_featproj.hip", "sfsn_projdf.hip", "sfsn_pack.cpp")]
 
 

@@ -25,6 +25,7 @@
 #include "sfsn_scan_dev.h"
 #include "sfsn_scan3_dev.h"
 #include "sfsn_scan3j_dev.h"
+#include "sfsn_scan3g_dev.h"
 #include "sfsn_feat_dev.h"
 
 // G = 1: shared gate weights (W [H][*] used for both gates); G = 2: separate forget / cell weights.
@@ -90,6 +91,22 @@ __global__ __launch_bounds__(1024) void gsn_scan3_kernel(const ScanParams p) {
     StackLink lk;
     lk.in = nullptr; lk.n_in = 0; lk.out = nullptr; lk.err = nullptr; lk.lag = 0; lk.dbg = nullptr;
     scan3_role<KS, RPW, OUT, 0, D0>(rl, lk, scan_smem, p.T, p.H, p.NT);
+}
+
+// Round 6: the same structure for SEPARATE gate weights (sfsn_scan3g_dev.h): both gates of a tile in one compute wave, 4 rows per workgroup
+template <int KS, int OUT>
+__global__ __launch_bounds__(1024) void gsn_scan3g_kernel(const ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char scan_smem[];
+    int s = 0;
+    for (int i = 1; i < p.nseg; ++i)
+        if ((int)blockIdx.x >= p.seg[i].tile0) s = i;
+    const ScanSegDev& sg = p.seg[s];
+    Scan3Role rl;
+    rl.zin = sg.zin; rl.w_hh = sg.w_hh; rl.w_dq = sg.w_dq; rl.bias = sg.bias; rl.bn_alpha = sg.bn_alpha; rl.bn_beta = sg.bn_beta;
+    rl.h_state = sg.h_state; rl.c_state = sg.c_state; rl.spikes_f32 = sg.spikes_f32; rl.spikes_i8 = sg.spikes_i8;
+    rl.R = sg.R; rl.row0 = ((int)blockIdx.x - sg.tile0) * 4;
+    rl.count = sg.count;
+    scan3g_role<KS, OUT>(rl, scan_smem, p.T, p.H, p.NT);
 }
 
 // ---- fused-input scan (layers >= 1, shared gates, 128 < H <= 256, 16 rows per workgroup) -----------------------------------
@@ -2269,6 +2286,23 @@ static int layer_scan_impl(const sfsn_scan_segment* segs, int n_segs, int T, int
     //  every wave fetches its own tile: 1.18 against 0.95 us per step at H = 224 -- that geometry keeps the old body)
     if (shared && NT <= 14 && rpw <= 8 && (out == 2 || out == 3) && !getenv("SFSN_SCAN_V2")) return launch_scan3(p, tiles, out, KS, st);
     if (w16) return SFSN_EUNSUPPORTED;  // only the scan3 kernels have the two-plane form: the caller uses sfsn_gsn_layer_scan
+    // round 6: separate gate weights, at most 14 tiles, 4 rows per workgroup: the IO-wave scan with both gates of a tile in one wave
+    // (sfsn_scan3g_dev.h; baseline_xl's sub-band layers: round 2's body spilled 116 registers there)
+    if (!shared && NT <= 14 && rpw == 4 && (out == 2 || out == 3) && !getenv("SFSN_SCAN_V2")) {
+#define SCAN3G_CASE(KS_, OUT_)                                                                                            \
+    if (KS == KS_ && out == OUT_) {                                                                                       \
+        const int lds = Scan3gCfg<KS_>::lds_bytes(NT);                                                                     \
+        if (lds <= 160 * 1024 - 64) {                                                                                     \
+            auto kern = gsn_scan3g_kernel<KS_, OUT_>;                                                                     \
+            static int seen[SFSN_MAX_DEVICES] = {0};                                                                      \
+            if (raise_lds(reinterpret_cast<const void*>(kern), lds, seen) != SFSN_OK) return SFSN_EHIP;                   \
+            hipLaunchKernelGGL(kern, dim3(tiles), dim3(1024), lds, st, p);                                                \
+            return hip_ok(hipGetLastError());                                                                             \
+        }                                                                                                                 \
+    }
+        SCAN3G_CASE(1, 2) SCAN3G_CASE(1, 3) SCAN3G_CASE(2, 2) SCAN3G_CASE(2, 3) SCAN3G_CASE(3, 2) SCAN3G_CASE(3, 3) SCAN3G_CASE(4, 2) SCAN3G_CASE(4, 3)
+#undef SCAN3G_CASE
+    }
     int NW, TPW;
     if (rpw == 4 && out <= 7) out |= 512;  // repacked-epilogue variant (see scan_body)
     if (shared) {

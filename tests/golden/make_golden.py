@@ -427,7 +427,7 @@ def main():
         frozen_case("frozen_l.npz", rw.FROZEN_L, rw.frozen_state_dict(rw.FROZEN_L, 33), 1, 24, False, False)
     if not only or "frozen_xl" in only:
         # baseline_xl sizes: separate forget / cell gate weights at full-band hidden size 320 (W_hh streamed from L2)
-        frozen_case("frozen_xl.npz", rw.FROZEN_XL, rw.frozen_state_dict(rw.FROZEN_XL, 34), 1, 20, False, False)
+        frozen_case("frozen_xl.npz", rw.FROZEN_XL, rw.frozen_state_dict(rw.FROZEN_XL, 34), 2, 64, False, False)  # (round 6: two clips x 64 frames -- the split scan and the G = 2 IO-wave scan meet a reference fixture with more than one row)
     if not only or "frozen_m_zoo" in only:
         # the trained baseline_m generator (the sizes bench.py runs: full-band 320, sub-band 224, deep-filter orders 5/3/1)
         frozen_case("frozen_m_zoo.npz", rw.FROZEN_M, zoo_weights("baseline_m"), 1, 100, False, True)

@@ -113,6 +113,32 @@ def test_scan_free_running_vs_oracle(hip, I, H, R, T, shared, bn):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H,R,T", [(224, 13, 21), (224, 4, 1), (224, 33, 2), (160, 9, 17), (96, 6, 11), (208, 16, 9)])
+def test_separate_gate_weights_scan_with_io_waves_equals_round_2_body(hip, H, R, T, monkeypatch):
+    """Round 6: sfsn_gsn_layer_scan with shared = 0 at 4 rows per workgroup and at most 14 tiles runs scan3g_role (both gates of a tile
+    in one compute wave, digit plane 0 of both in LDS; baseline_xl's sub-band layers: baseline_xl.toml:61,64, NEURON:137-139).  Bit
+    for bit round 2's body (SFSN_SCAN_V2=1) -- fp32 / int8 spikes, final h and c -- and, through test_scan_free_running_vs_oracle's
+    unshared shapes, the oracle."""
+    rng = np.random.default_rng(H * 3 + R)
+    sd, alpha, beta, bnp = make_layer(rng, 30, H, False, True)
+    x = rng.standard_normal((T, R, 30)).astype(np.float32)
+    zin = Oracle("f32").linear(x, sd["weight_ih"])
+    h0 = (rng.random((R, H)) > 0.5).astype(np.float32)
+    c0 = rng.standard_normal((R, H)).astype(np.float32)
+    new = run_scan(hip, zin, sd["weight_hh"], sd["bias_ih"], alpha, beta, False, h0, c0, want_mem=False)
+    monkeypatch.setenv("SFSN_SCAN_V2", "1")
+    old = run_scan(hip, zin, sd["weight_hh"], sd["bias_ih"], alpha, beta, False, h0, c0, want_mem=False)
+    monkeypatch.delenv("SFSN_SCAN_V2")
+    for a, b, nm in zip(new, old, ("spikes", "membrane", "spikes_i8", "h", "c")):
+        if a is not None:
+            np.testing.assert_array_equal(a, b, err_msg=nm)
+    assert new[2].any()
+    lean = run_scan(hip, zin, sd["weight_hh"], sd["bias_ih"], alpha, beta, False, h0, c0, want_mem=False, want_spk=False)
+    np.testing.assert_array_equal(lean[2], new[2])
+    np.testing.assert_array_equal(lean[4], new[4])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("H,R,T", [(320, 64, 60), (320, 21, 33), (272, 40, 25), (320, 130, 17)])
 def test_split_scan_for_large_separate_gate_weights_equals_the_streamed_scan(hip, H, R, T):
     """sfsn_gsn_layer_scan_split (round 5: separate gate weights that do not fit one CU -- baseline_xl's full-band model): the tiles
