@@ -749,8 +749,28 @@ def training_bench(args, model, dev, world, rank, rw, B, T):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     gn = float(torch.sqrt(sum((p_.grad.float() ** 2).sum() for p_ in model.parameters() if p_.grad is not None)))
-    # one more step (untimed) with HIP events around the layer-call launches: where the step's time is, per recurrent step
+    loss = float(loss.detach())  # (and no tensor of the eager steps' autograd graphs alive: GraphedTrainStep below refuses otherwise)
     from spiking_fullsubnet_amd import training as _tr
+    # the same step captured once in a HIP graph and replayed (training.GraphedTrainStep): what the host's share of the eager figure is
+    graphed = None
+    try:
+        gs = _tr.GraphedTrainStep(model, wave, lambda out: out[0].pow(2).mean() + out[1].mean())
+        gs(wave)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gs(wave)
+        torch.cuda.synchronize()
+        graphed = dict(ms_per_step=round((time.perf_counter() - t0) / steps * 1e3, 2), layer_call_launches_captured=gs.layer_calls_captured,
+                       note="forward + loss + backward replayed from one HIP graph: gradients bit-identical to the eager step "
+                            "(tests/test_training.py); at B = 64 the device is busy for the whole eager step (kernel time 74.7 of 75 ms, "
+                            "profiles/r06_training_b64_kernel_stats.csv), so the graph buys ~1 %; at small batches the host's share is "
+                            "larger (B = 8, T = 200: 12.2 -> 10.0 ms)")
+        del gs
+    except Exception as e:  # reported, never required for the line
+        graphed = dict(error=repr(e))
+    torch.cuda.empty_cache()
+    # one more step (untimed) with HIP events around the layer-call launches: where the step's time is, per recurrent step
     _tr.launch_log = []
     one()
     torch.cuda.synchronize()
@@ -782,7 +802,7 @@ def training_bench(args, model, dev, world, rank, rw, B, T):
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 2), "higher_is_better": False, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (0.05*randn waveform; seeded random weights, randomised BN stats)",
             "config": {"workload": "SURVEY 8f-4: training-mode forward + backward, per-step batch-statistics BatchNorm, triangle surrogate",
-                       "clips_per_gpu": B, "frames": T, "clip_frames_per_s": round(B * T / (ms / 1e3), 1), "loss": float(loss.detach()),
+                       "clips_per_gpu": B, "frames": T, "clip_frames_per_s": round(B * T / (ms / 1e3), 1), "loss": loss, "hip_graph_replay": graphed,
                        "grad_norm": gn, "optimizer_step": "not included (the reference's optimiser; out of scope)",
                        "cell_steps_per_training_step": 2 * 4 * T,
                        "note": "the same loop written as ATen operations per cell step (the reference's structure) takes 2.65 s at B=16 and "

@@ -33,7 +33,8 @@ python bench.py --streaming --waveform --host-io > $OUT/bench_streaming_waveform
 python bench.py --training --batch 64 > $OUT/bench_training.json 2>> $OUT/bench_default.err
 python bench.py --training --batch 16 > $OUT/bench_training_b16.json 2>> $OUT/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/training -o t -- python bench.py --training --batch 16 --steps 2 --warmup 1 > $OUT/training.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/training64 -o t -- python bench.py --training --batch 64 --steps 2 --warmup 1 > $OUT/training64.log 2>&1
 # what goes back is capped at 64 MiB: the big per-dispatch traces are not needed (the stats files are)
-rm -f $OUT/default/d_kernel_trace.csv $OUT/training/t_kernel_trace.csv $OUT/single_whole/s_kernel_trace.csv
+rm -f $OUT/default/d_kernel_trace.csv $OUT/training/t_kernel_trace.csv $OUT/training64/t_kernel_trace.csv $OUT/single_whole/s_kernel_trace.csv
 python -c "from spiking_fullsubnet_amd import _lib; print(_lib.source_hash())" > $OUT/source_hash.txt
 tail -c 600 $OUT/bench_default.json

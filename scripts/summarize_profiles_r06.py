@@ -12,7 +12,8 @@ shutil.copy(f"{base}/default/d_kernel_stats.csv", f"profiles/{rnd}_default_kerne
 shutil.copy(f"{base}/bench_default.json", f"profiles/{rnd}_bench_line.json")
 shutil.copy(f"{base}/bench_streaming.json", f"profiles/{rnd}_streaming_line.json")
 for src, dst in (("bench_streaming_waveform_host.json", "streaming_waveform_host_line.json"), ("bench_training.json", "training_line.json"),
-                 ("bench_training_b16.json", "training_line_b16.json"), ("training/t_kernel_stats.csv", "training_kernel_stats.csv")):
+                 ("bench_training_b16.json", "training_line_b16.json"), ("training/t_kernel_stats.csv", "training_kernel_stats.csv"),
+                 ("training64/t_kernel_stats.csv", "training_b64_kernel_stats.csv")):
     if os.path.exists(f"{base}/{src}"):
         shutil.copy(f"{base}/{src}", f"profiles/{rnd}_{dst}")
 if os.path.exists("gpurun_out/parity_report.jsonl"):

@@ -28,6 +28,7 @@ import contextlib
 import ctypes
 import os
 import threading
+import warnings
 from typing import List
 
 import torch
@@ -84,6 +85,8 @@ def _poll_pending(block: bool = False, new_forward: bool = False) -> None:
     advisor finding).  A forward is outside any pass that could still run that callback: the flag is cleared here, the next backward
     queues afresh (a forward recomputed INSIDE a backward pass -- activation checkpointing -- merely queues a second, idempotent check)."""
     global _final_check_queued
+    if _capturing():
+        return  # (no event queries / host reads inside a capture; GraphedTrainStep checked before it began)
     with _lock:
         if new_forward:
             _final_check_queued = False
@@ -108,6 +111,33 @@ def _poll_pending(block: bool = False, new_forward: bool = False) -> None:
 def _push_pending(ev, pin) -> None:
     with _lock:
         _pending.append((ev, pin))
+
+
+_capture_errs = None  # GraphedTrainStep sets a list while it captures: the layer calls' error words (device tensors of the graph's pool)
+
+
+def _capturing() -> bool:
+    return torch.cuda.is_current_stream_capturing()
+
+
+def _report(errs: torch.Tensor, dev, final: bool) -> None:
+    """A layer call's error word(s) (int32 device tensor, any shape) on their way to the host without blocking it: to pinned memory
+    behind the launches, looked at by the next layer call / at the end of the backward pass (final = called from a backward()).
+    While a HIP graph is being captured (GraphedTrainStep) nothing host-side may happen: the words are handed to the capturing
+    object, which reduces them inside the graph and reads the result after every replay."""
+    if _capturing():
+        if _capture_errs is None:
+            raise RuntimeError("a training layer call inside a HIP graph capture that training.GraphedTrainStep does not own: its error "
+                               "word would go unread -- capture the step with GraphedTrainStep")
+        _capture_errs.append(errs.reshape(-1).max())
+        return
+    pin = torch.empty((errs.numel(),), dtype=torch.int32, pin_memory=True)
+    pin.copy_(errs.reshape(-1), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    _push_pending(ev, pin)
+    if final:
+        _queue_final_check()
 
 
 def _queue_final_check() -> None:
@@ -302,11 +332,7 @@ class GSNLayerTrainFn(torch.autograd.Function):
             else:
                 # backward() reads the word too, but a forward that is never followed by one must not go unnoticed either: the word
                 # travels to pinned host memory behind the launches and the next layer call looks at it without blocking
-                pin = torch.empty((4,), dtype=torch.int32, pin_memory=True)
-                pin.copy_(scr[-4:], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(dev))
-                _push_pending(ev, pin)
+                _report(scr[-4:], dev, final=False)
         if use_bn and batch_stats and stats is not None and stats[2] is not None:
             stats[2].add_(T)  # num_batches_tracked: one BatchNorm call per time step
         ctx.save_for_backward(x, w_ih_c, w_hh_c, spikes, u, fg, gg, xhat if xhat is not None else zero, invstd if invstd is not None else zero,
@@ -384,12 +410,7 @@ class GSNLayerTrainFn(torch.autograd.Function):
         # recipe's optimizer.step() never sees the NaN gradients.
         bad = (scr[-4:].max() + ctx.scr[-4:].max()) > 0
         poison = torch.where(bad, torch.full((), float("nan"), **f32), torch.zeros((), **f32))
-        pin = torch.empty((4,), dtype=torch.int32, pin_memory=True)
-        pin.copy_(torch.maximum(scr[-4:], ctx.scr[-4:]), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        _push_pending(ev, pin)
-        _queue_final_check()
+        _report(torch.maximum(scr[-4:], ctx.scr[-4:]), dev, final=True)
         dz = (d_z if shared else d_gates).reshape(T * R, GH)
         dx = torch.mm(dz, w_ih).view(T, R, I).add_(poison)
         dw_ih = _tn_gemm(dz, x.reshape(T * R, I)).add_(poison)
@@ -476,11 +497,7 @@ class GSNLayersTrainFn(torch.autograd.Function):
             if int(errs.item()) != 0:
                 raise RuntimeError(_EXCHANGE_FAILED)
         else:
-            pin = torch.empty((1,), dtype=torch.int32, pin_memory=True)
-            pin.copy_(errs.reshape(1), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            _push_pending(ev, pin)
+            _report(errs, dev, final=False)
         if use_bn:
             for i in range(n):
                 stats = meta["stats"][i]
@@ -522,12 +539,7 @@ class GSNLayersTrainFn(torch.autograd.Function):
         # pinned memory, check_pending() when the backward pass has finished
         errs = torch.maximum(torch.stack([w[5][-4:] for w in work]).max(), ctx.fwd_err)
         poison = torch.where(errs > 0, torch.full((), float("nan"), **f32), torch.zeros((), **f32))
-        pin = torch.empty((1,), dtype=torch.int32, pin_memory=True)
-        pin.copy_(errs.reshape(1), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        _push_pending(ev, pin)
-        _queue_final_check()
+        _report(errs, dev, final=True)
         grads = []
         for i in range(n):
             x, w_ih, w_hh, spikes, u, fg, gg, xhat, invstd, bw = saved[10 * i:10 * i + 10]
@@ -641,11 +653,7 @@ class GSNStackTrainFn(torch.autograd.Function):
             if int(errs.item()) != 0:
                 raise RuntimeError(_EXCHANGE_FAILED)
         else:
-            pin = torch.empty((1,), dtype=torch.int32, pin_memory=True)
-            pin.copy_(errs.reshape(1), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            _push_pending(ev, pin)
+            _report(errs, dev, final=False)
         zero = torch.zeros((1,), **f32)
         saved = []
         for sk in stk:
@@ -777,12 +785,7 @@ class GSNStackTrainFn(torch.autograd.Function):
         # pinned memory, check_pending() when the backward pass has finished
         errs = torch.maximum(torch.stack([d["scr"][:, sk["nscr"] - 4:sk["nscr"]].max() for sk in stk for d in sk["lay"]]).max(), ctx.fwd_err)
         poison = torch.where(errs > 0, torch.full((), float("nan"), **f32), torch.zeros((), **f32))
-        pin = torch.empty((1,), dtype=torch.int32, pin_memory=True)
-        pin.copy_(errs.reshape(1), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        _push_pending(ev, pin)
-        _queue_final_check()
+        _report(errs, dev, final=True)
         dxs, grads = [], []
         for sk in stk:
             for d in sk["lay"]:
@@ -967,6 +970,37 @@ def _frozen_sequence_models(seqs, xs_bft, training: bool):
     return res
 
 
+def _istft(spec: torch.Tensor, n_fft: int, hop: int, win_length: int, window: torch.Tensor, length) -> torch.Tensor:
+    """torch.istft (center=True, onesided, not normalised: audio_feature.py:297-347) as differentiable ATen operations WITHOUT its
+    host-side check of the window envelope (`window_envelop.abs().min() > 1e-11` is a device-to-host read: a synchronisation per training
+    step, and not capturable in a HIP graph -- GraphedTrainStep).  The same arithmetic: inverse real FFT of every frame, times the
+    window, overlap-add, divided by the overlap-added squared window; the envelope of a Hann window at hop <= n_fft / 2 is positive on
+    every sample that is kept, the case the check exists for cannot occur."""
+    B, Fq, T = spec.shape
+    if win_length != n_fft:
+        left = (n_fft - win_length) // 2
+        window = F.pad(window, (left, n_fft - win_length - left))
+    total = n_fft + hop * (T - 1)
+
+    def overlap_add(fr):  # [b, T, n_fft] -> [b, total]
+        if n_fft % hop == 0:  # frame t's k-th hop-sized piece lands on piece t + k: n_fft / hop shifted sums (every reference config)
+            r = n_fft // hop
+            pieces = fr.reshape(fr.shape[0], T, r, hop)
+            acc = F.pad(pieces[:, :, 0], (0, 0, 0, r - 1))
+            for k in range(1, r):
+                acc = acc + F.pad(pieces[:, :, k], (0, 0, k, r - 1 - k))
+            return acc.reshape(fr.shape[0], total)
+        return F.fold(fr.transpose(1, 2), output_size=(1, total), kernel_size=(1, n_fft), stride=(1, hop)).reshape(fr.shape[0], total)
+
+    frames = torch.fft.irfft(spec.transpose(1, 2).contiguous(), n=n_fft, dim=-1) * window                   # [B, T, n_fft]
+    y = overlap_add(frames)
+    env = overlap_add((window * window)[None, None, :].expand(1, T, n_fft))[0]
+    start = n_fft // 2
+    end = total - start if length is None else start + int(length)
+    y = y[:, start:min(end, total)] / env[start:min(end, total)]
+    return F.pad(y, (0, end - total)) if end > total else y
+
+
 def _reflect(idx: torch.Tensor, nf: int) -> torch.Tensor:
     idx = torch.where(idx < 0, -idx, idx)
     return torch.where(idx > nf - 1, 2 * (nf - 1) - idx, idx)
@@ -1028,7 +1062,7 @@ def forward_live(model, wave: torch.Tensor):
         enh_groups.append(torch.complex(yr, yi))                                                             # [B, S, N c, T]
     enh = torch.cat(enh_groups, dim=2)
     enh_stft = torch.cat([enh, noisy[:, None, enh.shape[2]:].expand(B, S, Fq - enh.shape[2], T)], dim=2)     # bins past the groups pass through
-    enh_y = torch.istft(enh_stft.reshape(B * S, Fq, T), model.n_fft, model.hop_length, model.win_length, window=window, length=length)
+    enh_y = _istft(enh_stft.reshape(B * S, Fq, T), model.n_fft, model.hop_length, model.win_length, window, length)
     if S > 1:
         return enh_y.reshape(B, S, -1), fb_all, sb_all
     return enh_y, enh_stft[:, 0].abs(), fb_all, sb_all
@@ -1120,5 +1154,107 @@ def forward_frozen(model, wave: torch.Tensor):
         enh_groups.append(torch.complex(yr, yi))                                                                 # [B, N c, T]
     enh = torch.cat(enh_groups, dim=1)
     enh_stft = torch.cat([enh, noisy[:, enh.shape[1]:]], dim=1)                                                  # bins past the groups pass through
-    enh_y = torch.istft(enh_stft, model.n_fft, model.hop_length, model.win_length, window=window, length=length)
+    enh_y = _istft(enh_stft, model.n_fft, model.hop_length, model.win_length, window, length)
     return enh_y, enh_stft.abs(), fb_all, sb_all
+
+
+class GraphedTrainStep:
+    """One whole training step -- ``model(wave)``, ``loss_fn(outputs)``, ``loss.backward()`` and, when given, ``optimizer.step()`` --
+    captured ONCE in a HIP graph and replayed for every batch of the same shape (PyTorch's whole-network capture recipe).
+
+    Why: a step of the live baseline_m model at B = 64 is ~1000 kernels -- 84 resident layer-call launches with the library GEMMs and
+    element-wise operations of the chunk pipeline between them -- of 44 ms device time together, and the host needs longer than that
+    to enqueue them one by one (74.9 ms per step measured, the device idle 41 % of it: profiles/r06_training_kernel_stats.csv).
+    Replayed from a graph the host's share is one call.
+
+    The recipe's trainer (recipes/intel_ndns/spiking_fullsubnet/trainer.py:24-48) feeds fixed-length clips, so the shapes are static;
+    a batch of another shape needs its own GraphedTrainStep (or the eager path: ``model(wave)`` as before).
+
+    * ``example_wave`` [B, samples] fixes the shape; ``loss_fn(outputs) -> scalar``; the warm-up iterations (eager, on a side stream:
+      library handles, occupancy queries, the allocator's pool) run forward + backward only and the module's parameters and buffers
+      are put back afterwards (BatchNorm running statistics included), so capturing does not train.
+    * ``step(wave)`` copies the batch into the graph's input, replays, and returns the loss tensor (static: overwritten by the next
+      call); ``.outputs`` is the captured forward's return value, the gradients are in ``p.grad`` (static tensors written by every replay:
+      they are re-attached if someone set them to None in between).
+    * The layer calls' error words (a failed row-block exchange, see check_pending) are reduced INSIDE the graph and read after every
+      replay (one host synchronisation per step, as on the eager path): ``step`` raises RuntimeError -- if an optimizer step is part of
+      the graph the NaN-poisoned gradients have reached the weights by then, and the message says so.
+    * BatchNorm with ``momentum=None`` (cumulative average: the factor depends on a host-side counter) cannot be captured."""
+
+    def __init__(self, model, example_wave: torch.Tensor, loss_fn, optimizer=None, warmup: int = 2):
+        global _capture_errs
+        if not example_wave.is_cuda:
+            raise RuntimeError("spiking_fullsubnet_amd has no CPU path: move the module and its input to a HIP device")
+        for m_ in model.modules():
+            if isinstance(m_, torch.nn.modules.batchnorm._BatchNorm) and m_.momentum is None and model.training:
+                raise NotImplementedError("GraphedTrainStep: BatchNorm with momentum=None (cumulative moving average) needs a host-side "
+                                          "counter per step and cannot be captured")
+        self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
+        dev = example_wave.device
+        self.static_wave = example_wave.detach().clone()
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        check_pending()
+        keep = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)
+        stale = False
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._drop_grads()
+                with warnings.catch_warnings(record=True) as seen:
+                    warnings.simplefilter("always")
+                    loss_fn(model(self.static_wave)).backward()
+                stale = stale or any("AccumulateGrad node's stream does not match" in str(w_.message) for w_ in seen)
+        main.wait_stream(side)
+        if stale:
+            # the parameters' gradient accumulators were created by an earlier EAGER step on another stream and something still holds
+            # that step's autograd graph (a loss kept for logging, outputs): the captured backward would synchronise with that stream
+            # -- on ROCm 7 the capture then dies inside hipStreamEndCapture (a segmentation fault, measured)
+            raise RuntimeError("GraphedTrainStep: an autograd graph of an earlier eager step is still alive (a loss or output tensor kept "
+                               "around?) and pins the parameters' gradient accumulators to another stream -- drop those tensors "
+                               "(`del loss`, `loss = loss.item()`) before capturing")
+        torch.cuda.synchronize(dev)
+        check_pending()
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(keep[k])
+        del keep
+        self._drop_grads()  # (the captured backward then ASSIGNS the gradients: tensors of the graph's pool)
+        self._pin = torch.zeros((1,), dtype=torch.int32, pin_memory=True)
+        self._ev = torch.cuda.Event()
+        self.graph = torch.cuda.CUDAGraph()
+        _capture_errs = []
+        try:
+            with torch.cuda.graph(self.graph):
+                self.outputs = model(self.static_wave)
+                self.loss = loss_fn(self.outputs)
+                self.loss.backward()
+                if optimizer is not None:
+                    optimizer.step()
+                err = (torch.stack(_capture_errs).max() if _capture_errs else torch.zeros((), dtype=torch.int32, device=dev)).reshape(1)
+                self._pin.copy_(err, non_blocking=True)
+        finally:
+            self.layer_calls_captured, _capture_errs = len(_capture_errs), None
+        self.grads = [p.grad for p in self.params]
+
+    def _drop_grads(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self, wave: torch.Tensor) -> torch.Tensor:
+        if wave.shape != self.static_wave.shape:
+            raise ValueError(f"GraphedTrainStep was captured for waves of shape {tuple(self.static_wave.shape)}, got {tuple(wave.shape)}")
+        for p, g in zip(self.params, self.grads):
+            if p.grad is not g:
+                p.grad = g
+        self.static_wave.copy_(wave, non_blocking=True)
+        self.graph.replay()
+        self._ev.record()
+        self._ev.synchronize()
+        if int(self._pin[0]) != 0:
+            raise RuntimeError(_EXCHANGE_FAILED + (" -- the optimizer step inside the graph has already applied the NaN gradients: restore "
+                                                   "the weights from the last checkpoint" if self.optimizer is not None else ""))
+        return self.loss
+
+    __call__ = step

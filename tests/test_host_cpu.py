@@ -451,3 +451,21 @@ def test_training_entry_points_check_their_arguments_without_a_gpu():
     assert L.sfsn_features_proj(one, None, 1, 33, 8, 0, 0.5, j, 0, 0, 8, None, 0, None) == _lib.SFSN_EINVAL      # no jobs
     j[0].feat.x, j[0].w, j[0].z, j[0].H, j[0].ldz = 64, 64, 64, 30, 30
     assert L.sfsn_features_proj(one, None, 1, 33, 8, 0, 0.5, j, 1, 0, 8, None, 0, None) == _lib.SFSN_EUNSUPPORTED  # H % 4 (and 8 rows: not the bf16-split kernel's shape)
+
+
+@pytest.mark.parametrize("n_fft,hop,wl,T,length", [(512, 128, 512, 40, 128 * 39), (512, 128, 512, 40, None), (256, 64, 256, 17, 64 * 16 - 5),
+                                                   (512, 128, 400, 20, 128 * 19), (512, 256, 512, 9, 256 * 8 + 100), (512, 160, 512, 12, 160 * 11)])
+def test_training_istft_without_the_host_check_equals_torch_istft(n_fft, hop, wl, T, length):
+    """training._istft (no device-to-host read: capturable in a HIP graph) against torch.istft, values and gradient."""
+    import torch
+    from spiking_fullsubnet_amd.training import _istft
+    torch.manual_seed(0)
+    w = torch.hann_window(wl)
+    x = torch.randn(3, n_fft // 2 + 1, T, dtype=torch.complex64).requires_grad_()
+    a = torch.istft(x, n_fft, hop, wl, window=w, length=length)
+    b = _istft(x, n_fft, hop, wl, w, length)
+    assert a.shape == b.shape
+    assert float((a - b).abs().max()) <= 2e-7 * float(a.abs().max()) + 1e-9
+    ga, = torch.autograd.grad(a.pow(2).sum(), x)
+    gb, = torch.autograd.grad(b.pow(2).sum(), x)
+    assert float((ga - gb).abs().max()) <= 1e-6 * float(ga.abs().max())

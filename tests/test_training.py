@@ -551,3 +551,71 @@ def test_inference_entry_points_refuse_training_mode():
         m.forward_stft(stft)
     with pytest.raises(RuntimeError):
         m.streaming(batch=1)
+
+
+def test_training_step_replayed_from_a_hip_graph_equals_the_eager_step(chunked_stacks):
+    """training.GraphedTrainStep: forward + loss + backward of the tiny live model captured once and replayed on two different batches --
+    loss, every gradient and the BatchNorm buffers bit-identical to the eager step from the same state (the same kernels on the same
+    numbers); capturing itself leaves the module's state untouched; a wave of another shape is refused."""
+    import spiking_fullsubnet_amd as pkg
+    tr = chunked_stacks
+    kw = rw.LIVE_TINY
+    m = pkg.SpikingFullSubNet(**kw)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rw.live_state_dict(kw, 11).items()}, strict=True)
+    m = m.to(DEV).train()
+    waves = [_t(rw.synth_wave(4, 24, seed=s)) for s in (1, 2, 3)]
+    loss_fn = lambda out: out[0].pow(2).mean() + out[1].mean()
+    state0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    def restore():
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                v.copy_(state0[k])
+
+    eager = []
+    for w in waves[1:]:  # two consecutive eager steps (the running statistics carry over)
+        for p in m.parameters():
+            p.grad = None
+        loss = loss_fn(m(w))
+        loss.backward()
+        eager.append((float(loss), [p.grad.clone() for p in m.parameters()], {k: v.clone() for k, v in m.state_dict().items()}))
+        del loss
+    restore()
+    calls0 = tr._STACK_CALLS
+    gs = tr.GraphedTrainStep(m, waves[0], loss_fn)
+    assert tr._STACK_CALLS > calls0 and gs.layer_calls_captured >= 4  # (forward + backward of the full-band and the sub-band pipelines)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, state0[k]), f"capturing changed {k}"
+    for (l_e, g_e, st_e), w in zip(eager, waves[1:]):
+        l_g = gs(w)
+        assert float(l_g) == l_e
+        for (k, p), ge in zip(m.named_parameters(), g_e):
+            assert torch.equal(p.grad, ge), f"gradient of {k} differs between the replayed and the eager step"
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, st_e[k]), f"{k} differs after the replayed step"
+    for p in m.parameters():  # someone dropped the gradients between two steps: the graph's tensors are attached again
+        p.grad = None
+    gs(waves[2])
+    assert all(p.grad is not None for p in m.parameters())
+    with pytest.raises(ValueError, match="captured for waves of shape"):
+        gs(_t(rw.synth_wave(2, 24, seed=1)))
+    tr.check_pending()
+
+
+def test_graphed_training_step_refuses_a_module_whose_last_eager_graph_is_still_alive(chunked_stacks):
+    """An eager step on the default stream whose loss tensor is kept pins the parameters' gradient accumulators to that stream; the
+    captured backward would synchronise with it (on ROCm 7 hipStreamEndCapture then segfaults): refused with a message instead."""
+    import spiking_fullsubnet_amd as pkg
+    tr = chunked_stacks
+    kw = rw.LIVE_TINY
+    m = pkg.SpikingFullSubNet(**kw)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rw.live_state_dict(kw, 11).items()}, strict=True)
+    m = m.to(DEV).train()
+    w = _t(rw.synth_wave(4, 24, seed=1))
+    loss_fn = lambda out: out[0].pow(2).mean() + out[1].mean()
+    kept = loss_fn(m(w))
+    kept.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="autograd graph of an earlier eager step is still alive"):
+        tr.GraphedTrainStep(m, w, loss_fn)
+    del kept
+    tr.check_pending()
