@@ -105,3 +105,8 @@ rows = list(csv.DictReader(open(f"profiles/{rnd}_single_stream_whole_launch_kern
 for r in rows[:14]:
     print("%-70s calls %4s avg_us %9.1f pct %s" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
 print(json.dumps(pj, indent=1))
+
+# the strict forward's kernels in launch order (what gates what): profiles/r06_strict_timeline.txt
+if os.path.exists(f"{base}/single/s_kernel_trace.csv"):
+    import subprocess, sys
+    subprocess.run([sys.executable, "scripts/strict_timeline_r06.py", f"{base}/single/s_kernel_trace.csv"], stdout=subprocess.DEVNULL, check=False)
