@@ -309,6 +309,18 @@ class Engine:
         # millisecond before it is read has left the 256 MB Infinity Cache (the sub-band kernels move > 1 GB in between), and the
         # full-band scan -- two ring slots deep at H = 320 -- runs 1.9 instead of 1.6 us per frame from HBM (profiles/EXPERIMENTS.md)
         self.overlap_prep_ahead = os.environ.get("SFSN_PREP_AHEAD", "0") != "0"
+        # overlapped schedule, round 6 (profiles/r06_strict_timeline.txt: the full-band chain gates, ~100 us of small kernels between its
+        # stack launches, and they run beside the sub-band stream's feature / input-product launches that the same event releases):
+        #   prep_next   -- the full-band model's features + layer-0 input product of chunk c + 1 go out BEFORE chunk c's projection (which
+        #                  is what releases the sub-band stream): they run alone (27 instead of 82 us) and the next stack launch follows
+        #   post_stream -- the sub-band epilogue (sfsn_proj_deepfilter) of chunk c on a third stream: the sub-band stream goes on with
+        #                  chunk c + 1's features as soon as the pair launch is done
+        # Both bit-identical and both OFF: measured (scripts/exp_ovsched_r06.sh, three interleaved rounds, strict forward API / lean)
+        # default 2.41-2.45 / 2.36-2.38 ms; prep_next 2.42-2.46 / 2.34-2.36 (the small kernels leave the chain, the earlier stack launch
+        # meets the sub-band stream's feature launches instead); post_stream 2.54 / 2.46-2.48 (the epilogue's 0.84 GB beside the next
+        # pair launch costs that launch more than the 100-136 us it takes off the stream); both 2.60-2.64 / 2.53-2.56.
+        self.overlap_prep_next = os.environ.get("SFSN_OV_PREP_NEXT", "0") != "0"
+        self.overlap_post_stream = os.environ.get("SFSN_OV_POST_STREAM", "0") != "0"
         self.stack_wide = True
         self._stack_scratch: List[torch.Tensor] = []
         self._stack_err_pending: List[tuple] = []  # (event, pinned copy of a launch's error word): polled at the next forward
@@ -1072,6 +1084,7 @@ class Engine:
         # ---------------- streams: sequential = the current stream; pipelined = per stage one scan stream (own CUs) and one
         #                  stream for its time-parallel kernels (shared CU pool), chained by events
         n_stage = nl_fb + nl_sb
+        post_stream = None
         if pipeline:
             rpw_fb, rpw_sb = 16, 16
             fb_tiles = (B + rpw_fb - 1) // rpw_fb
@@ -1094,6 +1107,10 @@ class Engine:
                 else:
                     self._ov_streams[main.cuda_stream] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
             sa, sb_ = self._ov_streams[main.cuda_stream]
+            if self.overlap_post_stream:
+                if ("post", main.cuda_stream) not in self._ov_streams:
+                    self._ov_streams[("post", main.cuda_stream)] = torch.cuda.Stream(device=dev)
+                post_stream = self._ov_streams[("post", main.cuda_stream)]
             self._defer_err = []
             sstreams = gstreams = [sa] * nl_fb + [sb_] * nl_sb
             rpw_fb, rpw_sb = self.rows_per_wg
@@ -1101,6 +1118,8 @@ class Engine:
             fork.record(main)
             sa.wait_event(fork)
             sb_.wait_event(fork)
+            if post_stream is not None:
+                post_stream.wait_event(fork)
             if prep_ahead:
                 if ("aux", main.cuda_stream) not in self._ov_streams:
                     self._ov_streams[("aux", main.cuda_stream)] = torch.cuda.Stream(device=dev)
@@ -1154,23 +1173,36 @@ class Engine:
                         ev = torch.cuda.Event()
                         ev.record(aux_stream)
                         ready.append((ev, xg))
+                # prep_next (ungated model of the overlapped schedule = the full-band one; needs the chunk-local input term buffer free:
+                # the stack launch of chunk c is behind us on the same stream when chunk c + 1's product is enqueued)
+                nxt = bool(overlap and self.overlap_prep_next and gate_events is None and not ahead and sstreams[first] is gstreams[first])
+                post_h = hG[first]
+                on_post = bool(overlap and fused_post is not None and post_stream is not None and gate_events is not None)
+                xg_next = prep(bounds[0][0], bounds[0][1], d, hG[first]) if nxt else None
                 for c, (t0, nt) in enumerate(bounds):
                     if ahead:
                         dv, (ev, xg) = views[c], ready[c]
                         sstreams[first].wait_event(ev)
+                    elif nxt:
+                        dv, xg = d, xg_next
                     else:
                         dv = d
                         if staged and gate_events is not None:
                             gstreams[first].wait_event(gate_events[c])
                         xg = prep(t0, nt, dv, hG[first])
                     self._stage_stack(seqs, dv, t0, nt, hS[first], tag, wide, rpw_stack, xs_=xs_, xg=xg)
-                    if fused_post is None or not fused_post(t0, nt, hG[first]):
-                        self._stage_proj(seqs, d["s8"][nl - 1], d["proj"], t0, nt, hG[first], tag)
+                    if nxt and c + 1 < len(bounds):
+                        xg_next = prep(bounds[c + 1][0], bounds[c + 1][1], d, hG[first])
+                    if on_post:
+                        link(sstreams[first], post_stream)
+                        post_h = self._handle(post_stream)
+                    if fused_post is None or not fused_post(t0, nt, post_h):  # (the two-launch epilogue reads the same tensors)
+                        self._stage_proj(seqs, d["s8"][nl - 1], d["proj"], t0, nt, post_h, tag)
                         if post_fn is not None:
-                            post_fn(t0, nt, hG[first])
+                            post_fn(t0, nt, post_h)
                     if staged:
                         ev = torch.cuda.Event()
-                        ev.record(gstreams[first])
+                        ev.record(post_stream if on_post else gstreams[first])
                         done.append(ev)
                 return done
             # layer 0: groups whose real-valued input product can run inside the scan / the rest (input product first)
@@ -1301,7 +1333,8 @@ class Engine:
         else:
             sb_done = run_model(self.sb, sb, xs, nl_fb, feat_sb, "sb", rpw_sb, post_sb, fb_done if staged else None, fused_post_sb)
         if staged:
-            for s_ in {id(x): x for x in sstreams + gstreams + ([aux_stream] if prep_ahead else [])}.values():
+            extra = ([aux_stream] if prep_ahead else []) + ([post_stream] if (overlap and post_stream is not None) else [])
+            for s_ in {id(x): x for x in sstreams + gstreams + extra}.values():
                 link(s_, main)
         if self._defer_err:
             # the error words of this forward's stack launches: one maximum, one copy to pinned memory, on a stream of its own behind
