@@ -205,6 +205,46 @@ class _LinearTN(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last axis of [T, R, I] with I = 38 .. 158 (the sub-band feature rows; MODEL:91-93): ATen's kernels give a
+    block to every row (RowwiseMoments: 0.8 ms for 512,000 rows of 38 floats, its backward another 1.2) -- the same arithmetic out of a
+    handful of element-wise / short-reduction operations over the whole tensor is 2 x faster in both directions (round 6,
+    scripts/exp_train_glue_r06.py: 3.75 -> 1.73 ms per training step for the three groups; values within 3e-6)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        var, mean = torch.var_mean(x, dim=-1, unbiased=False, keepdim=True)
+        rstd = torch.rsqrt(var + eps)
+        xhat = (x - mean) * rstd
+        ctx.save_for_backward(xhat, rstd, w)
+        return torch.addcmul(b, xhat, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, rstd, w = ctx.saved_tensors
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            g = dy * w
+            dx = (g - g.mean(-1, keepdim=True) - xhat * (g * xhat).mean(-1, keepdim=True)) * rstd
+        n = dy.shape[-1]
+        if ctx.needs_input_grad[1]:
+            dw = (dy.reshape(-1, n) * xhat.reshape(-1, n)).sum(0)
+        if ctx.needs_input_grad[2]:
+            db = dy.reshape(-1, n).sum(0)
+        return dx, dw, db, None
+
+
+FAST_GLUE = os.environ.get("SFSN_TRAIN_FAST_GLUE", "1") != "0"  # round 6: _LayerNormFn, time-major feature rows, complex deep filter
+
+
+def _pre_ln(ln, x):
+    """seq.pre_layer_norm(x): an affine nn.LayerNorm over the last axis of a float32 HIP tensor through _LayerNormFn, else the module."""
+    if (FAST_GLUE and isinstance(ln, torch.nn.LayerNorm) and ln.elementwise_affine and ln.bias is not None and len(ln.normalized_shape) == 1
+            and x.is_cuda and x.dtype == torch.float32 and ln.weight.dtype == torch.float32):
+        return _LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
+    return ln(x)
+
+
 def _proj(lin, x):
     """seq.proj(x) (MODEL:49-52,118): nn.Linear -> _LinearTN on contiguous HIP tensors; anything else (Identity, ...) as it is."""
     if isinstance(lin, torch.nn.Linear) and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and lin.weight.dtype == torch.float32:
@@ -924,40 +964,64 @@ def gsn_stack(x: torch.Tensor, stack, training: bool) -> List[torch.Tensor]:
     return outs
 
 
-def sequence_model(seq, x_bft: torch.Tensor, training: bool):
-    """SequenceModel.forward (modeling_spiking_fullsubnet.py:81-125; LSTM variant :68-79): [R, I, T] -> ([R, P, T], all_layer_outputs)."""
+def sequence_model(seq, x_bft: torch.Tensor, training: bool, time_major: bool = False):
+    """SequenceModel.forward (modeling_spiking_fullsubnet.py:81-125; LSTM variant :68-79): [R, I, T] -> ([R, P, T], all_layer_outputs).
+    time_major: the input is [T, R, I] already (forward_live builds the rows that way: no transposed copy of the feature tensor)."""
     if seq.sequence_model_name == "LSTM":
-        x = x_bft.permute(0, 2, 1)
+        x = x_bft.permute(1, 0, 2) if time_major else x_bft.permute(0, 2, 1)
         if seq.use_pre_layer_norm:
             x = seq.pre_layer_norm(x)
         y, _ = seq.sequence_model(x)
         y = seq.output_activate_function(seq.proj(y))
         return y.permute(0, 2, 1), []
-    x = x_bft.permute(2, 0, 1)  # time-major
+    x = x_bft if time_major else x_bft.permute(2, 0, 1)  # time-major
     if seq.use_pre_layer_norm:
-        x = seq.pre_layer_norm(x)
+        x = _pre_ln(seq.pre_layer_norm, x)
     outs = gsn_stack(x.contiguous(), seq.sequence_model, training)
     y = _proj(seq.proj, outs[-1])
     outs = outs + [y]
     return seq.output_activate_function(y).permute(1, 2, 0), outs
 
 
-def sequence_models(seqs, xs_bft, training: bool):
+def sequence_models(seqs, xs_bft, training: bool, time_major: bool = False):
     """SequenceModel.forward of several independent models (the sub-band groups): their cell stacks go through gsn_stacks (layer l of
     all of them in one launch per direction).  Returns [(y [R, P, T], all_layer_outputs), ...]."""
     if any(seq.sequence_model_name == "LSTM" for seq in seqs) or len(seqs) < 2:
-        return [sequence_model(seq, x, training) for seq, x in zip(seqs, xs_bft)]
+        return [sequence_model(seq, x, training, time_major) for seq, x in zip(seqs, xs_bft)]
     xs = []
     for seq, x_bft in zip(seqs, xs_bft):
-        x = x_bft.permute(2, 0, 1)  # time-major
+        x = x_bft if time_major else x_bft.permute(2, 0, 1)  # time-major
         if seq.use_pre_layer_norm:
-            x = seq.pre_layer_norm(x)
+            x = _pre_ln(seq.pre_layer_norm, x)
         xs.append(x.contiguous())
     res = []
     for seq, outs in zip(seqs, gsn_stacks(xs, [seq.sequence_model for seq in seqs], training)):
         y = _proj(seq.proj, outs[-1])
         res.append((seq.output_activate_function(y).permute(1, 2, 0), outs + [y]))
     return res
+
+
+def _deep_filter(y: torch.Tensor, band: torch.Tensor, N: int, c: int, d: int, S: int) -> torch.Tensor:
+    """deepfiltering (MODEL:315-346) of one sub-band group: y [B N, P, T] with channel p = ((ri c + fci) d + di) S + si (the projection's
+    output), band [B, N c, T] complex (the noisy bins of the group) -> [B, S, N c, T] complex,
+    Y[f, t] = sum_di X[f, t - (d - 1) + di] C[di, f, t] with zeros left of the first frame.  One complex product over all taps and one sum
+    (round 6: the per-tap loop over real and imaginary planes was ~230 element-wise launches per training step, 3.2 -> 1.1 ms)."""
+    B, T = band.shape[0], band.shape[2]
+    coef = y.reshape(B, N, 2, c, d, S, T)
+    if FAST_GLUE:
+        cc = torch.complex(coef[:, :, 0], coef[:, :, 1]).permute(0, 3, 4, 1, 2, 5).reshape(B, d, S, N * c, T)
+        taps = F.pad(band, (d - 1, 0)).unfold(2, T, 1).permute(0, 2, 1, 3)                                    # [B, d, N c, T] (a view)
+        return (taps[:, :, None] * cc).sum(1)
+    cre = coef[:, :, 0].permute(0, 3, 4, 1, 2, 5).reshape(B, d, S, N * c, T)
+    cim = coef[:, :, 1].permute(0, 3, 4, 1, 2, 5).reshape(B, d, S, N * c, T)
+    xp = F.pad(torch.view_as_real(band), (0, 0, d - 1, 0))                                                   # causal: zeros on the left of T
+    xr, xi = xp[..., 0], xp[..., 1]
+    yr = yi = 0
+    for di in range(d):
+        a, b = xr[:, None, :, di:di + T], xi[:, None, :, di:di + T]
+        yr = yr + a * cre[:, di] - b * cim[:, di]
+        yi = yi + a * cim[:, di] + b * cre[:, di]
+    return torch.complex(yr, yi)
 
 
 def _frozen_sequence_models(seqs, xs_bft, training: bool):
@@ -1022,7 +1086,12 @@ def forward_live(model, wave: torch.Tensor):
     S = model.num_spks
     training = model.training
     fb_in = model.fb_input_size
-    fb_out, fb_all = sequence_model(model.fb_model, mag[:, :fb_in], training)  # [B, P, T]
+    # round 6: the feature rows are assembled time-major ([T, B N, I]: what the cell stacks read) from a transposed copy of the 65 MB
+    # magnitude instead of transposing the 230 MB of gathered rows afterwards
+    tm = bool(FAST_GLUE)
+    mag_t = mag.permute(2, 0, 1).contiguous() if tm else None                                                 # [T, B, nf]
+    fb_out, fb_all = sequence_model(model.fb_model, mag_t[:, :, :fb_in] if tm else mag[:, :fb_in], training, tm)  # [B, P, T]
+    fb_t = fb_out.permute(2, 0, 1) if tm else None                                                            # [T, B, P] (the projection's own layout)
     P_fb = fb_out.shape[1]
     sb = model.sb_model
     cut = list(sb.freq_cutoffs)
@@ -1039,27 +1108,20 @@ def forward_live(model, wave: torch.Tensor):
         k = torch.arange(N, device=dev)
         idx_noisy = _reflect(lo + k[:, None] * c - n + torch.arange(c + 2 * n, device=dev)[None, :], nf)   # [N, c + 2n]
         idx_fb = (lo + k[:, None] * c + torch.arange(c, device=dev)[None, :]) % P_fb                        # [N, c] (tiled full-band output)
-        x = torch.cat([mag[:, idx_noisy], fb_out[:, idx_fb]], dim=2)                                         # [B, N, I, T]
-        xs_g.append(x.reshape(B * N, x.shape[2], T))
-    ys_g = sequence_models(list(sb.sb_models), xs_g, training)                                               # [(y [B N, P, T], outs)]
+        if tm:
+            x = torch.cat([mag_t[:, :, idx_noisy], fb_t[:, :, idx_fb]], dim=3)                               # [T, B, N, I]
+            xs_g.append(x.reshape(T, B * N, x.shape[3]))
+        else:
+            x = torch.cat([mag[:, idx_noisy], fb_out[:, idx_fb]], dim=2)                                     # [B, N, I, T]
+            xs_g.append(x.reshape(B * N, x.shape[2], T))
+    ys_g = sequence_models(list(sb.sb_models), xs_g, training, tm)                                           # [(y [B N, P, T], outs)]
     for g, seq in enumerate(sb.sb_models):
         lo, hi, c, n, d = cut[g], cut[g + 1], sb.center_freq_sizes[g], sb.neighbor_freq_sizes[g], sb.df_orders[g]
         N = (hi - lo) // c
         y, outs = ys_g[g]
         sb_all.append(outs)
         # projection channel p = ((ri * c + fci) * d + di) * S + si  ->  coefficient [B, di, si, n * c + fci, T] (re, im)
-        coef = y.reshape(B, N, 2, c, d, S, T)
-        cre = coef[:, :, 0].permute(0, 3, 4, 1, 2, 5).reshape(B, d, S, N * c, T)
-        cim = coef[:, :, 1].permute(0, 3, 4, 1, 2, 5).reshape(B, d, S, N * c, T)
-        xg = noisy[:, lo:hi]                                                                                 # [B, N c, T]
-        xp = F.pad(torch.view_as_real(xg), (0, 0, d - 1, 0))                                                 # causal: zeros on the left of T
-        xr, xi = xp[..., 0], xp[..., 1]
-        yr = yi = 0
-        for di in range(d):  # Y[f, t] = sum_d X[f, t - (d_order - 1) + d] * C[d, f, t]
-            a, b = xr[:, None, :, di:di + T], xi[:, None, :, di:di + T]
-            yr = yr + a * cre[:, di] - b * cim[:, di]
-            yi = yi + a * cim[:, di] + b * cre[:, di]
-        enh_groups.append(torch.complex(yr, yi))                                                             # [B, S, N c, T]
+        enh_groups.append(_deep_filter(y, noisy[:, lo:hi], N, c, d, S))                                      # [B, S, N c, T]
     enh = torch.cat(enh_groups, dim=2)
     enh_stft = torch.cat([enh, noisy[:, None, enh.shape[2]:].expand(B, S, Fq - enh.shape[2], T)], dim=2)     # bins past the groups pass through
     enh_y = _istft(enh_stft.reshape(B * S, Fq, T), model.n_fft, model.hop_length, model.win_length, window, length)
@@ -1141,17 +1203,7 @@ def forward_frozen(model, wave: torch.Tensor):
         N = (hi - lo) // c
         y, outs = ys_g[g]
         sb_all.append(outs)
-        coef = y.reshape(B, N, 2, c, d, T)   # channel p = (ri * c + fci) * d + di  (:262-268)
-        cre = coef[:, :, 0].permute(0, 3, 1, 2, 4).reshape(B, d, N * c, T)
-        cim = coef[:, :, 1].permute(0, 3, 1, 2, 4).reshape(B, d, N * c, T)
-        xp = F.pad(torch.view_as_real(noisy[:, lo:hi]), (0, 0, d - 1, 0))                                        # causal: zeros on the left of T
-        xr, xi = xp[..., 0], xp[..., 1]
-        yr = yi = 0
-        for di in range(d):
-            a, b = xr[:, :, di:di + T], xi[:, :, di:di + T]
-            yr = yr + a * cre[:, di] - b * cim[:, di]
-            yi = yi + a * cim[:, di] + b * cre[:, di]
-        enh_groups.append(torch.complex(yr, yi))                                                                 # [B, N c, T]
+        enh_groups.append(_deep_filter(y, noisy[:, lo:hi], N, c, d, 1)[:, 0])   # channel p = (ri * c + fci) * d + di  (:262-268)  [B, N c, T]
     enh = torch.cat(enh_groups, dim=1)
     enh_stft = torch.cat([enh, noisy[:, enh.shape[1]:]], dim=1)                                                  # bins past the groups pass through
     enh_y = _istft(enh_stft, model.n_fft, model.hop_length, model.win_length, window, length)
