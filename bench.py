@@ -763,7 +763,7 @@ def training_bench(args, model, dev, world, rank, rw, B, T):
         torch.cuda.synchronize()
         graphed = dict(ms_per_step=round((time.perf_counter() - t0) / steps * 1e3, 2), layer_call_launches_captured=gs.layer_calls_captured,
                        note="forward + loss + backward replayed from one HIP graph: gradients bit-identical to the eager step "
-                            "(tests/test_training.py); at B = 64 the device is busy for the whole eager step (kernel time 74.7 of 75 ms, "
+                            "(tests/test_training.py); at B = 64 the device is busy for the whole eager step (kernel time 69.5 of 70 ms, "
                             "profiles/r06_training_b64_kernel_stats.csv), so the graph buys ~1 %; at small batches the host's share is "
                             "larger (B = 8, T = 200: 12.2 -> 10.0 ms)")
         del gs
@@ -806,7 +806,7 @@ def training_bench(args, model, dev, world, rank, rw, B, T):
                        "grad_norm": gn, "optimizer_step": "not included (the reference's optimiser; out of scope)",
                        "cell_steps_per_training_step": 2 * 4 * T,
                        "note": "the same loop written as ATen operations per cell step (the reference's structure) takes 2.65 s at B=16 and "
-                               "2.8 s at B=64 (scripts/exp_train.py); round 3 (one launch per cell step and direction): 315 ms at B=64; round 4 (one launch per layer call): 117 ms"},
+                               "2.8 s at B=64 (scripts/exp_train.py); round 3 (one launch per cell step and direction): 315 ms at B=64; round 4 (one launch per layer call): 117 ms; round 5 (the layers of a stack pipelined over chunks of frames in one grid): 75 ms; round 6 (LayerNorm, feature assembly and deep filter of the differentiable path rewritten): 69-70 ms"},
             "roofline": roof}))
 
 
