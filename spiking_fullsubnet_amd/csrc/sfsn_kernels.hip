@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512) void gsn_scan_fused_kernel(const ScanParams p)
 
 // Round 6: the fused-input scan at 16 rows per workgroup with IO-specialised waves (sfsn_scan3j_dev.h): what sfsn_gsn_layer_scan_fused
 // launches for H <= 224 (at most 14 tiles: one per compute wave + loader + storer); bit-identical to gsn_scan_fused_kernel.
-template <int KS, int TL, int OUT>
+template <int KS, int TL, int OUT, int OFF = 0>
 __global__ __launch_bounds__(1024) void gsn_scan_fused3_kernel(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char scan_smem[];
     int s = 0;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(1024) void gsn_scan_fused3_kernel(const ScanParams 
     rl.spikes_f32 = sg.spikes_f32; rl.spikes_i8 = sg.spikes_i8; rl.R = sg.R; rl.row0 = ((int)blockIdx.x - sg.tile0) * 16;
     rl.count = sg.count; rl.lsplit = p.lsplit;
     SFSN_WG_STAMP(p.wg_times, 0);
-    scan3j_role<KS, TL, OUT>(rl, scan_smem, p.T, p.H, p.NT);
+    scan3j_role<KS, TL, OUT, OFF>(rl, scan_smem, p.T, p.H, p.NT);
     SFSN_WG_STAMP(p.wg_times, 1);
 }
 
@@ -2424,6 +2424,26 @@ extern "C" int sfsn_gsn_layer_scan_fused(const sfsn_scan_segment* segs, const sf
         hipLaunchKernelGGL(kern, dim3(tiles), dim3(1024), lds3, st, p);                                                    \
         return hip_ok(hipGetLastError());                                                                                  \
     }
+        // 14 tiles (H = 224) and no fp32 spike tensor: the IO waves compute the input terms of tiles 12 / 13 (scan3j_role, OFF form).
+        // Measured (B = 64, T = 1000, 52 workgroups, ms per launch, scripts/exp_s3joff_r06.py): without fp32 spikes 1.320 -> 1.238; WITH
+        // them 1.333 -> 1.466 -- there the IO waves' fp32 stores (~1,400 clk per step between them) already fill SIMDs 2 / 3 up to the
+        // four-tile SIMDs' level (what SFSN_S3J_LSPLIT = 6 balanced), so the form is taken for OUT = 2 only.  SFSN_S3J_OFF = 0 / 1 / 2:
+        // never / OUT = 2 only (default) / always (A/B runs).
+        const int offm = getenv("SFSN_S3J_OFF") ? atoi(getenv("SFSN_S3J_OFF")) : 1;
+        if (p.NT == 14 && KS == 4 && tl && Scan3jCfg<4>::lds_bytes_off(14) <= 160 * 1024 - 64 && (offm == 2 || (offm == 1 && out == 2))) {
+            const int ldso = Scan3jCfg<4>::lds_bytes_off(14);
+#define FUSED3O_CASE(OUT_)                                                                                                 \
+    if (out == OUT_) {                                                                                                     \
+        auto kern = gsn_scan_fused3_kernel<4, 1, OUT_, 1>;                                                                 \
+        static int seen[SFSN_MAX_DEVICES] = {0};                                                                           \
+        if (raise_lds(reinterpret_cast<const void*>(kern), ldso, seen) != SFSN_OK) return SFSN_EHIP;                       \
+        p.wg_times = sfsn_wgprobe_take(2, tiles);                                                                          \
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(1024), ldso, st, p);                                                    \
+        return hip_ok(hipGetLastError());                                                                                  \
+    }
+            FUSED3O_CASE(2) FUSED3O_CASE(3)
+#undef FUSED3O_CASE
+        }
         FUSED3_CASE(3, 0, 2) FUSED3_CASE(3, 0, 3) FUSED3_CASE(3, 1, 2) FUSED3_CASE(3, 1, 3) FUSED3_CASE(4, 1, 2) FUSED3_CASE(4, 1, 3)
 #undef FUSED3_CASE
     }

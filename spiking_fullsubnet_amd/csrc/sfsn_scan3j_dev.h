@@ -42,6 +42,61 @@ struct Scan3jCfg {
     static constexpr int WIH_OFF = CST_OFF + 6 * HP * 4;
     __host__ __device__ static constexpr int plane_bytes(int NT) { return NT * KS * 1024; }
     __host__ __device__ static constexpr int lds_bytes(int NT) { return WIH_OFF + 2 * plane_bytes(NT); }
+    // OFF form (14 tiles): the input terms the two IO waves compute for tiles 12 and 13, [frame parity][tile - 12][lane] x 16 bytes
+    __host__ __device__ static constexpr int mbox_off(int NT) { return lds_bytes(NT); }
+    __host__ __device__ static constexpr int lds_bytes_off(int NT) { return lds_bytes(NT) + 4096; }
+};
+
+// The input term of frame f (ring slot f % D) for output tile `ct`, as the wave's four values per lane: 12 matrix instructions (full
+// 16x16x64 steps, zero padded k), planes 0 / 1 of W_ih from LDS two k-steps at a time, plane 2 from the caller's registers;
+// z = fma(exact sum, dq_ih, b_f) (= sfsn_spike_proj).  Used by the compute waves for their own tile and, in the OFF form, by the IO waves
+// for tiles 12 / 13.
+template <int KS>
+__device__ __forceinline__ v4f s3j_in_product(const char* smem, int f, const unsigned (&soff)[KS], unsigned woff, int PLANE, const v4i (&Wi2)[KS],
+                                              const char* cq) {
+    using C = Scan3jCfg<KS>;
+    constexpr int HP = C::HP;
+    const char* ring = smem + (f % C::D) * C::SLOT;
+    v4i e[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
+#pragma unroll
+    for (int k0 = 0; k0 < KS; k0 += 2) {
+        v4i sb[2], w0[2], w1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (k0 + i >= KS) continue;
+            sb[i] = *reinterpret_cast<const v4i*>(ring + soff[k0 + i]);
+            w0[i] = *reinterpret_cast<const v4i*>(smem + woff + (k0 + i) * 1024);
+            w1[i] = *reinterpret_cast<const v4i*>(smem + woff + PLANE + (k0 + i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (k0 + i >= KS) continue;
+            e[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0[i], sb[i], e[0], 0, 0, 0);
+            e[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wi2[k0 + i], sb[i], e[2], 0, 0, 0);
+            e[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[i], sb[i], e[1], 0, 0, 0);
+        }
+    }
+    const v4f dqi = *reinterpret_cast<const v4f*>(cq + 4 * HP * 4);
+    const v4f bf = *reinterpret_cast<const v4f*>(cq + 5 * HP * 4);
+    v4f z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[r] = __builtin_fmaf((float)((e[2][r] << 16) + (e[1][r] << 8) + e[0][r]), dqi[r], bf[r]);
+    return z;
+}
+
+struct Scan3jRole;
+// What an IO wave of the OFF form needs to compute tile `ct`'s input terms: plane 2 of its W_ih rows in registers, its fragment offsets
+template <int KS>
+struct S3jHelper {
+    v4i Wi2[KS];
+    unsigned soff[KS], woff;
+    const char* cq;
+    char* mbox;  // my lane's 16 bytes of parity 0; parity 1 at + 2048
+    __device__ __forceinline__ void init(const Scan3jRole& rl, char* smem, int NT, int ct, int lane);
+    __device__ __forceinline__ void run(const char* smem, int f, int PLANE) const {
+        const v4f z = s3j_in_product<KS>(smem, f, soff, woff, PLANE, Wi2, cq);
+        *reinterpret_cast<v4f*>(mbox + (f & 1) * 2048) = z;
+    }
 };
 
 struct Scan3jRole {
@@ -62,9 +117,28 @@ struct Scan3jRole {
     int lsplit;                 // fp32 store instructions per frame issued by the loader wave (the storer takes the rest)
 };
 
+template <int KS>
+__device__ __forceinline__ void S3jHelper<KS>::init(const Scan3jRole& rl, char* smem, int NT, int ct, int lane) {
+    using C = Scan3jCfg<KS>;
+    const int n = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        Wi2[ks] = *reinterpret_cast<const v4i*>(rl.w_ih + ((((size_t)2 * NT + ct) * KS + ks) * 64 + lane) * 16);
+        soff[ks] = (unsigned)(n * 256 + ((ks * 4 + q + n) & 15) * 16);
+    }
+    woff = (unsigned)(C::WIH_OFF + (ct * KS) * 1024 + lane * 16);
+    cq = smem + C::CST_OFF + (ct * 16 + q * 4) * 4;
+    mbox = smem + C::mbox_off(NT) + (ct - 12) * 1024 + lane * 16;
+}
+
 // TL = 1: H mod 64 in (0, 32]: the last k-step of the RECURRENT product is one 16x16x32 instruction (scan3i_role's form).
 // OUT bit 0: fp32 spikes, bit 1: int8 spikes (always).
-template <int KS, int TL, int OUT>
+// OFF = 1 (14 tiles only): with one tile per compute wave SIMDs 0 and 1 carry four tiles and SIMDs 2 and 3 three tiles and an IO wave,
+// and a SIMD's matrix instructions and VALU instructions share its time (file head) -- the step is the four-tile SIMDs'.  The input
+// term of the next frame is off the step's dependency chain, so the IO waves (SIMD 2: loader, SIMD 3: storer) compute it for tiles 12
+// (SIMD 0) and 13 (SIMD 1) and hand the four values per lane over through LDS at the step barrier (double-buffered by frame parity):
+// ~3.6 tiles' worth of work on every SIMD instead of 4 / 4 / 3 / 3.  The same instructions on the same operands: bit-identical.
+template <int KS, int TL, int OUT, int OFF = 0>
 __device__ __forceinline__ void scan3j_role(const Scan3jRole& rl, char* smem, int T, int H, int NT) {
     using C = Scan3jCfg<KS>;
     constexpr int RPW = 16, LDH = C::LDH, HP = C::HP, D = C::D, A = C::A, SLOT = C::SLOT, NP = C::NP, NCH = C::NCH;
@@ -133,40 +207,20 @@ __device__ __forceinline__ void scan3j_role(const Scan3jRole& rl, char* smem, in
         const char* cq = smem + C::CST_OFF + cj * 4;  // my four neurons' constants: vector k at cq + k * HP * 4
         v4f z = {0.f, 0.f, 0.f, 0.f};                 // the input term of my four values at the NEXT frame to be finished
 
-        // the input term of frame f (ring slot f % D) -> z: 12 matrix instructions (full 16x16x64 steps, zero padded k), planes 0 / 1 of
-        // W_ih from LDS two k-steps at a time, plane 2 from registers; z = fma(exact sum, dq_ih, b_f) (= sfsn_spike_proj)
-        auto in_product = [&](int f) __attribute__((always_inline)) {
-            const char* ring = smem + (f % D) * SLOT;
-            v4i e[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
-#pragma unroll
-            for (int k0 = 0; k0 < KS; k0 += 2) {
-                v4i sb[2], w0[2], w1[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (k0 + i >= KS) continue;
-                    sb[i] = *reinterpret_cast<const v4i*>(ring + soff[k0 + i]);
-                    w0[i] = *reinterpret_cast<const v4i*>(smem + woff + (k0 + i) * 1024);
-                    w1[i] = *reinterpret_cast<const v4i*>(smem + woff + PLANE + (k0 + i) * 1024);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (k0 + i >= KS) continue;
-                    e[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0[i], sb[i], e[0], 0, 0, 0);
-                    e[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wi2[k0 + i], sb[i], e[2], 0, 0, 0);
-                    e[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1[i], sb[i], e[1], 0, 0, 0);
-                }
-            }
-            const v4f dqi = *reinterpret_cast<const v4f*>(cq + 4 * HP * 4);
-            const v4f bf = *reinterpret_cast<const v4f*>(cq + 5 * HP * 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z[r] = __builtin_fmaf((float)((e[2][r] << 16) + (e[1][r] << 8) + e[0][r]), dqi[r], bf[r]);
-        };
+        const bool served = OFF && ct >= 12;  // (wave-uniform) my input terms come from an IO wave's mailbox
+        const char* mbox = smem + C::mbox_off(NT) + (ct >= 12 ? ct - 12 : 0) * 1024 + lane * 16;
+        auto in_product = [&](int f) __attribute__((always_inline)) { z = s3j_in_product<KS>(smem, f, soff, woff, PLANE, Wi2, cq); };
 
         __syncthreads();                       // initial state in hbuf[0], W_ih planes and constants in LDS
         __builtin_amdgcn_s_barrier();          // the loader's prologue frames (0 .. A - 1) have landed
-        in_product(0);
+        if (!served) in_product(0);
+        if constexpr (OFF) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();      // the IO waves' input terms of frame 0 are in the mailbox
+        }
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
+            if constexpr (OFF) if (served) z = *reinterpret_cast<const v4f*>(mbox + (t & 1) * 2048);
             const int8_t* hc = hbuf + (t & 1) * 16 * LDH;
             int8_t* hn = hbuf + ((t & 1) ^ 1) * 16 * LDH;
             v4i b[KSF > 0 ? KSF : 1];
@@ -211,7 +265,7 @@ __device__ __forceinline__ void scan3j_role(const Scan3jRole& rl, char* smem, in
             *reinterpret_cast<unsigned*>(hn + hoff) = pk;
             __builtin_amdgcn_sched_barrier(0);
             // off the chain: the input term of frame t + 1 (the loader clamps frames past the end to the last one: harmless work)
-            in_product(t + 1);
+            if (!served) in_product(t + 1);
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
         }
@@ -251,16 +305,24 @@ __device__ __forceinline__ void scan3j_role(const Scan3jRole& rl, char* smem, in
 #pragma unroll
             for (int p = 0; p < NP; ++p) dma16_to_lds<false>(__builtin_amdgcn_readfirstlane((unsigned)(slot * SLOT + p * 1024)), st, goff[p]);
         };
+        S3jHelper<KS> hp;
+        if constexpr (OFF) hp.init(rl, smem, NT, 12, lane);
         __syncthreads();
         for (int s0 = 0; s0 < A; ++s0) issue(s0, s0 < T ? s0 : (T > 0 ? T - 1 : 0));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
+        if constexpr (OFF) {
+            hp.run(smem, 0, PLANE);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             const int td = (t + A < T) ? t + A : T - 1;
             issue((t + A) % D, td);  // the slot of frame t - 1: read during step t - 2
             if constexpr (LSF) if (t > 0 && ff.nsf > 0) ff.run(hbuf + (t & 1) * 16 * LDH, rl.spikes_f32 + ((size_t)(t - 1) * R + row0) * H, lane);
+            if constexpr (OFF) hp.run(smem, t + 1, PLANE);  // tile 12's input term of frame t + 1 (landed before the barrier of step t - 1)
             wait_vmcnt_n(allow);     // frame t + 2 has landed: the compute waves read it during step t + 1
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();
@@ -298,11 +360,19 @@ __device__ __forceinline__ void scan3j_role(const Scan3jRole& rl, char* smem, in
             }
             if constexpr (F32) ff.run(hsrc, rl.spikes_f32 + ((size_t)ts * R + row0) * H, lane);
         };
+        S3jHelper<KS> hp;
+        if constexpr (OFF) hp.init(rl, smem, NT, 13, lane);
         __syncthreads();
         __builtin_amdgcn_s_barrier();
+        if constexpr (OFF) {
+            hp.run(smem, 0, PLANE);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             if (t > 0) flush(hbuf + (t & 1) * 16 * LDH, t - 1);  // = h_{t-1}
+            if constexpr (OFF) hp.run(smem, t + 1, PLANE);       // tile 13's input term of frame t + 1
             __builtin_amdgcn_s_waitcnt(0xc07f);                  // my LDS reads are done before the buffer is rewritten (step t + 1)
             __builtin_amdgcn_s_barrier();
         }
@@ -314,6 +384,7 @@ __device__ __forceinline__ void scan3j_role(const Scan3jRole& rl, char* smem, in
     // ================================================= spare waves (NT < 14): keep the barrier count =================================================
     __syncthreads();
     __builtin_amdgcn_s_barrier();
+    if constexpr (OFF) __builtin_amdgcn_s_barrier();
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         __builtin_amdgcn_s_waitcnt(0xc07f);

@@ -1541,6 +1541,32 @@ def test_fused_scan_with_io_waves_equals_round_2_body_and_the_two_calls(hip, H, 
     np.testing.assert_array_equal(lean[3], new[3])
 
 
+@pytest.mark.parametrize("R,T", [(37, 33), (16, 1), (64, 90)])
+def test_fused_scan_with_the_io_waves_computing_two_tiles_input_terms_is_bit_identical(hip, R, T, monkeypatch):
+    """scan3j_role's OFF form (H = 224, 14 tiles: the loader / storer waves compute the input terms of tiles 12 / 13 and hand them over
+    through LDS at the step barrier) -- the default without fp32 spikes, forced here WITH them too (SFSN_S3J_OFF=2) -- against the plain
+    form (SFSN_S3J_OFF=0): fp32 / int8 spikes, h, c and the spike count."""
+    H = 224
+    rng = np.random.default_rng(R * 31 + T)
+    sd, alpha, beta, bnp = make_layer(rng, H, H, True, True)
+    s_in = np.zeros((T, R, 256), np.int8)
+    s_in[:, :, :H] = rng.random((T, R, H)) < 0.25
+    h0 = (rng.random((R, H)) > 0.5).astype(np.float32)
+    c0 = rng.standard_normal((R, H)).astype(np.float32)
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("SFSN_S3J_OFF", mode)
+        res[mode] = (_run_fused(hip, s_in, sd, alpha, beta, h0, c0), _run_fused(hip, s_in, sd, alpha, beta, h0, c0, want_f32=False))
+    monkeypatch.delenv("SFSN_S3J_OFF")
+    for k in range(2):
+        for a, b, nm in zip(res["0"][k], res["2"][k], ("fp32 spikes", "int8 spikes", "h", "c", "count")):
+            if a is None:
+                assert b is None
+            else:
+                np.testing.assert_array_equal(a, b, err_msg=f"{nm} ({'with' if k == 0 else 'without'} fp32 spikes)")
+    assert res["2"][0][1].any()
+
+
 def _run_fused_x(hip, x, sd, alpha, beta, h0, c0, want_f32=True, segs_split=None):
     """sfsn_gsn_layer_scan_fused_x on fp32 feature rows x [T, R, I] (a layer 0): fp32 spikes (or None), int8 spikes, h, c, count."""
     from spiking_fullsubnet_amd._lib import FusedX, ScanSegment, check
